@@ -1,0 +1,89 @@
+/*
+ * mbx_oracle.h -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's (arancormonk/mbelib-neo v2.0.0) hot path, used
+ * to check the HIP kernels.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load it; the product (mbelib-neo_amd/) never links, imports or
+ * falls back to anything in oracle/.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_reference_golden.py checks this file
+ * against (a) every golden vector the reference's own tests hold for the path
+ * (tests/test_golden_pcm.c:78-84 FNV hashes, tests/test_ecc.c known answers,
+ * tests/test_params.c known answers, tests/test_floattoshort_parity.c edge values) and
+ * (b) fixtures produced by the real reference compiled here (oracle/_ref, see Makefile).
+ * Integer stages are bit-exact; float stages are bit-exact too except the values that
+ * pass through the 256-point FFT (the reference uses the vendored PFFFT, this file uses
+ * a double-precision FFT): those agree to ~1e-7 relative.
+ */
+#ifndef MBX_ORACLE_H
+#define MBX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mbx_tables.h"
+#include "mbx_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tables -------------------------------------------------------------------------- */
+int mbxo_load_tables(const void* blob, size_t n); /* 0, or -1 on bad magic/size/checksum */
+
+/* frame packing (host side of the boundary) ---------------------------------------- */
+int mbxo_pack_imbe_frame(const char fr[8][23], uint8_t out[MBX_IMBE_FRAME_BYTES]); /* 0 / -1 / -2 */
+int mbxo_pack_ambe_frame(const char fr[4][24], uint8_t out[MBX_AMBE_FRAME_BYTES]);
+void mbxo_unpack_imbe_frame(const uint8_t in[MBX_IMBE_FRAME_BYTES], char fr[8][23]);
+void mbxo_unpack_ambe_frame(const uint8_t in[MBX_AMBE_FRAME_BYTES], char fr[4][24]);
+void mbxo_record_to_bits(const mbx_param_record* rec, int nbits, char* bits);
+void mbxo_record_to_result(const mbx_param_record* rec, mbe_process_result* result);
+
+/* FEC stage (stateless) -------------------------------------------------------------- */
+int mbxo_golay2312_word(uint32_t cw, uint32_t* fixed);   /* returns corrected data bits */
+int mbxo_hamming1511_word(uint32_t cw, uint32_t* fixed); /* returns 0/1 */
+int mbxo_golay2312(const char* in, char* out);           /* char-array forms of the two above */
+int mbxo_hamming1511(const char* in, char* out);
+int mbxo_fec_imbe7200x4400(const uint8_t frame[MBX_IMBE_FRAME_BYTES], mbx_param_record* rec);
+int mbxo_fec_ambe3600x2450(const uint8_t frame[MBX_AMBE_FRAME_BYTES], mbx_param_record* rec);
+/* the reference's char-array entry points, same return/validation behaviour */
+int mbxo_decode_imbe7200x4400_frame(const char fr[8][23], char imbe_d[88], mbe_process_result* result);
+int mbxo_decode_ambe3600x2450_frame(const char fr[4][24], char ambe_d[49], mbe_process_result* result);
+
+/* stream stage ------------------------------------------------------------------------ */
+void mbxo_init_parms(mbe_parms* cur, mbe_parms* prev, mbe_parms* prev_enh);
+void mbxo_rng_default(mbx_stream_rng* rng);
+void mbxo_rng_seed(mbx_stream_rng* rng, uint32_t seed);
+int mbxo_decode_imbe4400_parms(const char* imbe_d, mbe_parms* cur, mbe_parms* prev);
+int mbxo_decode_ambe2450_parms(const char* ambe_d, mbe_parms* cur, mbe_parms* prev, int total_errors);
+int mbxo_process_imbe4400_dataf(float* out, mbe_process_result* result, const char imbe_d[88], mbe_parms* cur,
+                                mbe_parms* prev, mbe_parms* prev_enh, mbx_stream_rng* rng);
+int mbxo_process_ambe2450_dataf(float* out, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur,
+                                mbe_parms* prev, mbe_parms* prev_enh, mbx_stream_rng* rng);
+int mbxo_process_imbe7200x4400_framef(float* out, mbe_process_result* result, const char fr[8][23], char imbe_d[88],
+                                      mbe_parms* cur, mbe_parms* prev, mbe_parms* prev_enh, mbx_stream_rng* rng);
+int mbxo_process_ambe3600x2450_framef(float* out, mbe_process_result* result, const char fr[4][24], char ambe_d[49],
+                                      mbe_parms* cur, mbe_parms* prev, mbe_parms* prev_enh, mbx_stream_rng* rng);
+
+/* synthesis pieces -------------------------------------------------------------------- */
+float mbxo_spectral_amp_enhance(mbe_parms* cur); /* returns pre-enhancement Rm0 */
+void mbxo_adaptive_smoothing(mbe_parms* cur, const mbe_parms* prev);
+void mbxo_synthesize_speechf(float* out, mbe_parms* cur, mbe_parms* prev, mbx_stream_rng* rng);
+void mbxo_comfort_noisef(float* out, mbx_stream_rng* rng);
+void mbxo_tonef(float* out, const char* ambe_d, mbe_parms* cur);
+void mbxo_floattoshort(const float* in, int16_t* out);
+void mbxo_noise_next(float buffer[256], float* seed, float overlap[96], mbx_stream_rng* rng);
+
+/* batch driver: same contract as the HIP launcher's mbx_process_batch (include/mbx.h) */
+int mbxo_process_batch(int codec, int S, int T, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
+                       int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records);
+int mbxo_fec_batch(int codec, size_t n, const uint8_t* frames, mbx_param_record* records);
+void mbxo_floattoshort_batch(const float* in, int16_t* out, size_t nframes);
+void mbxo_synthesize_speech_batch(int S, mbe_parms* cur, mbe_parms* prev, mbx_stream_rng* rng, float* pcmf);
+
+uint32_t mbxo_fnv1a32(const void* data, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
