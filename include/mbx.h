@@ -1,0 +1,118 @@
+/*
+ * mbx.h -- C-ABI of the MI355X batch launcher (libmbx_hip.so).
+ *
+ * This is the drop-in boundary for the hot path: plain pointers and sizes, no C++ or torch
+ * types.  Every entry point names the reference interface it stands in for; `ref:` paths are
+ * relative to the reference repository (arancormonk/mbelib-neo v2.0.0).  The reference is a
+ * per-frame, per-thread C library (include/mbelib-neo/mbelib.h); a batch is S independent
+ * streams x T consecutive frames per stream, and what the reference keeps per *thread* is
+ * kept here per *stream* (mbx_stream_rng).
+ *
+ * Pointers whose name starts with d_ are DEVICE pointers (hipMalloc / torch CUDA tensors);
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  All launchers are
+ * asynchronous on `stream`, never allocate, never synchronise, and return 0 or a negative
+ * MBE_STATUS_* / MBX_E* code.  There is no CPU fallback: without a HIP device every launcher
+ * fails with MBX_ENODEVICE.
+ */
+#ifndef MBX_H
+#define MBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mbx_tables.h"
+#include "mbx_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBX_ENODEVICE (-100) /* no HIP device / HIP call failed */
+#define MBX_ENOTINIT  (-101) /* mbx_init() has not been called on this device */
+#define MBX_EBADTABLE (-102) /* table blob has the wrong magic, size or checksum */
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* Upload the constant tables (include/mbx_tables.h) to `device` and build the derived
+ * device tables (LCG jump-ahead, FFT twiddles).  Replaces the reference's lazily built
+ * thread-local plan/caches: ref src/core/mbelib.c:164-171 (mbe_get_fft_plan),
+ * src/imbe/imbe7200x4400.c:91-115, src/ambe/ambe3600x2450.c:54-78. */
+int mbx_init(int device, const void* table_blob, size_t table_bytes);
+void mbx_shutdown(void);
+/* FNV-1a-32 of the resident table blob (for the per-rank checksum after the broadcast). */
+uint32_t mbx_table_checksum(void);
+const char* mbx_last_error(void);
+
+/* ---- host-side frame packing (no device work) ----------------------------------------- */
+
+/* imbe_fr[8][23] / ambe_fr[4][24] arrays of 0/1 chars -> 18 / 9 byte wire frames.
+ * Validation follows ref src/internal/mbe_result.h:18-29: the WHOLE array is checked,
+ * NULL -> MBE_STATUS_INVALID_ARGUMENT, any cell outside {0,1} -> MBE_STATUS_INVALID_BITS
+ * and nothing is written. */
+int mbx_pack_imbe7200x4400(const char* frames /* n*8*23 */, size_t n, uint8_t* packed /* n*18 */);
+int mbx_pack_ambe3600x2450(const char* frames /* n*4*24 */, size_t n, uint8_t* packed /* n*9 */);
+/* parameter record -> the reference's imbe_d[88] / ambe_d[49] chars and mbe_process_result */
+void mbx_unpack_records(const mbx_param_record* rec, size_t n, int nbits /* 88|49 */, char* bits /* n*nbits, or NULL */,
+                        mbe_process_result* results /* n, or NULL */);
+
+/* ---- FEC stage: frames -> parameter records (stateless, one thread per frame) ---------- */
+
+/* ref: mbe_decodeImbe7200x4400Frame  include/mbelib-neo/mbelib.h:471, src/imbe/imbe7200x4400.c:709-744
+ *      (Golay(23,12) src/ecc/ecc.c:221-301, Hamming(15,11) src/ecc/ecc.c:366-408,
+ *       PR demodulation src/imbe/imbe7200x4400.c:636-673) */
+int mbx_fec_imbe7200x4400(const uint8_t* d_frames /* n*18 */, size_t n, mbx_param_record* d_records /* n */,
+                          void* stream);
+/* ref: mbe_decodeAmbe3600x2450Frame  include/mbelib-neo/mbelib.h:395, src/ambe/ambe3600x2450.c:649-682,
+ *      src/ambe/ambe_common.c:22-46, 75-100, 127-157 */
+int mbx_fec_ambe3600x2450(const uint8_t* d_frames /* n*9 */, size_t n, mbx_param_record* d_records /* n */,
+                          void* stream);
+
+/* ---- stream stage: parameter records + per-stream state -> PCM (one wavefront per stream) */
+
+/* ref: mbe_processImbe4400Dataf / mbe_processAmbe2450Dataf
+ *      include/mbelib-neo/mbelib.h:491, 415; src/imbe/imbe7200x4400.c:858-909;
+ *      src/ambe/ambe3600x2450.c:851-898 -- applied to frame t = 0..T-1 of every stream in order.
+ * d_records is stream-major (stream s, frame t at s*T + t) and carries the C0/C4 error context
+ * exactly as the frame-level entry points hand it over.
+ * d_state: 3 structs per stream {cur_mp, prev_mp, prev_mp_enhanced}, read and written.
+ * Outputs (each may be NULL): int16 PCM (mbe_floattoshort applied, ref src/core/mbelib.c:1296),
+ * float PCM, per-frame mbe_process_result. */
+int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
+                        mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                        void* stream);
+
+/* FEC stage + stream stage back to back:
+ * ref: mbe_processImbe7200x4400Frame[f] include/mbelib-neo/mbelib.h:505-511,
+ *      mbe_processAmbe3600x2450Frame[f] include/mbelib-neo/mbelib.h:429-435.
+ * d_records is a caller-provided S*T workspace (it also returns imbe_d / ambe_d). */
+int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,
+                      int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
+                      void* stream);
+
+/* ref: mbe_synthesizeSpeechf  include/mbelib-neo/mbelib.h:652, src/core/mbelib.c:1112-1115.
+ * One frame for each of S (cur, prev) pairs; both structs are updated like the reference does. */
+int mbx_synthesize_speech(int S, mbe_parms* d_cur, mbe_parms* d_prev, mbx_stream_rng* d_rng, float* d_pcmf,
+                          int16_t* d_pcm16, void* stream);
+
+/* ref: mbe_floattoshort  include/mbelib-neo/mbelib.h:675, src/core/mbelib.c:1148-1177 */
+int mbx_floattoshort(const float* d_in, int16_t* d_out, size_t nframes, void* stream);
+
+/* ---- convenience: same calls on HOST buffers (stages through device memory, synchronous) -- */
+int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
+                           int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records);
+int mbx_synthesize_speech_host(int S, mbe_parms* cur, mbe_parms* prev, mbx_stream_rng* rng, float* pcmf,
+                               int16_t* pcm16);
+int mbx_floattoshort_host(const float* in, int16_t* out, size_t nframes);
+int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* records);
+
+/* per-stream RNG helpers (host): ref mbe_setThreadRngSeed src/core/mbelib.c:173-181 */
+void mbx_rng_default(mbx_stream_rng* rng);
+void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed);
+
+/* name of the dominant kernel and last launch geometry, for the bench */
+const char* mbx_stream_kernel_name(int codec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBX_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of the C-ABI HIP launcher (include/mbx.h).  Fails loudly when the library
+is missing or cannot be initialised: there is no Python/CPU stand-in."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libmbx_hip.so"
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+_lib = None
+
+_vp = C.c_void_p
+_sz = C.c_size_t
+_SIGNATURES = {
+    "mbx_init": (C.c_int, [C.c_int, _vp, _sz]),
+    "mbx_shutdown": (None, []),
+    "mbx_table_checksum": (C.c_uint32, []),
+    "mbx_last_error": (C.c_char_p, []),
+    "mbx_pack_imbe7200x4400": (C.c_int, [_vp, _sz, _vp]),
+    "mbx_pack_ambe3600x2450": (C.c_int, [_vp, _sz, _vp]),
+    "mbx_unpack_records": (None, [_vp, _sz, C.c_int, _vp, _vp]),
+    "mbx_fec_imbe7200x4400": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "mbx_fec_ambe3600x2450": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "mbx_process_records": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_process_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_synthesize_speech": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_floattoshort": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "mbx_process_batch_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_synthesize_speech_host": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_floattoshort_host": (C.c_int, [_vp, _vp, _sz]),
+    "mbx_fec_host": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "mbx_rng_default": (None, [_vp]),
+    "mbx_rng_seed": (None, [_vp, C.c_uint32]),
+    "mbx_stream_kernel_name": (C.c_char_p, [C.c_int]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """The loaded library handle (loads on first use)."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise NativeLibraryError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  mbelib-neo_amd has no CPU fallback."
+            )
+        try:
+            handle = C.CDLL(path)
+        except OSError as e:  # e.g. libamdhip64 not found
+            raise NativeLibraryError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc < 0:
+        msg = lib().mbx_last_error()
+        raise NativeLibraryError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+    return rc

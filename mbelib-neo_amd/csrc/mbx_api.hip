@@ -1,0 +1,467 @@
+// mbx_api.hip -- the C-ABI of libmbx_hip.so (declared in include/mbx.h): table upload,
+// launchers, host-buffer conveniences.  No CPU compute path exists here: if HIP is not
+// usable every entry point fails with MBX_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mbx.h"
+#include "mbx_device.h"
+
+namespace mbx {
+// kernels (mbx_fec.hip, mbx_stream.hip)
+__global__ void fec_imbe7200x4400_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
+__global__ void fec_ambe3600x2450_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
+__global__ void floattoshort_kernel(const float*, int16_t*, size_t);
+__global__ void imbe_stream_kernel(int, int, const mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                   mbe_process_result*, DeviceTables);
+__global__ void ambe_stream_kernel(int, int, const mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                   mbe_process_result*, DeviceTables);
+__global__ void synth_speech_kernel(int, mbe_parms*, mbe_parms*, mbx_stream_rng*, float*, int16_t*, DeviceTables);
+}  // namespace mbx
+
+namespace {
+
+struct Context {
+    bool               ready = false;
+    int                device = -1;
+    mbx::DeviceTables  tabs{nullptr, nullptr};
+    void*              d_blob = nullptr;
+    void*              d_derived = nullptr;
+    uint32_t           checksum = 0;
+};
+Context     g_ctx;
+std::mutex  g_mu;
+std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[256];
+    if (e != hipSuccess) {
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    } else {
+        snprintf(buf, sizeof(buf), "%s", what);
+    }
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) {                        \
+            return fail(MBX_ENODEVICE, #expr, e_);     \
+        }                                              \
+    } while (0)
+
+uint32_t fnv1a(const uint8_t* p, size_t n) {
+    uint32_t h = 2166136261u;
+    for (size_t i = 0; i < n; ++i) {
+        h = (h ^ p[i]) * 16777619u;
+    }
+    return h;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(MBX_ENODEVICE, what, e);
+}
+
+int validate_bits(const char* bits, size_t count) {   // ref: src/internal/mbe_result.h:18-29
+    if (!bits) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        if (bits[i] != 0 && bits[i] != 1) {
+            return MBE_STATUS_INVALID_BITS;
+        }
+    }
+    return 0;
+}
+
+void pack_rows(const char* cells, int rows, int stride, const int* width, uint8_t* out, int nbytes) {
+    memset(out, 0, (size_t)nbytes);
+    int pos = 0;
+    for (int r = 0; r < rows; ++r) {
+        for (int j = width[r] - 1; j >= 0; --j, ++pos) {
+            if (cells[r * stride + j]) {
+                out[pos >> 3] |= (uint8_t)(0x80u >> (pos & 7));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) {
+            (void)hipFree(p);
+        }
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class U> U* as() { return static_cast<U*>(p); }
+};
+}  // namespace
+
+extern "C" {
+
+const char* mbx_last_error(void) { return g_err.c_str(); }
+
+int mbx_init(int device, const void* table_blob, size_t table_bytes) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!table_blob || table_bytes != sizeof(mbx_tables)) {
+        return fail(MBX_EBADTABLE, "table blob: wrong size");
+    }
+    const mbx_tables* host = static_cast<const mbx_tables*>(table_blob);
+    if (host->magic != MBX_TABLES_MAGIC || host->version != MBX_TABLES_VERSION || host->total_bytes != sizeof(mbx_tables)) {
+        return fail(MBX_EBADTABLE, "table blob: wrong magic/version");
+    }
+    const uint32_t sum = fnv1a(reinterpret_cast<const uint8_t*>(&host->checksum) + 4, sizeof(mbx_tables) - 16);
+    if (sum != host->checksum) {
+        return fail(MBX_EBADTABLE, "table blob: checksum mismatch");
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        return fail(MBX_ENODEVICE, "no HIP device");
+    }
+    if (device < 0 || device >= count) {
+        return fail(MBX_ENODEVICE, "device index out of range");
+    }
+    HIP_TRY(hipSetDevice(device));
+    if (g_ctx.ready) {
+        (void)hipFree(g_ctx.d_blob);
+        (void)hipFree(g_ctx.d_derived);
+        g_ctx = Context{};
+    }
+
+    // derived tables
+    std::vector<mbx::DerivedTables> dv(1);
+    mbx::DerivedTables& d = dv[0];
+    memset(&d, 0, sizeof(d));
+    uint32_t a = 1, c = 0;   // x_k = a*x_0 + c (mod 53125)
+    for (int k = 0; k <= 160; ++k) {
+        d.lcg_mul[k] = a;
+        d.lcg_add[k] = c;
+        a = (uint32_t)(((uint64_t)a * 171u) % 53125u);
+        c = (uint32_t)(((uint64_t)c * 171u + 11213u) % 53125u);
+    }
+    for (int k = 0; k < 256; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / 256.0;
+        d.twiddle[k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    for (int L = 1; L < 64; ++L) {
+        d.log2_int[L] = log2f((float)L);
+    }
+
+    HIP_TRY(hipMalloc(&g_ctx.d_blob, sizeof(mbx_tables)));
+    HIP_TRY(hipMalloc(&g_ctx.d_derived, sizeof(mbx::DerivedTables)));
+    HIP_TRY(hipMemcpy(g_ctx.d_blob, table_blob, sizeof(mbx_tables), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g_ctx.d_derived, &d, sizeof(d), hipMemcpyHostToDevice));
+    g_ctx.tabs.t = static_cast<const mbx_tables*>(g_ctx.d_blob);
+    g_ctx.tabs.d = static_cast<const mbx::DerivedTables*>(g_ctx.d_derived);
+    g_ctx.device = device;
+    g_ctx.checksum = host->checksum;
+    g_ctx.ready = true;
+    return 0;
+}
+
+void mbx_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_ctx.ready) {
+        (void)hipFree(g_ctx.d_blob);
+        (void)hipFree(g_ctx.d_derived);
+    }
+    g_ctx = Context{};
+}
+
+uint32_t mbx_table_checksum(void) { return g_ctx.ready ? g_ctx.checksum : 0u; }
+
+int mbx_pack_imbe7200x4400(const char* frames, size_t n, uint8_t* packed) {
+    static const int width[8] = {23, 23, 23, 23, 15, 15, 15, 7};
+    int rc = validate_bits(frames, n * 184u);
+    if (rc < 0) {
+        return rc;
+    }
+    if (!packed) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        pack_rows(frames + i * 184u, 8, 23, width, packed + i * MBX_IMBE_FRAME_BYTES, MBX_IMBE_FRAME_BYTES);
+    }
+    return 0;
+}
+
+int mbx_pack_ambe3600x2450(const char* frames, size_t n, uint8_t* packed) {
+    static const int width[4] = {24, 23, 11, 14};
+    int rc = validate_bits(frames, n * 96u);
+    if (rc < 0) {
+        return rc;
+    }
+    if (!packed) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        pack_rows(frames + i * 96u, 4, 24, width, packed + i * MBX_AMBE_FRAME_BYTES, MBX_AMBE_FRAME_BYTES);
+    }
+    return 0;
+}
+
+void mbx_unpack_records(const mbx_param_record* rec, size_t n, int nbits, char* bits, mbe_process_result* results) {
+    for (size_t i = 0; i < n; ++i) {
+        if (bits) {
+            for (int b = 0; b < nbits; ++b) {
+                bits[i * (size_t)nbits + b] = (char)((rec[i].w[b >> 5] >> (31 - (b & 31))) & 1u);
+            }
+        }
+        if (results) {
+            mbe_process_result& r = results[i];
+            r.c0_errors = (int)(rec[i].w[3] & 0xffu);
+            r.protected_errors = (int)((rec[i].w[3] >> 8) & 0xffu);
+            r.c4_errors = (int)((rec[i].w[3] >> 16) & 0xffu);
+            r.total_errors = r.c0_errors + r.protected_errors;
+            r.flags = (rec[i].w[3] >> 24) & 0xffu;
+        }
+    }
+}
+
+void mbx_rng_default(mbx_stream_rng* rng) {
+    memset(rng, 0, sizeof(*rng));
+    rng->unvoiced_seed_state = 3147u;
+}
+
+void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed) {   // ref: src/core/mbelib.c:173-181
+    if (seed == 0u) {
+        seed = 0x6d25357bu;
+    }
+    rng->cn_seed48 = (((uint64_t)seed) ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1ULL);
+    rng->cn_seeded = 1;
+    rng->unvoiced_seed_state = seed % 53125u;
+    rng->unvoiced_seed_override = 1;
+}
+
+#define REQUIRE_READY()                                           \
+    do {                                                          \
+        if (!g_ctx.ready) {                                       \
+            return fail(MBX_ENOTINIT, "mbx_init() not called");   \
+        }                                                         \
+    } while (0)
+
+int mbx_fec_imbe7200x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d_records, void* stream) {
+    REQUIRE_READY();
+    if (!d_frames || !d_records) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(mbx::fec_imbe7200x4400_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, n,
+                       d_records, g_ctx.tabs);
+    return check_launch("fec_imbe7200x4400_kernel");
+}
+
+int mbx_fec_ambe3600x2450(const uint8_t* d_frames, size_t n, mbx_param_record* d_records, void* stream) {
+    REQUIRE_READY();
+    if (!d_frames || !d_records) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(mbx::fec_ambe3600x2450_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, n,
+                       d_records, g_ctx.tabs);
+    return check_launch("fec_ambe3600x2450_kernel");
+}
+
+int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
+                        mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                        void* stream) {
+    REQUIRE_READY();
+    if (!d_records || !d_state || !d_rng || S < 0 || T < 0
+        || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0 || T == 0) {
+        return 0;
+    }
+    if (codec == MBX_CODEC_IMBE7200X4400) {
+        hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                           d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+        return check_launch("imbe_stream_kernel");
+    }
+    hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                       d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+    return check_launch("ambe_stream_kernel");
+}
+
+int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,
+                      int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
+                      void* stream) {
+    REQUIRE_READY();
+    if (!d_frames || !d_records || S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    const size_t n = (size_t)S * (size_t)T;
+    int rc = (codec == MBX_CODEC_IMBE7200X4400) ? mbx_fec_imbe7200x4400(d_frames, n, d_records, stream)
+                                                : mbx_fec_ambe3600x2450(d_frames, n, d_records, stream);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbx_process_records(codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+}
+
+int mbx_synthesize_speech(int S, mbe_parms* d_cur, mbe_parms* d_prev, mbx_stream_rng* d_rng, float* d_pcmf,
+                          int16_t* d_pcm16, void* stream) {
+    REQUIRE_READY();
+    if (!d_cur || !d_prev || !d_rng || S < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::synth_speech_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_cur, d_prev,
+                       d_rng, d_pcmf, d_pcm16, g_ctx.tabs);
+    return check_launch("synth_speech_kernel");
+}
+
+int mbx_floattoshort(const float* d_in, int16_t* d_out, size_t nframes, void* stream) {
+    REQUIRE_READY();
+    if (!d_in || !d_out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (nframes == 0) {
+        return 0;
+    }
+    const size_t nsamples = nframes * 160u;
+    const unsigned grid = (unsigned)((nsamples / 2 + 255) / 256);
+    hipLaunchKernelGGL(mbx::floattoshort_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_in, d_out, nsamples);
+    return check_launch("floattoshort_kernel");
+}
+
+const char* mbx_stream_kernel_name(int codec) {
+    return codec == MBX_CODEC_IMBE7200X4400 ? "imbe_stream_kernel" : "ambe_stream_kernel";
+}
+
+// ---- host-buffer conveniences ------------------------------------------------------------
+
+
+int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* records) {
+    REQUIRE_READY();
+    if (!frames || !records) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    const size_t fb = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES;
+    DevBuf df, dr;
+    HIP_TRY(df.alloc(n * fb));
+    HIP_TRY(dr.alloc(n * sizeof(mbx_param_record)));
+    HIP_TRY(hipMemcpy(df.p, frames, n * fb, hipMemcpyHostToDevice));
+    int rc = (codec == MBX_CODEC_IMBE7200X4400) ? mbx_fec_imbe7200x4400(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
+                                                : mbx_fec_ambe3600x2450(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr);
+    if (rc < 0) {
+        return rc;
+    }
+    HIP_TRY(hipMemcpy(records, dr.p, n * sizeof(mbx_param_record), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
+                           int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
+    REQUIRE_READY();
+    if (!frames || !state || !rng || S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    const size_t n = (size_t)S * (size_t)T;
+    const size_t fb = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES;
+    DevBuf df, ds, dg, d16, dfl, dres, drec;
+    HIP_TRY(df.alloc(n * fb));
+    HIP_TRY(ds.alloc((size_t)S * 3 * sizeof(mbe_parms)));
+    HIP_TRY(dg.alloc((size_t)S * sizeof(mbx_stream_rng)));
+    HIP_TRY(d16.alloc(n * 160 * sizeof(int16_t)));
+    HIP_TRY(dfl.alloc(n * 160 * sizeof(float)));
+    HIP_TRY(dres.alloc(n * sizeof(mbe_process_result)));
+    HIP_TRY(drec.alloc(n * sizeof(mbx_param_record)));
+    HIP_TRY(hipMemcpy(df.p, frames, n * fb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ds.p, state, (size_t)S * 3 * sizeof(mbe_parms), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dg.p, rng, (size_t)S * sizeof(mbx_stream_rng), hipMemcpyHostToDevice));
+    int rc = mbx_process_batch(codec, S, T, df.as<uint8_t>(), ds.as<mbe_parms>(), dg.as<mbx_stream_rng>(),
+                               pcm16 ? d16.as<int16_t>() : nullptr, pcmf ? dfl.as<float>() : nullptr,
+                               results ? dres.as<mbe_process_result>() : nullptr, drec.as<mbx_param_record>(), nullptr);
+    if (rc < 0) {
+        return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(state, ds.p, (size_t)S * 3 * sizeof(mbe_parms), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rng, dg.p, (size_t)S * sizeof(mbx_stream_rng), hipMemcpyDeviceToHost));
+    if (pcm16) {
+        HIP_TRY(hipMemcpy(pcm16, d16.p, n * 160 * sizeof(int16_t), hipMemcpyDeviceToHost));
+    }
+    if (pcmf) {
+        HIP_TRY(hipMemcpy(pcmf, dfl.p, n * 160 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (results) {
+        HIP_TRY(hipMemcpy(results, dres.p, n * sizeof(mbe_process_result), hipMemcpyDeviceToHost));
+    }
+    if (records) {
+        HIP_TRY(hipMemcpy(records, drec.p, n * sizeof(mbx_param_record), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int mbx_synthesize_speech_host(int S, mbe_parms* cur, mbe_parms* prev, mbx_stream_rng* rng, float* pcmf, int16_t* pcm16) {
+    REQUIRE_READY();
+    if (!cur || !prev || !rng || S < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    DevBuf dc, dp, dg, dfl, d16;
+    HIP_TRY(dc.alloc((size_t)S * sizeof(mbe_parms)));
+    HIP_TRY(dp.alloc((size_t)S * sizeof(mbe_parms)));
+    HIP_TRY(dg.alloc((size_t)S * sizeof(mbx_stream_rng)));
+    HIP_TRY(dfl.alloc((size_t)S * 160 * sizeof(float)));
+    HIP_TRY(d16.alloc((size_t)S * 160 * sizeof(int16_t)));
+    HIP_TRY(hipMemcpy(dc.p, cur, (size_t)S * sizeof(mbe_parms), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dp.p, prev, (size_t)S * sizeof(mbe_parms), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dg.p, rng, (size_t)S * sizeof(mbx_stream_rng), hipMemcpyHostToDevice));
+    int rc = mbx_synthesize_speech(S, dc.as<mbe_parms>(), dp.as<mbe_parms>(), dg.as<mbx_stream_rng>(),
+                                   pcmf ? dfl.as<float>() : nullptr, pcm16 ? d16.as<int16_t>() : nullptr, nullptr);
+    if (rc < 0) {
+        return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cur, dc.p, (size_t)S * sizeof(mbe_parms), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(prev, dp.p, (size_t)S * sizeof(mbe_parms), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rng, dg.p, (size_t)S * sizeof(mbx_stream_rng), hipMemcpyDeviceToHost));
+    if (pcmf) {
+        HIP_TRY(hipMemcpy(pcmf, dfl.p, (size_t)S * 160 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (pcm16) {
+        HIP_TRY(hipMemcpy(pcm16, d16.p, (size_t)S * 160 * sizeof(int16_t), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int mbx_floattoshort_host(const float* in, int16_t* out, size_t nframes) {
+    REQUIRE_READY();
+    if (!in || !out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    DevBuf di, dout;
+    HIP_TRY(di.alloc(nframes * 160 * sizeof(float)));
+    HIP_TRY(dout.alloc(nframes * 160 * sizeof(int16_t)));
+    HIP_TRY(hipMemcpy(di.p, in, nframes * 160 * sizeof(float), hipMemcpyHostToDevice));
+    int rc = mbx_floattoshort(di.as<float>(), dout.as<int16_t>(), nframes, nullptr);
+    if (rc < 0) {
+        return rc;
+    }
+    HIP_TRY(hipMemcpy(out, dout.p, nframes * 160 * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,1266 @@
+// mbx_stream.hip -- stream stage: parameter records + per-stream model state -> PCM.
+//
+// Layout: ONE STREAM PER WAVEFRONT (one 64-lane wave per workgroup).  The three mbe_parms
+// structs of the stream live in registers for the whole launch: lane l holds element l of
+// every per-harmonic array (Vl, Ml, log2Ml, PHIl, PSIl; L <= 56 < 64), previousUw[256] is four
+// registers per lane, noiseOverlap[96] two.  A struct copy (cur <- prev, prev <- cur ...) is a
+// handful of register moves.  The T frames of the stream are processed in order inside the
+// kernel, state never leaves the register file between frames, and it is read from / written to
+// HBM once per launch with coalesced dword accesses (a struct is 651 consecutive dwords).
+//
+// Stages and the reference code they replace (ref = arancormonk/mbelib-neo v2.0.0):
+//   decode_imbe      src/imbe/imbe7200x4400.c:117-354, 589-630      (a8)
+//   imbe policy      src/imbe/imbe7200x4400.c:56-81, 780-888        (a10)
+//   enhance          src/core/mbelib.c:412-661                      (a13)
+//   smooth           src/core/mbe_adaptive.c:151-266                (a14)
+//   comfort noise    src/core/mbe_adaptive.c:50-60, 116-131         (a20)
+//   noise            src/core/mbe_unvoiced_fft.c:304-341            (a15)
+//   phases           src/core/mbelib.c:901-951                      (a16)
+//   voiced bank      src/core/mbelib.c:208-319, 953-1040            (a17)
+//   unvoiced         src/core/mbe_unvoiced_fft.c:210-275, 546-761   (a18)
+//   clip / convert   src/core/mbelib.c:669-689, 1148-1177           (a19, a21)
+//
+// Numerics: integer decisions are reproduced exactly; float expressions keep the reference's
+// operand order with FMA contraction off, so differences come only from (1) libm vs ocml
+// transcendentals (<= 1-2 ulp), (2) the order of sums across harmonics, (3) the FFT.
+#include "mbx_device.h"
+
+namespace mbx {
+
+// ------------------------------------------------------------------------------------------
+// Register image of one mbe_parms.
+// ------------------------------------------------------------------------------------------
+struct Parms {
+    float    w0;
+    int      L, K;
+    int      Vl;       // lane l: Vl[l]
+    float    Ml, log2Ml, PHIl, PSIl;
+    float    gamma;
+    uint32_t tonePhase;
+    int      swn;
+    float    localEnergy;
+    int      amplitudeThreshold;
+    float    errorRate;
+    int      errorCountTotal, errorCount4, repeatCount;
+    float    mutingThreshold;
+    float    uw[4];    // previousUw[lane + 64*j]
+    float    noiseSeed;
+    float    ov[2];    // noiseOverlap[lane + 64*j]  (j = 1: lanes 0..31)
+};
+
+// dword offsets inside mbe_parms (include/mbx_types.h asserts the byte offsets)
+enum : int {
+    O_W0 = 0, O_L = 1, O_K = 2, O_VL = 3, O_ML = 60, O_LOG2ML = 117, O_PHI = 174, O_PSI = 231, O_GAMMA = 288,
+    O_TONEPHASE = 289, O_SWN = 290, O_LOCALENERGY = 291, O_AMPTHR = 292, O_ERRORRATE = 293, O_ERRTOTAL = 294,
+    O_ERR4 = 295, O_REPEAT = 296, O_MUTETHR = 297, O_UW = 298, O_NOISESEED = 554, O_OVERLAP = 555, PARMS_DWORDS = 651
+};
+
+__device__ __forceinline__ void load_parms(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+    const float* f = reinterpret_cast<const float*>(p);
+    const int* i = reinterpret_cast<const int*>(p);
+    const bool band = lane < MBX_BAND_SLOTS;
+    r.w0 = f[O_W0];
+    r.L = i[O_L];
+    r.K = i[O_K];
+    r.Vl = band ? i[O_VL + lane] : 0;
+    r.Ml = band ? f[O_ML + lane] : 0.0f;
+    r.log2Ml = band ? f[O_LOG2ML + lane] : 0.0f;
+    r.PHIl = band ? f[O_PHI + lane] : 0.0f;
+    r.PSIl = band ? f[O_PSI + lane] : 0.0f;
+    r.gamma = f[O_GAMMA];
+    r.tonePhase = (uint32_t)i[O_TONEPHASE];
+    r.swn = i[O_SWN];
+    r.localEnergy = f[O_LOCALENERGY];
+    r.amplitudeThreshold = i[O_AMPTHR];
+    r.errorRate = f[O_ERRORRATE];
+    r.errorCountTotal = i[O_ERRTOTAL];
+    r.errorCount4 = i[O_ERR4];
+    r.repeatCount = i[O_REPEAT];
+    r.mutingThreshold = f[O_MUTETHR];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.uw[j] = f[O_UW + lane + 64 * j];
+    }
+    r.noiseSeed = f[O_NOISESEED];
+    r.ov[0] = f[O_OVERLAP + lane];
+    r.ov[1] = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
+}
+
+__device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restrict__ p, int lane) {
+    float* f = reinterpret_cast<float*>(p);
+    int* i = reinterpret_cast<int*>(p);
+    if (lane == 0) {
+        f[O_W0] = r.w0;
+        i[O_L] = r.L;
+        i[O_K] = r.K;
+        f[O_GAMMA] = r.gamma;
+        i[O_TONEPHASE] = (int)r.tonePhase;
+        i[O_SWN] = r.swn;
+        f[O_LOCALENERGY] = r.localEnergy;
+        i[O_AMPTHR] = r.amplitudeThreshold;
+        f[O_ERRORRATE] = r.errorRate;
+        i[O_ERRTOTAL] = r.errorCountTotal;
+        i[O_ERR4] = r.errorCount4;
+        i[O_REPEAT] = r.repeatCount;
+        f[O_MUTETHR] = r.mutingThreshold;
+        f[O_NOISESEED] = r.noiseSeed;
+    }
+    if (lane < MBX_BAND_SLOTS) {
+        i[O_VL + lane] = r.Vl;
+        f[O_ML + lane] = r.Ml;
+        f[O_LOG2ML + lane] = r.log2Ml;
+        f[O_PHI + lane] = r.PHIl;
+        f[O_PSI + lane] = r.PSIl;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[O_UW + lane + 64 * j] = r.uw[j];
+    }
+    f[O_OVERLAP + lane] = r.ov[0];
+    if (lane < 32) {
+        f[O_OVERLAP + 64 + lane] = r.ov[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-wave LDS scratch.
+// ------------------------------------------------------------------------------------------
+constexpr int kTrStride = 65;   // 64 harmonics + 1 pad dword: column sums are conflict-free
+
+struct WaveScratch {
+    union {
+        float  tr[64 * kTrStride];   // voiced bank: [sample-in-block][harmonic] transposition tile
+        float2 fft[256];             // unvoiced: in-place radix-4 FFT
+    };
+    float scale[132];                // per-bin unvoiced scale, bins 0..128
+    float uwr[256];                  // real inverse-FFT output (natural order)
+    int   word[64];                  // IMBE parameter words b_m
+    float gm[32];                    // gains [0..15], block means Ri [16..31]
+    float cik[96];                   // IMBE [7][11], AMBE [5][18]
+};
+
+struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
+    unsigned long long cn_seed48;
+    uint32_t           cn_seeded, unv_state, unv_override;
+};
+
+// ------------------------------------------------------------------------------------------
+// IMBE 7200x4400 parameter decode.  Returns 0 (voice) or 1 (invalid fundamental).
+// Mutates `prev` exactly like the reference (padding of the prediction memory).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rec_bit(const uint32_t w[3], int i) { return (int)((w[i >> 5] >> (31 - (i & 31))) & 1u); }
+
+__device__ int decode_imbe(const uint32_t w[3], Parms& cur, Parms& prev, WaveScratch& S, const mbx_tables* T, int lane) {
+    int b0 = (int)(w[0] >> 26);
+    b0 = (b0 << 1) | rec_bit(w, 85);
+    b0 = (b0 << 1) | rec_bit(w, 86);
+    if (b0 > 207) {
+        return 1;
+    }
+    cur.w0 = T->imbe_w0[b0];
+    const int L = T->imbe_L[b0];
+    if (L == 0) {
+        return 1;
+    }
+    cur.L = L;
+    cur.K = T->imbe_K[b0];
+    const int L9 = L - 9;
+
+    // scatter the 79 payload bits into their parameter words (bit position = significance)
+    S.word[lane] = 0;
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int i = 6 + lane + 64 * pass;
+        if (i < 85 && rec_bit(w, i)) {
+            const uint8_t* e = T->imbe_bo[L9][i - 6];
+            atomicOr(&S.word[e[0]], 1 << e[1]);
+        }
+    }
+    wave_lds_sync();
+
+    // voicing: three harmonics per band, band K-1 first
+    if (lane >= 1 && lane <= L) {
+        int band = (cur.K - 1) - ((lane - 1) / 3);
+        band = band < 0 ? 0 : band;
+        cur.Vl = (S.word[1] >> band) & 1;
+    }
+
+    // gains -> 6-point inverse DCT
+    if (lane >= 1 && lane <= 6) {
+        float g;
+        if (lane == 1) {
+            g = T->imbe_B2[S.word[2] & 63];
+        } else {
+            const float nb = T->imbe_ba[L9][lane - 2][0];
+            const float step = T->imbe_ba[L9][lane - 2][1];
+            const int inb = (int)nb;
+            const int bm = inb > 0 ? (S.word[lane + 1] & ((1 << inb) - 1)) : 0;
+            g = (step * ((float)bm - ldexpf(1.0f, inb - 1) + 0.5f));
+        }
+        S.gm[lane] = g;
+    }
+    wave_lds_sync();
+    if (lane >= 1 && lane <= 6) {
+        float sum = 0;
+        for (int m = 1; m <= 6; ++m) {
+            const float am = (m == 1) ? 1.0f : 2.0f;
+            sum = sum + (am * S.gm[m] * T->imbe_ri_cos[m][lane]);
+        }
+        S.cik[lane * 11 + 1] = sum;
+    }
+    // higher-order coefficients: lane c <-> c-th coefficient in (block, k) order
+    if (lane < L - 6) {
+        int acc = 0, blk = 0, k = 0;
+        for (int i = 1; i <= 6; ++i) {
+            const int cnt = (int)T->imbe_ji[L9][i - 1] - 1;
+            if (blk == 0 && lane < acc + cnt) {
+                blk = i;
+                k = lane - acc + 2;
+            }
+            acc += cnt;
+        }
+        const int Bm = T->imbe_hoba[L9][lane];
+        float v = 0.0f;
+        if (Bm > 0 && blk != 0) {
+            const int bm = S.word[8 + lane] & ((1 << Bm) - 1);
+            v = ((T->imbe_quantstep[Bm - 1] * T->imbe_standdev[k - 2]) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
+        }
+        if (blk != 0) {
+            S.cik[blk * 11 + k] = v;
+        }
+    }
+    wave_lds_sync();
+
+    // per-block inverse DCT: lane l <-> (block, j)
+    float Tl = 0.0f;
+    if (lane >= 1 && lane <= L) {
+        int acc = 0;
+        bool done = false;
+        for (int i = 1; i <= 6; ++i) {
+            const int ji = T->imbe_ji[L9][i - 1];
+            if (!done && (lane - 1) < acc + ji) {
+                const int j = lane - acc;
+                float sum = 0;
+                for (int k = 1; k <= ji; ++k) {
+                    const float ak = (k == 1) ? 1.0f : 2.0f;
+                    sum = sum + (ak * S.cik[i * 11 + k] * T->imbe_idct_cos[ji][j][k]);
+                }
+                Tl = sum;
+                done = true;
+            }
+            acc += ji;
+        }
+    }
+
+    // log-magnitude prediction
+    const float rho = (L <= 15) ? 0.4f : ((L <= 24) ? ((0.03f * (float)L) - 0.05f) : 0.7f);
+    const int cur_L = L;   // 9..56
+    const int prev_L = prev.L < 1 ? 1 : (prev.L > 56 ? 56 : prev.L);
+    {
+        const float padM = lane_get(prev.Ml, prev_L), padL = lane_get(prev.log2Ml, prev_L);
+        if (lane > prev_L && lane <= cur_L) {
+            prev.Ml = padM;
+            prev.log2Ml = padL;
+        }
+        const float m1 = lane_get(prev.Ml, 1), l1 = lane_get(prev.log2Ml, 1);
+        if (lane == 0) {
+            prev.Ml = m1;
+            prev.log2Ml = l1;
+        }
+    }
+    const float pos = ((float)prev_L / (float)cur_L) * (float)lane;
+    int lo = (int)pos;
+    lo = lo < 0 ? 0 : (lo > 56 ? 56 : lo);
+    const float frac = pos - (float)lo;
+    const int hi = (lo + 1 > 56) ? 56 : lo + 1;
+    const float a = lane_get(prev.log2Ml, lo), b = lane_get(prev.log2Ml, hi);
+    const bool in = lane >= 1 && lane <= cur_L;
+    float Sum77 = wave_sum(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f);
+    Sum77 = ((rho / (float)cur_L) * Sum77);
+    if (in) {
+        const float c1 = (rho * ((float)1 - frac) * a);
+        const float c2 = (rho * frac * b);
+        cur.log2Ml = Tl + c1 + c2 - Sum77;
+        cur.Ml = exp2f(cur.log2Ml);
+    }
+    return 0;
+}
+
+__device__ __forceinline__ void imbe_headroom_reset(Parms& mp, int lane) {
+    mp.swn = 0;
+    mp.tonePhase = 0;
+    mp.w0 = (float)((4.0 * M_PI) / (134.0 + 39.5));
+    mp.L = 39;
+    mp.K = 12;
+    mp.gamma = 0.0f;
+    if (lane < MBX_BAND_SLOTS) {
+        mp.Vl = 0;
+        mp.Ml = 1.0f;
+        mp.log2Ml = 0.0f;
+    }
+    mp.repeatCount = 0;
+    mp.localEnergy = 75000.0f;
+    mp.amplitudeThreshold = 20480;
+    mp.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
+}
+
+// ------------------------------------------------------------------------------------------
+// Spectral amplitude enhancement; returns the pre-enhancement Rm0.
+// ------------------------------------------------------------------------------------------
+__device__ float enhance(Parms& cur, int lane) {
+    const int L = cur.L;
+    if (L < 1 || L > 56) {
+        return 0.0f;
+    }
+    float s_step, c_step;
+    sincosf(cur.w0, &s_step, &c_step);
+    // cos(l*w0) by the same rotation recurrence the reference runs; every lane runs it and
+    // latches its own harmonic
+    float c = 1.0f, s = 0.0f, cw = 0.0f;
+    for (int l = 1; l <= L; ++l) {
+        const float cn = (c * c_step) - (s * s_step);
+        const float sn = (s * c_step) + (c * s_step);
+        c = cn;
+        s = sn;
+        cw = (l == lane) ? c : cw;
+    }
+    const bool in = lane >= 1 && lane <= L;
+    const float Ml2 = cur.Ml * cur.Ml;
+    const float Rm0 = wave_sum(in ? Ml2 : 0.0f);
+    const float Rm1 = wave_sum(in ? (Ml2 * cw) : 0.0f);
+    const float R2m0 = Rm0 * Rm0;
+    const float R2m1 = Rm1 * Rm1;
+    if (in && cur.Ml != 0.0f) {
+        const float Wl = sqrtf(cur.Ml)
+                         * sqrtf(sqrtf(((float)0.96 * (float)M_PI * ((R2m0 + R2m1) - ((float)2 * Rm0 * Rm1 * cw)))
+                                       / (cur.w0 * Rm0 * (R2m0 - R2m1))));
+        if ((8 * lane) <= L) {
+        } else if (Wl > 1.2f) {
+            cur.Ml = 1.2f * cur.Ml;
+        } else if (Wl < 0.5f) {
+            cur.Ml = 0.5f * cur.Ml;
+        } else {
+            cur.Ml = Wl * cur.Ml;
+        }
+    }
+    float M = cur.Ml;
+    M = (M < 0.0f) ? -M : M;
+    const float sum = wave_sum(in ? (M * M) : 0.0f);
+    const float gamma = (sum == 0.0f) ? 1.0f : sqrtf(Rm0 / sum);
+    if (in) {
+        cur.Ml = gamma * cur.Ml;
+    }
+    return Rm0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adaptive smoothing.
+// ------------------------------------------------------------------------------------------
+__device__ void smooth(Parms& cur, const Parms& prev, float RM0, int lane) {
+    const int L = cur.L;
+    const float er = cur.errorRate;
+    const int et = cur.errorCountTotal, e4 = cur.errorCount4;
+    float pe = prev.localEnergy;
+    if (pe < 10000.0f) {
+        pe = 75000.0f;
+    }
+    float le = 0.95f * pe + 0.05f * RM0;
+    if (le < 10000.0f) {
+        le = 10000.0f;
+    }
+    cur.localEnergy = le;
+    const bool in = lane >= 1 && lane <= L;
+    if (!(er <= 0.005f && et <= 4)) {   // otherwise VM = FLT_MAX and nothing can exceed it
+        const float x8 = sqrtf(sqrtf(sqrtf(le)));
+        const float energy = x8 * x8 * x8;
+        float VM;
+        if (er <= 0.0125f && e4 == 0) {
+            VM = (45.255f * energy) / expf(277.26f * er);
+        } else {
+            VM = 1.414f * energy;
+        }
+        if (in && cur.Ml > VM) {
+            cur.Vl = 1;
+        }
+    } else if (in && cur.Ml > __FLT_MAX__) {
+        cur.Vl = 1;   // +inf amplitude still compares greater than FLT_MAX
+    }
+    const float Am = wave_sum(in ? cur.Ml : 0.0f);
+    int pt = prev.amplitudeThreshold;
+    if (pt <= 0) {
+        pt = 20480;
+    }
+    const int Tm = (er <= 0.005f && et <= 6) ? 20480 : (6000 - (300 * et) + pt);
+    cur.amplitudeThreshold = Tm;
+    if (Am > (float)Tm && Am > 0.0f) {
+        const float scale = (float)Tm / Am;
+        if (in) {
+            cur.Ml *= scale;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Comfort noise: 160 steps of the 48-bit Java LCG, evaluated by affine-map jump-ahead so that
+// lane j produces samples j, j+64, j+128.  Output in the lane = sample layout.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long java_lcg_jump(unsigned long long s, int k) {
+    const unsigned long long mask = (1ULL << 48) - 1ULL;
+    unsigned long long A = 1, C = 0, a = 0x5DEECE66DULL, c = 0xBULL;
+    for (int bit = 0; bit < 8; ++bit) {
+        if ((k >> bit) & 1) {
+            C = (a * C + c) & mask;
+            A = (A * a) & mask;
+        }
+        c = (a * c + c) & mask;
+        a = (a * a) & mask;
+    }
+    return (A * s + C) & mask;
+}
+
+__device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
+    if (!rng.cn_seeded) {
+        rng.cn_seed48 = (0x12345678ULL ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1ULL);
+        rng.cn_seeded = 1;
+    }
+    const float gain = (0.003f * 32767.0f) / 7.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n = lane + 64 * j;
+        const unsigned long long s = java_lcg_jump(rng.cn_seed48, n + 1);
+        const float u = ((float)(uint32_t)(s >> 24) / 16777216.0f) * 2.0f - 1.0f;
+        out[j] = u * gain;
+    }
+    rng.cn_seed48 = java_lcg_jump(rng.cn_seed48, 160);
+}
+
+// ------------------------------------------------------------------------------------------
+// Speech synthesis core (mbe_synthesizeSpeechCore).  `prev` is the enhanced previous model.
+// Output: out[j] = sample lane + 64*j (j = 0..2, sample < 160).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rotate(float& c, float& s, float cd, float sd) {
+    const float c2 = (c * cd) - (s * sd);
+    const float s2 = (s * cd) + (c * sd);
+    c = c2;
+    s = s2;
+}
+
+__device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
+                           WaveScratch& S, const DeviceTables& tabs, int lane) {
+    const mbx_tables* T = tabs.t;
+    const DerivedTables* D = tabs.d;
+    constexpr int N = 160;
+    out[0] = out[1] = out[2] = 0.0f;
+    if (cur.L < 1 || cur.L > 56 || prev.L < 1 || prev.L > 56) {
+        return;   // silence
+    }
+    if (!have_rm0) {
+        const bool in = lane >= 1 && lane <= cur.L;
+        rm0 = wave_sum(in ? (cur.Ml * cur.Ml) : 0.0f);
+    }
+    smooth(cur, prev, rm0, lane);
+
+    const bool rate_mutes = fabsf(cur.mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f;
+    if (cur.repeatCount >= MBE_MAX_FRAME_REPEATS || (rate_mutes && cur.errorRate > cur.mutingThreshold)) {
+        comfort_noise(out, rng, lane);
+        return;
+    }
+
+    // ---- white noise block: noise[i], i = lane + 64*j -------------------------------------
+    float nz[4];
+    if (cur.noiseSeed < 0.0f) {   // cold start: a block of zeros, then prime the generator
+        nz[0] = nz[1] = nz[2] = nz[3] = 0.0f;
+        cur.ov[0] = cur.ov[1] = 0.0f;
+        if (rng.unv_override) {
+            cur.noiseSeed = (float)rng.unv_state;
+            rng.unv_override = 0;
+        } else {
+            cur.noiseSeed = 3147.0f;
+        }
+    } else {
+        const uint32_t x0 = ((uint32_t)cur.noiseSeed) % 53125u;
+        auto at = [&](int k) -> float {   // k-th value of the LCG started at x0
+            k = k < 0 ? 0 : k;
+            return (float)((D->lcg_mul[k] * x0 + D->lcg_add[k]) % 53125u);
+        };
+        nz[0] = cur.ov[0];
+        nz[1] = (lane < 32) ? cur.ov[1] : at(lane - 32);
+        nz[2] = at(lane + 32);
+        nz[3] = at(lane + 96);
+        cur.ov[0] = at(lane + 64);
+        cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
+        cur.noiseSeed = at(160);
+    }
+
+    // ---- reconcile the two model lengths ---------------------------------------------------
+    int maxl;
+    if (cur.L > prev.L) {
+        maxl = cur.L;
+        if (lane > prev.L && lane <= maxl) {
+            prev.Ml = 0.0f;
+            prev.Vl = 1;
+        }
+    } else {
+        maxl = prev.L;
+        if (lane > cur.L && lane <= maxl) {
+            cur.Ml = 0.0f;
+            cur.Vl = 1;
+        }
+    }
+
+    // ---- phases ----------------------------------------------------------------------------
+    const int numUv = popc64(__ballot(lane <= cur.L && cur.Vl == 0));
+    const float cw0 = cur.w0, pw0 = prev.w0;
+    const float TWO_PI = 2.0f * (float)M_PI;
+    if (lane >= 1 && lane <= 56) {
+        float wrapped = fmodf(prev.PSIl, TWO_PI);
+        if (wrapped < 0.0f) {
+            wrapped += TWO_PI;
+        }
+        prev.PSIl = wrapped;
+        cur.PSIl = wrapped + ((pw0 + cw0) * ((float)(lane * N) / 2.0f));
+        if (lane <= (cur.L / 4)) {
+            cur.PHIl = cur.PSIl;
+        } else {
+            const float pl = ((2.0f * (float)M_PI / 53125.0f) * nz[0]) - (float)M_PI;
+            cur.PHIl = cur.PSIl + (((float)numUv * pl) / (float)cur.L);
+        }
+    }
+
+    // ---- voiced bank -----------------------------------------------------------------------
+    const bool band = lane >= 1 && lane <= maxl;
+    const bool cv = band && (cur.Vl == 1);
+    const bool pv = band && (prev.Vl == 1);
+    const bool stable = fabsf(cw0 - pw0) < (0.1f * cw0);
+    const bool interp = (lane < 8) && cv && pv && stable;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+
+    // (1) low harmonics with a stable pitch: lane = sample, loop over the (<= 7) harmonics
+    unsigned long long imask = __ballot(interp);
+    while (imask) {
+        const int l = __ffsll((long long)imask) - 1;
+        imask &= imask - 1;
+        const float pPHI = lane_get(prev.PHIl, l), cPHI = lane_get(cur.PHIl, l);
+        const float pM = lane_get(prev.Ml, l), cM = lane_get(cur.Ml, l);
+        const float pw0l = pw0 * (float)l;
+        const float dphi = cPHI - pPHI - (((pw0 + cw0) * (float)(l * N)) / 2.0f);
+        const float dw =
+            (1.0f / (float)N) * (dphi - (2.0f * (float)M_PI * floorf((dphi + (float)M_PI) / (2.0f * (float)M_PI))));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = lane + 64 * j;
+            const float theta = pPHI + ((pw0l + dw) * (float)n) + (((cw0 - pw0) * (float)(l * n * n)) / (float)(2 * N));
+            const float amp = pM + (((float)n / (float)N) * (cM - pM));
+            acc[j] += 2.0f * amp * cosf(theta);
+        }
+    }
+
+    // (2) windowed oscillators: lane = harmonic, advanced sample by sample with the reference's
+    //     plane rotation; the [sample][harmonic] tile goes through LDS and is summed per sample
+    {
+        const bool wv_p = pv && !interp, wv_c = cv && !interp;
+        const float cw0l = cw0 * (float)lane, pw0l = pw0 * (float)lane;
+        float gp = 0.0f, sdp = 0.0f, cdp = 0.0f, sp = 0.0f, cp = 0.0f;
+        float gc = 0.0f, sdc = 0.0f, cdc = 0.0f, sc = 0.0f, cc = 0.0f;
+        {
+            float a, b, c, d;
+            sincosf(pw0l, &a, &b);
+            sincosf(prev.PHIl, &c, &d);
+            if (wv_p) {
+                gp = 2.0f * prev.Ml;
+                sdp = a;
+                cdp = b;
+                sp = c;
+                cp = d;
+            }
+            sincosf(cw0l, &a, &b);
+            sincosf(cur.PHIl - (cw0l * (float)N), &c, &d);
+            if (wv_c) {
+                gc = 2.0f * cur.Ml;
+                sdc = a;
+                cdc = b;
+                sc = c;
+                cc = d;
+            }
+        }
+        const bool any = __ballot(wv_p || wv_c) != 0ULL;
+        if (any) {
+            const float* Ws = T->ws;
+            for (int nb = 0; nb < 3; ++nb) {
+                const int rows = (nb == 2) ? 32 : 64;
+                for (int i = 0; i < rows; ++i) {
+                    const int n = nb * 64 + i;
+                    // prev weight Ws[n+160] is zero from n = 105 on, cur weight Ws[n] below n = 56
+                    float v = 0.0f;
+                    if (n < 105) {
+                        v = gp * Ws[n + N] * cp;
+                        rotate(cp, sp, cdp, sdp);
+                    }
+                    if (n >= 56) {
+                        v += gc * Ws[n] * cc;
+                    }
+                    rotate(cc, sc, cdc, sdc);
+                    S.tr[i * kTrStride + lane] = v;
+                }
+                wave_lds_sync();
+                if (lane < rows) {
+                    float s = 0.0f;
+                    for (int h = 1; h <= maxl; ++h) {
+                        s += S.tr[lane * kTrStride + h];
+                    }
+                    acc[nb] += s;
+                }
+                wave_lds_sync();
+            }
+        }
+    }
+
+    // ---- unvoiced: window, 256-point FFT, per-band scaling, inverse FFT, overlap-add ----------
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            S.fft[i] = make_float2(nz[j] * T->uv_window[i], 0.0f);
+        }
+        S.scale[lane] = 0.0f;
+        S.scale[lane + 64] = 0.0f;
+        if (lane < 4) {
+            S.scale[128 + lane] = 0.0f;
+        }
+        wave_lds_sync();
+        // forward: radix-4 decimation in frequency, natural order in, base-4 digit-reversed out
+        for (int q = 64; q >= 1; q >>= 2) {
+            const int g = lane / q, jj = lane % q;
+            const int base = g * 4 * q + jj;
+            const int tstep = 64 / q;   // 256 / (4q)
+            const float2 a0 = S.fft[base], a1 = S.fft[base + q], a2 = S.fft[base + 2 * q], a3 = S.fft[base + 3 * q];
+            const float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
+            const float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
+            const float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+            const float2 u1 = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i*d13
+            const float2 u2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+            const float2 u3 = make_float2(d02.x - d13.y, d02.y + d13.x);   // d02 + i*d13
+            const float2 w1 = D->twiddle[(jj * tstep) & 255], w2 = D->twiddle[(2 * jj * tstep) & 255],
+                         w3 = D->twiddle[(3 * jj * tstep) & 255];
+            wave_lds_sync();
+            S.fft[base] = y0;
+            S.fft[base + q] = make_float2(u1.x * w1.x - u1.y * w1.y, u1.x * w1.y + u1.y * w1.x);
+            S.fft[base + 2 * q] = make_float2(u2.x * w2.x - u2.y * w2.y, u2.x * w2.y + u2.y * w2.x);
+            S.fft[base + 3 * q] = make_float2(u3.x * w3.x - u3.y * w3.y, u3.x * w3.y + u3.y * w3.x);
+            wave_lds_sync();
+        }
+        // per-band scale: lane = band
+        if (lane >= 1 && lane <= cur.L && cur.Vl == 0) {
+            const float mult = (256.0f / (2.0f * 3.14159265358979323846f)) * cur.w0;
+            int a = (int)ceilf(((float)lane - 0.5f) * mult);
+            int b = (int)ceilf(((float)lane + 0.5f) * mult);
+            a = a < 0 ? 0 : a;
+            b = b > 128 ? 128 : b;
+            float num = 0.0f;
+            for (int k = a; k < b; ++k) {
+                const float2 X = S.fft[rev4(k)];
+                num += (k == 0) ? (X.x * X.x) : ((X.x * X.x) + (X.y * X.y));
+            }
+            const int count = b - a;
+            if (count > 0 && num > 1e-10f) {
+                const float sc = 146.17696f * cur.Ml / sqrtf(num / (float)count);
+                for (int k = a; k < b; ++k) {
+                    S.scale[k] = sc;
+                }
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = lane + 64 * j;
+            const int k = rev4(p);
+            const float sc = S.scale[k > 128 ? 256 - k : k];
+            const float2 X = S.fft[p];
+            S.fft[p] = make_float2(X.x * sc, X.y * sc);
+        }
+        wave_lds_sync();
+        // inverse: radix-4 decimation in time, digit-reversed in, natural order out
+        for (int q = 1; q <= 64; q <<= 2) {
+            const int g = lane / q, jj = lane % q;
+            const int base = g * 4 * q + jj;
+            const int tstep = 64 / q;
+            const float2 w1 = D->twiddle[(jj * tstep) & 255], w2 = D->twiddle[(2 * jj * tstep) & 255],
+                         w3 = D->twiddle[(3 * jj * tstep) & 255];
+            const float2 x0 = S.fft[base], x1 = S.fft[base + q], x2 = S.fft[base + 2 * q], x3 = S.fft[base + 3 * q];
+            // multiply by conjugate twiddles
+            const float2 z1 = make_float2(x1.x * w1.x + x1.y * w1.y, x1.y * w1.x - x1.x * w1.y);
+            const float2 z2 = make_float2(x2.x * w2.x + x2.y * w2.y, x2.y * w2.x - x2.x * w2.y);
+            const float2 z3 = make_float2(x3.x * w3.x + x3.y * w3.y, x3.y * w3.x - x3.x * w3.y);
+            const float2 s02 = make_float2(x0.x + z2.x, x0.y + z2.y), d02 = make_float2(x0.x - z2.x, x0.y - z2.y);
+            const float2 s13 = make_float2(z1.x + z3.x, z1.y + z3.y), d13 = make_float2(z1.x - z3.x, z1.y - z3.y);
+            wave_lds_sync();
+            S.fft[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
+            S.fft[base + q] = make_float2(d02.x - d13.y, d02.y + d13.x);       // d02 + i*d13
+            S.fft[base + 2 * q] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            S.fft[base + 3 * q] = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i*d13
+            wave_lds_sync();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            const float v = S.fft[i].x * (1.0f / 256.0f);
+            cur.uw[j] = v;
+            S.uwr[i] = v;
+        }
+        wave_lds_sync();
+        // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = lane + 64 * j;
+            if (n < N) {
+                const float ps = (j == 0) ? prev.uw[2] : ((j == 1) ? prev.uw[3] : 0.0f);
+                const float cs = (n >= 32) ? S.uwr[n - 32] : 0.0f;
+                const float d = T->wola_denom[n];
+                if (d > 1e-10f) {
+                    acc[j] += ((T->wola_w_prev[n] * ps) + (T->wola_w_curr[n] * cs)) / d;
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+
+    // ---- soft clip ---------------------------------------------------------------------------
+    const float clip = (32767.0f * 0.95f) / 7.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float v = acc[j];
+        v = (v > clip) ? clip : ((v < -clip) ? -clip : v);
+        out[j] = v;
+    }
+}
+
+__device__ __forceinline__ int16_t to_pcm16(float x) {
+    const float top = 32767.0f * 0.95f;
+    const uint32_t bits = __float_as_uint(x);
+    const uint32_t mag = bits & 0x7FFFFFFFu;
+    float v;
+    if (mag > 0x7F800000u) {
+        v = 0.0f;
+    } else if (mag == 0x7F800000u) {
+        v = (bits & 0x80000000u) ? -top : top;
+    } else {
+        v = 7.0f * x;
+        v = (v > top) ? top : ((v < -top) ? -top : v);
+    }
+    return (int16_t)(int)v;
+}
+
+__device__ __forceinline__ void store_pcm(const float out[3], size_t frame, int16_t* pcm16, float* pcmf, int lane) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n = lane + 64 * j;
+        if (n < 160) {
+            if (pcmf) {
+                pcmf[frame * 160 + n] = out[j];
+            }
+            if (pcm16) {
+                pcm16[frame * 160 + n] = to_pcm16(out[j]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void load_rng(StreamRng& r, const mbx_stream_rng* p) {
+    r.cn_seed48 = p->cn_seed48;
+    r.cn_seeded = p->cn_seeded;
+    r.unv_state = p->unvoiced_seed_state;
+    r.unv_override = p->unvoiced_seed_override;
+}
+
+__device__ __forceinline__ void store_rng(const StreamRng& r, mbx_stream_rng* p, int lane) {
+    if (lane == 0) {
+        p->cn_seed48 = r.cn_seed48;
+        p->cn_seeded = r.cn_seeded;
+        p->unvoiced_seed_state = r.unv_state;
+        p->unvoiced_seed_override = r.unv_override;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, mbe_parms* __restrict__ state,
+                   mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                   mbe_process_result* __restrict__ results, DeviceTables tabs) {
+    __shared__ WaveScratch scratch;
+    const int s = blockIdx.x;
+    if (s >= S) {
+        return;
+    }
+    const int lane = lane_id();
+    Parms cur, prev, enh;
+    load_parms(cur, &state[3 * (size_t)s + 0], lane);
+    load_parms(prev, &state[3 * (size_t)s + 1], lane);
+    load_parms(enh, &state[3 * (size_t)s + 2], lane);
+    StreamRng rng;
+    load_rng(rng, &rngs[s]);
+
+    for (int t = 0; t < Tn; ++t) {
+        const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+        const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
+        const uint32_t w[3] = {rec.x, rec.y, rec.z};
+        const int c0 = (int)(rec.w & 0xffu), prot = (int)((rec.w >> 8) & 0xffu), c4 = (int)((rec.w >> 16) & 0xffu);
+        unsigned flags = (rec.w >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
+        const int total = c0 + prot;
+
+        // prepare (imbe4400_prepare_process)
+        cur.errorCount4 = c4;
+        cur.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
+        cur.errorCountTotal = total;
+        cur.errorRate = (0.95f * prev.errorRate) + (0.000365f * (float)total);
+
+        const int bad = decode_imbe(w, cur, prev, scratch, tabs.t, lane);
+        const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
+        const bool repeat = (bad == 1) || ((c0 >= 2) && ((float)total >= repeat_threshold));
+        if (!repeat) {
+            cur.repeatCount = 0;
+        } else {
+            if (prev.repeatCount > (MBE_MAX_FRAME_REPEATS - 1)) {
+                imbe_headroom_reset(cur, lane);
+            } else {
+                cur = prev;
+                cur.repeatCount++;
+            }
+            flags |= MBE_PROCESS_FLAG_REPEAT;
+        }
+        const bool muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
+        prev = cur;
+        const float rm0 = enhance(cur, lane);
+        float out[3];
+        synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
+        if (muted) {
+            flags |= MBE_PROCESS_FLAG_MUTE;
+        }
+        enh = cur;
+
+        store_pcm(out, f, pcm16, pcmf, lane);
+        if (results && lane == 0) {
+            mbe_process_result r;
+            r.c0_errors = c0;
+            r.protected_errors = total - c0;
+            r.c4_errors = c4;
+            r.total_errors = total;
+            r.flags = flags;
+            results[f] = r;
+        }
+    }
+
+    store_parms(cur, &state[3 * (size_t)s + 0], lane);
+    store_parms(prev, &state[3 * (size_t)s + 1], lane);
+    store_parms(enh, &state[3 * (size_t)s + 2], lane);
+    store_rng(rng, &rngs[s], lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// AMBE+2 3600x2450: parameter decode (a9), frame policy (a11), tone frames.
+//   ref src/ambe/ambe3600x2450.c:176-621 (decode), :716-877 (policy);
+//       src/ambe/ambe_common.c:191-271 (defaults / erasure model); src/core/mbelib.c:691-804 (tones)
+// ------------------------------------------------------------------------------------------
+__device__ void init_ambe_parms(Parms& p, int lane) {
+    p.swn = 0;
+    p.tonePhase = 0;
+    p.w0 = (float)((M_PI / 32.0) * (2.0 * M_PI));
+    p.L = 15;
+    p.K = 0;
+    p.gamma = 0.0f;
+    p.Ml = (lane < MBX_BAND_SLOTS) ? 1.0f : 0.0f;
+    p.Vl = 0;
+    p.log2Ml = 0.0f;
+    p.PHIl = 0.0f;
+    p.PSIl = 0.0f;
+    p.localEnergy = 75000.0f;
+    p.amplitudeThreshold = 20480;
+    p.errorRate = 0.0f;
+    p.errorCountTotal = 0;
+    p.errorCount4 = 0;
+    p.repeatCount = 0;
+    p.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
+    p.noiseSeed = -1.0f;
+    p.ov[0] = p.ov[1] = 0.0f;
+    p.uw[0] = p.uw[1] = p.uw[2] = p.uw[3] = 0.0f;
+}
+
+__device__ void set_ambe_erasure_parms(Parms& mp, const Parms& keep, int lane) {
+    mp.swn = 0;
+    mp.tonePhase = 0;
+    mp.w0 = 0.0f;
+    mp.L = 9;
+    mp.K = 0;
+    mp.gamma = 0.0f;
+    mp.Ml = (lane < MBX_BAND_SLOTS) ? 1.0f : 0.0f;
+    mp.Vl = 0;
+    mp.log2Ml = 0.0f;
+    mp.PHIl = keep.PHIl;
+    mp.PSIl = keep.PSIl;
+    mp.localEnergy = 75000.0f;
+    mp.amplitudeThreshold = 20480;
+    mp.noiseSeed = keep.noiseSeed;
+    mp.ov[0] = keep.ov[0];
+    mp.ov[1] = keep.ov[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mp.uw[j] = keep.uw[j];
+    }
+}
+
+__device__ __forceinline__ int pick_bits(const uint32_t w[3], int i0, int i1, int i2, int i3 = -1, int i4 = -1, int i5 = -1,
+                                         int i6 = -1, int i7 = -1, int i8 = -1) {
+    const int idx[9] = {i0, i1, i2, i3, i4, i5, i6, i7, i8};
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (idx[k] >= 0) {
+            v = (v << 1) | rec_bit(w, idx[k]);
+        }
+    }
+    return v;
+}
+
+// Returns 0 voice, 2 erasure, 7 tone.
+__device__ int decode_ambe(const uint32_t w[3], Parms& cur, Parms& prev, WaveScratch& S, const DeviceTables& tabs,
+                           int total_errors, int lane) {
+    const mbx_tables* T = tabs.t;
+    const int u0 = (int)(w[0] >> 20);
+    const int u1 = (int)((w[0] >> 8) & 0xfffu);
+    const unsigned long long two = ((unsigned long long)w[0] << 32) | w[1];
+    const int u3 = (int)((two >> 15) & 0x3fffu);
+    const bool tone_sig = (((u0 >> 6) & 0x3f) == 63) && (((u3 & 0xf) == 0) || (((u1 >> 8) & 0xf) == (u1 & 0xf)));
+    if (tone_sig && total_errors < 6) {
+        return 7;
+    }
+    const int b0 = pick_bits(w, 0, 1, 2, 3, 37, 38, 39);
+    if ((b0 >= 120 && b0 <= 123) || b0 == 126 || b0 == 127) {
+        return 2;
+    }
+    int L;
+    float f0;
+    const bool silence = (b0 == 124 || b0 == 125);
+    if (silence) {
+        f0 = (float)M_PI / 32.0f;
+        cur.w0 = f0 * (float)(2.0 * M_PI);
+        L = (b0 == 124) ? 15 : 14;
+        cur.L = L;
+        if (lane >= 1 && lane <= L) {
+            cur.Vl = 0;
+        }
+    } else {
+        f0 = T->ambe_w0[b0];
+        cur.w0 = (float)((double)(f0 * (float)2) * M_PI);
+        L = T->ambe_L[b0];
+        cur.L = L;
+    }
+    const float unvc = (float)0.2046 / sqrtf(cur.w0);
+
+    const int b1 = pick_bits(w, 4, 5, 6, 7, 35);
+    if (!silence && lane >= 1 && lane <= L) {
+        const int jl = (int)((float)lane * (float)16.0 * f0);
+        cur.Vl = T->ambe_vuv[b1][jl & 7];
+    }
+    const int b2 = pick_bits(w, 8, 9, 10, 11, 36);
+    cur.gamma = T->ambe_dg[b2] + ((float)0.5 * prev.gamma);
+
+    const int b3 = pick_bits(w, 12, 13, 14, 15, 16, 17, 18, 19, 40);
+    const int b4 = pick_bits(w, 20, 21, 22, 23, 41, 42, 43);
+    if (lane >= 1 && lane <= 8) {
+        float g = 0.0f;
+        if (lane >= 2 && lane <= 4) {
+            g = T->ambe_prba24[b3][lane - 2];
+        } else if (lane >= 5) {
+            g = T->ambe_prba58[b4][lane - 5];
+        }
+        S.gm[lane] = g;
+    }
+    wave_lds_sync();
+    if (lane >= 1 && lane <= 8) {
+        float sum = 0;
+        for (int m = 1; m <= 8; ++m) {
+            const float am = (m == 1) ? 1.0f : 2.0f;
+            sum = sum + (am * S.gm[m] * T->ambe_ri_cos[m][lane]);
+        }
+        S.gm[16 + lane] = sum;
+    }
+    wave_lds_sync();
+    const int b5 = pick_bits(w, 24, 25, 26, 27, 44);
+    const int b6 = pick_bits(w, 28, 29, 30, 45);
+    const int b7 = pick_bits(w, 31, 32, 33, 46);
+    const int b8 = pick_bits(w, 34, 47, 48);
+    if (lane >= 1 && lane <= 4) {
+        const float rconst = (float)(1.0 / (2.0 * M_SQRT2));
+        const float ra = S.gm[16 + 2 * lane - 1], rb = S.gm[16 + 2 * lane];
+        S.cik[lane * 18 + 1] = (float)0.5 * (ra + rb);
+        S.cik[lane * 18 + 2] = rconst * (ra - rb);
+        const float* hoc = (lane == 1) ? T->ambe_hoc_b5[b5]
+                                       : ((lane == 2) ? T->ambe_hoc_b6[b6] : ((lane == 3) ? T->ambe_hoc_b7[b7] : T->ambe_hoc_b8[b8]));
+        const int ji = T->ambe_lmprbl[L][lane - 1];
+        for (int k = 3; k <= ji; ++k) {
+            S.cik[lane * 18 + k] = (k > 6) ? 0.0f : hoc[k - 3];
+        }
+    }
+    wave_lds_sync();
+    float Tl = 0.0f;
+    if (lane >= 1 && lane <= L) {
+        int acc = 0;
+        bool done = false;
+        for (int i = 1; i <= 4; ++i) {
+            const int ji = T->ambe_lmprbl[L][i - 1];
+            if (!done && (lane - 1) < acc + ji) {
+                const int j = lane - acc;
+                float sum = 0;
+                for (int k = 1; k <= ji; ++k) {
+                    const float ak = (k == 1) ? 1.0f : 2.0f;
+                    sum = sum + (ak * S.cik[i * 18 + k] * T->ambe_idct_cos[ji][j][k]);
+                }
+                Tl = sum;
+                done = true;
+            }
+            acc += ji;
+        }
+    }
+
+    const int prev_L = prev.L < 1 ? 1 : (prev.L > 56 ? 56 : prev.L);
+    const int cur_L = L;
+    {
+        const float padM = lane_get(prev.Ml, prev_L), padL = lane_get(prev.log2Ml, prev_L);
+        if (lane > prev_L && lane <= cur_L) {
+            prev.Ml = padM;
+            prev.log2Ml = padL;
+        }
+        const float m1 = lane_get(prev.Ml, 1), l1 = lane_get(prev.log2Ml, 1);
+        if (lane == 0) {
+            prev.Ml = m1;
+            prev.log2Ml = l1;
+        }
+    }
+    const float pos = ((float)prev_L / (float)cur_L) * (float)lane;
+    int lo = (int)pos;
+    lo = lo > 56 ? 56 : lo;
+    const float frac = pos - (float)lo;
+    const float phi0 = lane_get(prev.PHIl, 0);   // the reference's log2Ml[57] aliases PHIl[0]
+    const float a = lane_get(prev.log2Ml, lo);
+    const float bnext = lane_get(prev.log2Ml, (lo + 1) & 63);
+    const float b = (lo + 1 > 56) ? phi0 : bnext;
+    const bool in = lane >= 1 && lane <= cur_L;
+    float Sum43 = wave_sum(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f);
+    Sum43 = (((float)0.65 / (float)cur_L) * Sum43);
+    float Sum42 = wave_sum(in ? Tl : 0.0f);
+    Sum42 = Sum42 / (float)cur_L;
+    const float BigGamma = cur.gamma - (0.5f * tabs.d->log2_int[cur_L]) - Sum42;
+    if (in) {
+        const float c1 = ((float)0.65 * ((float)1 - frac) * a);
+        const float c2 = ((float)0.65 * frac * b);
+        cur.log2Ml = Tl + c1 + c2 - Sum43 + BigGamma;
+        const float e = exp2f(cur.log2Ml);
+        cur.Ml = (cur.Vl == 1) ? e : (unvc * e);
+    }
+    return 0;
+}
+
+__constant__ float kDualToneHz[36][2] = {
+    {1336, 941}, {1209, 697}, {1336, 697}, {1477, 697}, {1209, 770}, {1336, 770}, {1477, 770}, {1209, 852}, {1336, 852},
+    {1477, 852}, {1633, 697}, {1633, 770}, {1633, 852}, {1633, 941}, {1209, 941}, {1477, 941}, {1162, 820}, {1052, 606},
+    {1162, 606}, {1279, 606}, {1052, 672}, {1162, 672}, {1279, 672}, {1052, 743}, {1162, 743}, {1279, 743}, {1430, 606},
+    {1430, 672}, {1430, 743}, {1430, 820}, {1052, 820}, {1279, 820}, {440, 350},  {480, 440},  {620, 480},  {490, 350},
+};
+
+__device__ bool tone_freqs(int id, float& f1, float& f2) {   // ref src/internal/mbe_tone.h:14-53
+    f1 = f2 = 0.0f;
+    if (id == 5) {
+        f1 = f2 = 156.25f;
+        return true;
+    }
+    if (id == 6) {
+        f1 = f2 = 187.5f;
+        return true;
+    }
+    if (id >= 7 && id <= 122) {
+        f1 = f2 = 31.25f * (float)id;
+        return true;
+    }
+    if (id >= 128 && id <= 163) {
+        f1 = kDualToneHz[id - 128][0];
+        f2 = kDualToneHz[id - 128][1];
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ uint32_t tone_step(double hz) {
+    const double step = (hz / 8000.0) * 4294967296.0;
+    return step <= 0.0 ? 0u : (uint32_t)(step + 0.5);
+}
+
+__device__ __forceinline__ float tone_sample(uint32_t phase) {
+    const float angle = (float)(((double)phase * ((2.0 * M_PI) / 4294967296.0)) - (M_PI / 2.0));
+    return sinf(angle);
+}
+
+// mbe_synthesizeTonef with a tone id already known to be valid
+__device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int lane) {
+    const int u0 = (int)(w[0] >> 20);
+    const int u1 = (int)((w[0] >> 8) & 0xfffu);
+    const unsigned long long two = ((unsigned long long)w[0] << 32) | w[1];
+    const int u3 = (int)((two >> 15) & 0x3fffu);
+    const int AD = ((u0 & 0x3f) << 1) + ((u3 >> 4) & 0x1);
+    const int ID1 = ((u1 & 0xfff) >> 4);
+    float f1, f2;
+    out[0] = out[1] = out[2] = 0.0f;
+    if (!tone_freqs(ID1, f1, f2) || f1 <= 0.0f) {
+        return;
+    }
+    const bool dual = (f2 > 0.0f) && (fabsf(f2 - f1) > 1e-6f);
+    const float clip = (32767.0f * 0.95f) / 7.0f;
+    const float gain = (((AD < 0) ? 0.0f : (float)AD) / 127.0f) * clip;
+    const uint32_t s1 = tone_step((double)f1);
+    const uint32_t s2 = dual ? tone_step((double)f2) : 0u;
+    const uint32_t p1 = (uint32_t)cur.swn, p2 = cur.tonePhase;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t n1 = (uint32_t)(lane + 64 * j + 1);
+        const float a = tone_sample(p1 + n1 * s1);
+        if (dual) {
+            const float b = tone_sample(p2 + n1 * s2);
+            out[j] = (0.5f * gain * a) + (0.5f * gain * b);
+        } else {
+            out[j] = gain * a;
+        }
+    }
+    cur.swn = (int)(p1 + 160u * s1);
+    cur.tonePhase = dual ? (p2 + 160u * s2) : p2;
+}
+
+__global__ void __launch_bounds__(64)
+ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, mbe_parms* __restrict__ state,
+                   mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                   mbe_process_result* __restrict__ results, DeviceTables tabs) {
+    __shared__ WaveScratch scratch;
+    const int s = blockIdx.x;
+    if (s >= S) {
+        return;
+    }
+    const int lane = lane_id();
+    Parms cur, prev, enh;
+    load_parms(cur, &state[3 * (size_t)s + 0], lane);
+    load_parms(prev, &state[3 * (size_t)s + 1], lane);
+    load_parms(enh, &state[3 * (size_t)s + 2], lane);
+    StreamRng rng;
+    load_rng(rng, &rngs[s]);
+
+    for (int t = 0; t < Tn; ++t) {
+        const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+        const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
+        const uint32_t w[3] = {rec.x, rec.y, rec.z};
+        const int c0 = (int)(rec.w & 0xffu), prot = (int)((rec.w >> 8) & 0xffu);
+        unsigned flags = (rec.w >> 24) & 0xffu;   // C0_VALID
+        const int total = c0 + prot;
+
+        // prepare (ambe2450_prepare_process)
+        if (fabsf(prev.mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f) {
+            init_ambe_parms(prev, lane);
+            cur = prev;
+            enh = prev;
+        }
+        cur.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
+        cur.errorCountTotal = total;
+        cur.errorCount4 = 0;
+        cur.errorRate = (0.95f * prev.errorRate) + (0.001064f * (float)total);
+
+        const int bad = decode_ambe(w, cur, prev, scratch, tabs, total, lane);
+        if (bad == 2) {
+            flags |= MBE_PROCESS_FLAG_ERASURE;
+            cur.repeatCount = 0;
+            set_ambe_erasure_parms(cur, prev, lane);
+        } else if (bad == 7) {
+            flags |= MBE_PROCESS_FLAG_TONE;
+            cur.repeatCount = 0;
+        } else if ((c0 >= 4) || ((c0 >= 2) && (total >= 6))) {
+            cur = prev;
+            cur.repeatCount++;
+            flags |= MBE_PROCESS_FLAG_REPEAT;
+        } else {
+            cur.repeatCount = 0;
+        }
+
+        float out[3];
+        if (bad == 0) {
+            if (cur.repeatCount < MBE_MAX_FRAME_REPEATS) {
+                prev = cur;
+                const float rm0 = enhance(cur, lane);
+                synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
+                enh = cur;
+            } else {
+                flags |= MBE_PROCESS_FLAG_MUTE;
+                comfort_noise(out, rng, lane);
+                init_ambe_parms(prev, lane);
+                cur = prev;
+                enh = prev;
+            }
+        } else if (bad == 7) {
+            const int id1 = (int)((w[0] >> 12) & 0xffu);   // parameter bits 12..19
+            float f1, f2;
+            if (tone_freqs(id1, f1, f2)) {
+                tone_frame(out, w, cur, lane);
+            } else if (!(prev.repeatCount >= MBE_MAX_FRAME_REPEATS)) {
+                Parms tmp = enh;
+                synth_core(out, tmp, enh, false, 0.0f, rng, scratch, tabs, lane);
+                enh = tmp;
+            } else {
+                comfort_noise(out, rng, lane);
+                init_ambe_parms(prev, lane);
+                cur = prev;
+                enh = prev;
+            }
+        } else {
+            comfort_noise(out, rng, lane);
+            prev = cur;
+            enh = cur;
+        }
+
+        store_pcm(out, f, pcm16, pcmf, lane);
+        if (results && lane == 0) {
+            mbe_process_result r;
+            r.c0_errors = c0;
+            r.protected_errors = total - c0;
+            r.c4_errors = 0;
+            r.total_errors = total;
+            r.flags = flags;
+            results[f] = r;
+        }
+    }
+
+    store_parms(cur, &state[3 * (size_t)s + 0], lane);
+    store_parms(prev, &state[3 * (size_t)s + 1], lane);
+    store_parms(enh, &state[3 * (size_t)s + 2], lane);
+    store_rng(rng, &rngs[s], lane);
+}
+
+// mbe_synthesizeSpeechf for S independent (cur, prev) pairs.
+__global__ void __launch_bounds__(64)
+synth_speech_kernel(int S, mbe_parms* __restrict__ curs, mbe_parms* __restrict__ prevs, mbx_stream_rng* __restrict__ rngs,
+                    float* __restrict__ pcmf, int16_t* __restrict__ pcm16, DeviceTables tabs) {
+    __shared__ WaveScratch scratch;
+    const int s = blockIdx.x;
+    if (s >= S) {
+        return;
+    }
+    const int lane = lane_id();
+    Parms cur, prev;
+    load_parms(cur, &curs[s], lane);
+    load_parms(prev, &prevs[s], lane);
+    StreamRng rng;
+    load_rng(rng, &rngs[s]);
+    float out[3];
+    synth_core(out, cur, prev, false, 0.0f, rng, scratch, tabs, lane);
+    store_pcm(out, (size_t)s, pcm16, pcmf, lane);
+    store_parms(cur, &curs[s], lane);
+    store_parms(prev, &prevs[s], lane);
+    store_rng(rng, &rngs[s], lane);
+}
+
+}  // namespace mbx

@@ -1,0 +1,177 @@
+"""BatchDecoder -- host mirror of the reference's frame-level entry points for a batch of
+streams.  One object owns the per-stream state ({cur, prev, prev_enhanced} + the per-stream
+RNG state that the reference keeps thread-local) in HBM and feeds frames through the C-ABI
+launcher.  torch is used for device memory and streams only.
+
+Reference interface mirrored (include/mbelib-neo/mbelib.h):
+  mbe_initMbeParms                      -> BatchDecoder(...)            (state defaults)
+  mbe_setThreadRngSeed                  -> seeds=...                    (per stream)
+  mbe_processImbe7200x4400Frame[f]      -> decode(frames, T)            codec=IMBE
+  mbe_processAmbe3600x2450Frame[f]      -> decode(frames, T)            codec=AMBE
+  mbe_decode*Frame                      -> fec(frames)
+"""
+import numpy as np
+
+from . import _native
+from .layout import (
+    CODEC_IMBE7200X4400,
+    FRAME_BYTES,
+    PARMS_DTYPE,
+    RECORD_DTYPE,
+    RESULT_DTYPE,
+    RNG_DTYPE,
+    init_state,
+    load_tables_blob,
+    rng_default,
+    rng_seeded,
+)
+
+_initialised = {}
+
+
+def ensure_init(device_index, blob=None):
+    """mbx_init once per (process, device); returns the blob checksum."""
+    if device_index not in _initialised:
+        blob = blob if blob is not None else load_tables_blob()
+        L = _native.lib()
+        _native.check(L.mbx_init(int(device_index), blob, len(blob)), "mbx_init")
+        _initialised[device_index] = L.mbx_table_checksum()
+    return _initialised[device_index]
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise _native.NativeLibraryError("no HIP device visible to torch; mbelib-neo_amd has no CPU fallback")
+    return torch
+
+
+class BatchDecoder:
+    def __init__(self, codec, streams, device=0, seeds=None, tables_blob=None):
+        torch = _torch()
+        self.codec = int(codec)
+        self.streams = int(streams)
+        self.device = torch.device("cuda", int(device))
+        torch.cuda.set_device(self.device)
+        ensure_init(self.device.index, tables_blob)
+        st = init_state(self.streams)
+        rg = rng_default(self.streams) if seeds is None else rng_seeded(seeds)
+        self.state = torch.from_numpy(st.view(np.uint8).reshape(-1)).to(self.device)
+        self.rng = torch.from_numpy(rg.view(np.uint8).reshape(-1)).to(self.device)
+
+    # -- state access (host copies) --------------------------------------------------------
+    def state_numpy(self):
+        return self.state.cpu().numpy().view(PARMS_DTYPE).reshape(self.streams, 3)
+
+    def rng_numpy(self):
+        return self.rng.cpu().numpy().view(RNG_DTYPE)
+
+    def set_state(self, state, rng=None):
+        torch = _torch()
+        self.state.copy_(torch.from_numpy(np.ascontiguousarray(state).view(np.uint8).reshape(-1)))
+        if rng is not None:
+            self.rng.copy_(torch.from_numpy(np.ascontiguousarray(rng).view(np.uint8).reshape(-1)))
+
+    def to_device(self, frames):
+        torch = _torch()
+        if isinstance(frames, np.ndarray):
+            return torch.from_numpy(np.ascontiguousarray(frames).reshape(-1)).to(self.device)
+        return frames
+
+    # -- launches ----------------------------------------------------------------------------
+    def fec(self, frames):
+        """FEC stage only: wire frames -> parameter records (device tensor of uint32 [n, 4])."""
+        torch = _torch()
+        d_frames = self.to_device(frames)
+        n = d_frames.numel() // FRAME_BYTES[self.codec]
+        rec = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        L = _native.lib()
+        fn = L.mbx_fec_imbe7200x4400 if self.codec == CODEC_IMBE7200X4400 else L.mbx_fec_ambe3600x2450
+        _native.check(fn(d_frames.data_ptr(), n, rec.data_ptr(), torch.cuda.current_stream().cuda_stream), "mbx_fec")
+        return rec
+
+    def make_outputs(self, T, want_pcm16=True, want_float=False, want_results=True):
+        torch = _torch()
+        n = self.streams * T
+        out = {"records": torch.empty((n, 4), dtype=torch.int32, device=self.device)}
+        out["pcm16"] = torch.empty((n, 160), dtype=torch.int16, device=self.device) if want_pcm16 else None
+        out["pcmf"] = torch.empty((n, 160), dtype=torch.float32, device=self.device) if want_float else None
+        out["results"] = torch.empty((n, 5), dtype=torch.int32, device=self.device) if want_results else None
+        return out
+
+    def decode(self, frames, T, want_pcm16=True, want_float=False, want_results=True, out=None):
+        """S x T frames, stream-major (stream s, frame t at index s*T + t).  Asynchronous on the
+        current torch stream; returns device tensors."""
+        torch = _torch()
+        d_frames = self.to_device(frames)
+        n = self.streams * int(T)
+        if d_frames.numel() != n * FRAME_BYTES[self.codec]:
+            raise ValueError("frames must hold streams*T wire frames")
+        if out is None:
+            out = self.make_outputs(T, want_pcm16, want_float, want_results)
+
+        def ptr(t):
+            return t.data_ptr() if t is not None else None
+
+        rc = _native.lib().mbx_process_batch(
+            self.codec, self.streams, int(T), d_frames.data_ptr(), self.state.data_ptr(), self.rng.data_ptr(),
+            ptr(out["pcm16"]), ptr(out["pcmf"]), ptr(out["results"]), out["records"].data_ptr(),
+            torch.cuda.current_stream().cuda_stream,
+        )
+        _native.check(rc, "mbx_process_batch")
+        return out
+
+
+def results_numpy(t):
+    return t.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+
+
+def records_numpy(t):
+    return t.cpu().numpy().view(RECORD_DTYPE).reshape(-1)
+
+
+def synthesize_speech(cur, prev, rng, device=0, want_pcm16=False):
+    """mbe_synthesizeSpeechf for S (cur, prev) pairs given as numpy PARMS arrays; returns
+    (pcmf [S,160], cur', prev', rng', pcm16 or None).  Host buffers in, host buffers out."""
+    ensure_init(device)
+    cur = np.ascontiguousarray(cur).copy()
+    prev = np.ascontiguousarray(prev).copy()
+    rng = np.ascontiguousarray(rng).copy()
+    S = cur.shape[0]
+    pcmf = np.empty((S, 160), dtype=np.float32)
+    pcm16 = np.empty((S, 160), dtype=np.int16) if want_pcm16 else None
+    rc = _native.lib().mbx_synthesize_speech_host(
+        S, cur.ctypes.data, prev.ctypes.data, rng.ctypes.data, pcmf.ctypes.data,
+        pcm16.ctypes.data if pcm16 is not None else None,
+    )
+    _native.check(rc, "mbx_synthesize_speech_host")
+    return pcmf, cur, prev, rng, pcm16
+
+
+def floattoshort(pcmf, device=0):
+    """mbe_floattoshort over [n,160] float frames (host in/out)."""
+    ensure_init(device)
+    pcmf = np.ascontiguousarray(pcmf, dtype=np.float32)
+    out = np.empty(pcmf.shape, dtype=np.int16)
+    _native.check(_native.lib().mbx_floattoshort_host(pcmf.ctypes.data, out.ctypes.data, pcmf.shape[0]), "mbx_floattoshort_host")
+    return out
+
+
+def process_batch_host(codec, S, T, frames, state, rng, device=0):
+    """Whole pipeline on host buffers (numpy in, numpy out): returns dict."""
+    ensure_init(device)
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    state = np.ascontiguousarray(state).copy()
+    rng = np.ascontiguousarray(rng).copy()
+    n = S * T
+    pcm16 = np.empty((n, 160), dtype=np.int16)
+    pcmf = np.empty((n, 160), dtype=np.float32)
+    results = np.empty(n, dtype=RESULT_DTYPE)
+    records = np.empty(n, dtype=RECORD_DTYPE)
+    rc = _native.lib().mbx_process_batch_host(
+        codec, S, T, frames.ctypes.data, state.ctypes.data, rng.ctypes.data, pcm16.ctypes.data, pcmf.ctypes.data,
+        results.ctypes.data, records.ctypes.data,
+    )
+    _native.check(rc, "mbx_process_batch_host")
+    return {"pcm16": pcm16, "pcmf": pcmf, "results": results, "records": records, "state": state, "rng": rng}

@@ -1,0 +1,183 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+TABLES = os.path.join(ROOT, "mbelib-neo_amd", "data", "mbx_tables.bin")
+
+import sys
+
+sys.path.insert(0, ROOT)
+from mbelib_neo_amd.layout import PARMS_DTYPE, RECORD_DTYPE, RESULT_DTYPE, RNG_DTYPE, FRAME_BYTES, PARAM_BITS  # noqa: E402
+
+_vp = C.c_void_p
+
+
+class Oracle:
+    def __init__(self, handle):
+        self.h = handle
+        h = handle
+        h.mbxo_load_tables.restype = C.c_int
+        h.mbxo_load_tables.argtypes = [_vp, C.c_size_t]
+        blob = open(TABLES, "rb").read()
+        assert h.mbxo_load_tables(blob, len(blob)) == 0, "oracle rejected the table blob"
+        h.mbxo_golay2312_word.restype = C.c_int
+        h.mbxo_golay2312_word.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
+        h.mbxo_hamming1511_word.restype = C.c_int
+        h.mbxo_hamming1511_word.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
+        for name in ("mbxo_pack_imbe_frame", "mbxo_pack_ambe_frame"):
+            getattr(h, name).restype = C.c_int
+            getattr(h, name).argtypes = [_vp, _vp]
+        for name in ("mbxo_decode_imbe7200x4400_frame", "mbxo_decode_ambe3600x2450_frame"):
+            getattr(h, name).restype = C.c_int
+            getattr(h, name).argtypes = [_vp, _vp, _vp]
+        for name in ("mbxo_decode_imbe4400_parms",):
+            getattr(h, name).restype = C.c_int
+            getattr(h, name).argtypes = [_vp, _vp, _vp]
+        h.mbxo_decode_ambe2450_parms.restype = C.c_int
+        h.mbxo_decode_ambe2450_parms.argtypes = [_vp, _vp, _vp, C.c_int]
+        for name in ("mbxo_process_imbe4400_dataf", "mbxo_process_ambe2450_dataf"):
+            getattr(h, name).restype = C.c_int
+            getattr(h, name).argtypes = [_vp] * 7
+        for name in ("mbxo_process_imbe7200x4400_framef", "mbxo_process_ambe3600x2450_framef"):
+            getattr(h, name).restype = C.c_int
+            getattr(h, name).argtypes = [_vp] * 8
+        h.mbxo_process_batch.restype = C.c_int
+        h.mbxo_process_batch.argtypes = [C.c_int, C.c_int, C.c_int] + [_vp] * 7
+        h.mbxo_fec_batch.restype = C.c_int
+        h.mbxo_fec_batch.argtypes = [C.c_int, C.c_size_t, _vp, _vp]
+        h.mbxo_floattoshort_batch.restype = None
+        h.mbxo_floattoshort_batch.argtypes = [_vp, _vp, C.c_size_t]
+        h.mbxo_synthesize_speech_batch.restype = None
+        h.mbxo_synthesize_speech_batch.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
+        h.mbxo_spectral_amp_enhance.restype = C.c_float
+        h.mbxo_spectral_amp_enhance.argtypes = [_vp]
+        h.mbxo_adaptive_smoothing.restype = None
+        h.mbxo_adaptive_smoothing.argtypes = [_vp, _vp]
+        h.mbxo_comfort_noisef.restype = None
+        h.mbxo_comfort_noisef.argtypes = [_vp, _vp]
+        h.mbxo_init_parms.restype = None
+        h.mbxo_init_parms.argtypes = [_vp, _vp, _vp]
+        h.mbxo_rng_default.restype = None
+        h.mbxo_rng_default.argtypes = [_vp]
+        h.mbxo_rng_seed.restype = None
+        h.mbxo_rng_seed.argtypes = [_vp, C.c_uint32]
+        h.mbxo_fnv1a32.restype = C.c_uint32
+        h.mbxo_fnv1a32.argtypes = [_vp, C.c_size_t]
+
+    # ---- small wrappers -----------------------------------------------------------------
+    def golay(self, cw):
+        out = C.c_uint32(0)
+        errs = self.h.mbxo_golay2312_word(int(cw), C.byref(out))
+        return out.value, errs
+
+    def hamming(self, cw):
+        out = C.c_uint32(0)
+        errs = self.h.mbxo_hamming1511_word(int(cw), C.byref(out))
+        return out.value, errs
+
+    def init_state(self, streams):
+        st = np.zeros((streams, 3), dtype=PARMS_DTYPE)
+        for s in range(streams):
+            self.h.mbxo_init_parms(st[s, 0:1].ctypes.data, st[s, 1:2].ctypes.data, st[s, 2:3].ctypes.data)
+        return st
+
+    def rng_seeded(self, seeds):
+        r = np.zeros(len(seeds), dtype=RNG_DTYPE)
+        for i, s in enumerate(seeds):
+            self.h.mbxo_rng_default(r[i : i + 1].ctypes.data)
+            self.h.mbxo_rng_seed(r[i : i + 1].ctypes.data, int(s) & 0xFFFFFFFF)
+        return r
+
+    def rng_default(self, n):
+        r = np.zeros(n, dtype=RNG_DTYPE)
+        for i in range(n):
+            self.h.mbxo_rng_default(r[i : i + 1].ctypes.data)
+        return r
+
+    def pack(self, codec, cells):
+        """cells: [n, 184|96] int8 -> (rc list, packed [n, 18|9])"""
+        cells = np.ascontiguousarray(cells, dtype=np.int8)
+        n = cells.shape[0]
+        out = np.zeros((n, FRAME_BYTES[codec]), dtype=np.uint8)
+        fn = self.h.mbxo_pack_imbe_frame if codec == 0 else self.h.mbxo_pack_ambe_frame
+        rcs = [fn(cells[i].ctypes.data, out[i].ctypes.data) for i in range(n)]
+        return rcs, out
+
+    def fec_batch(self, codec, frames):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = frames.size // FRAME_BYTES[codec]
+        rec = np.zeros(n, dtype=RECORD_DTYPE)
+        self.h.mbxo_fec_batch(codec, n, frames.ctypes.data, rec.ctypes.data)
+        return rec
+
+    def process_batch(self, codec, S, T, frames, state, rng):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        state = np.ascontiguousarray(state).copy()
+        rng = np.ascontiguousarray(rng).copy()
+        n = S * T
+        pcm16 = np.zeros((n, 160), dtype=np.int16)
+        pcmf = np.zeros((n, 160), dtype=np.float32)
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        records = np.zeros(n, dtype=RECORD_DTYPE)
+        rc = self.h.mbxo_process_batch(
+            codec, S, T, frames.ctypes.data, state.ctypes.data, rng.ctypes.data, pcm16.ctypes.data, pcmf.ctypes.data,
+            results.ctypes.data, records.ctypes.data,
+        )
+        assert rc == 0
+        return {"pcm16": pcm16, "pcmf": pcmf, "results": results, "records": records, "state": state, "rng": rng}
+
+    def synthesize_speech(self, cur, prev, rng):
+        cur = np.ascontiguousarray(cur).copy()
+        prev = np.ascontiguousarray(prev).copy()
+        rng = np.ascontiguousarray(rng).copy()
+        S = cur.shape[0]
+        pcmf = np.zeros((S, 160), dtype=np.float32)
+        self.h.mbxo_synthesize_speech_batch(S, cur.ctypes.data, prev.ctypes.data, rng.ctypes.data, pcmf.ctypes.data)
+        return pcmf, cur, prev, rng
+
+    def floattoshort(self, pcmf):
+        pcmf = np.ascontiguousarray(pcmf, dtype=np.float32).reshape(-1, 160)
+        out = np.zeros(pcmf.shape, dtype=np.int16)
+        self.h.mbxo_floattoshort_batch(pcmf.ctypes.data, out.ctypes.data, pcmf.shape[0])
+        return out
+
+    def fnv(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return self.h.mbxo_fnv1a32(arr.ctypes.data, arr.nbytes)
+
+
+def records_to_bits(records, nbits):
+    w = records["w"].astype(np.uint32)
+    out = np.zeros((w.shape[0], nbits), dtype=np.int8)
+    for i in range(nbits):
+        out[:, i] = (w[:, i >> 5] >> np.uint32(31 - (i & 31))) & 1
+    return out
+
+
+def records_to_results(records):
+    w3 = records["w"][:, 3].astype(np.uint32)
+    r = np.zeros(w3.shape[0], dtype=RESULT_DTYPE)
+    r["c0_errors"] = w3 & 0xFF
+    r["protected_errors"] = (w3 >> 8) & 0xFF
+    r["c4_errors"] = (w3 >> 16) & 0xFF
+    r["total_errors"] = r["c0_errors"] + r["protected_errors"]
+    r["flags"] = (w3 >> 24) & 0xFF
+    return r
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+        _cached = Oracle(C.CDLL(LIB))
+    return _cached

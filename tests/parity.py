@@ -1,0 +1,71 @@
+"""Comparison helpers shared by the oracle-vs-golden and HIP-vs-oracle tests.
+
+Tolerances: everything integer is bit-exact (parameter bits, error counts,
+flags, return codes, L/K/Vl, repeat counters, thresholds, the LCG noise state); float PCM
+relative RMS <= 1e-4 per batch and <= 1e-3 for the worst single frame; int16 PCM within
+1 LSB on >= 99.9 % of samples and never more than 3 LSB.
+"""
+import numpy as np
+
+from mbelib_neo_amd.layout import EXACT_FLOAT_FIELDS, FLOAT_FIELDS, INT_FIELDS
+
+PCM_REL_RMS = 1e-4
+PCM_WORST_FRAME = 1e-3
+STATE_REL_RMS = 1e-4
+
+
+def rel_rms(ref, got):
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    ok = np.isfinite(ref) & np.isfinite(got)
+    assert np.array_equal(np.isnan(ref), np.isnan(got)), "NaN pattern differs"
+    den = np.sum(ref[ok] ** 2)
+    num = np.sum((ref[ok] - got[ok]) ** 2)
+    return float(np.sqrt(num / den)) if den > 0 else float(np.sqrt(num))
+
+
+def check_pcm(ref_f, got_f, ref_s=None, got_s=None, rel=PCM_REL_RMS, worst=PCM_WORST_FRAME, what="pcm"):
+    ref_f = np.asarray(ref_f).reshape(-1, 160)
+    got_f = np.asarray(got_f).reshape(-1, 160)
+    total = rel_rms(ref_f, got_f)
+    assert total <= rel, f"{what}: relative RMS {total:.3e} > {rel:.1e}"
+    # worst frame, relative to the batch RMS level so silent frames do not blow the ratio up
+    level = np.sqrt(np.mean(ref_f.astype(np.float64) ** 2)) + 1e-30
+    err = np.sqrt(np.mean((ref_f.astype(np.float64) - got_f.astype(np.float64)) ** 2, axis=1))
+    frame_rms = np.sqrt(np.mean(ref_f.astype(np.float64) ** 2, axis=1))
+    ratio = err / np.maximum(frame_rms, 0.05 * level)
+    assert ratio.max() <= worst, f"{what}: worst frame relative error {ratio.max():.3e} > {worst:.1e} (frame {ratio.argmax()})"
+    out = {"rel_rms": total, "worst_frame": float(ratio.max())}
+    if ref_s is not None:
+        d = np.abs(np.asarray(ref_s, dtype=np.int32).reshape(-1) - np.asarray(got_s, dtype=np.int32).reshape(-1))
+        frac = float(np.mean(d <= 1))
+        assert d.max() <= 3, f"{what}: int16 differs by {d.max()} LSB"
+        assert frac >= 0.999, f"{what}: only {frac:.5f} of int16 samples within 1 LSB"
+        out["int16_exact"] = float(np.mean(d == 0))
+        out["int16_max"] = int(d.max())
+    return out
+
+
+def check_results(ref, got, what="results"):
+    for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
+        bad = np.nonzero(ref[name] != got[name])[0]
+        assert bad.size == 0, f"{what}: {name} differs at frames {bad[:8]} ref={ref[name][bad[:4]]} got={got[name][bad[:4]]}"
+
+
+def check_state(ref, got, rel=STATE_REL_RMS, what="state"):
+    """ref/got: arrays of PARMS_DTYPE with the same shape."""
+    ref = np.asarray(ref)
+    got = np.asarray(got)
+    for name in INT_FIELDS:
+        if not np.array_equal(ref[name], got[name]):
+            idx = np.argwhere(ref[name] != got[name])[0]
+            raise AssertionError(f"{what}: integer field {name} differs first at {tuple(idx)}: ref={ref[name][tuple(idx)]} got={got[name][tuple(idx)]}")
+    for name in EXACT_FLOAT_FIELDS:
+        a, b = ref[name].view(np.uint32), got[name].view(np.uint32)
+        assert np.array_equal(a, b), f"{what}: {name} (integer-valued noise state) differs"
+    out = {}
+    for name in FLOAT_FIELDS:
+        r = rel_rms(ref[name], got[name])
+        assert r <= rel, f"{what}: float field {name} relative RMS {r:.3e} > {rel:.1e}"
+        out[name] = r
+    return out

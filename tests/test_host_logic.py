@@ -1,0 +1,175 @@
+"""CPU suite for the host side: C-ABI exports, packers, frame generator, state constructors,
+stream sharding and the table broadcast (gloo, world_size 2).  No GPU compute here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    import mbelib_neo_amd as m
+    from mbelib_neo_amd import _native
+
+    header = open(os.path.join(ROOT, "include", "mbx.h")).read()
+    declared = set(re.findall(r"\b(mbx_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found in include/mbx.h"
+    assert os.path.exists(m.library_path()), "libmbx_hip.so not built (python -c 'import __graft_entry__ as g; g.build()')"
+    try:
+        handle = C.CDLL(m.library_path())
+    except OSError as e:
+        pytest.skip(f"HIP runtime not loadable here: {e}")
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"libmbx_hip.so does not export {name}"
+    assert declared == set(_native.EXPORTED_SYMBOLS)
+
+
+def test_launchers_fail_loudly_without_init_or_device():
+    from mbelib_neo_amd import _native
+
+    try:
+        L = _native.lib()
+    except _native.NativeLibraryError as e:
+        pytest.skip(str(e))
+    # no mbx_init(): every launcher refuses (no silent CPU path)
+    assert L.mbx_fec_imbe7200x4400(None, 1, None, None) == -101
+    assert L.mbx_process_records(0, 1, 1, None, None, None, None, None, None, None) == -101
+    blob = open(os.path.join(ROOT, "mbelib-neo_amd", "data", "mbx_tables.bin"), "rb").read()
+    import torch
+
+    if not torch.cuda.is_available():
+        assert L.mbx_init(0, blob, len(blob)) == -100  # MBX_ENODEVICE
+    bad = bytearray(blob)
+    bad[5000] ^= 1
+    assert L.mbx_init(0, bytes(bad), len(bad)) == -102  # checksum
+
+
+def test_packers_match_oracle_and_validate(oracle):
+    from mbelib_neo_amd import _native
+
+    try:
+        L = _native.lib()
+    except _native.NativeLibraryError as e:
+        pytest.skip(str(e))
+    rng = np.random.default_rng(1)
+    for codec, ncell, fn in ((0, 184, L.mbx_pack_imbe7200x4400), (1, 96, L.mbx_pack_ambe3600x2450)):
+        cells = rng.integers(0, 2, size=(64, ncell), dtype=np.int8)
+        _, ref = oracle.pack(codec, cells)
+        got = np.zeros_like(ref)
+        assert fn(cells.ctypes.data, 64, got.ctypes.data) == 0
+        assert np.array_equal(ref, got)
+        cells[7, ncell - 1] = -1
+        untouched = np.full_like(ref, 0x55)
+        assert fn(cells.ctypes.data, 64, untouched.ctypes.data) == -2 and (untouched == 0x55).all()
+        assert fn(None, 1, got.ctypes.data) == -1
+
+
+def test_state_constructors_match_oracle(oracle):
+    from mbelib_neo_amd.layout import init_state, rng_default, rng_seeded
+
+    assert init_state(3).tobytes() == oracle.init_state(3).tobytes()
+    seeds = [0, 1, 1234, 0xC0FFEE, 0xFFFFFFFF]
+    assert rng_seeded(seeds).tobytes() == oracle.rng_seeded(seeds).tobytes()
+    assert rng_default(2).tobytes() == oracle.rng_default(2).tobytes()
+
+
+def test_framegen_encoders_roundtrip_through_oracle_fec(oracle):
+    from mbelib_neo_amd import framegen
+
+    rng = framegen.rng_for(5)
+    bits = rng.integers(0, 2, size=(512, 88), dtype=np.uint8)
+    rec = oracle.fec_batch(0, framegen.encode_imbe7200x4400(bits))
+    assert np.array_equal(oracle_lib.records_to_bits(rec, 88), bits)
+    assert int(oracle_lib.records_to_results(rec)["total_errors"].max()) == 0
+    bits = rng.integers(0, 2, size=(512, 49), dtype=np.uint8)
+    rec = oracle.fec_batch(1, framegen.encode_ambe3600x2450(bits))
+    assert np.array_equal(oracle_lib.records_to_bits(rec, 49), bits)
+    assert int(oracle_lib.records_to_results(rec)["total_errors"].max()) == 0
+    # up to 3 flips per Golay word / 1 per Hamming word are corrected back to the same bits
+    frames = framegen.encode_imbe7200x4400(bits := rng.integers(0, 2, size=(256, 88), dtype=np.uint8))
+    noisy = frames.copy()
+    noisy[:, 0] ^= 0x41  # two flips in row 0
+    noisy[:, 12] ^= 0x08  # one flip in a Hamming row
+    rec = oracle.fec_batch(0, noisy)
+    assert np.array_equal(oracle_lib.records_to_bits(rec, 88), bits)
+    assert (oracle_lib.records_to_results(rec)["total_errors"] >= 1).all()
+
+
+def test_voiced_workload_is_all_voiced(oracle):
+    from mbelib_neo_amd import framegen
+
+    S = 256
+    rng = framegen.rng_for(2)
+    frames = np.concatenate([framegen.imbe_clean_voiced_frames(S, rng)[:, None, :]] * 2, axis=1).reshape(S * 2, 18)
+    out = oracle.process_batch(0, S, 2, frames, oracle.init_state(S), oracle.rng_seeded(range(S)))
+    st = out["state"]
+    for s in range(S):
+        L = int(st[s, 1]["L"])
+        assert (st[s, 1]["Vl"][1 : L + 1] == 1).all()  # pre-enhancement snapshot: every band voiced
+    assert int(out["results"]["total_errors"].max()) == 0 and int(out["results"]["flags"].max()) == 0x06
+
+
+def test_shard_range_partitions_streams():
+    from mbelib_neo_amd.parallel import shard_range
+
+    for total, world in ((65536, 8), (10, 3), (7, 8), (0, 4)):
+        got = [shard_range(total, world, r) for r in range(world)]
+        assert sum(c for _, c in got) == total
+        nxt = 0
+        for first, count in got:
+            assert first == nxt
+            nxt += count
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import mbelib_neo_amd as m
+from mbelib_neo_amd.parallel import broadcast_tables, shard_range, blob_checksum
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+blob = broadcast_tables(m.load_tables_blob() if rank == 0 else None)
+assert blob == m.load_tables_blob()
+cs = torch.tensor([blob_checksum(blob)], dtype=torch.int64)
+got = [torch.zeros_like(cs) for _ in range(world)]
+dist.all_gather(got, cs)
+assert all(int(g) == int(cs) for g in got)
+# sharded decode of 8 streams with the ORACLE standing in for the device (test only): the union
+# of the shards must equal the unsharded result, i.e. sharding needs no exchange step
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import oracle_lib
+from mbelib_neo_amd import framegen
+o = oracle_lib.load()
+S, T = 8, 3
+frames = framegen.random_frames(0, S * T, framegen.rng_for(11)).reshape(S, T, 18)
+first, count = shard_range(S, world, rank)
+mine = o.process_batch(0, count, T, frames[first:first + count].reshape(-1, 18), o.init_state(count),
+                       o.rng_seeded(np.arange(first, first + count) + 1234))
+h = torch.tensor([o.fnv(mine["pcm16"])], dtype=torch.int64)
+hs = [torch.zeros_like(h) for _ in range(world)]
+dist.all_gather(hs, h)
+if rank == 0:
+    full = o.process_batch(0, S, T, frames.reshape(-1, 18), o.init_state(S), o.rng_seeded(np.arange(S) + 1234))
+    parts = [full["pcm16"].reshape(S, T, 160)[f:f + c] for f, c in (shard_range(S, world, r) for r in range(world))]
+    assert [int(x) for x in hs] == [o.fnv(np.ascontiguousarray(p)) for p in parts]
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_table_broadcast_and_sharding_world_size_2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)

@@ -1,0 +1,237 @@
+"""CPU suite: pins the ORACLE (oracle/mbx_oracle.c) to the reference.
+
+Two kinds of evidence:
+  * the golden values the reference's own tests hold -- FNV-1a hashes of tests/test_golden_pcm.c:78-84,
+    the Golay/Hamming known answers of tests/test_ecc.c, the scalar known answers of
+    tests/test_params.c, the edge values of tests/test_floattoshort_parity.c;
+  * fixtures written by oracle/tools/gen_fixtures.c linked against the real reference
+    (IEEE scalar build, oracle/Makefile) -- tests/golden/*.bin.
+"""
+import numpy as np
+import pytest
+
+import golden_io
+import oracle_lib
+import parity
+from mbelib_neo_amd.layout import PARMS_DTYPE, RESULT_DTYPE
+
+REF_F32_HASH_SCALAR = 0x59741032  # reference tests/test_golden_pcm.c:78
+REF_S16_HASH = 0x4EDB8636  # reference tests/test_golden_pcm.c:84
+
+
+def test_golden_synth_hashes(oracle):
+    g = golden_io.golden_synth()
+    assert int(g["hash_f32"]) == REF_F32_HASH_SCALAR and int(g["hash_s16"]) == REF_S16_HASH  # fixture == reference test
+    rng = oracle.rng_seeded([0xC0FFEE])
+    pcmf, cur, prev, _ = oracle.synthesize_speech(g["cur_in"].reshape(1), g["prev_in"].reshape(1), rng)
+    s16 = oracle.floattoshort(pcmf)
+    # int16 hash is reproduced exactly; the float hash depends on PFFFT's rounding, so floats are
+    # compared numerically (the oracle's FFT is double precision)
+    assert oracle.fnv(s16) == REF_S16_HASH
+    m = parity.check_pcm(g["pcmf"], pcmf, g["pcm16"], s16, rel=1e-6, worst=1e-5)
+    assert m["int16_exact"] == 1.0
+    parity.check_state(g["cur_out"].reshape(1), cur, rel=1e-6)
+    parity.check_state(g["prev_out"].reshape(1), prev, rel=1e-6)
+
+
+def test_ecc_known_answers(oracle):
+    golay, ham = golden_io.ecc_kat()
+    for r in golay:
+        out, errs = oracle.golay(int(r["inp"]))
+        assert (out, errs) == (int(r["out"]), int(r["errs"]))
+    # reference tests/test_ecc.c:356-375: data 0xA55 with bit 5 flipped decodes back to 0xA55
+    last = golay[-1]
+    assert (int(last["out"]) >> 11) == 0xA55 and int(last["errs"]) == 1
+    for r in ham[::7]:  # every 7th of the exhaustive 32768 (the HIP test runs all of them)
+        out, errs = oracle.hamming(int(r["inp"]))
+        assert (out, errs) == (int(r["out"]), int(r["errs"]))
+
+
+@pytest.mark.parametrize("codec", [0, 1])
+def test_fec_fixtures(oracle, codec):
+    fx = golden_io.fec(codec)
+    rcs, packed = oracle.pack(codec, fx["cells"])
+    assert all(rc == 0 for rc in rcs)
+    rec = oracle.fec_batch(codec, packed)
+    nbits = 88 if codec == 0 else 49
+    assert np.array_equal(oracle_lib.records_to_bits(rec, nbits), fx["bits"])
+    res = oracle_lib.records_to_results(rec)
+    parity.check_results(fx["result"], res)
+    assert np.array_equal(res["total_errors"], fx["ret"])
+
+
+@pytest.mark.parametrize("codec", [0, 1])
+def test_invalid_bits_rejected(oracle, codec):
+    # reference tests/test_input_validation.c:72-122: any cell outside {0,1} -> -2, NULL -> -1
+    ncell = 184 if codec == 0 else 96
+    cells = np.zeros((1, ncell), dtype=np.int8)
+    cells[0, ncell - 1] = 2  # even an unused cell is validated
+    rcs, _ = oracle.pack(codec, cells)
+    assert rcs == [-2]
+    fn = oracle.h.mbxo_pack_imbe_frame if codec == 0 else oracle.h.mbxo_pack_ambe_frame
+    assert fn(None, None) == -1
+
+
+@pytest.mark.parametrize("codec", [0, 1])
+def test_stream_fixtures(oracle, codec):
+    S, T, fx = golden_io.stream(codec)
+    frames = fx["frames"]
+    _, packed = oracle.pack(codec, frames["cells"].reshape(S * T, -1))
+    out = oracle.process_batch(codec, S, T, packed, oracle.init_state(S), oracle.rng_seeded([1234 + s for s in range(S)]))
+    nbits = 88 if codec == 0 else 49
+    assert np.array_equal(oracle_lib.records_to_bits(out["records"], nbits), frames["bits"].reshape(S * T, nbits))
+    parity.check_results(frames["result"].reshape(-1), out["results"])
+    assert np.array_equal(out["results"]["total_errors"], frames["ret"].reshape(-1))
+    m = parity.check_pcm(frames["pcmf"], out["pcmf"], frames["pcm16"], out["pcm16"], rel=1e-6, worst=1e-5)
+    assert m["int16_max"] <= 1
+    parity.check_state(fx["final"], out["state"], rel=1e-6)
+    flags = frames["result"]["flags"].reshape(-1)
+    if codec == 0:
+        assert (flags & 0x40).any() and (flags & 0x80).any()  # repeat and mute are covered
+    else:
+        assert (flags & 0x20).any() and (flags & 0x10).any() and (flags & 0x40).any()  # erasure, tone, repeat
+
+
+def test_synth_sequences(oracle):
+    # the reference's bench recipes as multi-frame known answers (bench/bench_synth.c:40-67,
+    # bench/bench_unvoiced.c:33-52,87)
+    frames, fx = golden_io.synth_seq()
+    for recipe in range(2):
+        cur = np.zeros(1, dtype=PARMS_DTYPE)
+        st = oracle.init_state(1)
+        cur[0] = st[0, 0]
+        l = np.arange(57)
+        if recipe == 0:
+            rng = oracle.rng_seeded([0x123456])
+            cur["w0"] = np.float32(0.09378)
+            cur["L"] = 40
+            for k in range(1, 41):
+                cur["Vl"][0, k] = int((k % 3) != 0)
+                cur["Ml"][0, k] = np.float32(0.05) + np.float32(0.002) * np.float32(k)
+                cur["log2Ml"][0, k] = 0.0
+                cur["PHIl"][0, k] = np.float32(k) * np.float32(0.1)
+                cur["PSIl"][0, k] = np.float32(k) * np.float32(0.05)
+        else:
+            rng = oracle.rng_seeded([0xBEEF])
+            cur["w0"] = np.float32(0.11)
+            cur["L"] = 36
+            for k in range(1, 37):
+                cur["Vl"][0, k] = 0
+                cur["Ml"][0, k] = np.float32(0.03) + np.float32(0.002) * np.float32(k & 7)
+                cur["PHIl"][0, k] = 0.0
+                cur["PSIl"][0, k] = 0.0
+        prev = cur.copy()
+        got = []
+        for i in range(frames):
+            if recipe == 0:
+                cur["w0"] = np.float32(0.09) if (i & 1) else np.float32(0.11)
+                for k in range(1, 41):
+                    cur["Vl"][0, k] = 1 if ((i + k) % 5) else 0
+                    cur["Ml"][0, k] = np.float32(0.04) + np.float32(0.003) * np.float32((i + k) % 7)
+            else:
+                cur["w0"] = np.float32(0.10) if (i & 1) else np.float32(0.12)
+            pcmf, cur, prev, rng = oracle.synthesize_speech(cur, prev, rng)
+            prev = cur.copy()
+            got.append(pcmf[0])
+        parity.check_pcm(fx[recipe]["pcmf"], np.array(got), rel=1e-6, worst=1e-5, what=f"recipe{recipe}")
+        parity.check_state(fx[recipe]["cur"].reshape(1), cur, rel=1e-6)
+
+
+def test_floattoshort_exact(oracle):
+    fx = golden_io.f2s()  # inputs of reference tests/test_floattoshort_parity.c:36-68
+    for case in fx:
+        assert np.array_equal(oracle.floattoshort(case["inp"])[0], case["out"])
+    # the reference test's own scalar model: NaN -> 0, +-Inf -> +-31128, clip at 31128.65
+    edge = np.zeros(160, dtype=np.float32)
+    edge[:3] = [np.nan, np.inf, -np.inf]
+    assert list(oracle.floattoshort(edge)[0][:3]) == [0, 31128, -31128]
+
+
+def test_parameter_known_answers(oracle):
+    t_imbe, t_ambe, full_imbe, full_ambe = golden_io.params_kat()
+    h = oracle.h
+    for b0 in range(256):
+        d = np.zeros(88, dtype=np.int8)
+        for i in range(8):
+            d[i if i < 6 else (85 if i == 6 else 86)] = (b0 >> (7 - i)) & 1
+        st = oracle.init_state(1)
+        rc = h.mbxo_decode_imbe4400_parms(d.ctypes.data, st[0, 0:1].ctypes.data, st[0, 1:2].ctypes.data)
+        r = t_imbe[b0]
+        assert rc == r["rc"]
+        if rc == 0:
+            assert st[0, 0]["w0"] == r["w0"] and st[0, 0]["L"] == r["L"] and st[0, 0]["K"] == r["K"]
+    # reference tests/test_params.c:227-253 spot values
+    import math
+    for b0 in (0, 100, 206):
+        w0 = np.float32((4.0 * math.pi) / (b0 + 39.5))
+        L = int(0.9254 * int((math.pi / float(w0)) + 0.25))
+        assert abs(float(t_imbe[b0]["w0"]) - float(w0)) <= 1e-6 and t_imbe[b0]["L"] == L
+        assert t_imbe[b0]["K"] == ((L + 2) // 3 if L < 37 else 12)
+    for b0 in range(128):
+        d = np.zeros(49, dtype=np.int8)
+        for k, i in enumerate((0, 1, 2, 3, 37, 38, 39)):
+            d[i] = (b0 >> (6 - k)) & 1
+        st = oracle.init_state(1)
+        rc = h.mbxo_decode_ambe2450_parms(d.ctypes.data, st[0, 0:1].ctypes.data, st[0, 1:2].ctypes.data, -1)
+        r = t_ambe[b0]
+        assert rc == r["rc"], b0
+        if rc == 0:
+            assert st[0, 0]["w0"] == r["w0"] and st[0, 0]["L"] == r["L"]
+    # reference tests/test_params.c:303-341: AMBE b0 0 -> L 9, 119 -> L 56, silence 124/125 -> L 15/14
+    assert t_ambe[0]["L"] == 9 and t_ambe[119]["L"] == 56 and t_ambe[124]["L"] == 15 and t_ambe[125]["L"] == 14
+    for codec, fx in ((0, full_imbe), (1, full_ambe)):
+        for r in fx:
+            st = oracle.init_state(1)
+            l = np.arange(57)
+            st[0, 1]["log2Ml"] = (np.float32(0.25) * ((l * 7) % 11).astype(np.float32) - np.float32(1.0)).astype(np.float32)
+            st[0, 1]["Ml"] = np.exp2(st[0, 1]["log2Ml"].astype(np.float32)).astype(np.float32)
+            st[0, 1]["L"] = r["prev_L"]
+            st[0, 1]["gamma"] = 1.5
+            bits = np.ascontiguousarray(r["bits"])
+            if codec == 0:
+                rc = h.mbxo_decode_imbe4400_parms(bits.ctypes.data, st[0, 0:1].ctypes.data, st[0, 1:2].ctypes.data)
+            else:
+                rc = h.mbxo_decode_ambe2450_parms(bits.ctypes.data, st[0, 0:1].ctypes.data, st[0, 1:2].ctypes.data, -1)
+            assert rc == r["rc"]
+            if rc == 0:
+                parity.check_state(r["cur"].reshape(1), st[0, 0:1], rel=2e-7)
+
+
+def test_misc_known_answers(oracle):
+    fx = golden_io.misc_kat()
+    h = oracle.h
+    # reference tests/test_params.c:573-594: Tm is not clamped, -2999 scales Ml negative
+    assert int(fx["tm"]) == -2999
+    st = oracle.init_state(1)
+    cur, prev = st[0, 0:1], st[0, 1:2]
+    cur["L"] = 4
+    cur["Ml"][0, 1:5] = 10.0
+    cur["Vl"][0, 1:5] = 0
+    cur["errorRate"] = 0.5
+    cur["errorCountTotal"] = 30
+    cur["errorCount4"] = 2
+    prev["amplitudeThreshold"] = 1
+    h.mbxo_adaptive_smoothing(cur.ctypes.data, prev.ctypes.data)
+    assert int(cur["amplitudeThreshold"][0]) == -2999 and cur["Ml"][0, 1] == fx["ml1"] and cur["Ml"][0, 1] < 0
+    assert cur["localEnergy"][0] == fx["local_energy"]
+    # reference tests/test_params.c:596-618: seeded comfort noise; cold-start seed = 0x1234 % 53125
+    rng = oracle.rng_seeded([0x12345678])
+    noise = np.zeros(160, dtype=np.float32)
+    h.mbxo_comfort_noisef(noise.ctypes.data, rng.ctypes.data)
+    assert np.array_equal(noise, fx["comfort"])
+    assert float(fx["cold_seed"]) == float(0x1234 % 53125)
+    # reference tests/test_params.c:717-740: repeat headroom reset -> default model, L = 39
+    st = oracle.init_state(1)
+    st[0, 1]["repeatCount"] = 4
+    st[0, 0] = st[0, 1]
+    res = np.zeros(1, dtype=RESULT_DTYPE)
+    res["total_errors"] = 6
+    out = np.zeros(160, dtype=np.float32)
+    d = np.zeros(88, dtype=np.int8)
+    rng = oracle.rng_seeded([77])
+    rc = h.mbxo_process_imbe4400_dataf(out.ctypes.data, res.ctypes.data, d.ctypes.data, st[0, 0:1].ctypes.data,
+                                       st[0, 1:2].ctypes.data, st[0, 2:3].ctypes.data, rng.ctypes.data)
+    assert rc == int(fx["hr_rc"]) and int(st[0, 0]["L"]) == 39 and int(st[0, 0]["repeatCount"]) == 0
+    parity.check_results(fx["hr_result"].reshape(1), res)
+    parity.check_state(fx["hr_cur"].reshape(1), st[0, 0:1], rel=1e-6)
+    parity.check_pcm(fx["hr_pcm"], out, rel=1e-6, worst=1e-5)
