@@ -54,6 +54,12 @@ def lib():
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  mbelib-neo_amd has no CPU fallback."
             )
+        # torch ships its own HIP runtime; load it first so that this library binds to the SAME
+        # libamdhip64 instance (device pointers and streams are shared with torch tensors).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             handle = C.CDLL(path)
         except OSError as e:  # e.g. libamdhip64 not found
