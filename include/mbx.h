@@ -97,6 +97,22 @@ int mbx_synthesize_speech(int S, mbe_parms* d_cur, mbe_parms* d_prev, mbx_stream
 /* ref: mbe_floattoshort  include/mbelib-neo/mbelib.h:675, src/core/mbelib.c:1148-1177 */
 int mbx_floattoshort(const float* d_in, int16_t* d_out, size_t nframes, void* stream);
 
+/* ---- single stages of the public API, batched (one wavefront per struct) ------------------- */
+
+/* ref: mbe_spectralAmpEnhance  include/mbelib-neo/mbelib.h:623, src/core/mbelib.c:641-666 */
+int mbx_spectral_amp_enhance(int S, mbe_parms* d_parms, void* stream);
+/* ref: mbe_applyAdaptiveSmoothing  include/mbelib-neo/mbelib.h:725, src/core/mbe_adaptive.c:268-276 */
+int mbx_adaptive_smoothing(int S, mbe_parms* d_cur, const mbe_parms* d_prev, void* stream);
+/* ref: mbe_synthesizeComfortNoisef / mbe_synthesizeComfortNoise  include/mbelib-neo/mbelib.h:706-712 */
+int mbx_comfort_noise(int S, mbx_stream_rng* d_rng, float* d_pcmf, int16_t* d_pcm16, void* stream);
+/* ref: mbe_golay2312 / mbe_checkGolayBlock (kind 0), mbe_hamming1511 (kind 1)  include/mbelib-neo/mbelib.h:231-253.
+ * One code word per element: bit j of in[i] is cell j; out[i] is the corrected word (Golay parity bits
+ * pass through like the reference), errs[i] the corrected-bit count (may be NULL). */
+int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream);
+/* Loads and stores the state triplet of S streams without touching it: the HBM-traffic floor of the
+ * stream stage (used by bench.py --calibrate to price the access pattern; not a reference function). */
+int mbx_state_copy(int S, mbe_parms* d_state, void* stream);
+
 /* ---- convenience: same calls on HOST buffers (stages through device memory, synchronous) -- */
 int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
                            int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records);

@@ -33,6 +33,11 @@ _SIGNATURES = {
     "mbx_process_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_synthesize_speech": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_floattoshort": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "mbx_spectral_amp_enhance": (C.c_int, [C.c_int, _vp, _vp]),
+    "mbx_adaptive_smoothing": (C.c_int, [C.c_int, _vp, _vp, _vp]),
+    "mbx_comfort_noise": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),
+    "mbx_ecc_words": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "mbx_state_copy": (C.c_int, [C.c_int, _vp, _vp]),
     "mbx_process_batch_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_synthesize_speech_host": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "mbx_floattoshort_host": (C.c_int, [_vp, _vp, _sz]),

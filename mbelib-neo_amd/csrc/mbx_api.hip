@@ -23,6 +23,11 @@ __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, mbe_parms*
 __global__ void ambe_stream_kernel(int, int, const mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
                                    mbe_process_result*, DeviceTables);
 __global__ void synth_speech_kernel(int, mbe_parms*, mbe_parms*, mbx_stream_rng*, float*, int16_t*, DeviceTables);
+__global__ void enhance_kernel(int, mbe_parms*);
+__global__ void smoothing_kernel(int, mbe_parms*, const mbe_parms*);
+__global__ void comfort_noise_kernel(int, mbx_stream_rng*, float*, int16_t*);
+__global__ void state_copy_kernel(int, mbe_parms*);
+__global__ void ecc_words_kernel(int, const uint32_t*, size_t, uint32_t*, int32_t*, DeviceTables);
 }  // namespace mbx
 
 namespace {
@@ -344,6 +349,68 @@ int mbx_floattoshort(const float* d_in, int16_t* d_out, size_t nframes, void* st
     const unsigned grid = (unsigned)((nsamples / 2 + 255) / 256);
     hipLaunchKernelGGL(mbx::floattoshort_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_in, d_out, nsamples);
     return check_launch("floattoshort_kernel");
+}
+
+int mbx_spectral_amp_enhance(int S, mbe_parms* d_parms, void* stream) {
+    REQUIRE_READY();
+    if (!d_parms || S < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::enhance_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_parms);
+    return check_launch("enhance_kernel");
+}
+
+int mbx_adaptive_smoothing(int S, mbe_parms* d_cur, const mbe_parms* d_prev, void* stream) {
+    REQUIRE_READY();
+    if (!d_cur || !d_prev || S < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::smoothing_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_cur, d_prev);
+    return check_launch("smoothing_kernel");
+}
+
+int mbx_comfort_noise(int S, mbx_stream_rng* d_rng, float* d_pcmf, int16_t* d_pcm16, void* stream) {
+    REQUIRE_READY();
+    if (!d_rng || S < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::comfort_noise_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_rng, d_pcmf,
+                       d_pcm16);
+    return check_launch("comfort_noise_kernel");
+}
+
+int mbx_state_copy(int S, mbe_parms* d_state, void* stream) {
+    REQUIRE_READY();
+    if (!d_state || S < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::state_copy_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_state);
+    return check_launch("state_copy_kernel");
+}
+
+int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream) {
+    REQUIRE_READY();
+    if (!d_in || !d_out || (kind != 0 && kind != 1)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::ecc_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind,
+                       d_in, n, d_out, d_errs, g_ctx.tabs);
+    return check_launch("ecc_words_kernel");
 }
 
 const char* mbx_stream_kernel_name(int codec) {

@@ -818,7 +818,8 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
 
         const int bad = decode_imbe(w, cur, prev, scratch, tabs.t, lane);
         const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
-        const bool repeat = (bad == 1) || ((c0 >= 2) && ((float)total >= repeat_threshold));
+        const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
+        const bool repeat = (bad == 1) || (c0_valid ? ((c0 >= 2) && ((float)total >= repeat_threshold)) : (total > 5));
         if (!repeat) {
             cur.repeatCount = 0;
         } else {
@@ -1179,7 +1180,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         } else if (bad == 7) {
             flags |= MBE_PROCESS_FLAG_TONE;
             cur.repeatCount = 0;
-        } else if ((c0 >= 4) || ((c0 >= 2) && (total >= 6))) {
+        } else if (((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? ((c0 >= 4) || ((c0 >= 2) && (total >= 6))) : (total > 3)) {
             cur = prev;
             cur.repeatCount++;
             flags |= MBE_PROCESS_FLAG_REPEAT;
@@ -1261,6 +1262,78 @@ synth_speech_kernel(int S, mbe_parms* __restrict__ curs, mbe_parms* __restrict__
     store_parms(cur, &curs[s], lane);
     store_parms(prev, &prevs[s], lane);
     store_rng(rng, &rngs[s], lane);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Single-stage entry points of the public API, batched: one wavefront per struct.
+//   mbe_spectralAmpEnhance       ref src/core/mbelib.c:663-666
+//   mbe_applyAdaptiveSmoothing   ref src/core/mbe_adaptive.c:268-276
+//   mbe_synthesizeComfortNoisef  ref src/core/mbe_adaptive.c:116-131
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+enhance_kernel(int S, mbe_parms* __restrict__ parms) {
+    const int s = blockIdx.x;
+    if (s >= S) {
+        return;
+    }
+    const int lane = lane_id();
+    Parms cur;
+    load_parms(cur, &parms[s], lane);
+    (void)enhance(cur, lane);
+    store_parms(cur, &parms[s], lane);
+}
+
+__global__ void __launch_bounds__(64)
+smoothing_kernel(int S, mbe_parms* __restrict__ curs, const mbe_parms* __restrict__ prevs) {
+    const int s = blockIdx.x;
+    if (s >= S) {
+        return;
+    }
+    const int lane = lane_id();
+    Parms cur, prev;
+    load_parms(cur, &curs[s], lane);
+    load_parms(prev, &prevs[s], lane);
+    if (cur.L >= 1 && cur.L <= 56 && prev.L >= 1 && prev.L <= 56) {
+        const bool in = lane >= 1 && lane <= cur.L;
+        const float rm0 = wave_sum(in ? (cur.Ml * cur.Ml) : 0.0f);
+        smooth(cur, prev, rm0, lane);
+        store_parms(cur, &curs[s], lane);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+comfort_noise_kernel(int S, mbx_stream_rng* __restrict__ rngs, float* __restrict__ pcmf, int16_t* __restrict__ pcm16) {
+    const int s = blockIdx.x;
+    if (s >= S) {
+        return;
+    }
+    const int lane = lane_id();
+    StreamRng rng;
+    load_rng(rng, &rngs[s]);
+    float out[3];
+    comfort_noise(out, rng, lane);
+    store_pcm(out, (size_t)s, pcm16, pcmf, lane);
+    store_rng(rng, &rngs[s], lane);
+}
+
+// The state-I/O floor of the stream kernels: load the three structs and store them back.
+// Used by bench.py (--calibrate) to price the HBM traffic of the access pattern and to calibrate
+// the FETCH_SIZE / WRITE_SIZE counters on a known byte count.
+__global__ void __launch_bounds__(64)
+state_copy_kernel(int S, mbe_parms* __restrict__ state) {
+    const int s = blockIdx.x;
+    if (s >= S) {
+        return;
+    }
+    const int lane = lane_id();
+    Parms a, b, c;
+    load_parms(a, &state[3 * (size_t)s + 0], lane);
+    load_parms(b, &state[3 * (size_t)s + 1], lane);
+    load_parms(c, &state[3 * (size_t)s + 2], lane);
+    store_parms(a, &state[3 * (size_t)s + 0], lane);
+    store_parms(b, &state[3 * (size_t)s + 1], lane);
+    store_parms(c, &state[3 * (size_t)s + 2], lane);
 }
 
 }  // namespace mbx

@@ -1,0 +1,59 @@
+"""ctypes binding of the per-frame drop-in library (libmbe_neo_amd.so, include/mbe_neo_amd.h)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "mbelib-neo_amd", "libmbe_neo_amd.so")
+HEADER = os.path.join(ROOT, "include", "mbe_neo_amd.h")
+
+_vp = C.c_void_p
+
+
+def declared_symbols():
+    return sorted(set(re.findall(r"\b(mbe_[A-Za-z0-9_]+)\s*\(", open(HEADER).read())))
+
+
+def load():
+    try:
+        import torch  # noqa: F401  (same HIP runtime instance as torch, see mbelib-neo_amd/_native.py)
+    except ImportError:
+        pass
+    h = C.CDLL(PATH)
+    for name in declared_symbols():
+        fn = getattr(h, name)
+        fn.argtypes = None
+    for name in ("mbe_processImbe7200x4400Framef", "mbe_processImbe7200x4400Frame", "mbe_processAmbe3600x2450Framef",
+                 "mbe_processAmbe3600x2450Frame"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 7
+    for name in ("mbe_processImbe4400Dataf", "mbe_processImbe4400Data", "mbe_processAmbe2450Dataf", "mbe_processAmbe2450Data"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 6
+    for name in ("mbe_decodeImbe7200x4400Frame", "mbe_decodeAmbe3600x2450Frame"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 3
+    for name in ("mbe_golay2312", "mbe_hamming1511"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp, _vp]
+    h.mbe_checkGolayBlock.restype = C.c_int
+    h.mbe_checkGolayBlock.argtypes = [C.POINTER(C.c_long)]
+    h.mbe_setThreadRngSeed.argtypes = [C.c_uint32]
+    h.mbe_setThreadRngSeed.restype = None
+    for name, n in (("mbe_initMbeParms", 3), ("mbe_moveMbeParms", 2), ("mbe_useLastMbeParms", 2), ("mbe_synthesizeSpeechf", 3),
+                    ("mbe_synthesizeSpeech", 3), ("mbe_floattoshort", 2), ("mbe_spectralAmpEnhance", 1),
+                    ("mbe_applyAdaptiveSmoothing", 2), ("mbe_synthesizeComfortNoisef", 1), ("mbe_synthesizeComfortNoise", 1),
+                    ("mbe_synthesizeSilencef", 1), ("mbe_synthesizeSilence", 1), ("mbe_initProcessResult", 1)):
+        getattr(h, name).restype = None
+        getattr(h, name).argtypes = [_vp] * n
+    for name in ("mbe_requiresMuting", "mbe_isMaxFrameRepeat", "mbe_requiresAdaptiveSmoothing"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp]
+    h.mbe_versionString.restype = C.c_char_p
+    return h
+
+
+def p(a):
+    return a.ctypes.data if a is not None else None

@@ -1,0 +1,381 @@
+"""GPU suite for the per-frame drop-in API (libmbe_neo_amd.so).  These read like the reference's
+own CTest programs (tests/test_frame_paths.c, test_input_validation.c, test_floattoshort_parity.c,
+test_golden_pcm.c, test_ecc.c, test_params.c) -- same scenarios, same assertions -- with the
+library under test swapped for the MI355X one."""
+import math
+
+import numpy as np
+import pytest
+
+import golden_io
+import parity
+import shim_lib
+from shim_lib import p
+from mbelib_neo_amd.layout import PARMS_DTYPE, RESULT_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+AMBE_THR = np.float32(0.096)
+IMBE_THR = np.float32(0.0875)
+
+
+@pytest.fixture(scope="module")
+def mbe():
+    return shim_lib.load()
+
+
+def new_state(mbe):
+    st = np.zeros(3, dtype=PARMS_DTYPE)
+    mbe.mbe_initMbeParms(p(st[0:1]), p(st[1:2]), p(st[2:3]))
+    return st[0:1], st[1:2], st[2:3]
+
+
+def result(total=0, **kw):
+    r = np.zeros(1, dtype=RESULT_DTYPE)
+    r["total_errors"] = total
+    for k, v in kw.items():
+        r[k] = v
+    return r
+
+
+def fnv1a32(buf):
+    h = 2166136261
+    for b in np.ascontiguousarray(buf).view(np.uint8).reshape(-1):
+        h = ((h ^ int(b)) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def set_imbe_b0(d, b0):
+    for i in range(8):
+        d[i if i < 6 else (85 if i == 6 else 86)] = (b0 >> (7 - i)) & 1
+
+
+def set_ambe_b0(d, b0):
+    for k, i in enumerate((0, 1, 2, 3, 37, 38, 39)):
+        d[i] = (b0 >> (6 - k)) & 1
+
+
+def seed_speech_params(mbe):  # tests/test_params.c:137-150
+    cur, prev, dummy = new_state(mbe)
+    cur["w0"] = np.float32(0.10)
+    cur["L"] = 12
+    for l in range(1, 13):
+        cur["Vl"][0, l] = 1 if (l % 3) else 0
+        cur["Ml"][0, l] = np.float32(0.03) + np.float32(0.001) * np.float32(l)
+        cur["PHIl"][0, l] = 0.0
+        cur["PSIl"][0, l] = 0.0
+    prev[...] = cur
+    return cur, prev
+
+
+# ---- test_api.c ---------------------------------------------------------------------------------
+def test_api_basics(mbe):
+    assert mbe.mbe_versionString().startswith(b"2.")
+    r = result(5)
+    mbe.mbe_initProcessResult(p(r))
+    assert r.tobytes() == bytes(20)
+    mbe.mbe_initProcessResult(None)  # NULL is a no-op
+
+
+# ---- test_golden_pcm.c --------------------------------------------------------------------------
+def test_golden_pcm(mbe):
+    g = golden_io.golden_synth()
+
+    def run():
+        cur, prev = g["cur_in"].reshape(1).copy(), g["prev_in"].reshape(1).copy()
+        out_f = np.zeros(160, dtype=np.float32)
+        out_s = np.zeros(160, dtype=np.int16)
+        mbe.mbe_setThreadRngSeed(0xC0FFEE)
+        mbe.mbe_synthesizeSpeechf(p(out_f), p(cur), p(prev))
+        mbe.mbe_floattoshort(p(out_f), p(out_s))
+        return out_f, out_s
+
+    f1, s1 = run()
+    f2, s2 = run()
+    assert f1.tobytes() == f2.tobytes() and s1.tobytes() == s2.tobytes()  # determinism
+    m = parity.check_pcm(g["pcmf"], f1, g["pcm16"], s1)
+    print("golden pcm via mbe_synthesizeSpeechf:", m, "int16 hash 0x%08X" % fnv1a32(s1))
+    assert np.abs(f1).max() < 2e4 and np.abs(s1.astype(np.int32)).max() < 32000  # the reference's sanity bounds
+
+
+# ---- test_floattoshort_parity.c --------------------------------------------------------------------
+def test_floattoshort_parity(mbe):
+    def reference_floattoshort(x):  # tests/test_floattoshort_parity.c:20-34
+        audio = np.float32(7.0) * np.float32(x)
+        if audio != audio:
+            audio = np.float32(0.0)
+        top = np.float32(32767.0) * np.float32(0.95)
+        audio = min(max(audio, -top), top)
+        return int(np.float32(audio))  # C cast truncates toward zero
+
+    for case in golden_io.f2s():
+        out = np.zeros(160, dtype=np.int16)
+        out2 = np.zeros(160, dtype=np.int16)
+        mbe.mbe_floattoshort(p(case["inp"].copy()), p(out))
+        mbe.mbe_floattoshort(p(case["inp"].copy()), p(out2))
+        assert out.tobytes() == out2.tobytes()
+        with np.errstate(invalid="ignore", over="ignore"):
+            exp = [reference_floattoshort(v) for v in case["inp"]]
+        assert list(out) == exp
+        assert np.array_equal(out, case["out"])
+    mbe.mbe_floattoshort(None, None)  # NULL helpers are no-ops
+
+
+# ---- test_ecc.c -------------------------------------------------------------------------------------
+def test_ecc_known_answers(mbe):
+    from mbelib_neo_amd import framegen
+
+    # Hamming(15,11): a code word is a fixed point and every single-bit flip is restored (:186-259)
+    rng = np.random.default_rng(3)
+    for data in rng.integers(0, 2048, size=12):
+        cw = int(framegen.hamming1511_encode(np.array([data]))[0])
+        code = np.array([(cw >> j) & 1 for j in range(15)], dtype=np.int8)
+        out = np.zeros(15, dtype=np.int8)
+        assert mbe.mbe_hamming1511(p(code), p(out)) == 0 and np.array_equal(out, code)
+        for j in range(15):
+            bad = code.copy()
+            bad[j] ^= 1
+            assert mbe.mbe_hamming1511(p(bad), p(out)) == 1 and np.array_equal(out, code)
+    # Golay: data 0xA55, 1-bit error at data bit 5 -> mbe_checkGolayBlock returns 0xA55 (:356-375)
+    cw = int(framegen.golay2312_encode(np.array([0xA55]))[0])
+    import ctypes as C
+
+    blk = C.c_long(cw ^ (1 << (11 + 5)))
+    assert mbe.mbe_checkGolayBlock(C.byref(blk)) == 0 and blk.value == 0xA55
+    code = np.array([(cw >> j) & 1 for j in range(23)], dtype=np.int8)
+    out = np.zeros(23, dtype=np.int8)
+    for flips in ((11,), (12, 20), (13, 17, 22)):
+        bad = code.copy()
+        for j in flips:
+            bad[j] ^= 1
+        assert mbe.mbe_golay2312(p(bad), p(out)) == len(flips) and np.array_equal(out, code)
+    bad = code.copy()
+    bad[3] = 2
+    assert mbe.mbe_golay2312(p(bad), p(out)) == -2 and mbe.mbe_golay2312(p(code), None) == -1
+
+
+# ---- test_frame_paths.c -------------------------------------------------------------------------------
+def test_frame_paths(mbe):
+    for codec, cells_shape, nd, framef, frame, dataf, data, decode in (
+        (0, 184, 88, mbe.mbe_processImbe7200x4400Framef, mbe.mbe_processImbe7200x4400Frame, mbe.mbe_processImbe4400Dataf,
+         mbe.mbe_processImbe4400Data, mbe.mbe_decodeImbe7200x4400Frame),
+        (1, 96, 49, mbe.mbe_processAmbe3600x2450Framef, mbe.mbe_processAmbe3600x2450Frame, mbe.mbe_processAmbe2450Dataf,
+         mbe.mbe_processAmbe2450Data, mbe.mbe_decodeAmbe3600x2450Frame),
+    ):
+        fr = np.zeros(cells_shape, dtype=np.int8)
+        fr[[1, 9, 30, 47]] = 1  # a sparse frame
+        for want_short in (False, True):
+            cur, prev, enh = new_state(mbe)
+            out = np.zeros(160, dtype=np.int16 if want_short else np.float32)
+            d = np.zeros(nd, dtype=np.int8)
+            r = result()
+            ret = (frame if want_short else framef)(p(out), p(r), p(fr), p(d), p(cur), p(prev), p(enh))
+            assert ret >= 0 and ret == int(r["total_errors"][0]) == int(r["c0_errors"][0] + r["protected_errors"][0])
+            assert np.isfinite(out.astype(np.float64)).all() and np.abs(out.astype(np.float64)).max() < 20000
+            # decode-only entry agrees, then the Dataf entry with that context gives the same PCM
+            d2 = np.zeros(nd, dtype=np.int8)
+            r2 = result()
+            assert decode(p(fr), p(d2), p(r2)) == ret and np.array_equal(d, d2)
+            cur2, prev2, enh2 = new_state(mbe)
+            out2 = np.zeros_like(out)
+            assert (data if want_short else dataf)(p(out2), p(r2), p(d2), p(cur2), p(prev2), p(enh2)) == ret
+            assert out.tobytes() == out2.tobytes() and cur.tobytes() == cur2.tobytes()
+            # result may be NULL
+            cur3, prev3, enh3 = new_state(mbe)
+            out3 = np.zeros_like(out)
+            assert (frame if want_short else framef)(p(out3), None, p(fr), p(d), p(cur3), p(prev3), p(enh3)) == ret
+
+
+# ---- test_input_validation.c ------------------------------------------------------------------------------
+def test_input_validation(mbe):
+    cur, prev, enh = new_state(mbe)
+    before = (cur.tobytes(), prev.tobytes(), enh.tobytes())
+    fr = np.zeros(184, dtype=np.int8)
+    fr[100] = 2
+    out = np.full(160, 123.0, dtype=np.float32)
+    d = np.full(88, 9, dtype=np.int8)
+    r = result(3)
+    assert mbe.mbe_processImbe7200x4400Framef(p(out), p(r), p(fr), p(d), p(cur), p(prev), p(enh)) == -2
+    assert (out == 123.0).all() and (d == 9).all() and (cur.tobytes(), prev.tobytes(), enh.tobytes()) == before
+    afr = np.zeros(96, dtype=np.int8)
+    afr[95] = -1  # an unused cell still counts
+    ad = np.full(49, 9, dtype=np.int8)
+    assert mbe.mbe_processAmbe3600x2450Framef(p(out), p(r), p(afr), p(ad), p(cur), p(prev), p(enh)) == -2
+    assert (out == 123.0).all() and (ad == 9).all()
+    fr[100] = 0
+    assert mbe.mbe_processImbe7200x4400Framef(None, p(r), p(fr), p(d), p(cur), p(prev), p(enh)) == -1
+    assert mbe.mbe_processImbe7200x4400Framef(p(out), p(r), p(fr), None, p(cur), p(prev), p(enh)) == -1
+    assert mbe.mbe_processImbe7200x4400Frame(None, p(r), p(fr), p(d), p(cur), p(prev), p(enh)) == -1
+    assert mbe.mbe_processImbe4400Dataf(p(out), p(r), p(d * 0), None, p(prev), p(enh)) == -1
+    # inconsistent result context -> INVALID_ARGUMENT, nothing written
+    d0 = np.zeros(88, dtype=np.int8)
+    for bad in (result(3, c0_errors=2, protected_errors=2), result(0, flags=0x100), result(1, c0_errors=-1),
+                result(2, c0_errors=3, flags=0x02), result(185)):
+        out[:] = 123.0
+        assert mbe.mbe_processImbe4400Dataf(p(out), p(bad), p(d0), p(cur), p(prev), p(enh)) == -1
+        assert (out == 123.0).all() and (cur.tobytes(), prev.tobytes(), enh.tobytes()) == before
+    d0[7] = 5
+    assert mbe.mbe_processImbe4400Dataf(p(out), p(result()), p(d0), p(cur), p(prev), p(enh)) == -2
+    # L outside [1, 56]: synthesis gives silence, enhancement/smoothing are no-ops
+    cur["L"] = 0
+    out[:] = 5.0
+    mbe.mbe_synthesizeSpeechf(p(out), p(cur), p(prev))
+    assert (out == 0.0).all()
+    snap = cur.tobytes()
+    mbe.mbe_spectralAmpEnhance(p(cur))
+    mbe.mbe_applyAdaptiveSmoothing(p(cur), p(prev))
+    assert cur.tobytes() == snap
+    for fn in (mbe.mbe_spectralAmpEnhance, mbe.mbe_synthesizeComfortNoisef, mbe.mbe_synthesizeSilencef):
+        fn(None)
+    mbe.mbe_synthesizeSpeechf(None, p(cur), p(prev))
+    mbe.mbe_moveMbeParms(None, p(cur))
+    assert mbe.mbe_requiresMuting(None) == 0 and mbe.mbe_isMaxFrameRepeat(None) == 0
+
+
+# ---- test_params.c ------------------------------------------------------------------------------------------
+def test_params_repeat_policy_without_c0_context(mbe):
+    # :343-395 -- absent C0_VALID the repeat decision depends on total errors only
+    for dataf, nd, setb0, total in ((mbe.mbe_processAmbe2450Dataf, 49, set_ambe_b0, 5), (mbe.mbe_processImbe4400Dataf, 88, set_imbe_b0, 11)):
+        d = np.zeros(nd, dtype=np.int8)
+        setb0(d, 0)
+        out = np.zeros(160, dtype=np.float32)
+        got = []
+        for ctx in (dict(c0_errors=0), dict(c0_errors=4 if nd == 49 else 2, protected_errors=total - (4 if nd == 49 else 2))):
+            cur, prev, enh = new_state(mbe)
+            r = result(total, **ctx)
+            assert dataf(p(out), p(r), p(d), p(cur), p(prev), p(enh)) >= 0
+            got.append((int(cur["repeatCount"][0]), bool(r["flags"][0] & 0x40)))
+        assert got[0] == got[1] and got[0][1]
+
+
+def test_params_tone_gate_and_erasure_defaults(mbe):
+    # :435-460
+    d = np.zeros(49, dtype=np.int8)
+    d[0:6] = 1  # tone signature, U3 nibble 0
+    set_ambe_b0(d, 120)
+    d[4] = d[5] = 1
+    out = np.zeros(160, dtype=np.float32)
+    cur, prev, enh = new_state(mbe)
+    r = result(5)
+    assert mbe.mbe_processAmbe2450Dataf(p(out), p(r), p(d), p(cur), p(prev), p(enh)) >= 0 and (r["flags"][0] & 0x10)
+    cur, prev, enh = new_state(mbe)
+    r = result(6)
+    assert mbe.mbe_processAmbe2450Dataf(p(out), p(r), p(d), p(cur), p(prev), p(enh)) >= 0
+    assert not (r["flags"][0] & 0x10) and (r["flags"][0] & 0x20)
+    assert float(cur["w0"][0]) == 0.0 and int(cur["L"][0]) == 9 and float(prev["w0"][0]) == 0.0 and int(prev["L"][0]) == 9
+
+
+def test_params_muting_semantics(mbe):
+    # :514-549 -- AMBE ignores error-rate muting, IMBE applies it; muted frames still advance localEnergy
+    out = np.zeros(160, dtype=np.float32)
+    cur, prev = seed_speech_params(mbe)
+    cur["mutingThreshold"] = AMBE_THR
+    cur["errorRate"] = 1.0
+    before = cur["noiseSeed"].tobytes()
+    mbe.mbe_synthesizeSpeechf(p(out), p(cur), p(prev))
+    assert cur["noiseSeed"].tobytes() != before
+    cur, prev = seed_speech_params(mbe)
+    cur["mutingThreshold"] = IMBE_THR
+    cur["errorRate"] = 1.0
+    before, energy = cur["noiseSeed"].tobytes(), cur["localEnergy"].tobytes()
+    mbe.mbe_synthesizeSpeechf(p(out), p(cur), p(prev))
+    assert cur["noiseSeed"].tobytes() == before and cur["localEnergy"].tobytes() != energy
+
+
+def test_params_phase_wrap_and_numuv(mbe):
+    # :551-571 previous PSI is wrapped to [0, 2pi) before it is advanced
+    out = np.zeros(160, dtype=np.float32)
+    cur, prev = seed_speech_params(mbe)
+    raw = np.float32(20.0 * math.pi) + np.float32(0.321)
+    prev["PSIl"][0, 5] = raw
+    mbe.mbe_synthesizeSpeechf(p(out), p(cur), p(prev))
+    wrapped = math.fmod(float(raw), float(np.float32(2.0 * math.pi)))
+    assert abs(float(prev["PSIl"][0, 5]) - wrapped) <= 1e-5
+    assert abs(float(cur["PSIl"][0, 5]) - (wrapped + (float(prev["w0"][0]) + float(cur["w0"][0])) * 400.0)) <= 1e-3
+    # :620-642 the unvoiced-band count used for the phase jitter includes index 0
+    cur, prev, enh = new_state(mbe)
+    cur["w0"] = np.float32(0.10)
+    cur["L"] = 12
+    cur["Vl"][0, :] = 1
+    cur["Vl"][0, :13] = 0
+    cur["Ml"][0, :] = 0.0
+    cur["Ml"][0, :13] = 0.05
+    cur["PHIl"][0, :] = 0.0
+    cur["PSIl"][0, :] = 0.0
+    prev[...] = cur
+    mbe.mbe_synthesizeSpeechf(p(out), p(cur), p(prev))
+    psi = float(prev["PSIl"][0, 12]) + (float(prev["w0"][0]) + float(cur["w0"][0])) * (12 * 160 / 2.0)
+    assert abs(float(cur["PHIl"][0, 12]) - (psi + (13 * -math.pi) / 12)) <= 1e-3
+
+
+def test_params_tm_seeds_headroom_c4(mbe):
+    fx = golden_io.misc_kat()
+    # :573-594 Tm is not clamped
+    cur, prev, enh = new_state(mbe)
+    cur["L"] = 4
+    cur["Ml"][0, 1:5] = 10.0
+    cur["Vl"][0, 1:5] = 0
+    cur["errorRate"] = 0.5
+    cur["errorCountTotal"] = 30
+    cur["errorCount4"] = 2
+    prev["amplitudeThreshold"] = 1
+    mbe.mbe_applyAdaptiveSmoothing(p(cur), p(prev))
+    assert int(cur["amplitudeThreshold"][0]) == -2999 and float(cur["Ml"][0, 1]) < 0.0
+    assert abs(float(cur["Ml"][0, 1]) - float(fx["ml1"])) <= 1e-6 * abs(float(fx["ml1"]))
+    # :596-618 seeding drives both generators; cold-start seed = 0x1234 % 53125
+    a, b, c = (np.zeros(160, dtype=np.float32) for _ in range(3))
+    mbe.mbe_setThreadRngSeed(0x12345678)
+    mbe.mbe_synthesizeComfortNoisef(p(a))
+    mbe.mbe_setThreadRngSeed(0x12345678)
+    mbe.mbe_synthesizeComfortNoisef(p(b))
+    mbe.mbe_setThreadRngSeed(0x12340000)
+    mbe.mbe_synthesizeComfortNoisef(p(c))
+    assert a.tobytes() == b.tobytes() and a.tobytes() != c.tobytes() and np.array_equal(a, fx["comfort"])
+    cur, prev = seed_speech_params(mbe)
+    cur["noiseSeed"] = -1.0
+    cur["noiseOverlap"][0, :] = 0
+    mbe.mbe_setThreadRngSeed(0x1234)
+    mbe.mbe_synthesizeSpeechf(p(a), p(cur), p(prev))
+    assert float(cur["noiseSeed"][0]) == float(0x1234 % 53125)
+    # :717-740 repeat headroom reset -> default model
+    cur, prev, enh = new_state(mbe)
+    prev["repeatCount"] = 4
+    cur[...] = prev
+    d = np.zeros(88, dtype=np.int8)
+    r = result(6)
+    mbe.mbe_setThreadRngSeed(77)
+    assert mbe.mbe_processImbe4400Dataf(p(a), p(r), p(d), p(cur), p(prev), p(enh)) >= 0
+    assert int(cur["repeatCount"][0]) == 0 and int(cur["L"][0]) == 39 and int(cur["Vl"][0, 1]) == 0 and float(cur["Ml"][0, 1]) > 0
+    assert abs(float(cur["w0"][0]) - (4.0 * math.pi) / (134.0 + 39.5)) <= 1e-5
+    parity.check_pcm(fx["hr_pcm"], a)
+    # :644-703 C4 bookkeeping
+    for flags, c4, expect in ((0, 0, 0), (0x04, 3, 3), (0x02, 0, 0)):
+        cur, prev, enh = new_state(mbe)
+        cur["errorCount4"] = 7
+        r = result(3 if flags == 0x04 else (1 if flags == 0x02 else 0), flags=flags, c4_errors=c4,
+                   protected_errors=3 if flags == 0x04 else 0, c0_errors=1 if flags == 0x02 else 0)
+        assert mbe.mbe_processImbe4400Dataf(p(a), p(r), p(d), p(cur), p(prev), p(enh)) >= 0
+        assert int(cur["errorCount4"][0]) == expect
+
+
+def test_streams_frame_by_frame_match_reference_goldens(mbe):
+    """The same golden streams as the batch test, but driven one frame at a time through the
+    reference-style entry points with per-thread RNG seeding."""
+    for codec, fn, nd in ((0, mbe.mbe_processImbe7200x4400Framef, 88), (1, mbe.mbe_processAmbe3600x2450Framef, 49)):
+        S, T, fx = golden_io.stream(codec)
+        for s in (0, 1, 2, 5):
+            cur, prev, enh = new_state(mbe)
+            mbe.mbe_setThreadRngSeed(1234 + s)
+            got = []
+            for t in range(T):
+                fr = fx["frames"][s, t]
+                out = np.zeros(160, dtype=np.float32)
+                d = np.zeros(nd, dtype=np.int8)
+                r = result()
+                ret = fn(p(out), p(r), p(fr["cells"].copy()), p(d), p(cur), p(prev), p(enh))
+                assert ret == int(fr["ret"]) and np.array_equal(d, fr["bits"])
+                parity.check_results(fr["result"].reshape(1), r)
+                got.append(out)
+            parity.check_pcm(fx["frames"][s]["pcmf"], np.array(got))
+            st = np.concatenate([cur, prev, enh])
+            parity.check_state(fx["final"][s], st)

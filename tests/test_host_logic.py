@@ -173,3 +173,17 @@ def test_table_broadcast_and_sharding_world_size_2(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_shim_library_exports_every_declared_symbol():
+    import shim_lib
+
+    assert os.path.exists(shim_lib.PATH), "libmbe_neo_amd.so not built"
+    names = shim_lib.declared_symbols()
+    assert len(names) >= 30
+    try:
+        handle = C.CDLL(shim_lib.PATH)
+    except OSError as e:
+        pytest.skip(f"HIP runtime not loadable here: {e}")
+    for name in names:
+        assert hasattr(handle, name), f"libmbe_neo_amd.so does not export {name}"
