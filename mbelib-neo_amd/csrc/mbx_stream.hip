@@ -125,11 +125,12 @@ __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restric
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS scratch.
 // ------------------------------------------------------------------------------------------
-constexpr int kTrStride = 65;   // 64 harmonics + 1 pad dword: column sums are conflict-free
+constexpr int kTrStride = 68;   // 64 harmonics + 4 pad dwords: rows stay 16-B aligned and the
+                                // ds_read_b128 column sums are bank-conflict free (row*68 mod 64 = row*4)
 
 struct WaveScratch {
     union {
-        float  tr[64 * kTrStride];   // voiced bank: [sample-in-block][harmonic] transposition tile
+        alignas(16) float tr[64 * kTrStride];   // voiced bank: [sample-in-block][harmonic] transposition tile
         float2 fft[256];             // unvoiced: in-place radix-4 FFT
     };
     float scale[132];                // per-bin unvoiced scale, bins 0..128
@@ -586,33 +587,86 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         const bool any = __ballot(wv_p || wv_c) != 0ULL;
         if (any) {
+            // window values for this lane's samples (lane = sample); broadcast per sample with
+            // v_readlane instead of a memory load inside the recurrence
             const float* Ws = T->ws;
+            int wp_bits[3], wc_bits[3];
+#pragma unroll
             for (int nb = 0; nb < 3; ++nb) {
-                const int rows = (nb == 2) ? 32 : 64;
-                for (int i = 0; i < rows; ++i) {
-                    const int n = nb * 64 + i;
-                    // prev weight Ws[n+160] is zero from n = 105 on, cur weight Ws[n] below n = 56
-                    float v = 0.0f;
-                    if (n < 105) {
-                        v = gp * Ws[n + N] * cp;
-                        rotate(cp, sp, cdp, sdp);
-                    }
-                    if (n >= 56) {
-                        v += gc * Ws[n] * cc;
-                    }
-                    rotate(cc, sc, cdc, sdc);
-                    S.tr[i * kTrStride + lane] = v;
-                }
+                const int n = lane + 64 * nb;
+                wp_bits[nb] = __float_as_int((n < N) ? Ws[n + N] : 0.0f);
+                wc_bits[nb] = __float_as_int((n < N) ? Ws[n] : 0.0f);
+            }
+            // sum the 64 harmonic columns of this lane's sample row (columns of lanes that are not
+            // active hold exact zeros, so the fixed trip count does not change the value)
+            auto flush = [&](int nb, int rows) {
                 wave_lds_sync();
                 if (lane < rows) {
-                    float s = 0.0f;
-                    for (int h = 1; h <= maxl; ++h) {
-                        s += S.tr[lane * kTrStride + h];
+                    const float4* row = reinterpret_cast<const float4*>(&S.tr[lane * kTrStride]);
+                    float sacc = 0.0f;
+#pragma unroll 1
+                    for (int c = 0; c < 4; ++c) {
+                        float4 q[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            q[k] = row[4 * c + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            sacc += q[k].x;
+                            sacc += q[k].y;
+                            sacc += q[k].z;
+                            sacc += q[k].w;
+                        }
                     }
-                    acc[nb] += s;
+                    acc[nb] += sacc;
                 }
                 wave_lds_sync();
+            };
+            // prev weight Ws[n+160] is zero from n = 105 on, cur weight Ws[n] below n = 56; the
+            // cur oscillator still advances through its first 56 samples like the reference's does
+#pragma unroll 8
+            for (int n = 0; n < 56; ++n) {
+                const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[0], n));
+                S.tr[n * kTrStride + lane] = gp * wp * cp;
+                rotate(cp, sp, cdp, sdp);
+                rotate(cc, sc, cdc, sdc);
             }
+#pragma unroll 8
+            for (int n = 56; n < 64; ++n) {
+                const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[0], n));
+                const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[0], n));
+                float v = gp * wp * cp;
+                v += gc * wc * cc;
+                S.tr[n * kTrStride + lane] = v;
+                rotate(cp, sp, cdp, sdp);
+                rotate(cc, sc, cdc, sdc);
+            }
+            flush(0, 64);
+#pragma unroll 8
+            for (int n = 64; n < 105; ++n) {
+                const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[1], n - 64));
+                const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[1], n - 64));
+                float v = gp * wp * cp;
+                v += gc * wc * cc;
+                S.tr[(n - 64) * kTrStride + lane] = v;
+                rotate(cp, sp, cdp, sdp);
+                rotate(cc, sc, cdc, sdc);
+            }
+#pragma unroll 8
+            for (int n = 105; n < 128; ++n) {
+                const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[1], n - 64));
+                S.tr[(n - 64) * kTrStride + lane] = 0.0f + gc * wc * cc;
+                rotate(cc, sc, cdc, sdc);
+            }
+            flush(1, 64);
+#pragma unroll 8
+            for (int n = 128; n < 160; ++n) {
+                const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[2], n - 128));
+                S.tr[(n - 128) * kTrStride + lane] = 0.0f + gc * wc * cc;
+                rotate(cc, sc, cdc, sdc);
+            }
+            flush(2, 32);
         }
     }
 
@@ -785,7 +839,7 @@ __device__ __forceinline__ void store_rng(const StreamRng& r, mbx_stream_rng* p,
 // ------------------------------------------------------------------------------------------
 // IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, mbe_parms* __restrict__ state,
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                    mbe_process_result* __restrict__ results, DeviceTables tabs) {
@@ -1136,7 +1190,7 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
     cur.tonePhase = dual ? (p2 + 160u * s2) : p2;
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, mbe_parms* __restrict__ state,
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                    mbe_process_result* __restrict__ results, DeviceTables tabs) {
