@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--workload", default="imbe_voiced", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (mbx_debug_set_ablation); results invalid")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +131,7 @@ def main():
     d_frames = dec.to_device(frames)
     out = dec.make_outputs(T, want_pcm16=True, want_float=False, want_results=True)
     L = _native.lib()
+    L.mbx_debug_set_ablation(0)
     stream = torch.cuda.current_stream().cuda_stream
     fec = L.mbx_fec_imbe7200x4400 if codec == 0 else L.mbx_fec_ambe3600x2450
     n = S * T
@@ -148,6 +150,7 @@ def main():
 
     for _ in range(max(1, args.warmup)):  # the first pass also warms the model state
         step()
+    L.mbx_debug_set_ablation(args.ablate)  # development aid; 0 in every reported run
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
@@ -188,7 +191,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not args.ablate else f"synthetic, ABLATED stages mask={args.ablate} (timing only, INVALID as a result)",
         "config": {
             "workload": desc,
             "streams_per_gpu": S,

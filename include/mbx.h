@@ -125,6 +125,11 @@ int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* r
 void mbx_rng_default(mbx_stream_rng* rng);
 void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed);
 
+/* Development aid for profiling: disables stages of the stream kernels (results become meaningless,
+ * timing only; bit 0 decode, 1 enhance, 2 oscillator set-up, 3 oscillator loop, 4 interpolated low
+ * harmonics, 5 unvoiced FFT path, 6 phase update, 7 whole synthesis).  0 = normal operation. */
+void mbx_debug_set_ablation(int mask);
+
 /* name of the dominant kernel and last launch geometry, for the bench */
 const char* mbx_stream_kernel_name(int codec);
 

@@ -35,7 +35,7 @@ namespace {
 struct Context {
     bool               ready = false;
     int                device = -1;
-    mbx::DeviceTables  tabs{nullptr, nullptr};
+    mbx::DeviceTables  tabs{nullptr, nullptr, 0};
     void*              d_blob = nullptr;
     void*              d_derived = nullptr;
     uint32_t           checksum = 0;
@@ -143,7 +143,9 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     if (g_ctx.ready) {
         (void)hipFree(g_ctx.d_blob);
         (void)hipFree(g_ctx.d_derived);
+        const int keep = g_ctx.tabs.ablate;
         g_ctx = Context{};
+        g_ctx.tabs.ablate = keep;
     }
 
     // derived tables
@@ -412,6 +414,8 @@ int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int
                        d_in, n, d_out, d_errs, g_ctx.tabs);
     return check_launch("ecc_words_kernel");
 }
+
+void mbx_debug_set_ablation(int mask) { g_ctx.tabs.ablate = mask; }
 
 const char* mbx_stream_kernel_name(int codec) {
     return codec == MBX_CODEC_IMBE7200X4400 ? "imbe_stream_kernel" : "ambe_stream_kernel";

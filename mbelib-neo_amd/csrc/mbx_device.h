@@ -24,6 +24,7 @@ struct DerivedTables {
 struct DeviceTables {
     const mbx_tables*    t;
     const DerivedTables* d;
+    int                  ablate;   // timing-only stage mask (mbx_debug_set_ablation); 0 in normal use
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }

@@ -23,7 +23,13 @@
 // Numerics: integer decisions are reproduced exactly; float expressions keep the reference's
 // operand order with FMA contraction off, so differences come only from (1) libm vs ocml
 // transcendentals (<= 1-2 ulp), (2) the order of sums across harmonics, (3) the FFT.
+#include <type_traits>
+
 #include "mbx_device.h"
+
+#ifndef MBX_STREAM_WAVES_PER_SIMD
+#define MBX_STREAM_WAVES_PER_SIMD 2   // occupancy target of the stream kernels (caps VGPRs at 512 / n)
+#endif
 
 namespace mbx {
 
@@ -127,14 +133,17 @@ __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restric
 // ------------------------------------------------------------------------------------------
 constexpr int kTrStride = 68;   // 64 harmonics + 4 pad dwords: rows stay 16-B aligned and the
                                 // ds_read_b128 column sums are bank-conflict free (row*68 mod 64 = row*4)
+constexpr int kTrRows = 32;     // samples per transposition tile
 
 struct WaveScratch {
     union {
-        alignas(16) float tr[64 * kTrStride];   // voiced bank: [sample-in-block][harmonic] transposition tile
-        float2 fft[256];             // unvoiced: in-place radix-4 FFT
+        alignas(16) float tr[kTrRows * kTrStride];   // voiced bank: [sample-in-block][harmonic] tile
+        struct {                                      // unvoiced path (the tile is dead by then)
+            float2 fft[256];                          //   in-place radix-4 FFT
+            float  uwr[256];                          //   real inverse-FFT output (natural order)
+            float  scale[132];                        //   per-bin scale, bins 0..128
+        };
     };
-    float scale[132];                // per-bin unvoiced scale, bins 0..128
-    float uwr[256];                  // real inverse-FFT output (natural order)
     int   word[64];                  // IMBE parameter words b_m
     float gm[32];                    // gains [0..15], block means Ri [16..31]
     float cik[96];                   // IMBE [7][11], AMBE [5][18]
@@ -514,7 +523,7 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     const int numUv = popc64(__ballot(lane <= cur.L && cur.Vl == 0));
     const float cw0 = cur.w0, pw0 = prev.w0;
     const float TWO_PI = 2.0f * (float)M_PI;
-    if (lane >= 1 && lane <= 56) {
+    if (lane >= 1 && lane <= 56 && !(tabs.ablate & 64)) {
         float wrapped = fmodf(prev.PSIl, TWO_PI);
         if (wrapped < 0.0f) {
             wrapped += TWO_PI;
@@ -538,7 +547,7 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     float acc[3] = {0.0f, 0.0f, 0.0f};
 
     // (1) low harmonics with a stable pitch: lane = sample, loop over the (<= 7) harmonics
-    unsigned long long imask = __ballot(interp);
+    unsigned long long imask = (tabs.ablate & 16) ? 0ULL : __ballot(interp);
     while (imask) {
         const int l = __ffsll((long long)imask) - 1;
         imask &= imask - 1;
@@ -560,7 +569,7 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     // (2) windowed oscillators: lane = harmonic, advanced sample by sample with the reference's
     //     plane rotation; the [sample][harmonic] tile goes through LDS and is summed per sample
     {
-        const bool wv_p = pv && !interp, wv_c = cv && !interp;
+        const bool wv_p = pv && !interp && !(tabs.ablate & 4), wv_c = cv && !interp && !(tabs.ablate & 4);
         const float cw0l = cw0 * (float)lane, pw0l = pw0 * (float)lane;
         float gp = 0.0f, sdp = 0.0f, cdp = 0.0f, sp = 0.0f, cp = 0.0f;
         float gc = 0.0f, sdc = 0.0f, cdc = 0.0f, sc = 0.0f, cc = 0.0f;
@@ -585,7 +594,7 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 cc = d;
             }
         }
-        const bool any = __ballot(wv_p || wv_c) != 0ULL;
+        const bool any = (__ballot(wv_p || wv_c) != 0ULL) && !(tabs.ablate & 8);
         if (any) {
             // window values for this lane's samples (lane = sample); broadcast per sample with
             // v_readlane instead of a memory load inside the recurrence
@@ -597,81 +606,69 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 wp_bits[nb] = __float_as_int((n < N) ? Ws[n + N] : 0.0f);
                 wc_bits[nb] = __float_as_int((n < N) ? Ws[n] : 0.0f);
             }
-            // sum the 64 harmonic columns of this lane's sample row (columns of lanes that are not
-            // active hold exact zeros, so the fixed trip count does not change the value)
-            auto flush = [&](int nb, int rows) {
+            // Tile of 32 samples x 64 harmonic columns.  Row r is summed by two lanes (r: columns
+            // 0..31, r+32: columns 32..63; columns of inactive lanes hold exact zeros), the halves
+            // are combined across the lane pair and land in the lane that owns sample 32*b + r.
+            auto flush = [&](int b) {
                 wave_lds_sync();
-                if (lane < rows) {
-                    const float4* row = reinterpret_cast<const float4*>(&S.tr[lane * kTrStride]);
-                    float sacc = 0.0f;
-#pragma unroll 1
-                    for (int c = 0; c < 4; ++c) {
-                        float4 q[4];
+                const float4* row = reinterpret_cast<const float4*>(&S.tr[(lane & 31) * kTrStride + (lane & 32)]);
+                float4 q[8];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            q[k] = row[4 * c + k];
-                        }
+                for (int k = 0; k < 8; ++k) {
+                    q[k] = row[k];
+                }
+                float sacc = 0.0f;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            sacc += q[k].x;
-                            sacc += q[k].y;
-                            sacc += q[k].z;
-                            sacc += q[k].w;
-                        }
-                    }
-                    acc[nb] += sacc;
+                for (int k = 0; k < 8; ++k) {
+                    sacc += q[k].x;
+                    sacc += q[k].y;
+                    sacc += q[k].z;
+                    sacc += q[k].w;
+                }
+                sacc += __shfl_xor(sacc, 32, kWave);
+                if ((lane >> 5) == (b & 1)) {
+                    acc[b >> 1] += sacc;
                 }
                 wave_lds_sync();
             };
             // prev weight Ws[n+160] is zero from n = 105 on, cur weight Ws[n] below n = 56; the
             // cur oscillator still advances through its first 56 samples like the reference's does
+            auto segment = [&](int n0, int n1, auto has_prev, auto has_cur, int wreg) {
 #pragma unroll 8
-            for (int n = 0; n < 56; ++n) {
-                const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[0], n));
-                S.tr[n * kTrStride + lane] = gp * wp * cp;
-                rotate(cp, sp, cdp, sdp);
-                rotate(cc, sc, cdc, sdc);
-            }
-#pragma unroll 8
-            for (int n = 56; n < 64; ++n) {
-                const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[0], n));
-                const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[0], n));
-                float v = gp * wp * cp;
-                v += gc * wc * cc;
-                S.tr[n * kTrStride + lane] = v;
-                rotate(cp, sp, cdp, sdp);
-                rotate(cc, sc, cdc, sdc);
-            }
-            flush(0, 64);
-#pragma unroll 8
-            for (int n = 64; n < 105; ++n) {
-                const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[1], n - 64));
-                const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[1], n - 64));
-                float v = gp * wp * cp;
-                v += gc * wc * cc;
-                S.tr[(n - 64) * kTrStride + lane] = v;
-                rotate(cp, sp, cdp, sdp);
-                rotate(cc, sc, cdc, sdc);
-            }
-#pragma unroll 8
-            for (int n = 105; n < 128; ++n) {
-                const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[1], n - 64));
-                S.tr[(n - 64) * kTrStride + lane] = 0.0f + gc * wc * cc;
-                rotate(cc, sc, cdc, sdc);
-            }
-            flush(1, 64);
-#pragma unroll 8
-            for (int n = 128; n < 160; ++n) {
-                const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[2], n - 128));
-                S.tr[(n - 128) * kTrStride + lane] = 0.0f + gc * wc * cc;
-                rotate(cc, sc, cdc, sdc);
-            }
-            flush(2, 32);
+                for (int n = n0; n < n1; ++n) {
+                    float v = 0.0f;
+                    if constexpr (decltype(has_prev)::value) {
+                        const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[wreg], n & 63));
+                        v = gp * wp * cp;
+                        rotate(cp, sp, cdp, sdp);
+                    }
+                    if constexpr (decltype(has_cur)::value) {
+                        const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[wreg], n & 63));
+                        v += gc * wc * cc;
+                    }
+                    S.tr[(n & 31) * kTrStride + lane] = v;
+                    rotate(cc, sc, cdc, sdc);
+                }
+            };
+            using Yes = std::true_type;
+            using No = std::false_type;
+            segment(0, 32, Yes{}, No{}, 0);
+            flush(0);
+            segment(32, 56, Yes{}, No{}, 0);
+            segment(56, 64, Yes{}, Yes{}, 0);
+            flush(1);
+            segment(64, 96, Yes{}, Yes{}, 1);
+            flush(2);
+            segment(96, 105, Yes{}, Yes{}, 1);
+            segment(105, 128, No{}, Yes{}, 1);
+            flush(3);
+            segment(128, 160, No{}, Yes{}, 2);
+            flush(4);
         }
     }
 
     // ---- unvoiced: window, 256-point FFT, per-band scaling, inverse FFT, overlap-add ----------
-    {
+    if (!(tabs.ablate & 32)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = lane + 64 * j;
@@ -839,61 +836,86 @@ __device__ __forceinline__ void store_rng(const StreamRng& r, mbx_stream_rng* p,
 // ------------------------------------------------------------------------------------------
 // IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
 imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, mbe_parms* __restrict__ state,
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                   mbe_process_result* __restrict__ results, DeviceTables tabs) {
+                   mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
     const int s = blockIdx.x;
     if (s >= S) {
         return;
     }
-    const int lane = lane_id();
-    Parms cur, prev, enh;
-    load_parms(cur, &state[3 * (size_t)s + 0], lane);
-    load_parms(prev, &state[3 * (size_t)s + 1], lane);
-    load_parms(enh, &state[3 * (size_t)s + 2], lane);
+    const int lane_in = lane_id();
+    // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
+    // registers for the whole launch; `prev` is only needed from the start of a frame to the
+    // snapshot and `enh` only from the snapshot to the end of synthesis, so both are parked in
+    // their own HBM/L2 slots in between (exactly the loads and stores a T = 1 launch needs anyway).
+    mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
+    mbe_parms* const slot_prev = &state[3 * (size_t)s + 1];
+    mbe_parms* const slot_enh = &state[3 * (size_t)s + 2];
+    Parms cur;
+    load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
     load_rng(rng, &rngs[s]);
 
     for (int t = 0; t < Tn; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+        // Keep per-frame table values out of the loop-carried register set: without this the compiler
+        // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
+        // across the frame loop, which halves the occupancy.
+        DeviceTables ft = tabs_in;
+        int lane = lane_in;
+        asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
+        const DeviceTables& tabs = ft;
         const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
         const uint32_t w[3] = {rec.x, rec.y, rec.z};
         const int c0 = (int)(rec.w & 0xffu), prot = (int)((rec.w >> 8) & 0xffu), c4 = (int)((rec.w >> 16) & 0xffu);
         unsigned flags = (rec.w >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
         const int total = c0 + prot;
+        bool muted;
+        {
+            Parms prev;
+            load_parms(prev, slot_prev, lane);
 
-        // prepare (imbe4400_prepare_process)
-        cur.errorCount4 = c4;
-        cur.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
-        cur.errorCountTotal = total;
-        cur.errorRate = (0.95f * prev.errorRate) + (0.000365f * (float)total);
+            // prepare (imbe4400_prepare_process)
+            cur.errorCount4 = c4;
+            cur.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
+            cur.errorCountTotal = total;
+            cur.errorRate = (0.95f * prev.errorRate) + (0.000365f * (float)total);
 
-        const int bad = decode_imbe(w, cur, prev, scratch, tabs.t, lane);
-        const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
-        const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
-        const bool repeat = (bad == 1) || (c0_valid ? ((c0 >= 2) && ((float)total >= repeat_threshold)) : (total > 5));
-        if (!repeat) {
-            cur.repeatCount = 0;
-        } else {
-            if (prev.repeatCount > (MBE_MAX_FRAME_REPEATS - 1)) {
-                imbe_headroom_reset(cur, lane);
+            const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(w, cur, prev, scratch, tabs.t, lane);
+            const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
+            const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
+            const bool repeat =
+                (bad == 1) || (c0_valid ? ((c0 >= 2) && ((float)total >= repeat_threshold)) : (total > 5));
+            if (!repeat) {
+                cur.repeatCount = 0;
             } else {
-                cur = prev;
-                cur.repeatCount++;
+                if (prev.repeatCount > (MBE_MAX_FRAME_REPEATS - 1)) {
+                    imbe_headroom_reset(cur, lane);
+                } else {
+                    cur = prev;
+                    cur.repeatCount++;
+                }
+                flags |= MBE_PROCESS_FLAG_REPEAT;
             }
-            flags |= MBE_PROCESS_FLAG_REPEAT;
+            muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
         }
-        const bool muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
-        prev = cur;
-        const float rm0 = enhance(cur, lane);
-        float out[3];
-        synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
+        store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
+        float out[3] = {0.0f, 0.0f, 0.0f};
+        {
+            Parms enh;
+            load_parms(enh, slot_enh, lane);
+            const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
+            if (!(tabs.ablate & 128)) {
+                synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
+            }
+        }
         if (muted) {
             flags |= MBE_PROCESS_FLAG_MUTE;
         }
-        enh = cur;
+        store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
+        __threadfence_block();               // the next frame of this wave reloads both slots
 
         store_pcm(out, f, pcm16, pcmf, lane);
         if (results && lane == 0) {
@@ -907,10 +929,8 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         }
     }
 
-    store_parms(cur, &state[3 * (size_t)s + 0], lane);
-    store_parms(prev, &state[3 * (size_t)s + 1], lane);
-    store_parms(enh, &state[3 * (size_t)s + 2], lane);
-    store_rng(rng, &rngs[s], lane);
+    store_parms(cur, slot_cur, lane_in);
+    store_rng(rng, &rngs[s], lane_in);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1190,92 +1210,121 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
     cur.tonePhase = dual ? (p2 + 160u * s2) : p2;
 }
 
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
 ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, mbe_parms* __restrict__ state,
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                   mbe_process_result* __restrict__ results, DeviceTables tabs) {
+                   mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
     const int s = blockIdx.x;
     if (s >= S) {
         return;
     }
-    const int lane = lane_id();
-    Parms cur, prev, enh;
-    load_parms(cur, &state[3 * (size_t)s + 0], lane);
-    load_parms(prev, &state[3 * (size_t)s + 1], lane);
-    load_parms(enh, &state[3 * (size_t)s + 2], lane);
+    const int lane_in = lane_id();
+    // Same register discipline as the IMBE kernel: `cur` resident, `prev` / `enh` parked in their slots.
+    mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
+    mbe_parms* const slot_prev = &state[3 * (size_t)s + 1];
+    mbe_parms* const slot_enh = &state[3 * (size_t)s + 2];
+    Parms cur;
+    load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
     load_rng(rng, &rngs[s]);
 
     for (int t = 0; t < Tn; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+        // Keep per-frame table values out of the loop-carried register set: without this the compiler
+        // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
+        // across the frame loop, which halves the occupancy.
+        DeviceTables ft = tabs_in;
+        int lane = lane_in;
+        asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
+        const DeviceTables& tabs = ft;
         const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
         const uint32_t w[3] = {rec.x, rec.y, rec.z};
         const int c0 = (int)(rec.w & 0xffu), prot = (int)((rec.w >> 8) & 0xffu);
         unsigned flags = (rec.w >> 24) & 0xffu;   // C0_VALID
         const int total = c0 + prot;
+        int bad;
+        bool prev_max_repeat;
+        {
+            Parms prev;
+            load_parms(prev, slot_prev, lane);
+            // prepare (ambe2450_prepare_process): state that came from the generic initialiser is
+            // replaced by the AMBE defaults in all three structs
+            if (fabsf(prev.mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f) {
+                init_ambe_parms(prev, lane);
+                cur = prev;
+                store_parms(prev, slot_prev, lane);
+                store_parms(prev, slot_enh, lane);
+                __threadfence_block();
+            }
+            cur.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
+            cur.errorCountTotal = total;
+            cur.errorCount4 = 0;
+            cur.errorRate = (0.95f * prev.errorRate) + (0.001064f * (float)total);
 
-        // prepare (ambe2450_prepare_process)
-        if (fabsf(prev.mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f) {
-            init_ambe_parms(prev, lane);
-            cur = prev;
-            enh = prev;
-        }
-        cur.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
-        cur.errorCountTotal = total;
-        cur.errorCount4 = 0;
-        cur.errorRate = (0.95f * prev.errorRate) + (0.001064f * (float)total);
-
-        const int bad = decode_ambe(w, cur, prev, scratch, tabs, total, lane);
-        if (bad == 2) {
-            flags |= MBE_PROCESS_FLAG_ERASURE;
-            cur.repeatCount = 0;
-            set_ambe_erasure_parms(cur, prev, lane);
-        } else if (bad == 7) {
-            flags |= MBE_PROCESS_FLAG_TONE;
-            cur.repeatCount = 0;
-        } else if (((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? ((c0 >= 4) || ((c0 >= 2) && (total >= 6))) : (total > 3)) {
-            cur = prev;
-            cur.repeatCount++;
-            flags |= MBE_PROCESS_FLAG_REPEAT;
-        } else {
-            cur.repeatCount = 0;
+            bad = decode_ambe(w, cur, prev, scratch, tabs, total, lane);
+            prev_max_repeat = prev.repeatCount >= MBE_MAX_FRAME_REPEATS;
+            if (bad == 2) {
+                flags |= MBE_PROCESS_FLAG_ERASURE;
+                cur.repeatCount = 0;
+                set_ambe_erasure_parms(cur, prev, lane);
+            } else if (bad == 7) {
+                flags |= MBE_PROCESS_FLAG_TONE;
+                cur.repeatCount = 0;
+            } else if (((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? ((c0 >= 4) || ((c0 >= 2) && (total >= 6))) : (total > 3)) {
+                cur = prev;
+                cur.repeatCount++;
+                flags |= MBE_PROCESS_FLAG_REPEAT;
+            } else {
+                cur.repeatCount = 0;
+            }
         }
 
         float out[3];
+        auto reinit_all = [&]() {   // mbe_initAmbeParms_common(cur, prev, prev_enhanced)
+            init_ambe_parms(cur, lane);
+            store_parms(cur, slot_prev, lane);
+            store_parms(cur, slot_enh, lane);
+        };
         if (bad == 0) {
             if (cur.repeatCount < MBE_MAX_FRAME_REPEATS) {
-                prev = cur;
+                store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
+                Parms enh;
+                load_parms(enh, slot_enh, lane);
                 const float rm0 = enhance(cur, lane);
                 synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
-                enh = cur;
+                store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
             } else {
                 flags |= MBE_PROCESS_FLAG_MUTE;
                 comfort_noise(out, rng, lane);
-                init_ambe_parms(prev, lane);
-                cur = prev;
-                enh = prev;
+                reinit_all();
             }
         } else if (bad == 7) {
             const int id1 = (int)((w[0] >> 12) & 0xffu);   // parameter bits 12..19
             float f1, f2;
             if (tone_freqs(id1, f1, f2)) {
                 tone_frame(out, w, cur, lane);
-            } else if (!(prev.repeatCount >= MBE_MAX_FRAME_REPEATS)) {
-                Parms tmp = enh;
-                synth_core(out, tmp, enh, false, 0.0f, rng, scratch, tabs, lane);
-                enh = tmp;
+            } else if (!prev_max_repeat) {
+                // invalid tone id: run the synthesiser on a copy of the enhanced model.  `cur` is parked
+                // in its slot meanwhile so that still only two structs are live.
+                store_parms(cur, slot_cur, lane);
+                __threadfence_block();
+                Parms enh;
+                load_parms(enh, slot_enh, lane);
+                cur = enh;
+                synth_core(out, cur, enh, false, 0.0f, rng, scratch, tabs, lane);
+                store_parms(cur, slot_enh, lane);
+                load_parms(cur, slot_cur, lane);
             } else {
                 comfort_noise(out, rng, lane);
-                init_ambe_parms(prev, lane);
-                cur = prev;
-                enh = prev;
+                reinit_all();
             }
         } else {
             comfort_noise(out, rng, lane);
-            prev = cur;
-            enh = cur;
+            store_parms(cur, slot_prev, lane);
+            store_parms(cur, slot_enh, lane);
         }
+        __threadfence_block();   // the next frame of this wave reloads the parked structs
 
         store_pcm(out, f, pcm16, pcmf, lane);
         if (results && lane == 0) {
@@ -1289,10 +1338,8 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         }
     }
 
-    store_parms(cur, &state[3 * (size_t)s + 0], lane);
-    store_parms(prev, &state[3 * (size_t)s + 1], lane);
-    store_parms(enh, &state[3 * (size_t)s + 2], lane);
-    store_rng(rng, &rngs[s], lane);
+    store_parms(cur, slot_cur, lane_in);
+    store_rng(rng, &rngs[s], lane_in);
 }
 
 // mbe_synthesizeSpeechf for S independent (cur, prev) pairs.
