@@ -10,7 +10,7 @@
  *
  * Pointers whose name starts with d_ are DEVICE pointers (hipMalloc / torch CUDA tensors);
  * `stream` is a hipStream_t passed as void* (NULL = default stream).  All launchers are
- * asynchronous on `stream`, never allocate, never synchronise, and return 0 or a negative
+ * asynchronous on `stream`, never synchronise, never allocate (after mbx_reserve()), and return 0 or a negative
  * MBE_STATUS_* / MBX_E* code.  There is no CPU fallback: without a HIP device every launcher
  * fails with MBX_ENODEVICE.
  */
@@ -42,6 +42,12 @@ void mbx_shutdown(void);
 /* FNV-1a-32 of the resident table blob (for the per-rank checksum after the broadcast). */
 uint32_t mbx_table_checksum(void);
 const char* mbx_last_error(void);
+
+/* Size the internal workspace of the stream stage (256 B per frame for the expanded parameters) for
+ * launches of up to `max_frames` = S*T frames.  Launchers never allocate once this has been called
+ * with a large enough value (required before graph capture); without it mbx_process_records() grows
+ * the workspace on demand, which synchronises the device. */
+int mbx_reserve(size_t max_frames);
 
 /* ---- host-side frame packing (no device work) ----------------------------------------- */
 
@@ -78,6 +84,16 @@ int mbx_fec_ambe3600x2450(const uint8_t* d_frames /* n*9 */, size_t n, mbx_param
  * Outputs (each may be NULL): int16 PCM (mbe_floattoshort applied, ref src/core/mbelib.c:1296),
  * float PCM, per-frame mbe_process_result. */
 int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
+                        mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                        void* stream);
+
+/* The two halves of mbx_process_records(), exposed so that a caller (bench.py) can time them apart:
+ * mbx_expand_records() runs the frame-parallel, stateless half of the parameter decode (one thread per
+ * frame: fundamental, voicing, dequantisation, block inverse DCTs; ref src/imbe/imbe7200x4400.c:117-270,
+ * src/ambe/ambe3600x2450.c:176-387) into the internal workspace; mbx_stream_expanded() runs the
+ * stateful half (prediction, policy, synthesis) on that workspace, one wavefront per stream. */
+int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream);
+int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream);
 

@@ -22,6 +22,7 @@ _sz = C.c_size_t
 _SIGNATURES = {
     "mbx_init": (C.c_int, [C.c_int, _vp, _sz]),
     "mbx_shutdown": (None, []),
+    "mbx_reserve": (C.c_int, [_sz]),
     "mbx_table_checksum": (C.c_uint32, []),
     "mbx_last_error": (C.c_char_p, []),
     "mbx_pack_imbe7200x4400": (C.c_int, [_vp, _sz, _vp]),
@@ -30,6 +31,8 @@ _SIGNATURES = {
     "mbx_fec_imbe7200x4400": (C.c_int, [_vp, _sz, _vp, _vp]),
     "mbx_fec_ambe3600x2450": (C.c_int, [_vp, _sz, _vp, _vp]),
     "mbx_process_records": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_expand_records": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "mbx_stream_expanded": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_synthesize_speech": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_floattoshort": (C.c_int, [_vp, _vp, _sz, _vp]),

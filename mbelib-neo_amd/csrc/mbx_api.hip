@@ -18,10 +18,12 @@ namespace mbx {
 __global__ void fec_imbe7200x4400_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
 __global__ void fec_ambe3600x2450_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
 __global__ void floattoshort_kernel(const float*, int16_t*, size_t);
-__global__ void imbe_stream_kernel(int, int, const mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
-                                   mbe_process_result*, DeviceTables);
-__global__ void ambe_stream_kernel(int, int, const mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
-                                   mbe_process_result*, DeviceTables);
+__global__ void expand_imbe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
+__global__ void expand_ambe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
+__global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                   int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                   int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void synth_speech_kernel(int, mbe_parms*, mbe_parms*, mbx_stream_rng*, float*, int16_t*, DeviceTables);
 __global__ void enhance_kernel(int, mbe_parms*);
 __global__ void smoothing_kernel(int, mbe_parms*, const mbe_parms*);
@@ -39,6 +41,8 @@ struct Context {
     void*              d_blob = nullptr;
     void*              d_derived = nullptr;
     uint32_t           checksum = 0;
+    mbx::FrameParams*  workspace = nullptr;   // expand-stage output, grow-only (mbx_reserve)
+    size_t             workspace_frames = 0;
 };
 Context     g_ctx;
 std::mutex  g_mu;
@@ -143,6 +147,7 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     if (g_ctx.ready) {
         (void)hipFree(g_ctx.d_blob);
         (void)hipFree(g_ctx.d_derived);
+        (void)hipFree(g_ctx.workspace);
         const int keep = g_ctx.tabs.ablate;
         g_ctx = Context{};
         g_ctx.tabs.ablate = keep;
@@ -166,6 +171,15 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     for (int L = 1; L < 64; ++L) {
         d.log2_int[L] = log2f((float)L);
     }
+    memset(d.imbe_inv_bo, 255, sizeof(d.imbe_inv_bo));
+    for (int l9 = 0; l9 < 48; ++l9) {
+        for (int i = 0; i < 79; ++i) {
+            const int word = host->imbe_bo[l9][i][0], bit = host->imbe_bo[l9][i][1];
+            if (word < 58 && bit < 12) {
+                d.imbe_inv_bo[l9][word][bit] = (uint8_t)(i + 6);
+            }
+        }
+    }
 
     HIP_TRY(hipMalloc(&g_ctx.d_blob, sizeof(mbx_tables)));
     HIP_TRY(hipMalloc(&g_ctx.d_derived, sizeof(mbx::DerivedTables)));
@@ -184,6 +198,7 @@ void mbx_shutdown(void) {
     if (g_ctx.ready) {
         (void)hipFree(g_ctx.d_blob);
         (void)hipFree(g_ctx.d_derived);
+        (void)hipFree(g_ctx.workspace);
     }
     g_ctx = Context{};
 }
@@ -260,6 +275,22 @@ void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed) {   // ref: src/core/mbeli
         }                                                         \
     } while (0)
 
+int mbx_reserve(size_t max_frames) {
+    REQUIRE_READY();
+    if (max_frames <= g_ctx.workspace_frames) {
+        return 0;
+    }
+    if (g_ctx.workspace) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(g_ctx.workspace));
+        g_ctx.workspace = nullptr;
+        g_ctx.workspace_frames = 0;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_ctx.workspace), max_frames * sizeof(mbx::FrameParams)));
+    g_ctx.workspace_frames = max_frames;
+    return 0;
+}
+
 int mbx_fec_imbe7200x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d_records, void* stream) {
     REQUIRE_READY();
     if (!d_frames || !d_records) {
@@ -288,7 +319,30 @@ int mbx_fec_ambe3600x2450(const uint8_t* d_frames, size_t n, mbx_param_record* d
     return check_launch("fec_ambe3600x2450_kernel");
 }
 
-int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
+int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream) {
+    REQUIRE_READY();
+    if (!d_records || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    int rc = mbx_reserve(n);
+    if (rc < 0) {
+        return rc;
+    }
+    const unsigned egrid = (unsigned)((n + 63) / 64);
+    if (codec == MBX_CODEC_IMBE7200X4400) {
+        hipLaunchKernelGGL(mbx::expand_imbe_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
+                           g_ctx.workspace, g_ctx.tabs);
+    } else {
+        hipLaunchKernelGGL(mbx::expand_ambe_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
+                           g_ctx.workspace, g_ctx.tabs);
+    }
+    return check_launch("expand_kernel");
+}
+
+int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream) {
     REQUIRE_READY();
@@ -299,14 +353,30 @@ int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_recor
     if (S == 0 || T == 0) {
         return 0;
     }
+    if ((size_t)S * (size_t)T > g_ctx.workspace_frames) {
+        return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_stream_expanded: mbx_expand_records() has not been run for this batch");
+    }
     if (codec == MBX_CODEC_IMBE7200X4400) {
         hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
-                           d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+                           g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
         return check_launch("imbe_stream_kernel");
     }
     hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
-                       d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+                       g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
     return check_launch("ambe_stream_kernel");
+}
+
+int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
+                        mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                        void* stream) {
+    if (S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = mbx_expand_records(codec, d_records, (size_t)S * (size_t)T, stream);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbx_stream_expanded(codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
 }
 
 int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,

@@ -1,0 +1,281 @@
+// mbx_expand.hip -- stateless half of the parameter decode, ONE THREAD PER FRAME.
+//
+// Everything in mbe_decodeImbe4400Parms / mbe_decodeAmbe2450Parms that depends only on the 88 / 49
+// parameter bits -- fundamental, voicing decisions, gain / PRBA / higher-order coefficient
+// dequantisation, the block inverse DCTs that yield the prediction residuals T_l -- is independent
+// between frames, so it runs here with full thread parallelism and in the reference's own
+// (sequential) summation order.  What is left for the stream kernel is the part that needs the
+// previous frame: the log-magnitude prediction.
+//
+// Replaces (ref = arancormonk/mbelib-neo v2.0.0):
+//   IMBE  src/imbe/imbe7200x4400.c:117-270  (fundamental, bit layout, voicing, gains, Ri, HOC, IDCT)
+//   AMBE  src/ambe/ambe3600x2450.c:176-387, 461-553  (classification, V/UV, gain, PRBA, HOC, IDCT)
+#include "mbx_device.h"
+
+namespace mbx {
+
+__device__ __forceinline__ int rbit(const uint32_t w[3], int i) { return (int)((w[i >> 5] >> (31 - (i & 31))) & 1u); }
+
+// value of IMBE parameter word m: bit `pos` comes from payload bit inv[m][pos] (255 = not allocated)
+__device__ __forceinline__ int imbe_word(const uint32_t w[3], const uint8_t* inv_m, int nbits) {
+    int v = 0;
+    for (int pos = 0; pos < nbits; ++pos) {
+        const int src = inv_m[pos];
+        if (src != 255) {
+            v |= rbit(w, src) << pos;
+        }
+    }
+    return v;
+}
+
+// per-thread staging row: 64 dwords + 1 pad so that the block-wide transposed write-out is conflict free
+constexpr int kRow = 65;
+
+__device__ __forceinline__ void write_out(const float (*tile)[kRow], FrameParams* out, size_t first, size_t n) {
+    // all 64 threads of the block copy the 64 staged rows, one 256-byte row per step (coalesced)
+    __syncthreads();
+    const int lane = threadIdx.x;
+    for (int r = 0; r < 64; ++r) {
+        if (first + r < n) {
+            reinterpret_cast<float*>(&out[first + r])[lane] = tile[r][lane];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
+    __shared__ float tile[64][kRow];
+    const mbx_tables* T = tabs.t;
+    const size_t first = (size_t)blockIdx.x * 64;
+    const size_t i = first + threadIdx.x;
+    float* row = tile[threadIdx.x];
+    if (i < n) {
+        const uint4 rec = *reinterpret_cast<const uint4*>(&recs[i]);
+        const uint32_t w[3] = {rec.x, rec.y, rec.z};
+        int b0 = (int)(w[0] >> 26);
+        b0 = (b0 << 1) | rbit(w, 85);
+        b0 = (b0 << 1) | rbit(w, 86);
+        int bad = 0, L = 0, K = 0;
+        float w0 = 0.0f;
+        if (b0 > 207) {
+            bad = 1;
+        } else {
+            w0 = T->imbe_w0[b0];
+            L = T->imbe_L[b0];
+            K = T->imbe_K[b0];
+            if (L == 0) {
+                bad = 1;   // the reference sets w0 but leaves L alone in this case
+            }
+        }
+        uint32_t vlo = 0, vhi = 0;
+        if (!bad) {
+            const int L9 = L - 9;
+            const uint8_t(*inv)[12] = tabs.d->imbe_inv_bo[L9];
+            // voicing: three harmonics per band, band K-1 first
+            const int b1 = imbe_word(w, inv[1], 12);
+            for (int l = 1; l <= L; ++l) {
+                int band = (K - 1) - ((l - 1) / 3);
+                band = band < 0 ? 0 : band;
+                if ((b1 >> band) & 1) {
+                    if (l <= 32) {
+                        vlo |= 1u << (l - 1);
+                    } else {
+                        vhi |= 1u << (l - 33);
+                    }
+                }
+            }
+            // gains -> 6-point inverse DCT
+            float Gm[7];
+            Gm[1] = T->imbe_B2[imbe_word(w, inv[2], 6)];
+#pragma unroll
+            for (int g = 2; g < 7; ++g) {
+                const float nb = T->imbe_ba[L9][g - 2][0];
+                const float step = T->imbe_ba[L9][g - 2][1];
+                const int inb = (int)nb;
+                const int bm = imbe_word(w, inv[g + 1], inb);
+                Gm[g] = (step * ((float)bm - ldexpf(1.0f, inb - 1) + 0.5f));
+            }
+            float Ri[7];
+#pragma unroll
+            for (int r = 1; r <= 6; ++r) {
+                float sum = 0;
+#pragma unroll
+                for (int m = 1; m <= 6; ++m) {
+                    const float am = (m == 1) ? 1.0f : 2.0f;
+                    sum = sum + (am * Gm[m] * T->imbe_ri_cos[m][r]);
+                }
+                Ri[r] = sum;
+            }
+            // higher-order coefficients and the per-block inverse DCT, block by block
+            int m = 8, l = 1;
+#pragma unroll
+            for (int blk = 1; blk <= 6; ++blk) {
+                const int ji = T->imbe_ji[L9][blk - 1];
+                float C[11];
+                C[1] = Ri[blk];
+#pragma unroll
+                for (int k = 2; k <= 10; ++k) {
+                    float v = 0.0f;
+                    if (k <= ji) {
+                        const int Bm = T->imbe_hoba[L9][m - 8];
+                        if (Bm > 0) {
+                            const int bm = imbe_word(w, inv[m], Bm);
+                            v = ((T->imbe_quantstep[Bm - 1] * T->imbe_standdev[k - 2]) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
+                        }
+                        ++m;
+                    }
+                    C[k] = v;
+                }
+                for (int j = 1; j <= ji; ++j) {
+                    float sum = 0;
+#pragma unroll
+                    for (int k = 1; k <= 10; ++k) {
+                        if (k <= ji) {
+                            const float ak = (k == 1) ? 1.0f : 2.0f;
+                            sum = sum + (ak * C[k] * T->imbe_idct_cos[ji][j][k]);
+                        }
+                    }
+                    row[l++] = sum;
+                }
+            }
+        }
+        row[57] = __uint_as_float(vlo);
+        row[58] = __uint_as_float(vhi);
+        row[59] = w0;
+        row[60] = __int_as_float(L);
+        row[61] = __int_as_float(K);
+        row[62] = __uint_as_float(rec.w);
+        row[63] = __int_as_float(bad);
+    }
+    write_out(tile, out, first, n);
+}
+
+__device__ __forceinline__ int pick(const uint32_t w[3], int i0, int i1, int i2, int i3 = -1, int i4 = -1, int i5 = -1,
+                                    int i6 = -1, int i7 = -1, int i8 = -1) {
+    const int idx[9] = {i0, i1, i2, i3, i4, i5, i6, i7, i8};
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (idx[k] >= 0) {
+            v = (v << 1) | rbit(w, idx[k]);
+        }
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64)
+expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
+    __shared__ float tile[64][kRow];
+    const mbx_tables* T = tabs.t;
+    const size_t first = (size_t)blockIdx.x * 64;
+    const size_t i = first + threadIdx.x;
+    float* row = tile[threadIdx.x];
+    if (i < n) {
+        const uint4 rec = *reinterpret_cast<const uint4*>(&recs[i]);
+        const uint32_t w[3] = {rec.x, rec.y, rec.z};
+        const int total_errors = (int)(rec.w & 0xffu) + (int)((rec.w >> 8) & 0xffu);
+        const int u0 = (int)(w[0] >> 20);
+        const int u1 = (int)((w[0] >> 8) & 0xfffu);
+        const unsigned long long two = ((unsigned long long)w[0] << 32) | w[1];
+        const int u3 = (int)((two >> 15) & 0x3fffu);
+        const bool tone_sig = (((u0 >> 6) & 0x3f) == 63) && (((u3 & 0xf) == 0) || (((u1 >> 8) & 0xf) == (u1 & 0xf)));
+        int bad = 0, L = 0;
+        float w0 = 0.0f, f0 = 0.0f, dg = 0.0f, sum42 = 0.0f;
+        uint32_t vlo = 0, vhi = 0;
+        const int b0 = pick(w, 0, 1, 2, 3, 37, 38, 39);
+        bool silence = false;
+        if (tone_sig && total_errors < 6) {
+            bad = 7;
+        } else if ((b0 >= 120 && b0 <= 123) || b0 == 126 || b0 == 127) {
+            bad = 2;
+        } else if (b0 == 124 || b0 == 125) {
+            silence = true;
+            f0 = (float)M_PI / 32.0f;
+            w0 = f0 * (float)(2.0 * M_PI);
+            L = (b0 == 124) ? 15 : 14;
+        } else {
+            f0 = T->ambe_w0[b0];
+            w0 = (float)((double)(f0 * (float)2) * M_PI);
+            L = T->ambe_L[b0];
+        }
+        if (bad == 0) {
+            if (!silence) {
+                const int b1 = pick(w, 4, 5, 6, 7, 35);
+                for (int l = 1; l <= L; ++l) {
+                    const int jl = (int)((float)l * (float)16.0 * f0);
+                    if (T->ambe_vuv[b1][jl & 7]) {
+                        if (l <= 32) {
+                            vlo |= 1u << (l - 1);
+                        } else {
+                            vhi |= 1u << (l - 33);
+                        }
+                    }
+                }
+            }
+            dg = T->ambe_dg[pick(w, 8, 9, 10, 11, 36)];
+            const int b3 = pick(w, 12, 13, 14, 15, 16, 17, 18, 19, 40);
+            const int b4 = pick(w, 20, 21, 22, 23, 41, 42, 43);
+            float Gm[9];
+            Gm[1] = 0.0f;
+            Gm[2] = T->ambe_prba24[b3][0];
+            Gm[3] = T->ambe_prba24[b3][1];
+            Gm[4] = T->ambe_prba24[b3][2];
+            Gm[5] = T->ambe_prba58[b4][0];
+            Gm[6] = T->ambe_prba58[b4][1];
+            Gm[7] = T->ambe_prba58[b4][2];
+            Gm[8] = T->ambe_prba58[b4][3];
+            float Ri[9];
+#pragma unroll
+            for (int r = 1; r <= 8; ++r) {
+                float sum = 0;
+#pragma unroll
+                for (int m = 1; m <= 8; ++m) {
+                    const float am = (m == 1) ? 1.0f : 2.0f;
+                    sum = sum + (am * Gm[m] * T->ambe_ri_cos[m][r]);
+                }
+                Ri[r] = sum;
+            }
+            const float rconst = (float)(1.0 / (2.0 * M_SQRT2));
+            const int hb[5] = {0, pick(w, 24, 25, 26, 27, 44), pick(w, 28, 29, 30, 45), pick(w, 31, 32, 33, 46), pick(w, 34, 47, 48)};
+            int l = 1;
+            float tsum = 0.0f;
+#pragma unroll
+            for (int blk = 1; blk <= 4; ++blk) {
+                const int ji = T->ambe_lmprbl[L][blk - 1];
+                const float* hoc = (blk == 1) ? T->ambe_hoc_b5[hb[1]]
+                                              : ((blk == 2) ? T->ambe_hoc_b6[hb[2]] : ((blk == 3) ? T->ambe_hoc_b7[hb[3]] : T->ambe_hoc_b8[hb[4]]));
+                float C[18];
+                C[1] = (float)0.5 * (Ri[2 * blk - 1] + Ri[2 * blk]);
+                C[2] = rconst * (Ri[2 * blk - 1] - Ri[2 * blk]);
+#pragma unroll
+                for (int k = 3; k <= 17; ++k) {
+                    C[k] = (k <= 6 && k <= ji) ? hoc[k - 3] : 0.0f;
+                }
+                for (int j = 1; j <= ji; ++j) {
+                    float sum = 0;
+#pragma unroll
+                    for (int k = 1; k <= 17; ++k) {
+                        if (k <= ji) {
+                            const float ak = (k == 1) ? 1.0f : 2.0f;
+                            sum = sum + (ak * C[k] * T->ambe_idct_cos[ji][j][k]);
+                        }
+                    }
+                    row[l++] = sum;
+                    tsum += sum;   // Sum42 in the reference's order (l ascending)
+                }
+            }
+            sum42 = tsum / (float)L;
+        }
+        row[0] = dg;
+        row[57] = __uint_as_float(vlo);
+        row[58] = __uint_as_float(vhi);
+        row[59] = w0;
+        row[60] = __int_as_float(L);
+        row[61] = sum42;
+        row[62] = __uint_as_float(rec.w);
+        row[63] = __int_as_float(bad);
+    }
+    write_out(tile, out, first, n);
+}
+
+}  // namespace mbx

@@ -160,107 +160,26 @@ struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int rec_bit(const uint32_t w[3], int i) { return (int)((w[i >> 5] >> (31 - (i & 31))) & 1u); }
 
-__device__ int decode_imbe(const uint32_t w[3], Parms& cur, Parms& prev, WaveScratch& S, const mbx_tables* T, int lane) {
-    int b0 = (int)(w[0] >> 26);
-    b0 = (b0 << 1) | rec_bit(w, 85);
-    b0 = (b0 << 1) | rec_bit(w, 86);
-    if (b0 > 207) {
+// Frame parameters from the expand stage (mbx_expand.hip): v[1..56] prediction residuals T_l,
+// v[57..58] voicing bits, v[59] w0, v[60] L, v[61] K (IMBE) / mean residual (AMBE), v[62] error
+// context word, v[63] frame class, v[0] AMBE gain increment.
+__device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev, int lane) {
+    const int bad = __float_as_int(fp[63]);
+    if (bad != 0) {
+        if (fp[59] != 0.0f) {
+            cur.w0 = fp[59];   // valid b0 with an out-of-range L: the reference has already stored w0
+        }
         return 1;
     }
-    cur.w0 = T->imbe_w0[b0];
-    const int L = T->imbe_L[b0];
-    if (L == 0) {
-        return 1;
-    }
+    cur.w0 = fp[59];
+    const int L = __float_as_int(fp[60]);
     cur.L = L;
-    cur.K = T->imbe_K[b0];
-    const int L9 = L - 9;
-
-    // scatter the 79 payload bits into their parameter words (bit position = significance)
-    S.word[lane] = 0;
-    wave_lds_sync();
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int i = 6 + lane + 64 * pass;
-        if (i < 85 && rec_bit(w, i)) {
-            const uint8_t* e = T->imbe_bo[L9][i - 6];
-            atomicOr(&S.word[e[0]], 1 << e[1]);
-        }
-    }
-    wave_lds_sync();
-
-    // voicing: three harmonics per band, band K-1 first
-    if (lane >= 1 && lane <= L) {
-        int band = (cur.K - 1) - ((lane - 1) / 3);
-        band = band < 0 ? 0 : band;
-        cur.Vl = (S.word[1] >> band) & 1;
-    }
-
-    // gains -> 6-point inverse DCT
-    if (lane >= 1 && lane <= 6) {
-        float g;
-        if (lane == 1) {
-            g = T->imbe_B2[S.word[2] & 63];
-        } else {
-            const float nb = T->imbe_ba[L9][lane - 2][0];
-            const float step = T->imbe_ba[L9][lane - 2][1];
-            const int inb = (int)nb;
-            const int bm = inb > 0 ? (S.word[lane + 1] & ((1 << inb) - 1)) : 0;
-            g = (step * ((float)bm - ldexpf(1.0f, inb - 1) + 0.5f));
-        }
-        S.gm[lane] = g;
-    }
-    wave_lds_sync();
-    if (lane >= 1 && lane <= 6) {
-        float sum = 0;
-        for (int m = 1; m <= 6; ++m) {
-            const float am = (m == 1) ? 1.0f : 2.0f;
-            sum = sum + (am * S.gm[m] * T->imbe_ri_cos[m][lane]);
-        }
-        S.cik[lane * 11 + 1] = sum;
-    }
-    // higher-order coefficients: lane c <-> c-th coefficient in (block, k) order
-    if (lane < L - 6) {
-        int acc = 0, blk = 0, k = 0;
-        for (int i = 1; i <= 6; ++i) {
-            const int cnt = (int)T->imbe_ji[L9][i - 1] - 1;
-            if (blk == 0 && lane < acc + cnt) {
-                blk = i;
-                k = lane - acc + 2;
-            }
-            acc += cnt;
-        }
-        const int Bm = T->imbe_hoba[L9][lane];
-        float v = 0.0f;
-        if (Bm > 0 && blk != 0) {
-            const int bm = S.word[8 + lane] & ((1 << Bm) - 1);
-            v = ((T->imbe_quantstep[Bm - 1] * T->imbe_standdev[k - 2]) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
-        }
-        if (blk != 0) {
-            S.cik[blk * 11 + k] = v;
-        }
-    }
-    wave_lds_sync();
-
-    // per-block inverse DCT: lane l <-> (block, j)
+    cur.K = __float_as_int(fp[61]);
+    const unsigned long long vbits = ((unsigned long long)__float_as_uint(fp[58]) << 32) | __float_as_uint(fp[57]);
     float Tl = 0.0f;
     if (lane >= 1 && lane <= L) {
-        int acc = 0;
-        bool done = false;
-        for (int i = 1; i <= 6; ++i) {
-            const int ji = T->imbe_ji[L9][i - 1];
-            if (!done && (lane - 1) < acc + ji) {
-                const int j = lane - acc;
-                float sum = 0;
-                for (int k = 1; k <= ji; ++k) {
-                    const float ak = (k == 1) ? 1.0f : 2.0f;
-                    sum = sum + (ak * S.cik[i * 11 + k] * T->imbe_idct_cos[ji][j][k]);
-                }
-                Tl = sum;
-                done = true;
-            }
-            acc += ji;
-        }
+        cur.Vl = (int)((vbits >> (lane - 1)) & 1ULL);
+        Tl = fp[lane];
     }
 
     // log-magnitude prediction
@@ -571,6 +490,14 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
 
     // (1) low harmonics with a stable pitch: lane = sample, loop over the (<= 7) harmonics
     unsigned long long imask = (tabs.ablate & 16) ? 0ULL : __ballot(interp);
+    float nf[3], nfrac[3], nsq[3];   // n, n/N (exact reference quotient) and n*n for this lane's samples
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n = lane + 64 * j;
+        nf[j] = (float)n;
+        nfrac[j] = (float)n / (float)N;
+        nsq[j] = (float)(n * n);
+    }
     while (imask) {
         const int l = __ffsll((long long)imask) - 1;
         imask &= imask - 1;
@@ -582,9 +509,10 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             (1.0f / (float)N) * (dphi - (2.0f * (float)M_PI * floorf((dphi + (float)M_PI) / (2.0f * (float)M_PI))));
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int n = lane + 64 * j;
-            const float theta = pPHI + ((pw0l + dw) * (float)n) + (((cw0 - pw0) * (float)(l * n * n)) / (float)(2 * N));
-            const float amp = pM + (((float)n / (float)N) * (cM - pM));
+            // (float)(l*n*n) is exact below 2^24, so l * n^2 in float is the same value; the division by
+            // 2N = 320 becomes a multiplication by its rounded reciprocal (<= 1 ulp of a phase term < 16 rad)
+            const float theta = pPHI + ((pw0l + dw) * nf[j]) + (((cw0 - pw0) * ((float)l * nsq[j])) * (1.0f / 320.0f));
+            const float amp = pM + (nfrac[j] * (cM - pM));
             acc[j] += 2.0f * amp * cos_reduced(theta);
         }
     }
@@ -600,12 +528,12 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             float a, b, c, d;
             sincosf(pw0l, &a, &b);
             sincosf(prev.PHIl, &c, &d);
-            if (wv_p) {
+            if (wv_p) {   // the oscillator state carries the gain 2*Ml (a rotation is linear)
                 gp = 2.0f * prev.Ml;
                 sdp = a;
                 cdp = b;
-                sp = c;
-                cp = d;
+                sp = gp * c;
+                cp = gp * d;
             }
             sincosf(cw0l, &a, &b);
             sincosf(cur.PHIl - (cw0l * (float)N), &c, &d);
@@ -613,8 +541,8 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 gc = 2.0f * cur.Ml;
                 sdc = a;
                 cdc = b;
-                sc = c;
-                cc = d;
+                sc = gc * c;
+                cc = gc * d;
             }
         }
         const bool any = (__ballot(wv_p || wv_c) != 0ULL) && !(tabs.ablate & 8);
@@ -662,12 +590,12 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                     float v = 0.0f;
                     if constexpr (decltype(has_prev)::value) {
                         const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[wreg], n & 63));
-                        v = gp * wp * cp;
+                        v = wp * cp;
                         rotate(cp, sp, cdp, sdp);
                     }
                     if constexpr (decltype(has_cur)::value) {
                         const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[wreg], n & 63));
-                        v += gc * wc * cc;
+                        v += wc * cc;
                     }
                     S.tr[(n & 31) * kTrStride + lane] = v;
                     if constexpr (decltype(has_cur)::value) {
@@ -873,7 +801,8 @@ __device__ __forceinline__ void store_rng(const StreamRng& r, mbx_stream_rng* p,
 // IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
-imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, mbe_parms* __restrict__ state,
+imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                   mbe_parms* __restrict__ state,
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                    mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
@@ -903,10 +832,10 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         int lane = lane_in;
         asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
         const DeviceTables& tabs = ft;
-        const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
-        const uint32_t w[3] = {rec.x, rec.y, rec.z};
-        const int c0 = (int)(rec.w & 0xffu), prot = (int)((rec.w >> 8) & 0xffu), c4 = (int)((rec.w >> 16) & 0xffu);
-        unsigned flags = (rec.w >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
+        const float* fp = params[f].v;
+        const uint32_t errw = __float_as_uint(fp[62]);
+        const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
+        unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
         const int total = c0 + prot;
         bool muted;
         {
@@ -919,7 +848,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             cur.errorCountTotal = total;
             cur.errorRate = (0.95f * prev.errorRate) + (0.000365f * (float)total);
 
-            const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(w, cur, prev, scratch, tabs.t, lane);
+            const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, lane);
             const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
             const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
             const bool repeat =
@@ -1034,105 +963,22 @@ __device__ __forceinline__ int pick_bits(const uint32_t w[3], int i0, int i1, in
     return v;
 }
 
-// Returns 0 voice, 2 erasure, 7 tone.
-__device__ int decode_ambe(const uint32_t w[3], Parms& cur, Parms& prev, WaveScratch& S, const DeviceTables& tabs,
-                           int total_errors, int lane) {
-    const mbx_tables* T = tabs.t;
-    const int u0 = (int)(w[0] >> 20);
-    const int u1 = (int)((w[0] >> 8) & 0xfffu);
-    const unsigned long long two = ((unsigned long long)w[0] << 32) | w[1];
-    const int u3 = (int)((two >> 15) & 0x3fffu);
-    const bool tone_sig = (((u0 >> 6) & 0x3f) == 63) && (((u3 & 0xf) == 0) || (((u1 >> 8) & 0xf) == (u1 & 0xf)));
-    if (tone_sig && total_errors < 6) {
-        return 7;
+// Returns 0 voice, 2 erasure, 7 tone (classified by the expand stage).
+__device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DeviceTables& tabs, int lane) {
+    const int bad = __float_as_int(fp[63]);
+    if (bad != 0) {
+        return bad;
     }
-    const int b0 = pick_bits(w, 0, 1, 2, 3, 37, 38, 39);
-    if ((b0 >= 120 && b0 <= 123) || b0 == 126 || b0 == 127) {
-        return 2;
-    }
-    int L;
-    float f0;
-    const bool silence = (b0 == 124 || b0 == 125);
-    if (silence) {
-        f0 = (float)M_PI / 32.0f;
-        cur.w0 = f0 * (float)(2.0 * M_PI);
-        L = (b0 == 124) ? 15 : 14;
-        cur.L = L;
-        if (lane >= 1 && lane <= L) {
-            cur.Vl = 0;
-        }
-    } else {
-        f0 = T->ambe_w0[b0];
-        cur.w0 = (float)((double)(f0 * (float)2) * M_PI);
-        L = T->ambe_L[b0];
-        cur.L = L;
-    }
+    cur.w0 = fp[59];
+    const int L = __float_as_int(fp[60]);
+    cur.L = L;
     const float unvc = (float)0.2046 / sqrtf(cur.w0);
-
-    const int b1 = pick_bits(w, 4, 5, 6, 7, 35);
-    if (!silence && lane >= 1 && lane <= L) {
-        const int jl = (int)((float)lane * (float)16.0 * f0);
-        cur.Vl = T->ambe_vuv[b1][jl & 7];
-    }
-    const int b2 = pick_bits(w, 8, 9, 10, 11, 36);
-    cur.gamma = T->ambe_dg[b2] + ((float)0.5 * prev.gamma);
-
-    const int b3 = pick_bits(w, 12, 13, 14, 15, 16, 17, 18, 19, 40);
-    const int b4 = pick_bits(w, 20, 21, 22, 23, 41, 42, 43);
-    if (lane >= 1 && lane <= 8) {
-        float g = 0.0f;
-        if (lane >= 2 && lane <= 4) {
-            g = T->ambe_prba24[b3][lane - 2];
-        } else if (lane >= 5) {
-            g = T->ambe_prba58[b4][lane - 5];
-        }
-        S.gm[lane] = g;
-    }
-    wave_lds_sync();
-    if (lane >= 1 && lane <= 8) {
-        float sum = 0;
-        for (int m = 1; m <= 8; ++m) {
-            const float am = (m == 1) ? 1.0f : 2.0f;
-            sum = sum + (am * S.gm[m] * T->ambe_ri_cos[m][lane]);
-        }
-        S.gm[16 + lane] = sum;
-    }
-    wave_lds_sync();
-    const int b5 = pick_bits(w, 24, 25, 26, 27, 44);
-    const int b6 = pick_bits(w, 28, 29, 30, 45);
-    const int b7 = pick_bits(w, 31, 32, 33, 46);
-    const int b8 = pick_bits(w, 34, 47, 48);
-    if (lane >= 1 && lane <= 4) {
-        const float rconst = (float)(1.0 / (2.0 * M_SQRT2));
-        const float ra = S.gm[16 + 2 * lane - 1], rb = S.gm[16 + 2 * lane];
-        S.cik[lane * 18 + 1] = (float)0.5 * (ra + rb);
-        S.cik[lane * 18 + 2] = rconst * (ra - rb);
-        const float* hoc = (lane == 1) ? T->ambe_hoc_b5[b5]
-                                       : ((lane == 2) ? T->ambe_hoc_b6[b6] : ((lane == 3) ? T->ambe_hoc_b7[b7] : T->ambe_hoc_b8[b8]));
-        const int ji = T->ambe_lmprbl[L][lane - 1];
-        for (int k = 3; k <= ji; ++k) {
-            S.cik[lane * 18 + k] = (k > 6) ? 0.0f : hoc[k - 3];
-        }
-    }
-    wave_lds_sync();
+    const unsigned long long vbits = ((unsigned long long)__float_as_uint(fp[58]) << 32) | __float_as_uint(fp[57]);
+    cur.gamma = fp[0] + ((float)0.5 * prev.gamma);
     float Tl = 0.0f;
     if (lane >= 1 && lane <= L) {
-        int acc = 0;
-        bool done = false;
-        for (int i = 1; i <= 4; ++i) {
-            const int ji = T->ambe_lmprbl[L][i - 1];
-            if (!done && (lane - 1) < acc + ji) {
-                const int j = lane - acc;
-                float sum = 0;
-                for (int k = 1; k <= ji; ++k) {
-                    const float ak = (k == 1) ? 1.0f : 2.0f;
-                    sum = sum + (ak * S.cik[i * 18 + k] * T->ambe_idct_cos[ji][j][k]);
-                }
-                Tl = sum;
-                done = true;
-            }
-            acc += ji;
-        }
+        cur.Vl = (int)((vbits >> (lane - 1)) & 1ULL);
+        Tl = fp[lane];
     }
 
     const int prev_L = prev.L < 1 ? 1 : (prev.L > 56 ? 56 : prev.L);
@@ -1160,8 +1006,7 @@ __device__ int decode_ambe(const uint32_t w[3], Parms& cur, Parms& prev, WaveScr
     const bool in = lane >= 1 && lane <= cur_L;
     float Sum43 = wave_sum(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f);
     Sum43 = (((float)0.65 / (float)cur_L) * Sum43);
-    float Sum42 = wave_sum(in ? Tl : 0.0f);
-    Sum42 = Sum42 / (float)cur_L;
+    const float Sum42 = fp[61];   // mean residual, summed in the reference's order by the expand stage
     const float BigGamma = cur.gamma - (0.5f * tabs.d->log2_int[cur_L]) - Sum42;
     if (in) {
         const float c1 = ((float)0.65 * ((float)1 - frac) * a);
@@ -1247,7 +1092,8 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
 }
 
 __global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
-ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, mbe_parms* __restrict__ state,
+ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                   mbe_parms* __restrict__ state,
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                    mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
@@ -1274,10 +1120,10 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         int lane = lane_in;
         asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
         const DeviceTables& tabs = ft;
-        const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
-        const uint32_t w[3] = {rec.x, rec.y, rec.z};
-        const int c0 = (int)(rec.w & 0xffu), prot = (int)((rec.w >> 8) & 0xffu);
-        unsigned flags = (rec.w >> 24) & 0xffu;   // C0_VALID
+        const float* fp = params[f].v;
+        const uint32_t errw = __float_as_uint(fp[62]);
+        const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu);
+        unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID
         const int total = c0 + prot;
         int bad;
         bool prev_max_repeat;
@@ -1298,7 +1144,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             cur.errorCount4 = 0;
             cur.errorRate = (0.95f * prev.errorRate) + (0.001064f * (float)total);
 
-            bad = decode_ambe(w, cur, prev, scratch, tabs, total, lane);
+            bad = decode_ambe(fp, cur, prev, tabs, lane);
             prev_max_repeat = prev.repeatCount >= MBE_MAX_FRAME_REPEATS;
             if (bad == 2) {
                 flags |= MBE_PROCESS_FLAG_ERASURE;
@@ -1336,6 +1182,8 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
                 reinit_all();
             }
         } else if (bad == 7) {
+            const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
+            const uint32_t w[3] = {rec.x, rec.y, rec.z};
             const int id1 = (int)((w[0] >> 12) & 0xffu);   // parameter bits 12..19
             float f1, f2;
             if (tone_freqs(id1, f1, f2)) {
