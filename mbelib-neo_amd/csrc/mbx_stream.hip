@@ -140,7 +140,7 @@ struct WaveScratch {
         alignas(16) float tr[kTrRows * kTrStride];   // voiced bank: [sample-in-block][harmonic] tile
         struct {                                      // unvoiced path (the tile is dead by then)
             float2 fft[256];                          //   in-place radix-4 FFT
-            float  uwr[256];                          //   real inverse-FFT output (natural order)
+            float  mag2[132];                         //   |X(k)|^2, k = 0..128
             float  scale[132];                        //   per-bin scale, bins 0..128
         };
     };
@@ -632,20 +632,43 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     }
 
     // ---- unvoiced: window, 256-point FFT, per-band scaling, inverse FFT, overlap-add ----------
+    // Radix-4, 4 points per lane.  Element i = lane + 64*r lives in lane `lane`, so the first forward
+    // stage (span 64) and the last inverse stage run straight from / into registers; the three
+    // middle stages of each transform exchange through LDS.  Forward is decimation in frequency
+    // (natural in, base-4 digit-reversed out), inverse is decimation in time (digit-reversed in,
+    // natural out): no reordering pass.  Twiddles e^{-2 pi i m/256} come from v_sin/v_cos (their
+    // argument is in revolutions, m/256 is exact), not from memory.
     if (!(tabs.ablate & 32)) {
+        auto twiddle = [](int m) -> float2 {
+            const float rev = (float)(m & 255) * (1.0f / 256.0f);
+            return make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev));
+        };
+        auto cmul = [](float2 u, float2 w) -> float2 { return make_float2(u.x * w.x - u.y * w.y, u.x * w.y + u.y * w.x); };
+        auto cmulc = [](float2 u, float2 w) -> float2 { return make_float2(u.x * w.x + u.y * w.y, u.y * w.x - u.x * w.y); };
+        float win[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = lane + 64 * j;
-            S.fft[i] = make_float2(nz[j] * T->uv_window[i], 0.0f);
+        for (int r = 0; r < 4; ++r) {
+            win[r] = T->uv_window[lane + 64 * r];
         }
+        const float wden[3] = {T->wola_denom[lane], T->wola_denom[lane + 64], (lane < 32) ? T->wola_denom[lane + 128] : 1.0f};
+        const float wprev[2] = {T->wola_w_prev[lane], T->wola_w_prev[lane + 64]};   // w(n) is 0 from n = 106 on
+        const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
         S.scale[lane] = 0.0f;
         S.scale[lane + 64] = 0.0f;
         if (lane < 4) {
             S.scale[128 + lane] = 0.0f;
         }
+        {   // forward stage 1 (span 64): real inputs straight from registers
+            const float a0 = nz[0] * win[0], a1 = nz[1] * win[1], a2 = nz[2] * win[2], a3 = nz[3] * win[3];
+            const float s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+            S.fft[lane] = make_float2(s02 + s13, 0.0f);
+            S.fft[lane + 64] = cmul(make_float2(d02, -d13), twiddle(lane));
+            S.fft[lane + 128] = cmul(make_float2(s02 - s13, 0.0f), twiddle(2 * lane));
+            S.fft[lane + 192] = cmul(make_float2(d02, d13), twiddle(3 * lane));
+        }
         wave_lds_sync();
-        // forward: radix-4 decimation in frequency, natural order in, base-4 digit-reversed out
-        for (int q = 64; q >= 1; q >>= 2) {
+#pragma unroll
+        for (int q = 16; q >= 1; q >>= 2) {
             const int g = lane / q, jj = lane % q;
             const int base = g * 4 * q + jj;
             const int tstep = 64 / q;   // 256 / (4q)
@@ -656,16 +679,31 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const float2 u1 = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i*d13
             const float2 u2 = make_float2(s02.x - s13.x, s02.y - s13.y);
             const float2 u3 = make_float2(d02.x - d13.y, d02.y + d13.x);   // d02 + i*d13
-            const float2 w1 = D->twiddle[(jj * tstep) & 255], w2 = D->twiddle[(2 * jj * tstep) & 255],
-                         w3 = D->twiddle[(3 * jj * tstep) & 255];
             wave_lds_sync();
             S.fft[base] = y0;
-            S.fft[base + q] = make_float2(u1.x * w1.x - u1.y * w1.y, u1.x * w1.y + u1.y * w1.x);
-            S.fft[base + 2 * q] = make_float2(u2.x * w2.x - u2.y * w2.y, u2.x * w2.y + u2.y * w2.x);
-            S.fft[base + 3 * q] = make_float2(u3.x * w3.x - u3.y * w3.y, u3.x * w3.y + u3.y * w3.x);
+            if (q == 1) {   // last forward stage: all twiddles are 1
+                S.fft[base + 1] = u1;
+                S.fft[base + 2] = u2;
+                S.fft[base + 3] = u3;
+            } else {
+                S.fft[base + q] = cmul(u1, twiddle(jj * tstep));
+                S.fft[base + 2 * q] = cmul(u2, twiddle(2 * jj * tstep));
+                S.fft[base + 3 * q] = cmul(u3, twiddle(3 * jj * tstep));
+            }
             wave_lds_sync();
         }
-        // per-band scale: lane = band
+        // |X(k)|^2 for k = 0..128 in natural order (position p holds bin rev4(p))
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pidx = lane + 64 * r;
+            const int k = rev4(pidx);
+            if (k <= 128) {
+                const float2 X = S.fft[pidx];
+                S.mag2[k] = (k == 0) ? (X.x * X.x) : ((X.x * X.x) + (X.y * X.y));
+            }
+        }
+        wave_lds_sync();
+        // per-band scale: lane = band; a band spans at most 14 bins (w0 <= 4 pi / 39.5)
         if (lane >= 1 && lane <= cur.L && cur.Vl == 0) {
             const float mult = (256.0f / (2.0f * 3.14159265358979323846f)) * cur.w0;
             int a = (int)ceilf(((float)lane - 0.5f) * mult);
@@ -673,9 +711,16 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             a = a < 0 ? 0 : a;
             b = b > 128 ? 128 : b;
             float num = 0.0f;
-            for (int k = a; k < b; ++k) {
-                const float2 X = S.fft[rev4(k)];
-                num += (k == 0) ? (X.x * X.x) : ((X.x * X.x) + (X.y * X.y));
+#pragma unroll
+            for (int c = 0; c < 14; ++c) {
+                const int k = a + c;
+                const float m2 = S.mag2[k < 128 ? k : 128];
+                if (k < b) {
+                    num += m2;
+                }
+            }
+            for (int k = a + 14; k < b; ++k) {   // not reached for valid w0; keeps odd states exact
+                num += S.mag2[k];
             }
             const int count = b - a;
             if (count > 0 && num > 1e-10f) {
@@ -687,26 +732,27 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         wave_lds_sync();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = lane + 64 * j;
-            const int k = rev4(p);
+        for (int r = 0; r < 4; ++r) {
+            const int pidx = lane + 64 * r;
+            const int k = rev4(pidx);
             const float sc = S.scale[k > 128 ? 256 - k : k];
-            const float2 X = S.fft[p];
-            S.fft[p] = make_float2(X.x * sc, X.y * sc);
+            const float2 X = S.fft[pidx];
+            S.fft[pidx] = make_float2(X.x * sc, X.y * sc);
         }
         wave_lds_sync();
-        // inverse: radix-4 decimation in time, digit-reversed in, natural order out
-        for (int q = 1; q <= 64; q <<= 2) {
+        // inverse stages with spans 1, 4, 16 through LDS
+#pragma unroll
+        for (int q = 1; q <= 16; q <<= 2) {
             const int g = lane / q, jj = lane % q;
             const int base = g * 4 * q + jj;
             const int tstep = 64 / q;
-            const float2 w1 = D->twiddle[(jj * tstep) & 255], w2 = D->twiddle[(2 * jj * tstep) & 255],
-                         w3 = D->twiddle[(3 * jj * tstep) & 255];
-            const float2 x0 = S.fft[base], x1 = S.fft[base + q], x2 = S.fft[base + 2 * q], x3 = S.fft[base + 3 * q];
-            // multiply by conjugate twiddles
-            const float2 z1 = make_float2(x1.x * w1.x + x1.y * w1.y, x1.y * w1.x - x1.x * w1.y);
-            const float2 z2 = make_float2(x2.x * w2.x + x2.y * w2.y, x2.y * w2.x - x2.x * w2.y);
-            const float2 z3 = make_float2(x3.x * w3.x + x3.y * w3.y, x3.y * w3.x - x3.x * w3.y);
+            const float2 x0 = S.fft[base];
+            float2 z1 = S.fft[base + q], z2 = S.fft[base + 2 * q], z3 = S.fft[base + 3 * q];
+            if (q != 1) {   // multiply by the conjugate twiddles
+                z1 = cmulc(z1, twiddle(jj * tstep));
+                z2 = cmulc(z2, twiddle(2 * jj * tstep));
+                z3 = cmulc(z3, twiddle(3 * jj * tstep));
+            }
             const float2 s02 = make_float2(x0.x + z2.x, x0.y + z2.y), d02 = make_float2(x0.x - z2.x, x0.y - z2.y);
             const float2 s13 = make_float2(z1.x + z3.x, z1.y + z3.y), d13 = make_float2(z1.x - z3.x, z1.y - z3.y);
             wave_lds_sync();
@@ -716,25 +762,27 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             S.fft[base + 3 * q] = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i*d13
             wave_lds_sync();
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = lane + 64 * j;
-            const float v = S.fft[i].x * (1.0f / 256.0f);
-            cur.uw[j] = v;
-            S.uwr[i] = v;
+        {   // last inverse stage (span 64): only the real parts are needed, results stay in registers
+            const float2 x0 = S.fft[lane];
+            const float2 z1 = cmulc(S.fft[lane + 64], twiddle(lane));
+            const float2 z2 = cmulc(S.fft[lane + 128], twiddle(2 * lane));
+            const float2 z3 = cmulc(S.fft[lane + 192], twiddle(3 * lane));
+            const float s02 = x0.x + z2.x, d02 = x0.x - z2.x, s13 = z1.x + z3.x, d13y = z1.y - z3.y;
+            cur.uw[0] = (s02 + s13) * (1.0f / 256.0f);
+            cur.uw[1] = (d02 - d13y) * (1.0f / 256.0f);   // Re(d02 + i*d13)
+            cur.uw[2] = (s02 - s13) * (1.0f / 256.0f);
+            cur.uw[3] = (d02 + d13y) * (1.0f / 256.0f);   // Re(d02 - i*d13)
         }
-        wave_lds_sync();
-        // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2)
+        // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
+        // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int n = lane + 64 * j;
-            if (n < N) {
-                const float ps = (j == 0) ? prev.uw[2] : ((j == 1) ? prev.uw[3] : 0.0f);
-                const float cs = (n >= 32) ? S.uwr[n - 32] : 0.0f;
-                const float d = T->wola_denom[n];
-                if (d > 1e-10f) {
-                    acc[j] += ((T->wola_w_prev[n] * ps) + (T->wola_w_curr[n] * cs)) / d;
-                }
+            const float give = (lane < 32) ? cur.uw[j] : ((j == 0) ? 0.0f : cur.uw[j - 1]);
+            const float cs = __shfl_xor(give, 32, kWave);
+            const float ps = (j == 0) ? prev.uw[2] : ((j == 1) ? prev.uw[3] : 0.0f);
+            const float wp = (j < 2) ? wprev[j] : 0.0f;
+            if ((lane + 64 * j) < N && wden[j] > 1e-10f) {
+                acc[j] += ((wp * ps) + (wcurr[j] * cs)) / wden[j];
             }
         }
         wave_lds_sync();
