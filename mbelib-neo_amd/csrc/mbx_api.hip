@@ -331,7 +331,7 @@ int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, v
     if (rc < 0) {
         return rc;
     }
-    const unsigned egrid = (unsigned)((n + 63) / 64);
+    const unsigned egrid = (unsigned)((n + 7) / 8);   // 8 frames per 64-lane workgroup
     if (codec == MBX_CODEC_IMBE7200X4400) {
         hipLaunchKernelGGL(mbx::expand_imbe_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
                            g_ctx.workspace, g_ctx.tabs);

@@ -1,54 +1,65 @@
-// mbx_expand.hip -- stateless half of the parameter decode, ONE THREAD PER FRAME.
+// mbx_expand.hip -- stateless half of the parameter decode, EIGHT LANES PER FRAME.
 //
 // Everything in mbe_decodeImbe4400Parms / mbe_decodeAmbe2450Parms that depends only on the 88 / 49
 // parameter bits -- fundamental, voicing decisions, gain / PRBA / higher-order coefficient
 // dequantisation, the block inverse DCTs that yield the prediction residuals T_l -- is independent
-// between frames, so it runs here with full thread parallelism and in the reference's own
-// (sequential) summation order.  What is left for the stream kernel is the part that needs the
-// previous frame: the log-magnitude prediction.
+// between frames.  It runs here, 8 frames per wavefront: sub-lane 0 of a frame does the header and
+// the voicing bits, sub-lanes 1..6 (IMBE) / 1..4 (AMBE) own one inverse-DCT block each.  Sums keep the
+// reference's sequential order inside a block, so the residuals are bit-identical to the CPU path.
+// What is left for the stream kernel is the part that needs the previous frame: the prediction.
 //
 // Replaces (ref = arancormonk/mbelib-neo v2.0.0):
 //   IMBE  src/imbe/imbe7200x4400.c:117-270  (fundamental, bit layout, voicing, gains, Ri, HOC, IDCT)
 //   AMBE  src/ambe/ambe3600x2450.c:176-387, 461-553  (classification, V/UV, gain, PRBA, HOC, IDCT)
+//
+// Output record (FrameParams, 64 dwords): v[1..56] T_l, v[57..58] voicing bits, v[59] w0, v[60] L,
+// v[61] K (IMBE) / mean residual Sum42 (AMBE), v[62] error-context word, v[63] frame class
+// (0 voice, 1 invalid IMBE fundamental, 2 AMBE erasure, 7 AMBE tone), v[0] AMBE gain increment.
 #include "mbx_device.h"
 
 namespace mbx {
 
+constexpr int kFramesPerBlock = 8;
+constexpr int kRow = 65;   // 64 dwords + 1 pad
+
 __device__ __forceinline__ int rbit(const uint32_t w[3], int i) { return (int)((w[i >> 5] >> (31 - (i & 31))) & 1u); }
 
-// value of IMBE parameter word m: bit `pos` comes from payload bit inv[m][pos] (255 = not allocated)
+// value of IMBE parameter word m: bit `pos` comes from payload bit inv[pos] (255 = not allocated).
+// The 12-byte table row is fetched with three dword loads, not bit by bit.
 __device__ __forceinline__ int imbe_word(const uint32_t w[3], const uint8_t* inv_m, int nbits) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(inv_m);
+    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
     int v = 0;
-    for (int pos = 0; pos < nbits; ++pos) {
-        const int src = inv_m[pos];
-        if (src != 255) {
+#pragma unroll
+    for (int pos = 0; pos < 12; ++pos) {
+        const uint32_t word = (pos < 4) ? q0 : ((pos < 8) ? q1 : q2);
+        const int src = (int)((word >> (8 * (pos & 3))) & 0xffu);
+        if (pos < nbits && src != 255) {
             v |= rbit(w, src) << pos;
         }
     }
     return v;
 }
 
-// per-thread staging row: 64 dwords + 1 pad so that the block-wide transposed write-out is conflict free
-constexpr int kRow = 65;
-
 __device__ __forceinline__ void write_out(const float (*tile)[kRow], FrameParams* out, size_t first, size_t n) {
-    // all 64 threads of the block copy the 64 staged rows, one 256-byte row per step (coalesced)
     __syncthreads();
     const int lane = threadIdx.x;
-    for (int r = 0; r < 64; ++r) {
+#pragma unroll
+    for (int r = 0; r < kFramesPerBlock; ++r) {
         if (first + r < n) {
-            reinterpret_cast<float*>(&out[first + r])[lane] = tile[r][lane];
+            reinterpret_cast<float*>(&out[first + r])[lane] = tile[r][lane];   // one coalesced 256-byte row
         }
     }
 }
 
 __global__ void __launch_bounds__(64)
 expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
-    __shared__ float tile[64][kRow];
+    __shared__ float tile[kFramesPerBlock][kRow];
     const mbx_tables* T = tabs.t;
-    const size_t first = (size_t)blockIdx.x * 64;
-    const size_t i = first + threadIdx.x;
-    float* row = tile[threadIdx.x];
+    const size_t first = (size_t)blockIdx.x * kFramesPerBlock;
+    const int fi = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const size_t i = first + fi;
+    float* row = tile[fi];
     if (i < n) {
         const uint4 rec = *reinterpret_cast<const uint4*>(&recs[i]);
         const uint32_t w[3] = {rec.x, rec.y, rec.z};
@@ -64,27 +75,37 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             L = T->imbe_L[b0];
             K = T->imbe_K[b0];
             if (L == 0) {
-                bad = 1;   // the reference sets w0 but leaves L alone in this case
+                bad = 1;   // the reference has stored w0 but not L in this case
             }
         }
-        uint32_t vlo = 0, vhi = 0;
-        if (!bad) {
-            const int L9 = L - 9;
-            const uint8_t(*inv)[12] = tabs.d->imbe_inv_bo[L9];
-            // voicing: three harmonics per band, band K-1 first
-            const int b1 = imbe_word(w, inv[1], 12);
-            for (int l = 1; l <= L; ++l) {
-                int band = (K - 1) - ((l - 1) / 3);
-                band = band < 0 ? 0 : band;
-                if ((b1 >> band) & 1) {
+        const int L9 = bad ? 0 : L - 9;
+        const uint8_t(*inv)[12] = tabs.d->imbe_inv_bo[L9];
+        if (sub == 0) {
+            uint32_t vlo = 0, vhi = 0;
+            if (!bad) {   // voicing: three harmonics per band, band K-1 first
+                const int b1 = imbe_word(w, inv[1], 12);
+                for (int l = 1; l <= L; ++l) {
+                    int band = (K - 1) - ((l - 1) / 3);
+                    band = band < 0 ? 0 : band;
+                    const uint32_t v = (uint32_t)((b1 >> band) & 1);
                     if (l <= 32) {
-                        vlo |= 1u << (l - 1);
+                        vlo |= v << (l - 1);
                     } else {
-                        vhi |= 1u << (l - 33);
+                        vhi |= v << (l - 33);
                     }
                 }
             }
-            // gains -> 6-point inverse DCT
+            row[0] = 0.0f;
+            row[57] = __uint_as_float(vlo);
+            row[58] = __uint_as_float(vhi);
+            row[59] = w0;
+            row[60] = __int_as_float(L);
+            row[61] = __int_as_float(K);
+            row[62] = __uint_as_float(rec.w);
+            row[63] = __int_as_float(bad);
+        } else if (sub <= 6 && !bad) {
+            const int blk = sub;
+            // gains (all six are needed for this block's mean Ri)
             float Gm[7];
             Gm[1] = T->imbe_B2[imbe_word(w, inv[2], 6)];
 #pragma unroll
@@ -95,57 +116,49 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
                 const int bm = imbe_word(w, inv[g + 1], inb);
                 Gm[g] = (step * ((float)bm - ldexpf(1.0f, inb - 1) + 0.5f));
             }
-            float Ri[7];
-#pragma unroll
-            for (int r = 1; r <= 6; ++r) {
+            float C[11];
+            {
                 float sum = 0;
 #pragma unroll
                 for (int m = 1; m <= 6; ++m) {
                     const float am = (m == 1) ? 1.0f : 2.0f;
-                    sum = sum + (am * Gm[m] * T->imbe_ri_cos[m][r]);
+                    sum = sum + (am * Gm[m] * T->imbe_ri_cos[m][blk]);
                 }
-                Ri[r] = sum;
+                C[1] = sum;
             }
-            // higher-order coefficients and the per-block inverse DCT, block by block
+            // where this block's coefficients and harmonics start
             int m = 8, l = 1;
+            for (int q = 1; q < blk; ++q) {
+                const int jq = T->imbe_ji[L9][q - 1];
+                m += jq - 1;
+                l += jq;
+            }
+            const int ji = T->imbe_ji[L9][blk - 1];
 #pragma unroll
-            for (int blk = 1; blk <= 6; ++blk) {
-                const int ji = T->imbe_ji[L9][blk - 1];
-                float C[11];
-                C[1] = Ri[blk];
+            for (int k = 2; k <= 10; ++k) {
+                float v = 0.0f;
+                if (k <= ji) {
+                    const int Bm = T->imbe_hoba[L9][m - 8];
+                    if (Bm > 0) {
+                        const int bm = imbe_word(w, inv[m], Bm);
+                        v = ((T->imbe_quantstep[Bm - 1] * T->imbe_standdev[k - 2]) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
+                    }
+                    ++m;
+                }
+                C[k] = v;
+            }
+            for (int j = 1; j <= ji; ++j) {
+                float sum = 0;
 #pragma unroll
-                for (int k = 2; k <= 10; ++k) {
-                    float v = 0.0f;
+                for (int k = 1; k <= 10; ++k) {
                     if (k <= ji) {
-                        const int Bm = T->imbe_hoba[L9][m - 8];
-                        if (Bm > 0) {
-                            const int bm = imbe_word(w, inv[m], Bm);
-                            v = ((T->imbe_quantstep[Bm - 1] * T->imbe_standdev[k - 2]) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
-                        }
-                        ++m;
+                        const float ak = (k == 1) ? 1.0f : 2.0f;
+                        sum = sum + (ak * C[k] * T->imbe_idct_cos[ji][j][k]);
                     }
-                    C[k] = v;
                 }
-                for (int j = 1; j <= ji; ++j) {
-                    float sum = 0;
-#pragma unroll
-                    for (int k = 1; k <= 10; ++k) {
-                        if (k <= ji) {
-                            const float ak = (k == 1) ? 1.0f : 2.0f;
-                            sum = sum + (ak * C[k] * T->imbe_idct_cos[ji][j][k]);
-                        }
-                    }
-                    row[l++] = sum;
-                }
+                row[l++] = sum;
             }
         }
-        row[57] = __uint_as_float(vlo);
-        row[58] = __uint_as_float(vhi);
-        row[59] = w0;
-        row[60] = __int_as_float(L);
-        row[61] = __int_as_float(K);
-        row[62] = __uint_as_float(rec.w);
-        row[63] = __int_as_float(bad);
     }
     write_out(tile, out, first, n);
 }
@@ -165,25 +178,29 @@ __device__ __forceinline__ int pick(const uint32_t w[3], int i0, int i1, int i2,
 
 __global__ void __launch_bounds__(64)
 expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
-    __shared__ float tile[64][kRow];
+    __shared__ float tile[kFramesPerBlock][kRow];
     const mbx_tables* T = tabs.t;
-    const size_t first = (size_t)blockIdx.x * 64;
-    const size_t i = first + threadIdx.x;
-    float* row = tile[threadIdx.x];
+    const size_t first = (size_t)blockIdx.x * kFramesPerBlock;
+    const int fi = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const size_t i = first + fi;
+    float* row = tile[fi];
+    int bad = 0, L = 0;
+    float w0 = 0.0f, f0 = 0.0f;
+    bool silence = false;
+    uint32_t w[3] = {0, 0, 0}, errw = 0;
     if (i < n) {
         const uint4 rec = *reinterpret_cast<const uint4*>(&recs[i]);
-        const uint32_t w[3] = {rec.x, rec.y, rec.z};
+        w[0] = rec.x;
+        w[1] = rec.y;
+        w[2] = rec.z;
+        errw = rec.w;
         const int total_errors = (int)(rec.w & 0xffu) + (int)((rec.w >> 8) & 0xffu);
         const int u0 = (int)(w[0] >> 20);
         const int u1 = (int)((w[0] >> 8) & 0xfffu);
         const unsigned long long two = ((unsigned long long)w[0] << 32) | w[1];
         const int u3 = (int)((two >> 15) & 0x3fffu);
         const bool tone_sig = (((u0 >> 6) & 0x3f) == 63) && (((u3 & 0xf) == 0) || (((u1 >> 8) & 0xf) == (u1 & 0xf)));
-        int bad = 0, L = 0;
-        float w0 = 0.0f, f0 = 0.0f, dg = 0.0f, sum42 = 0.0f;
-        uint32_t vlo = 0, vhi = 0;
         const int b0 = pick(w, 0, 1, 2, 3, 37, 38, 39);
-        bool silence = false;
         if (tone_sig && total_errors < 6) {
             bad = 7;
         } else if ((b0 >= 120 && b0 <= 123) || b0 == 126 || b0 == 127) {
@@ -198,21 +215,8 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             w0 = (float)((double)(f0 * (float)2) * M_PI);
             L = T->ambe_L[b0];
         }
-        if (bad == 0) {
-            if (!silence) {
-                const int b1 = pick(w, 4, 5, 6, 7, 35);
-                for (int l = 1; l <= L; ++l) {
-                    const int jl = (int)((float)l * (float)16.0 * f0);
-                    if (T->ambe_vuv[b1][jl & 7]) {
-                        if (l <= 32) {
-                            vlo |= 1u << (l - 1);
-                        } else {
-                            vhi |= 1u << (l - 33);
-                        }
-                    }
-                }
-            }
-            dg = T->ambe_dg[pick(w, 8, 9, 10, 11, 36)];
+        if (sub >= 1 && sub <= 4 && bad == 0) {
+            const int blk = sub;
             const int b3 = pick(w, 12, 13, 14, 15, 16, 17, 18, 19, 40);
             const int b4 = pick(w, 20, 21, 22, 23, 41, 42, 43);
             float Gm[9];
@@ -224,45 +228,64 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             Gm[6] = T->ambe_prba58[b4][1];
             Gm[7] = T->ambe_prba58[b4][2];
             Gm[8] = T->ambe_prba58[b4][3];
-            float Ri[9];
+            float Ra = 0, Rb = 0;   // Ri[2*blk-1], Ri[2*blk]
 #pragma unroll
-            for (int r = 1; r <= 8; ++r) {
-                float sum = 0;
-#pragma unroll
-                for (int m = 1; m <= 8; ++m) {
-                    const float am = (m == 1) ? 1.0f : 2.0f;
-                    sum = sum + (am * Gm[m] * T->ambe_ri_cos[m][r]);
-                }
-                Ri[r] = sum;
+            for (int m = 1; m <= 8; ++m) {
+                const float am = (m == 1) ? 1.0f : 2.0f;
+                Ra = Ra + (am * Gm[m] * T->ambe_ri_cos[m][2 * blk - 1]);
+                Rb = Rb + (am * Gm[m] * T->ambe_ri_cos[m][2 * blk]);
             }
             const float rconst = (float)(1.0 / (2.0 * M_SQRT2));
-            const int hb[5] = {0, pick(w, 24, 25, 26, 27, 44), pick(w, 28, 29, 30, 45), pick(w, 31, 32, 33, 46), pick(w, 34, 47, 48)};
+            const int hbits = (blk == 1) ? pick(w, 24, 25, 26, 27, 44)
+                                         : ((blk == 2) ? pick(w, 28, 29, 30, 45) : ((blk == 3) ? pick(w, 31, 32, 33, 46) : pick(w, 34, 47, 48)));
+            const float* hoc = (blk == 1) ? T->ambe_hoc_b5[hbits]
+                                          : ((blk == 2) ? T->ambe_hoc_b6[hbits] : ((blk == 3) ? T->ambe_hoc_b7[hbits] : T->ambe_hoc_b8[hbits]));
             int l = 1;
-            float tsum = 0.0f;
+            for (int q = 1; q < blk; ++q) {
+                l += T->ambe_lmprbl[L][q - 1];
+            }
+            const int ji = T->ambe_lmprbl[L][blk - 1];
+            float C[18];
+            C[1] = (float)0.5 * (Ra + Rb);
+            C[2] = rconst * (Ra - Rb);
 #pragma unroll
-            for (int blk = 1; blk <= 4; ++blk) {
-                const int ji = T->ambe_lmprbl[L][blk - 1];
-                const float* hoc = (blk == 1) ? T->ambe_hoc_b5[hb[1]]
-                                              : ((blk == 2) ? T->ambe_hoc_b6[hb[2]] : ((blk == 3) ? T->ambe_hoc_b7[hb[3]] : T->ambe_hoc_b8[hb[4]]));
-                float C[18];
-                C[1] = (float)0.5 * (Ri[2 * blk - 1] + Ri[2 * blk]);
-                C[2] = rconst * (Ri[2 * blk - 1] - Ri[2 * blk]);
+            for (int k = 3; k <= 17; ++k) {
+                C[k] = (k <= 6 && k <= ji) ? hoc[k - 3] : 0.0f;
+            }
+            for (int j = 1; j <= ji; ++j) {
+                float sum = 0;
 #pragma unroll
-                for (int k = 3; k <= 17; ++k) {
-                    C[k] = (k <= 6 && k <= ji) ? hoc[k - 3] : 0.0f;
-                }
-                for (int j = 1; j <= ji; ++j) {
-                    float sum = 0;
-#pragma unroll
-                    for (int k = 1; k <= 17; ++k) {
-                        if (k <= ji) {
-                            const float ak = (k == 1) ? 1.0f : 2.0f;
-                            sum = sum + (ak * C[k] * T->ambe_idct_cos[ji][j][k]);
-                        }
+                for (int k = 1; k <= 17; ++k) {
+                    if (k <= ji) {
+                        const float ak = (k == 1) ? 1.0f : 2.0f;
+                        sum = sum + (ak * C[k] * T->ambe_idct_cos[ji][j][k]);
                     }
-                    row[l++] = sum;
-                    tsum += sum;   // Sum42 in the reference's order (l ascending)
                 }
+                row[l++] = sum;
+            }
+        }
+    }
+    __syncthreads();
+    if (i < n && sub == 0) {
+        uint32_t vlo = 0, vhi = 0;
+        float dg = 0.0f, sum42 = 0.0f;
+        if (bad == 0) {
+            if (!silence) {
+                const int b1 = pick(w, 4, 5, 6, 7, 35);
+                for (int l = 1; l <= L; ++l) {
+                    const int jl = (int)((float)l * (float)16.0 * f0);
+                    const uint32_t v = T->ambe_vuv[b1][jl & 7];
+                    if (l <= 32) {
+                        vlo |= v << (l - 1);
+                    } else {
+                        vhi |= v << (l - 33);
+                    }
+                }
+            }
+            dg = T->ambe_dg[pick(w, 8, 9, 10, 11, 36)];
+            float tsum = 0.0f;   // Sum42 in the reference's order (l ascending)
+            for (int l = 1; l <= L; ++l) {
+                tsum += row[l];
             }
             sum42 = tsum / (float)L;
         }
@@ -272,7 +295,7 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         row[59] = w0;
         row[60] = __int_as_float(L);
         row[61] = sum42;
-        row[62] = __uint_as_float(rec.w);
+        row[62] = __uint_as_float(errw);
         row[63] = __int_as_float(bad);
     }
     write_out(tile, out, first, n);

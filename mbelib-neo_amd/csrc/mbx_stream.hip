@@ -28,7 +28,7 @@
 #include "mbx_device.h"
 
 #ifndef MBX_STREAM_WAVES_PER_SIMD
-#define MBX_STREAM_WAVES_PER_SIMD 2   // occupancy target of the stream kernels (caps VGPRs at 512 / n)
+#define MBX_STREAM_WAVES_PER_SIMD 5   // occupancy target of the stream kernels (caps VGPRs at 512 / n)
 #endif
 
 namespace mbx {
@@ -54,6 +54,12 @@ struct Parms {
     float    ov[2];    // noiseOverlap[lane + 64*j]  (j = 1: lanes 0..31)
 };
 
+// Wave-uniform values (every scalar field of mbe_parms) are pinned to SGPRs: the VGPR file is what
+// limits occupancy here, and a scalar costs 1/64 of a VGPR even when it has to be spilled.
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
 // dword offsets inside mbe_parms (include/mbx_types.h asserts the byte offsets)
 enum : int {
     O_W0 = 0, O_L = 1, O_K = 2, O_VL = 3, O_ML = 60, O_LOG2ML = 117, O_PHI = 174, O_PSI = 231, O_GAMMA = 288,
@@ -65,29 +71,29 @@ __device__ __forceinline__ void load_parms(Parms& r, const mbe_parms* __restrict
     const float* f = reinterpret_cast<const float*>(p);
     const int* i = reinterpret_cast<const int*>(p);
     const bool band = lane < MBX_BAND_SLOTS;
-    r.w0 = f[O_W0];
-    r.L = i[O_L];
-    r.K = i[O_K];
+    r.w0 = uni(f[O_W0]);
+    r.L = uni(i[O_L]);
+    r.K = uni(i[O_K]);
     r.Vl = band ? i[O_VL + lane] : 0;
     r.Ml = band ? f[O_ML + lane] : 0.0f;
     r.log2Ml = band ? f[O_LOG2ML + lane] : 0.0f;
     r.PHIl = band ? f[O_PHI + lane] : 0.0f;
     r.PSIl = band ? f[O_PSI + lane] : 0.0f;
-    r.gamma = f[O_GAMMA];
-    r.tonePhase = (uint32_t)i[O_TONEPHASE];
-    r.swn = i[O_SWN];
-    r.localEnergy = f[O_LOCALENERGY];
-    r.amplitudeThreshold = i[O_AMPTHR];
-    r.errorRate = f[O_ERRORRATE];
-    r.errorCountTotal = i[O_ERRTOTAL];
-    r.errorCount4 = i[O_ERR4];
-    r.repeatCount = i[O_REPEAT];
-    r.mutingThreshold = f[O_MUTETHR];
+    r.gamma = uni(f[O_GAMMA]);
+    r.tonePhase = (uint32_t)uni(i[O_TONEPHASE]);
+    r.swn = uni(i[O_SWN]);
+    r.localEnergy = uni(f[O_LOCALENERGY]);
+    r.amplitudeThreshold = uni(i[O_AMPTHR]);
+    r.errorRate = uni(f[O_ERRORRATE]);
+    r.errorCountTotal = uni(i[O_ERRTOTAL]);
+    r.errorCount4 = uni(i[O_ERR4]);
+    r.repeatCount = uni(i[O_REPEAT]);
+    r.mutingThreshold = uni(f[O_MUTETHR]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         r.uw[j] = f[O_UW + lane + 64 * j];
     }
-    r.noiseSeed = f[O_NOISESEED];
+    r.noiseSeed = uni(f[O_NOISESEED]);
     r.ov[0] = f[O_OVERLAP + lane];
     r.ov[1] = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
 }
@@ -128,12 +134,66 @@ __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restric
     }
 }
 
+// Partial loads.  The stream kernels do not need every field of the previous structs:
+//   * decode reads from prev_mp only the prediction memory (Ml, log2Ml), L, errorRate, repeatCount,
+//     gamma, mutingThreshold (+ PHIl[0], which AMBE's log2Ml[57] aliases); the rest of prev_mp
+//     matters only on a repeat / erasure, where it is fetched on demand;
+//   * synthesis reads from prev_mp_enhanced only w0, L, Vl, Ml, PHIl, PSIl, the second half of
+//     previousUw and the two smoothing memories.
+// Unread fields stay zero and are optimised away: fewer registers, and ~40 % less state read traffic.
+__device__ __forceinline__ void load_prev_view(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+    const float* f = reinterpret_cast<const float*>(p);
+    const int* i = reinterpret_cast<const int*>(p);
+    const bool band = lane < MBX_BAND_SLOTS;
+    r = Parms{};
+    r.L = uni(i[O_L]);
+    r.Ml = band ? f[O_ML + lane] : 0.0f;
+    r.log2Ml = band ? f[O_LOG2ML + lane] : 0.0f;
+    r.PHIl = band ? f[O_PHI + lane] : 0.0f;
+    r.gamma = uni(f[O_GAMMA]);
+    r.errorRate = uni(f[O_ERRORRATE]);
+    r.repeatCount = uni(i[O_REPEAT]);
+    r.mutingThreshold = uni(f[O_MUTETHR]);
+}
+
+__device__ __forceinline__ void load_enh_view(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+    const float* f = reinterpret_cast<const float*>(p);
+    const int* i = reinterpret_cast<const int*>(p);
+    const bool band = lane < MBX_BAND_SLOTS;
+    r = Parms{};
+    r.w0 = uni(f[O_W0]);
+    r.L = uni(i[O_L]);
+    r.Vl = band ? i[O_VL + lane] : 0;
+    r.Ml = band ? f[O_ML + lane] : 0.0f;
+    r.PHIl = band ? f[O_PHI + lane] : 0.0f;
+    r.PSIl = band ? f[O_PSI + lane] : 0.0f;
+    r.localEnergy = uni(f[O_LOCALENERGY]);
+    r.amplitudeThreshold = uni(i[O_AMPTHR]);
+    r.uw[2] = f[O_UW + lane + 128];
+    r.uw[3] = f[O_UW + lane + 192];
+}
+
+// the synthesis-continuity fields an AMBE erasure keeps from prev_mp
+__device__ __forceinline__ void load_continuity(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+    const float* f = reinterpret_cast<const float*>(p);
+    const bool band = lane < MBX_BAND_SLOTS;
+    r.PHIl = band ? f[O_PHI + lane] : 0.0f;
+    r.PSIl = band ? f[O_PSI + lane] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.uw[j] = f[O_UW + lane + 64 * j];
+    }
+    r.noiseSeed = uni(f[O_NOISESEED]);
+    r.ov[0] = f[O_OVERLAP + lane];
+    r.ov[1] = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
+}
+
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS scratch.
 // ------------------------------------------------------------------------------------------
 constexpr int kTrStride = 68;   // 64 harmonics + 4 pad dwords: rows stay 16-B aligned and the
                                 // ds_read_b128 column sums are bank-conflict free (row*68 mod 64 = row*4)
-constexpr int kTrRows = 32;     // samples per transposition tile
+constexpr int kTrRows = 16;     // samples per transposition tile
 
 struct WaveScratch {
     union {
@@ -144,9 +204,6 @@ struct WaveScratch {
             float  scale[132];                        //   per-bin scale, bins 0..128
         };
     };
-    int   word[64];                  // IMBE parameter words b_m
-    float gm[32];                    // gains [0..15], block means Ri [16..31]
-    float cik[96];                   // IMBE [7][11], AMBE [5][18]
 };
 
 struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
@@ -164,17 +221,17 @@ __device__ __forceinline__ int rec_bit(const uint32_t w[3], int i) { return (int
 // v[57..58] voicing bits, v[59] w0, v[60] L, v[61] K (IMBE) / mean residual (AMBE), v[62] error
 // context word, v[63] frame class, v[0] AMBE gain increment.
 __device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev, int lane) {
-    const int bad = __float_as_int(fp[63]);
+    const int bad = uni(__float_as_int(fp[63]));
     if (bad != 0) {
         if (fp[59] != 0.0f) {
             cur.w0 = fp[59];   // valid b0 with an out-of-range L: the reference has already stored w0
         }
         return 1;
     }
-    cur.w0 = fp[59];
-    const int L = __float_as_int(fp[60]);
+    cur.w0 = uni(fp[59]);
+    const int L = uni(__float_as_int(fp[60]));
     cur.L = L;
-    cur.K = __float_as_int(fp[61]);
+    cur.K = uni(__float_as_int(fp[61]));
     const unsigned long long vbits = ((unsigned long long)__float_as_uint(fp[58]) << 32) | __float_as_uint(fp[57]);
     float Tl = 0.0f;
     if (lane >= 1 && lane <= L) {
@@ -328,7 +385,7 @@ __device__ void smooth(Parms& cur, const Parms& prev, float RM0, int lane) {
     if (le < 10000.0f) {
         le = 10000.0f;
     }
-    cur.localEnergy = le;
+    cur.localEnergy = uni(le);
     const bool in = lane >= 1 && lane <= L;
     if (!(er <= 0.005f && et <= 4)) {   // otherwise VM = FLT_MAX and nothing can exceed it
         const float x8 = sqrtf(sqrtf(sqrtf(le)));
@@ -425,7 +482,7 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         nz[0] = nz[1] = nz[2] = nz[3] = 0.0f;
         cur.ov[0] = cur.ov[1] = 0.0f;
         if (rng.unv_override) {
-            cur.noiseSeed = (float)rng.unv_state;
+            cur.noiseSeed = uni((float)rng.unv_state);
             rng.unv_override = 0;
         } else {
             cur.noiseSeed = 3147.0f;
@@ -442,7 +499,7 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         nz[3] = at(lane + 96);
         cur.ov[0] = at(lane + 64);
         cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
-        cur.noiseSeed = at(160);
+        cur.noiseSeed = uni(at(160));
     }
 
     // ---- reconcile the two model lengths ---------------------------------------------------
@@ -557,33 +614,34 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 wp_bits[nb] = __float_as_int((n < N) ? Ws[n + N] : 0.0f);
                 wc_bits[nb] = __float_as_int((n < N) ? Ws[n] : 0.0f);
             }
-            // Tile of 32 samples x 64 harmonic columns.  Row r is summed by two lanes (r: columns
-            // 0..31, r+32: columns 32..63; columns of inactive lanes hold exact zeros), the halves
-            // are combined across the lane pair and land in the lane that owns sample 32*b + r.
+            // Tile of 16 samples x 64 harmonic columns.  Row r is summed by the four lanes 4r..4r+3
+            // (16 columns each; columns of inactive lanes hold exact zeros), the quarters are combined
+            // inside the quad and the total is fetched by the lane that owns sample 16*b + r.
             auto flush = [&](int b) {
                 wave_lds_sync();
-                const float4* row = reinterpret_cast<const float4*>(&S.tr[(lane & 31) * kTrStride + (lane & 32)]);
-                float4 q[8];
+                const float4* row = reinterpret_cast<const float4*>(&S.tr[(lane >> 2) * kTrStride + 16 * (lane & 3)]);
+                float4 q[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     q[k] = row[k];
                 }
                 float sacc = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     sacc += q[k].x;
                     sacc += q[k].y;
                     sacc += q[k].z;
                     sacc += q[k].w;
                 }
-                sacc += __shfl_xor(sacc, 32, kWave);
-                if ((lane >> 5) == (b & 1)) {
-                    acc[b >> 1] += sacc;
+                sacc += __shfl_xor(sacc, 1, kWave);
+                sacc += __shfl_xor(sacc, 2, kWave);
+                const float total = __shfl(sacc, 4 * (lane & 15), kWave);
+                if ((lane >> 4) == (b & 3)) {
+                    acc[b >> 2] += total;
                 }
                 wave_lds_sync();
             };
-            // prev weight Ws[n+160] is zero from n = 105 on, cur weight Ws[n] below n = 56; the
-            // cur oscillator still advances through its first 56 samples like the reference's does
+            // prev weight Ws[n+160] is zero from n = 105 on, cur weight Ws[n] below n = 56
             auto segment = [&](int n0, int n1, auto has_prev, auto has_cur, int wreg) {
 #pragma unroll 8
                 for (int n = n0; n < n1; ++n) {
@@ -596,18 +654,20 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                     if constexpr (decltype(has_cur)::value) {
                         const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[wreg], n & 63));
                         v += wc * cc;
-                    }
-                    S.tr[(n & 31) * kTrStride + lane] = v;
-                    if constexpr (decltype(has_cur)::value) {
                         rotate(cc, sc, cdc, sdc);
                     }
+                    S.tr[(n & (kTrRows - 1)) * kTrStride + lane] = v;
                 }
             };
             using Yes = std::true_type;
             using No = std::false_type;
-            segment(0, 32, Yes{}, No{}, 0);
+            segment(0, 16, Yes{}, No{}, 0);
             flush(0);
-            segment(32, 56, Yes{}, No{}, 0);
+            segment(16, 32, Yes{}, No{}, 0);
+            flush(1);
+            segment(32, 48, Yes{}, No{}, 0);
+            flush(2);
+            segment(48, 56, Yes{}, No{}, 0);
             {   // the cur oscillator contributes nothing below n = 56 (Ws[n] = 0): advance it there with
                 // 7 steps of (cdc, sdc)^8 instead of 56 single steps
                 float c8 = cdc, s8 = sdc;
@@ -620,14 +680,20 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 }
             }
             segment(56, 64, Yes{}, Yes{}, 0);
-            flush(1);
-            segment(64, 96, Yes{}, Yes{}, 1);
-            flush(2);
-            segment(96, 105, Yes{}, Yes{}, 1);
-            segment(105, 128, No{}, Yes{}, 1);
             flush(3);
-            segment(128, 160, No{}, Yes{}, 2);
+            segment(64, 80, Yes{}, Yes{}, 1);
             flush(4);
+            segment(80, 96, Yes{}, Yes{}, 1);
+            flush(5);
+            segment(96, 105, Yes{}, Yes{}, 1);
+            segment(105, 112, No{}, Yes{}, 1);
+            flush(6);
+            segment(112, 128, No{}, Yes{}, 1);
+            flush(7);
+            segment(128, 144, No{}, Yes{}, 2);
+            flush(8);
+            segment(144, 160, No{}, Yes{}, 2);
+            flush(9);
         }
     }
 
@@ -650,9 +716,6 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         for (int r = 0; r < 4; ++r) {
             win[r] = T->uv_window[lane + 64 * r];
         }
-        const float wden[3] = {T->wola_denom[lane], T->wola_denom[lane + 64], (lane < 32) ? T->wola_denom[lane + 128] : 1.0f};
-        const float wprev[2] = {T->wola_w_prev[lane], T->wola_w_prev[lane + 64]};   // w(n) is 0 from n = 106 on
-        const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
         S.scale[lane] = 0.0f;
         S.scale[lane + 64] = 0.0f;
         if (lane < 4) {
@@ -775,6 +838,9 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
         // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
+        const float wden[3] = {T->wola_denom[lane], T->wola_denom[lane + 64], (lane < 32) ? T->wola_denom[lane + 128] : 1.0f};
+        const float wprev[2] = {T->wola_w_prev[lane], T->wola_w_prev[lane + 64]};   // w(n) is 0 from n = 106 on
+        const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float give = (lane < 32) ? cur.uw[j] : ((j == 0) ? 0.0f : cur.uw[j - 1]);
@@ -881,20 +947,20 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
         const DeviceTables& tabs = ft;
         const float* fp = params[f].v;
-        const uint32_t errw = __float_as_uint(fp[62]);
+        const uint32_t errw = uni(__float_as_uint(fp[62]));
         const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
         unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
         const int total = c0 + prot;
         bool muted;
         {
             Parms prev;
-            load_parms(prev, slot_prev, lane);
+            load_prev_view(prev, slot_prev, lane);
 
             // prepare (imbe4400_prepare_process)
             cur.errorCount4 = c4;
             cur.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
             cur.errorCountTotal = total;
-            cur.errorRate = (0.95f * prev.errorRate) + (0.000365f * (float)total);
+            cur.errorRate = uni((0.95f * prev.errorRate) + (0.000365f * (float)total));
 
             const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, lane);
             const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
@@ -907,7 +973,11 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
                 if (prev.repeatCount > (MBE_MAX_FRAME_REPEATS - 1)) {
                     imbe_headroom_reset(cur, lane);
                 } else {
-                    cur = prev;
+                    // cur_mp := prev_mp.  Only the prediction memory was loaded (and padded by the
+                    // decode); everything else is fetched from the slot now.
+                    load_parms(cur, slot_prev, lane);
+                    cur.Ml = prev.Ml;
+                    cur.log2Ml = prev.log2Ml;
                     cur.repeatCount++;
                 }
                 flags |= MBE_PROCESS_FLAG_REPEAT;
@@ -918,7 +988,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         float out[3] = {0.0f, 0.0f, 0.0f};
         {
             Parms enh;
-            load_parms(enh, slot_enh, lane);
+            load_enh_view(enh, slot_enh, lane);
             const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
             if (!(tabs.ablate & 128)) {
                 synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
@@ -1013,16 +1083,16 @@ __device__ __forceinline__ int pick_bits(const uint32_t w[3], int i0, int i1, in
 
 // Returns 0 voice, 2 erasure, 7 tone (classified by the expand stage).
 __device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DeviceTables& tabs, int lane) {
-    const int bad = __float_as_int(fp[63]);
+    const int bad = uni(__float_as_int(fp[63]));
     if (bad != 0) {
         return bad;
     }
-    cur.w0 = fp[59];
-    const int L = __float_as_int(fp[60]);
+    cur.w0 = uni(fp[59]);
+    const int L = uni(__float_as_int(fp[60]));
     cur.L = L;
     const float unvc = (float)0.2046 / sqrtf(cur.w0);
     const unsigned long long vbits = ((unsigned long long)__float_as_uint(fp[58]) << 32) | __float_as_uint(fp[57]);
-    cur.gamma = fp[0] + ((float)0.5 * prev.gamma);
+    cur.gamma = uni(fp[0] + ((float)0.5 * prev.gamma));
     float Tl = 0.0f;
     if (lane >= 1 && lane <= L) {
         cur.Vl = (int)((vbits >> (lane - 1)) & 1ULL);
@@ -1169,7 +1239,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
         const DeviceTables& tabs = ft;
         const float* fp = params[f].v;
-        const uint32_t errw = __float_as_uint(fp[62]);
+        const uint32_t errw = uni(__float_as_uint(fp[62]));
         const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu);
         unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID
         const int total = c0 + prot;
@@ -1177,7 +1247,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         bool prev_max_repeat;
         {
             Parms prev;
-            load_parms(prev, slot_prev, lane);
+            load_prev_view(prev, slot_prev, lane);
             // prepare (ambe2450_prepare_process): state that came from the generic initialiser is
             // replaced by the AMBE defaults in all three structs
             if (fabsf(prev.mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f) {
@@ -1190,19 +1260,22 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             cur.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
             cur.errorCountTotal = total;
             cur.errorCount4 = 0;
-            cur.errorRate = (0.95f * prev.errorRate) + (0.001064f * (float)total);
+            cur.errorRate = uni((0.95f * prev.errorRate) + (0.001064f * (float)total));
 
             bad = decode_ambe(fp, cur, prev, tabs, lane);
             prev_max_repeat = prev.repeatCount >= MBE_MAX_FRAME_REPEATS;
             if (bad == 2) {
                 flags |= MBE_PROCESS_FLAG_ERASURE;
                 cur.repeatCount = 0;
+                load_continuity(prev, slot_prev, lane);   // phases, overlap-add and noise state of prev_mp
                 set_ambe_erasure_parms(cur, prev, lane);
             } else if (bad == 7) {
                 flags |= MBE_PROCESS_FLAG_TONE;
                 cur.repeatCount = 0;
             } else if (((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? ((c0 >= 4) || ((c0 >= 2) && (total >= 6))) : (total > 3)) {
-                cur = prev;
+                load_parms(cur, slot_prev, lane);   // cur_mp := prev_mp (see the IMBE kernel)
+                cur.Ml = prev.Ml;
+                cur.log2Ml = prev.log2Ml;
                 cur.repeatCount++;
                 flags |= MBE_PROCESS_FLAG_REPEAT;
             } else {
@@ -1220,7 +1293,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             if (cur.repeatCount < MBE_MAX_FRAME_REPEATS) {
                 store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
                 Parms enh;
-                load_parms(enh, slot_enh, lane);
+                load_enh_view(enh, slot_enh, lane);
                 const float rm0 = enhance(cur, lane);
                 synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
                 store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
