@@ -136,6 +136,14 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     if (sum != host->checksum) {
         return fail(MBX_EBADTABLE, "table blob: checksum mismatch");
     }
+    // the voiced-bank kernel relies on the shape of the synthesis window (mbx_stream.hip): zero / ramp / one / ramp / zero
+    for (int k = 0; k < 321; ++k) {
+        const float v = host->ws[k];
+        const bool ok = (k <= 55 || k >= 265) ? (v == 0.0f) : ((k >= 105 && k <= 215) ? (v == 1.0f) : (v > 0.0f && v < 1.0f));
+        if (!ok) {
+            return fail(MBX_EBADTABLE, "table blob: unexpected synthesis window shape");
+        }
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         return fail(MBX_ENODEVICE, "no HIP device");

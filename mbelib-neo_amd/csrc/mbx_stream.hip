@@ -604,15 +604,19 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         const bool any = (__ballot(wv_p || wv_c) != 0ULL) && !(tabs.ablate & 8);
         if (any) {
-            // window values for this lane's samples (lane = sample); broadcast per sample with
-            // v_readlane instead of a memory load inside the recurrence
+            // The synthesis window (checked by mbx_init): Ws[0..55] = 0, linear ramp on 56..104, 1 on
+            // 105..215, ramp down on 216..264, 0 from 265.  So with prev weight Ws[n+160] and cur weight Ws[n]:
+            //   n in [0, 56)    prev only, weight exactly 1      (no multiply)
+            //   n in [56, 108)  both, weights from the table     (prev weight is 0 from n = 105)
+            //   n in [108, 160) cur only, weight exactly 1
+            // Window values are held lane = sample and broadcast with v_readlane.
             const float* Ws = T->ws;
-            int wp_bits[3], wc_bits[3];
+            int wp_bits[2], wc_bits[2];
 #pragma unroll
-            for (int nb = 0; nb < 3; ++nb) {
+            for (int nb = 0; nb < 2; ++nb) {
                 const int n = lane + 64 * nb;
-                wp_bits[nb] = __float_as_int((n < N) ? Ws[n + N] : 0.0f);
-                wc_bits[nb] = __float_as_int((n < N) ? Ws[n] : 0.0f);
+                wp_bits[nb] = __float_as_int(Ws[n + N]);
+                wc_bits[nb] = __float_as_int(Ws[n]);
             }
             // Tile of 16 samples x 64 harmonic columns.  Row r is summed by the four lanes 4r..4r+3
             // (16 columns each; columns of inactive lanes hold exact zeros), the quarters are combined
@@ -641,59 +645,72 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 }
                 wave_lds_sync();
             };
-            // prev weight Ws[n+160] is zero from n = 105 on, cur weight Ws[n] below n = 56
-            auto segment = [&](int n0, int n1, auto has_prev, auto has_cur, int wreg) {
-#pragma unroll 8
-                for (int n = n0; n < n1; ++n) {
-                    float v = 0.0f;
-                    if constexpr (decltype(has_prev)::value) {
-                        const float wp = __int_as_float(__builtin_amdgcn_readlane(wp_bits[wreg], n & 63));
-                        v = wp * cp;
-                        rotate(cp, sp, cdp, sdp);
-                    }
-                    if constexpr (decltype(has_cur)::value) {
-                        const float wc = __int_as_float(__builtin_amdgcn_readlane(wc_bits[wreg], n & 63));
-                        v += wc * cc;
-                        rotate(cc, sc, cdc, sdc);
-                    }
-                    S.tr[(n & (kTrRows - 1)) * kTrStride + lane] = v;
-                }
-            };
-            using Yes = std::true_type;
-            using No = std::false_type;
-            segment(0, 16, Yes{}, No{}, 0);
-            flush(0);
-            segment(16, 32, Yes{}, No{}, 0);
-            flush(1);
-            segment(32, 48, Yes{}, No{}, 0);
-            flush(2);
-            segment(48, 56, Yes{}, No{}, 0);
-            {   // the cur oscillator contributes nothing below n = 56 (Ws[n] = 0): advance it there with
-                // 7 steps of (cdc, sdc)^8 instead of 56 single steps
-                float c8 = cdc, s8 = sdc;
-                square_rotation(c8, s8);
-                square_rotation(c8, s8);
+            // Oscillators advance four samples at a time: the three samples in between only need the
+            // cosine, c_{n+k} = c_n cos(k d) - s_n sin(k d), so a block of four costs 10 operations per
+            // oscillator instead of 16 (and fewer sequential roundings than single steps).
+            float c2p = cdp, s2p = sdp;
+            square_rotation(c2p, s2p);
+            float c3p = c2p, s3p = s2p;
+            rotate(c3p, s3p, cdp, sdp);
+            float c4p = c2p, s4p = s2p;
+            square_rotation(c4p, s4p);
+            float c2c = cdc, s2c = sdc;
+            square_rotation(c2c, s2c);
+            float c3c = c2c, s3c = s2c;
+            rotate(c3c, s3c, cdc, sdc);
+            float c4c = c2c, s4c = s2c;
+            square_rotation(c4c, s4c);
+            {   // the cur oscillator contributes nothing below n = 56: advance it there with 7 steps of 8
+                float c8 = c4c, s8 = s4c;
                 square_rotation(c8, s8);
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
                     rotate(cc, sc, c8, s8);
                 }
             }
-            segment(56, 64, Yes{}, Yes{}, 0);
-            flush(3);
-            segment(64, 80, Yes{}, Yes{}, 1);
-            flush(4);
-            segment(80, 96, Yes{}, Yes{}, 1);
-            flush(5);
-            segment(96, 105, Yes{}, Yes{}, 1);
-            segment(105, 112, No{}, Yes{}, 1);
-            flush(6);
-            segment(112, 128, No{}, Yes{}, 1);
-            flush(7);
-            segment(128, 144, No{}, Yes{}, 2);
-            flush(8);
-            segment(144, 160, No{}, Yes{}, 2);
-            flush(9);
+            auto readw = [&](const int (&bits)[2], int n) -> float {
+                return __int_as_float(__builtin_amdgcn_readlane(bits[n >> 6], n & 63));
+            };
+#pragma unroll
+            for (int b = 0; b < 10; ++b) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int n0 = 16 * b + 4 * qd;
+                    float v0, v1, v2, v3;
+                    if (n0 < 56) {
+                        v0 = cp;
+                        v1 = fmaf(cp, cdp, -(sp * sdp));
+                        v2 = fmaf(cp, c2p, -(sp * s2p));
+                        v3 = fmaf(cp, c3p, -(sp * s3p));
+                        rotate(cp, sp, c4p, s4p);
+                    } else if (n0 < 108) {
+                        const float p1 = fmaf(cp, cdp, -(sp * sdp)), p2 = fmaf(cp, c2p, -(sp * s2p)), p3 = fmaf(cp, c3p, -(sp * s3p));
+                        const float q1 = fmaf(cc, cdc, -(sc * sdc)), q2 = fmaf(cc, c2c, -(sc * s2c)), q3 = fmaf(cc, c3c, -(sc * s3c));
+                        v0 = readw(wp_bits, n0) * cp;
+                        v1 = readw(wp_bits, n0 + 1) * p1;
+                        v2 = readw(wp_bits, n0 + 2) * p2;
+                        v3 = readw(wp_bits, n0 + 3) * p3;
+                        v0 += readw(wc_bits, n0) * cc;
+                        v1 += readw(wc_bits, n0 + 1) * q1;
+                        v2 += readw(wc_bits, n0 + 2) * q2;
+                        v3 += readw(wc_bits, n0 + 3) * q3;
+                        rotate(cp, sp, c4p, s4p);
+                        rotate(cc, sc, c4c, s4c);
+                    } else {
+                        v0 = cc;
+                        v1 = fmaf(cc, cdc, -(sc * sdc));
+                        v2 = fmaf(cc, c2c, -(sc * s2c));
+                        v3 = fmaf(cc, c3c, -(sc * s3c));
+                        rotate(cc, sc, c4c, s4c);
+                    }
+                    float* dst = &S.tr[(4 * qd) * kTrStride + lane];
+                    dst[0] = v0;
+                    dst[kTrStride] = v1;
+                    dst[2 * kTrStride] = v2;
+                    dst[3 * kTrStride] = v3;
+                }
+                flush(b);
+            }
         }
     }
 
@@ -952,6 +969,10 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
         const int total = c0 + prot;
         bool muted;
+        // The parts of prev_mp_enhanced that synthesis reads are requested now, together with prev_mp,
+        // so that one memory latency covers both (they are first used after the decode).
+        Parms enh;
+        load_enh_view(enh, slot_enh, lane);
         {
             Parms prev;
             load_prev_view(prev, slot_prev, lane);
@@ -987,8 +1008,6 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
         float out[3] = {0.0f, 0.0f, 0.0f};
         {
-            Parms enh;
-            load_enh_view(enh, slot_enh, lane);
             const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
             if (!(tabs.ablate & 128)) {
                 synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
