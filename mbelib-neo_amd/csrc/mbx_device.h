@@ -38,12 +38,28 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1
 // One wavefront per workgroup: the barrier only orders this wave's LDS traffic.
 __device__ __forceinline__ void wave_lds_sync() { __syncthreads(); }
 
+// DPP lane exchange inside a row of 16 lanes (no LDS round trip)
+template <int kCtrl>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), kCtrl, 0xf, 0xf, true));
+}
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;   // lane i <-> 7-i inside each group of 8
+constexpr int kDppMirror = 0x140;       // lane i <-> 15-i inside each row of 16
+
+// Sum over the 64 lanes, returned wave-uniform (the same bits in every lane): four DPP steps reduce
+// each row of 16, the four row totals are read back with v_readlane and added in a fixed order.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        v += __shfl_xor(v, m, kWave);
-    }
-    return v;
+    v += dpp_f32<kDppXor1>(v);
+    v += dpp_f32<kDppXor2>(v);
+    v += dpp_f32<kDppHalfMirror>(v);
+    v += dpp_f32<kDppMirror>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return ((r0 + r1) + r2) + r3;
 }
 
 __device__ __forceinline__ float lane_get(float v, int src) { return __shfl(v, src, kWave); }

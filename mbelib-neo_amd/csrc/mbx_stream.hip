@@ -637,8 +637,8 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                     sacc += q[k].z;
                     sacc += q[k].w;
                 }
-                sacc += __shfl_xor(sacc, 1, kWave);
-                sacc += __shfl_xor(sacc, 2, kWave);
+                sacc += dpp_f32<kDppXor1>(sacc);
+                sacc += dpp_f32<kDppXor2>(sacc);
                 const float total = __shfl(sacc, 4 * (lane & 15), kWave);
                 if ((lane >> 4) == (b & 3)) {
                     acc[b >> 2] += total;
