@@ -1302,49 +1302,56 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             }
         }
 
-        float out[3];
-        auto reinit_all = [&]() {   // mbe_initAmbeParms_common(cur, prev, prev_enhanced)
-            init_ambe_parms(cur, lane);
-            store_parms(cur, slot_prev, lane);
-            store_parms(cur, slot_enh, lane);
-        };
+        // One call site each for the synthesiser and the noise generator (code size: the synthesiser is
+        // ~20 KB of instructions and the instruction cache holds 64 KB).
+        enum { kVoice, kToneFallback, kTone, kNoiseReinit, kNoiseErasure } action;
+        uint32_t tw[3] = {0u, 0u, 0u};
         if (bad == 0) {
-            if (cur.repeatCount < MBE_MAX_FRAME_REPEATS) {
-                store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
-                Parms enh;
-                load_enh_view(enh, slot_enh, lane);
-                const float rm0 = enhance(cur, lane);
-                synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
-                store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
-            } else {
+            action = (cur.repeatCount < MBE_MAX_FRAME_REPEATS) ? kVoice : kNoiseReinit;
+            if (action == kNoiseReinit) {
                 flags |= MBE_PROCESS_FLAG_MUTE;
-                comfort_noise(out, rng, lane);
-                reinit_all();
             }
         } else if (bad == 7) {
             const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
-            const uint32_t w[3] = {rec.x, rec.y, rec.z};
-            const int id1 = (int)((w[0] >> 12) & 0xffu);   // parameter bits 12..19
+            tw[0] = rec.x;
+            tw[1] = rec.y;
+            tw[2] = rec.z;
+            const int id1 = (int)((tw[0] >> 12) & 0xffu);   // parameter bits 12..19
             float f1, f2;
-            if (tone_freqs(id1, f1, f2)) {
-                tone_frame(out, w, cur, lane);
-            } else if (!prev_max_repeat) {
-                // invalid tone id: run the synthesiser on a copy of the enhanced model.  `cur` is parked
-                // in its slot meanwhile so that still only two structs are live.
-                store_parms(cur, slot_cur, lane);
+            action = tone_freqs(id1, f1, f2) ? kTone : (!prev_max_repeat ? kToneFallback : kNoiseReinit);
+        } else {
+            action = kNoiseErasure;
+        }
+
+        float out[3];
+        Parms enh;
+        float rm0 = 0.0f;
+        if (action == kVoice) {
+            store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
+            load_enh_view(enh, slot_enh, lane);
+            rm0 = enhance(cur, lane);
+        } else if (action == kToneFallback) {
+            // invalid tone id: run the synthesiser on a copy of the enhanced model.  `cur` is parked in
+            // its slot meanwhile so that still only two structs are live.
+            store_parms(cur, slot_cur, lane);
+            __threadfence_block();
+            load_parms(enh, slot_enh, lane);
+            cur = enh;
+        }
+        if (action == kVoice || action == kToneFallback) {
+            synth_core(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane);
+            store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := synthesised model
+            if (action == kToneFallback) {
                 __threadfence_block();
-                Parms enh;
-                load_parms(enh, slot_enh, lane);
-                cur = enh;
-                synth_core(out, cur, enh, false, 0.0f, rng, scratch, tabs, lane);
-                store_parms(cur, slot_enh, lane);
                 load_parms(cur, slot_cur, lane);
-            } else {
-                comfort_noise(out, rng, lane);
-                reinit_all();
             }
+        } else if (action == kTone) {
+            tone_frame(out, tw, cur, lane);
         } else {
             comfort_noise(out, rng, lane);
+            if (action == kNoiseReinit) {   // mbe_initAmbeParms_common(cur, prev, prev_enhanced)
+                init_ambe_parms(cur, lane);
+            }
             store_parms(cur, slot_prev, lane);
             store_parms(cur, slot_enh, lane);
         }
