@@ -35,8 +35,15 @@ struct DeviceTables {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 
-// One wavefront per workgroup: the barrier only orders this wave's LDS traffic.
-__device__ __forceinline__ void wave_lds_sync() { __syncthreads(); }
+// One wavefront per workgroup: lanes exchange data through LDS, and LDS operations of one wave are
+// executed in issue order, so all that is needed is that the compiler keeps the program order of the
+// LDS accesses.  A wavefront-scope fence does exactly that and -- unlike __syncthreads(), whose
+// workgroup-scope fence waits for vmcnt(0) -- does not drain outstanding global stores / loads.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // DPP lane exchange inside a row of 16 lanes (no LDS round trip)
 template <int kCtrl>

@@ -455,9 +455,42 @@ __device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
 // Speech synthesis core (mbe_synthesizeSpeechCore).  `prev` is the enhanced previous model.
 // Output: out[j] = sample lane + 64*j (j = 0..2, sample < 160).
 // ------------------------------------------------------------------------------------------
+// Window constants of this lane, packed.  Every value of the two synthesis windows is a multiple of
+// 0.02 (mbx_init checks that (float)(k * 0.02) reproduces each table entry bit for bit), so a lane's
+// 13 values fit four registers as 8-bit step counts.  A persistent kernel loads them once; inside the
+// frame they are unpacked where needed, so the synthesis issues no vector loads for tables -- a
+// requirement for keeping the next stream's LDS-DMA prefetch in flight (vmcnt completes in order).
+struct LaneWindows {
+    uint32_t ws;     // Ws[lane+160], Ws[lane+224], Ws[lane], Ws[lane+64]   (prev n, prev n+64, cur n, cur n+64)
+    uint32_t uv;     // uv_window[lane + 64 r], r = 0..3
+    uint32_t wola;   // wola_w_prev[lane], wola_w_prev[lane+64], wola_w_curr[lane], wola_w_curr[lane+64]
+    uint32_t wola2;  // wola_w_curr[lane+128] (lanes 0..31)
+};
+
+__device__ __forceinline__ uint32_t win_step(float v) { return (uint32_t)__float2int_rn(v * 50.0f); }
+__device__ __forceinline__ float win_value(uint32_t packed, int idx) {
+    return (float)((double)((packed >> (8 * idx)) & 0xffu) * 0.02);
+}
+
+__device__ __forceinline__ void load_lane_windows(LaneWindows& w, const mbx_tables* T, int lane) {
+    w.ws = win_step(T->ws[lane + 160]) | (win_step(T->ws[lane + 224]) << 8) | (win_step(T->ws[lane]) << 16)
+           | (win_step(T->ws[lane + 64]) << 24);
+    w.uv = win_step(T->uv_window[lane]) | (win_step(T->uv_window[lane + 64]) << 8) | (win_step(T->uv_window[lane + 128]) << 16)
+           | (win_step(T->uv_window[lane + 192]) << 24);
+    w.wola = win_step(T->wola_w_prev[lane]) | (win_step(T->wola_w_prev[lane + 64]) << 8) | (win_step(T->wola_w_curr[lane]) << 16)
+             | (win_step(T->wola_w_curr[lane + 64]) << 24);
+    w.wola2 = (lane < 32) ? win_step(T->wola_w_curr[lane + 128]) : 0u;
+}
+
+// Called by synth_core once the frame's last table-driven vector load (the LCG jump-ahead constants)
+// has been issued: from here to the end of the frame the synthesis only stores.
+struct NoHook {
+    __device__ void operator()() const {}
+};
+
+template <class Hook>
 __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
-                           WaveScratch& S, const DeviceTables& tabs, int lane) {
-    const mbx_tables* T = tabs.t;
+                           WaveScratch& S, const DeviceTables& tabs, const LaneWindows& lw, Hook&& after_loads, int lane) {
     const DerivedTables* D = tabs.d;
     constexpr int N = 160;
     out[0] = out[1] = out[2] = 0.0f;
@@ -501,6 +534,8 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
         cur.noiseSeed = uni(at(160));
     }
+
+    after_loads();
 
     // ---- reconcile the two model lengths ---------------------------------------------------
     int maxl;
@@ -610,14 +645,11 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             //   n in [56, 108)  both, weights from the table     (prev weight is 0 from n = 105)
             //   n in [108, 160) cur only, weight exactly 1
             // Window values are held lane = sample and broadcast with v_readlane.
-            const float* Ws = T->ws;
             int wp_bits[2], wc_bits[2];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int n = lane + 64 * nb;
-                wp_bits[nb] = __float_as_int(Ws[n + N]);
-                wc_bits[nb] = __float_as_int(Ws[n]);
-            }
+            wp_bits[0] = __float_as_int(win_value(lw.ws, 0));
+            wp_bits[1] = __float_as_int(win_value(lw.ws, 1));
+            wc_bits[0] = __float_as_int(win_value(lw.ws, 2));
+            wc_bits[1] = __float_as_int(win_value(lw.ws, 3));
             // Tile of 16 samples x 64 harmonic columns.  Row r is summed by the four lanes 4r..4r+3
             // (16 columns each; columns of inactive lanes hold exact zeros), the quarters are combined
             // inside the quad and the total is fetched by the lane that owns sample 16*b + r.
@@ -731,7 +763,7 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         float win[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            win[r] = T->uv_window[lane + 64 * r];
+            win[r] = win_value(lw.uv, r);
         }
         S.scale[lane] = 0.0f;
         S.scale[lane + 64] = 0.0f;
@@ -855,9 +887,11 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
         // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
-        const float wden[3] = {T->wola_denom[lane], T->wola_denom[lane + 64], (lane < 32) ? T->wola_denom[lane + 128] : 1.0f};
-        const float wprev[2] = {T->wola_w_prev[lane], T->wola_w_prev[lane + 64]};   // w(n) is 0 from n = 106 on
-        const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
+        const float wprev[2] = {win_value(lw.wola, 0), win_value(lw.wola, 1)};   // w(n) is 0 from n = 106 on
+        const float wcurr[3] = {win_value(lw.wola, 2), win_value(lw.wola, 3), win_value(lw.wola2, 0)};
+        // the denominators as the reference's plan builds them (src/core/mbe_unvoiced_fft.c:165-169)
+        const float wden[3] = {(wprev[0] * wprev[0]) + (wcurr[0] * wcurr[0]), (wprev[1] * wprev[1]) + (wcurr[1] * wcurr[1]),
+                               (lane < 32) ? (wcurr[2] * wcurr[2]) : 1.0f};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float give = (lane < 32) ? cur.uw[j] : ((j == 0) ? 0.0f : cur.uw[j - 1]);
@@ -929,7 +963,72 @@ __device__ __forceinline__ void store_rng(const StreamRng& r, mbx_stream_rng* p,
 }
 
 // ------------------------------------------------------------------------------------------
-// IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
+// Persistent waves with an LDS-DMA prefetch of the next stream.
+//
+// A wave walks streams s = blockIdx.x, blockIdx.x + gridDim.x, ...  While it synthesises the last
+// frame of stream s, the state of stream s' = s + gridDim.x (and the parameters of its first frame)
+// is already streaming from HBM into the wave's LDS stage with global_load_lds -- no VGPR is tied up
+// by the transfer, so the memory-level parallelism no longer depends on the register-limited
+// occupancy.  The DMA is issued by the `after_loads` hook of synth_core, i.e. after the frame's last
+// ordinary vector load: vmcnt retires in order, so an ordinary load issued later would have to wait
+// for the whole prefetch.
+// ------------------------------------------------------------------------------------------
+struct StageBuf {              // one 64-dword chunk per global_load_lds instruction
+    uint32_t cur[11 * 64];     // cur_mp, dwords 0..650
+    uint32_t prev[5 * 64];     // prev_mp, dwords 0..297 (everything the decode reads)
+    uint32_t enh[5 * 64];      // prev_mp_enhanced, dwords 0..297
+    uint32_t enh_uw[2 * 64];   // prev_mp_enhanced.previousUw[128..255]
+    uint32_t fp[64];           // FrameParams of the stream's first frame
+};
+
+__device__ __forceinline__ void dma_dword(const uint32_t* gsrc, uint32_t* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
+}
+
+__device__ __forceinline__ void prefetch_stream(StageBuf& st, const mbe_parms* triplet, const FrameParams* first_frame, int lane) {
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(triplet);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const int idx = 64 * k + lane;
+        dma_dword(g + (idx < PARMS_DWORDS ? idx : PARMS_DWORDS - 1), &st.cur[64 * k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int idx = 64 * k + lane;
+        const int c = idx < O_UW ? idx : O_UW - 1;
+        dma_dword(g + PARMS_DWORDS + c, &st.prev[64 * k]);
+        dma_dword(g + 2 * PARMS_DWORDS + c, &st.enh[64 * k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        dma_dword(g + 2 * PARMS_DWORDS + O_UW + 128 + 64 * k + lane, &st.enh_uw[64 * k]);
+    }
+    dma_dword(reinterpret_cast<const uint32_t*>(first_frame) + lane, &st.fp[0]);
+}
+
+__device__ __forceinline__ void wait_prefetch() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_lds_sync();
+}
+
+__device__ __forceinline__ void load_enh_view_staged(Parms& r, const StageBuf& st, int lane) {
+    const bool band = lane < MBX_BAND_SLOTS;
+    r = Parms{};
+    r.w0 = uni(__uint_as_float(st.enh[O_W0]));
+    r.L = uni((int)st.enh[O_L]);
+    r.Vl = band ? (int)st.enh[O_VL + lane] : 0;
+    r.Ml = band ? __uint_as_float(st.enh[O_ML + lane]) : 0.0f;
+    r.PHIl = band ? __uint_as_float(st.enh[O_PHI + lane]) : 0.0f;
+    r.PSIl = band ? __uint_as_float(st.enh[O_PSI + lane]) : 0.0f;
+    r.localEnergy = uni(__uint_as_float(st.enh[O_LOCALENERGY]));
+    r.amplitudeThreshold = uni((int)st.enh[O_AMPTHR]);
+    r.uw[2] = __uint_as_float(st.enh_uw[lane]);
+    r.uw[3] = __uint_as_float(st.enh_uw[64 + lane]);
+}
+
+// ------------------------------------------------------------------------------------------
+// IMBE 7200x4400 stream kernel: persistent single-wave workgroups, each walking a strided set of streams.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
 imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
@@ -937,102 +1036,134 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                    mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
-    const int s = blockIdx.x;
+    __shared__ StageBuf stage;
+    (void)records;
+    const int lane_in = lane_id();
+    int s = blockIdx.x;
     if (s >= S) {
         return;
     }
-    const int lane_in = lane_id();
-    // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
-    // registers for the whole launch; `prev` is only needed from the start of a frame to the
-    // snapshot and `enh` only from the snapshot to the end of synthesis, so both are parked in
-    // their own HBM/L2 slots in between (exactly the loads and stores a T = 1 launch needs anyway).
-    mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
-    mbe_parms* const slot_prev = &state[3 * (size_t)s + 1];
-    mbe_parms* const slot_enh = &state[3 * (size_t)s + 2];
-    Parms cur;
-    load_parms(cur, slot_cur, lane_in);
-    StreamRng rng;
-    load_rng(rng, &rngs[s]);
+    LaneWindows lw;
+    load_lane_windows(lw, tabs_in.t, lane_in);
+    prefetch_stream(stage, &state[3 * (size_t)s], &params[(size_t)s * (size_t)Tn], lane_in);
 
-    for (int t = 0; t < Tn; ++t) {
-        const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
-        // Keep per-frame table values out of the loop-carried register set: without this the compiler
-        // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
-        // across the frame loop, which halves the occupancy.
-        DeviceTables ft = tabs_in;
-        int lane = lane_in;
-        asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
-        const DeviceTables& tabs = ft;
-        const float* fp = params[f].v;
-        const uint32_t errw = uni(__float_as_uint(fp[62]));
-        const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
-        unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
-        const int total = c0 + prot;
-        bool muted;
-        // The parts of prev_mp_enhanced that synthesis reads are requested now, together with prev_mp,
-        // so that one memory latency covers both (they are first used after the decode).
-        Parms enh;
-        load_enh_view(enh, slot_enh, lane);
-        {
-            Parms prev;
-            load_prev_view(prev, slot_prev, lane);
+    for (; s < S; s += gridDim.x) {
+        // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
+        // registers for the whole stream; `prev` is only needed from the start of a frame to the
+        // snapshot and `enh` only from there to the end of synthesis, so both are parked in their own
+        // HBM/L2 slots in between (exactly the loads and stores a T = 1 launch needs anyway).
+        mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
+        mbe_parms* const slot_prev = &state[3 * (size_t)s + 1];
+        mbe_parms* const slot_enh = &state[3 * (size_t)s + 2];
+        const int next = s + (int)gridDim.x;
+        StreamRng rng;
+        load_rng(rng, &rngs[s]);
+        wait_prefetch();   // the stage now holds this stream's state and its first frame's parameters
+        Parms cur;
+        load_parms(cur, reinterpret_cast<const mbe_parms*>(stage.cur), lane_in);
 
-            // prepare (imbe4400_prepare_process)
-            cur.errorCount4 = c4;
-            cur.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
-            cur.errorCountTotal = total;
-            cur.errorRate = uni((0.95f * prev.errorRate) + (0.000365f * (float)total));
-
-            const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, lane);
-            const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
-            const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
-            const bool repeat =
-                (bad == 1) || (c0_valid ? ((c0 >= 2) && ((float)total >= repeat_threshold)) : (total > 5));
-            if (!repeat) {
-                cur.repeatCount = 0;
+        for (int t = 0; t < Tn; ++t) {
+            const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+            // Keep per-frame table values out of the loop-carried register set: without this the compiler
+            // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
+            // across the frame loop, which halves the occupancy.
+            DeviceTables ft = tabs_in;
+            int lane = lane_in;
+            asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
+            const DeviceTables& tabs = ft;
+            const bool staged = (t == 0);
+            const float* fp = staged ? reinterpret_cast<const float*>(stage.fp) : params[f].v;
+            const uint32_t errw = uni(__float_as_uint(fp[62]));
+            const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
+            unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
+            const int total = c0 + prot;
+            bool muted;
+            // The parts of prev_mp_enhanced that synthesis reads are fetched now, together with prev_mp,
+            // so that one memory latency covers both (they are first used after the decode).
+            Parms enh;
+            if (staged) {
+                load_enh_view_staged(enh, stage, lane);
             } else {
-                if (prev.repeatCount > (MBE_MAX_FRAME_REPEATS - 1)) {
-                    imbe_headroom_reset(cur, lane);
+                load_enh_view(enh, slot_enh, lane);
+            }
+            {
+                Parms prev;
+                if (staged) {
+                    load_prev_view(prev, reinterpret_cast<const mbe_parms*>(stage.prev), lane);
                 } else {
-                    // cur_mp := prev_mp.  Only the prediction memory was loaded (and padded by the
-                    // decode); everything else is fetched from the slot now.
-                    load_parms(cur, slot_prev, lane);
-                    cur.Ml = prev.Ml;
-                    cur.log2Ml = prev.log2Ml;
-                    cur.repeatCount++;
+                    load_prev_view(prev, slot_prev, lane);
                 }
-                flags |= MBE_PROCESS_FLAG_REPEAT;
-            }
-            muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
-        }
-        store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
-        float out[3] = {0.0f, 0.0f, 0.0f};
-        {
-            const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
-            if (!(tabs.ablate & 128)) {
-                synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
-            }
-        }
-        if (muted) {
-            flags |= MBE_PROCESS_FLAG_MUTE;
-        }
-        store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
-        __threadfence_block();               // the next frame of this wave reloads both slots
 
-        store_pcm(out, f, pcm16, pcmf, lane);
-        if (results && lane == 0) {
-            mbe_process_result r;
-            r.c0_errors = c0;
-            r.protected_errors = total - c0;
-            r.c4_errors = c4;
-            r.total_errors = total;
-            r.flags = flags;
-            results[f] = r;
+                // prepare (imbe4400_prepare_process)
+                cur.errorCount4 = c4;
+                cur.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
+                cur.errorCountTotal = total;
+                cur.errorRate = uni((0.95f * prev.errorRate) + (0.000365f * (float)total));
+
+                const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, lane);
+                const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
+                const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
+                const bool repeat =
+                    (bad == 1) || (c0_valid ? ((c0 >= 2) && ((float)total >= repeat_threshold)) : (total > 5));
+                if (!repeat) {
+                    cur.repeatCount = 0;
+                } else {
+                    if (prev.repeatCount > (MBE_MAX_FRAME_REPEATS - 1)) {
+                        imbe_headroom_reset(cur, lane);
+                    } else {
+                        // cur_mp := prev_mp.  Only the prediction memory was loaded (and padded by the
+                        // decode); everything else is fetched from the slot now.
+                        load_parms(cur, slot_prev, lane);
+                        cur.Ml = prev.Ml;
+                        cur.log2Ml = prev.log2Ml;
+                        cur.repeatCount++;
+                    }
+                    flags |= MBE_PROCESS_FLAG_REPEAT;
+                }
+                muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
+            }
+            store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
+            float out[3] = {0.0f, 0.0f, 0.0f};
+            // During the last frame of this stream the next stream's state starts streaming into the
+            // stage (everything staged for this stream has been consumed by now).
+            bool prefetch_due = (t == Tn - 1) && (next < S);
+            auto start_prefetch = [&]() {
+                if (prefetch_due) {
+                    wave_lds_sync();
+                    prefetch_stream(stage, &state[3 * (size_t)next], &params[(size_t)next * (size_t)Tn], lane);
+                    prefetch_due = false;
+                }
+            };
+            {
+                const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
+                if (!(tabs.ablate & 128)) {
+                    synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lw, start_prefetch, lane);
+                }
+            }
+            start_prefetch();   // muted / silent frames leave the synthesiser before the hook
+            if (muted) {
+                flags |= MBE_PROCESS_FLAG_MUTE;
+            }
+            store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
+            if (t + 1 < Tn) {
+                __threadfence_block();           // the next frame of this wave reloads both slots
+            }
+
+            store_pcm(out, f, pcm16, pcmf, lane);
+            if (results && lane == 0) {
+                mbe_process_result r;
+                r.c0_errors = c0;
+                r.protected_errors = total - c0;
+                r.c4_errors = c4;
+                r.total_errors = total;
+                r.flags = flags;
+                results[f] = r;
+            }
         }
+
+        store_parms(cur, slot_cur, lane_in);
+        store_rng(rng, &rngs[s], lane_in);
     }
-
-    store_parms(cur, slot_cur, lane_in);
-    store_rng(rng, &rngs[s], lane_in);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1247,6 +1378,8 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
     load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
     load_rng(rng, &rngs[s]);
+    LaneWindows lw;
+    load_lane_windows(lw, tabs_in.t, lane_in);
 
     for (int t = 0; t < Tn; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
@@ -1339,7 +1472,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             cur = enh;
         }
         if (action == kVoice || action == kToneFallback) {
-            synth_core(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane);
+            synth_core(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lw, NoHook{}, lane);
             store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := synthesised model
             if (action == kToneFallback) {
                 __threadfence_block();
@@ -1389,7 +1522,9 @@ synth_speech_kernel(int S, mbe_parms* __restrict__ curs, mbe_parms* __restrict__
     StreamRng rng;
     load_rng(rng, &rngs[s]);
     float out[3];
-    synth_core(out, cur, prev, false, 0.0f, rng, scratch, tabs, lane);
+    LaneWindows lw;
+    load_lane_windows(lw, tabs.t, lane);
+    synth_core(out, cur, prev, false, 0.0f, rng, scratch, tabs, lw, NoHook{}, lane);
     store_pcm(out, (size_t)s, pcm16, pcmf, lane);
     store_parms(cur, &curs[s], lane);
     store_parms(prev, &prevs[s], lane);
