@@ -43,7 +43,6 @@ struct Context {
     uint32_t           checksum = 0;
     mbx::FrameParams*  workspace = nullptr;   // expand-stage output, grow-only (mbx_reserve)
     size_t             workspace_frames = 0;
-    int                imbe_grid = 0;         // resident single-wave workgroups of the persistent IMBE kernel
 };
 Context     g_ctx;
 std::mutex  g_mu;
@@ -145,24 +144,6 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
             return fail(MBX_EBADTABLE, "table blob: unexpected synthesis window shape");
         }
     }
-    // ... and on every window value being an exact multiple of 0.02 (they are kept as 8-bit step counts)
-    {
-        auto is_step = [](float v) {
-            const long k = lroundf(v * 50.0f);
-            return k >= 0 && k <= 50 && (float)((double)k * 0.02) == v;
-        };
-        bool ok = true;
-        for (int k = 0; k < 321; ++k) ok = ok && is_step(host->ws[k]);
-        for (int k = 0; k < 256; ++k) ok = ok && is_step(host->uv_window[k]);
-        for (int k = 0; k < 160; ++k) {
-            ok = ok && is_step(host->wola_w_prev[k]) && is_step(host->wola_w_curr[k]);
-            ok = ok && host->wola_denom[k] == (host->wola_w_prev[k] * host->wola_w_prev[k]) + (host->wola_w_curr[k] * host->wola_w_curr[k]);
-            ok = ok && (k < 106 || host->wola_w_prev[k] == 0.0f);
-        }
-        if (!ok) {
-            return fail(MBX_EBADTABLE, "table blob: window values are not multiples of 0.02");
-        }
-    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         return fail(MBX_ENODEVICE, "no HIP device");
@@ -214,13 +195,6 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     HIP_TRY(hipMemcpy(g_ctx.d_derived, &d, sizeof(d), hipMemcpyHostToDevice));
     g_ctx.tabs.t = static_cast<const mbx_tables*>(g_ctx.d_blob);
     g_ctx.tabs.d = static_cast<const mbx::DerivedTables*>(g_ctx.d_derived);
-    {   // the persistent stream kernel runs exactly as many single-wave workgroups as fit on the chip
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mbx::imbe_stream_kernel, 64, 0));
-        g_ctx.imbe_grid = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
-    }
     g_ctx.device = device;
     g_ctx.checksum = host->checksum;
     g_ctx.ready = true;
@@ -391,8 +365,7 @@ int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_recor
         return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_stream_expanded: mbx_expand_records() has not been run for this batch");
     }
     if (codec == MBX_CODEC_IMBE7200X4400) {
-        const int grid = S < g_ctx.imbe_grid ? S : g_ctx.imbe_grid;
-        hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+        hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
         return check_launch("imbe_stream_kernel");
     }

@@ -191,17 +191,19 @@ __device__ __forceinline__ void load_continuity(Parms& r, const mbe_parms* __res
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS scratch.
 // ------------------------------------------------------------------------------------------
-constexpr int kTrStride = 68;   // 64 harmonics + 4 pad dwords: rows stay 16-B aligned and the
-                                // ds_read_b128 column sums are bank-conflict free (row*68 mod 64 = row*4)
-constexpr int kTrRows = 16;     // samples per transposition tile
+typedef float v2f __attribute__((ext_vector_type(2)));   // two samples per lane: v_pk_{mul,fma}_f32
+__device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
 
 struct WaveScratch {
     union {
-        alignas(16) float tr[kTrRows * kTrStride];   // voiced bank: [sample-in-block][harmonic] tile
-        struct {                                      // unvoiced path (the tile is dead by then)
-            float2 fft[256];                          //   in-place radix-4 FFT
-            float  mag2[132];                         //   |X(k)|^2, k = 0..128
-            float  scale[132];                        //   per-bin scale, bins 0..128
+        struct {                       // voiced bank: complex amplitudes of harmonic l, (A, -B, -d B, -d A)
+            alignas(16) float4 coef_prev[64];
+            alignas(16) float4 coef_cur[64];
+        };
+        struct {                       // unvoiced path (the coefficients are dead by then)
+            float2 fft[256];           //   in-place radix-4 FFT
+            float  mag2[132];          //   |X(k)|^2, k = 0..128
+            float  scale[132];         //   per-bin scale, bins 0..128
         };
     };
 };
@@ -314,6 +316,36 @@ __device__ __forceinline__ void square_rotation(float& c, float& s) {
 __device__ __forceinline__ float cos_reduced(float x) {
     const double rev = (double)x * 0.15915494309189533577;
     return __builtin_amdgcn_cosf((float)(rev - floor(rev)));
+}
+
+// e^{2 pi i rev}: double-precision reduction, hardware v_cos/v_sin (phase error <= 2.8e-7, mostly the
+// rounding of the reduced argument to float; tools/phasor_accuracy.hip)
+__device__ __forceinline__ void unit_phasor_hw(double rev, float& c, float& s) {
+    const float r = (float)(rev - floor(rev));
+    c = __builtin_amdgcn_cosf(r);
+    s = __builtin_amdgcn_sinf(r);
+}
+
+// The same to float accuracy (phase error <= 8.3e-8, rms 2.4e-8): quadrant reduction in double,
+// Taylor polynomials on [-pi/4, pi/4].  Used where the error is amplified afterwards.
+__device__ __forceinline__ void unit_phasor(double rev, float& c, float& s) {
+    const double rr = rev - floor(rev);
+    const double q = rint(rr * 4.0);
+    const float x = (float)((rr - (q * 0.25)) * 6.283185307179586);
+    const float x2 = x * x;
+    float sp = fmaf(x2, 2.7557319e-6f, -1.9841270e-4f);
+    sp = fmaf(sp, x2, 8.3333333e-3f);
+    sp = fmaf(sp, x2, -1.6666667e-1f);
+    sp = fmaf(sp * x2, x, x);
+    float cp = fmaf(x2, -2.7557319e-7f, 2.4801587e-5f);
+    cp = fmaf(cp, x2, -1.3888889e-3f);
+    cp = fmaf(cp, x2, 4.1666667e-2f);
+    cp = fmaf(cp, x2, -0.5f);
+    cp = fmaf(cp, x2, 1.0f);
+    const int k = (int)q;
+    const float ss = (k & 1) ? cp : sp, cc = (k & 1) ? sp : cp;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -455,42 +487,9 @@ __device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
 // Speech synthesis core (mbe_synthesizeSpeechCore).  `prev` is the enhanced previous model.
 // Output: out[j] = sample lane + 64*j (j = 0..2, sample < 160).
 // ------------------------------------------------------------------------------------------
-// Window constants of this lane, packed.  Every value of the two synthesis windows is a multiple of
-// 0.02 (mbx_init checks that (float)(k * 0.02) reproduces each table entry bit for bit), so a lane's
-// 13 values fit four registers as 8-bit step counts.  A persistent kernel loads them once; inside the
-// frame they are unpacked where needed, so the synthesis issues no vector loads for tables -- a
-// requirement for keeping the next stream's LDS-DMA prefetch in flight (vmcnt completes in order).
-struct LaneWindows {
-    uint32_t ws;     // Ws[lane+160], Ws[lane+224], Ws[lane], Ws[lane+64]   (prev n, prev n+64, cur n, cur n+64)
-    uint32_t uv;     // uv_window[lane + 64 r], r = 0..3
-    uint32_t wola;   // wola_w_prev[lane], wola_w_prev[lane+64], wola_w_curr[lane], wola_w_curr[lane+64]
-    uint32_t wola2;  // wola_w_curr[lane+128] (lanes 0..31)
-};
-
-__device__ __forceinline__ uint32_t win_step(float v) { return (uint32_t)__float2int_rn(v * 50.0f); }
-__device__ __forceinline__ float win_value(uint32_t packed, int idx) {
-    return (float)((double)((packed >> (8 * idx)) & 0xffu) * 0.02);
-}
-
-__device__ __forceinline__ void load_lane_windows(LaneWindows& w, const mbx_tables* T, int lane) {
-    w.ws = win_step(T->ws[lane + 160]) | (win_step(T->ws[lane + 224]) << 8) | (win_step(T->ws[lane]) << 16)
-           | (win_step(T->ws[lane + 64]) << 24);
-    w.uv = win_step(T->uv_window[lane]) | (win_step(T->uv_window[lane + 64]) << 8) | (win_step(T->uv_window[lane + 128]) << 16)
-           | (win_step(T->uv_window[lane + 192]) << 24);
-    w.wola = win_step(T->wola_w_prev[lane]) | (win_step(T->wola_w_prev[lane + 64]) << 8) | (win_step(T->wola_w_curr[lane]) << 16)
-             | (win_step(T->wola_w_curr[lane + 64]) << 24);
-    w.wola2 = (lane < 32) ? win_step(T->wola_w_curr[lane + 128]) : 0u;
-}
-
-// Called by synth_core once the frame's last table-driven vector load (the LCG jump-ahead constants)
-// has been issued: from here to the end of the frame the synthesis only stores.
-struct NoHook {
-    __device__ void operator()() const {}
-};
-
-template <class Hook>
 __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
-                           WaveScratch& S, const DeviceTables& tabs, const LaneWindows& lw, Hook&& after_loads, int lane) {
+                           WaveScratch& S, const DeviceTables& tabs, int lane) {
+    const mbx_tables* T = tabs.t;
     const DerivedTables* D = tabs.d;
     constexpr int N = 160;
     out[0] = out[1] = out[2] = 0.0f;
@@ -534,8 +533,6 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
         cur.noiseSeed = uni(at(160));
     }
-
-    after_loads();
 
     // ---- reconcile the two model lengths ---------------------------------------------------
     int maxl;
@@ -609,140 +606,94 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
     }
 
-    // (2) windowed oscillators: lane = harmonic, advanced sample by sample with the reference's
-    //     plane rotation; the [sample][harmonic] tile goes through LDS and is summed per sample
+    // (2) windowed oscillators.  The reference advances one oscillator per harmonic sample by sample
+    //     (src/core/mbelib.c:213-218).  Here the recurrence runs along the OTHER axis: lane = sample
+    //     (two samples per lane, packed fp32 math), loop over the harmonics l = 1..maxl, and the phasor
+    //     e^{i l w0 n} of a sample is advanced from harmonic to harmonic by its own step e^{i w0 n}:
+    //         sum_l Re[(A_l + i B_l) e^{i l w0 n}],  A_l + i B_l = 2 M_l e^{i phi_l}
+    //     The complex amplitudes are computed lane = harmonic and broadcast from LDS (two ds_read_b128
+    //     per harmonic); there is no transposition tile and no cross-lane sum.  The synthesis window
+    //     depends on the sample only and is applied once, after the sum.
+    //       prev part: samples n = lane, lane + 64          weight Ws[n + 160] (zero from n = 105)
+    //       cur part:  samples n = lane + 32, lane + 96     weight Ws[n]       (zero below n = 56)
+    //     The reference's oscillator turns by theta_l = fl(w0 * l) per sample, not by l * w0; the
+    //     difference d_l (exact from one FMA, |d_l| < 1.2e-7) grows to 2e-5 rad over a frame, so it is
+    //     carried to first order: cos(x + d n) = cos x - d n sin x, a second sum weighted by n.
     {
         const bool wv_p = pv && !interp && !(tabs.ablate & 4), wv_c = cv && !interp && !(tabs.ablate & 4);
-        const float cw0l = cw0 * (float)lane, pw0l = pw0 * (float)lane;
-        float gp = 0.0f, sdp = 0.0f, cdp = 0.0f, sp = 0.0f, cp = 0.0f;
-        float gc = 0.0f, sdc = 0.0f, cdc = 0.0f, sc = 0.0f, cc = 0.0f;
-        {
-            float a, b, c, d;
-            sincosf(pw0l, &a, &b);
-            sincosf(prev.PHIl, &c, &d);
-            if (wv_p) {   // the oscillator state carries the gain 2*Ml (a rotation is linear)
-                gp = 2.0f * prev.Ml;
-                sdp = a;
-                cdp = b;
-                sp = gp * c;
-                cp = gp * d;
-            }
-            sincosf(cw0l, &a, &b);
-            sincosf(cur.PHIl - (cw0l * (float)N), &c, &d);
-            if (wv_c) {
-                gc = 2.0f * cur.Ml;
-                sdc = a;
-                cdc = b;
-                sc = gc * c;
-                cc = gc * d;
-            }
-        }
         const bool any = (__ballot(wv_p || wv_c) != 0ULL) && !(tabs.ablate & 8);
         if (any) {
-            // The synthesis window (checked by mbx_init): Ws[0..55] = 0, linear ramp on 56..104, 1 on
-            // 105..215, ramp down on 216..264, 0 from 265.  So with prev weight Ws[n+160] and cur weight Ws[n]:
-            //   n in [0, 56)    prev only, weight exactly 1      (no multiply)
-            //   n in [56, 108)  both, weights from the table     (prev weight is 0 from n = 105)
-            //   n in [108, 160) cur only, weight exactly 1
-            // Window values are held lane = sample and broadcast with v_readlane.
-            int wp_bits[2], wc_bits[2];
-            wp_bits[0] = __float_as_int(win_value(lw.ws, 0));
-            wp_bits[1] = __float_as_int(win_value(lw.ws, 1));
-            wc_bits[0] = __float_as_int(win_value(lw.ws, 2));
-            wc_bits[1] = __float_as_int(win_value(lw.ws, 3));
-            // Tile of 16 samples x 64 harmonic columns.  Row r is summed by the four lanes 4r..4r+3
-            // (16 columns each; columns of inactive lanes hold exact zeros), the quarters are combined
-            // inside the quad and the total is fetched by the lane that owns sample 16*b + r.
-            auto flush = [&](int b) {
-                wave_lds_sync();
-                const float4* row = reinterpret_cast<const float4*>(&S.tr[(lane >> 2) * kTrStride + 16 * (lane & 3)]);
-                float4 q[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    q[k] = row[k];
+            constexpr double kInv2Pi = 0.15915494309189533577;
+            {   // lane = harmonic: (A, -B, -d B, -d A) for the prev and the cur model
+                const float fl = (float)lane;
+                const float pw0l = pw0 * fl, cw0l = cw0 * fl;
+                float4 cp4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cc4 = cp4;
+                float c, d;
+                unit_phasor_hw((double)prev.PHIl * kInv2Pi, c, d);
+                if (wv_p) {
+                    const float g = 2.0f * prev.Ml, dl = -fmaf(pw0, fl, -pw0l);
+                    const float A = g * c, B = g * d;
+                    cp4 = make_float4(A, -B, -(dl * B), -(dl * A));
                 }
-                float sacc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    sacc += q[k].x;
-                    sacc += q[k].y;
-                    sacc += q[k].z;
-                    sacc += q[k].w;
+                unit_phasor_hw((double)(cur.PHIl - (cw0l * (float)N)) * kInv2Pi, c, d);
+                if (wv_c) {
+                    const float g = 2.0f * cur.Ml, dl = -fmaf(cw0, fl, -cw0l);
+                    const float A = g * c, B = g * d;
+                    cc4 = make_float4(A, -B, -(dl * B), -(dl * A));
                 }
-                sacc += dpp_f32<kDppXor1>(sacc);
-                sacc += dpp_f32<kDppXor2>(sacc);
-                const float total = __shfl(sacc, 4 * (lane & 15), kWave);
-                if ((lane >> 4) == (b & 3)) {
-                    acc[b >> 2] += total;
-                }
-                wave_lds_sync();
-            };
-            // Oscillators advance four samples at a time: the three samples in between only need the
-            // cosine, c_{n+k} = c_n cos(k d) - s_n sin(k d), so a block of four costs 10 operations per
-            // oscillator instead of 16 (and fewer sequential roundings than single steps).
-            float c2p = cdp, s2p = sdp;
-            square_rotation(c2p, s2p);
-            float c3p = c2p, s3p = s2p;
-            rotate(c3p, s3p, cdp, sdp);
-            float c4p = c2p, s4p = s2p;
-            square_rotation(c4p, s4p);
-            float c2c = cdc, s2c = sdc;
-            square_rotation(c2c, s2c);
-            float c3c = c2c, s3c = s2c;
-            rotate(c3c, s3c, cdc, sdc);
-            float c4c = c2c, s4c = s2c;
-            square_rotation(c4c, s4c);
-            {   // the cur oscillator contributes nothing below n = 56: advance it there with 7 steps of 8
-                float c8 = c4c, s8 = s4c;
-                square_rotation(c8, s8);
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    rotate(cc, sc, c8, s8);
-                }
+                S.coef_prev[lane] = cp4;
+                S.coef_cur[lane] = cc4;
             }
-            auto readw = [&](const int (&bits)[2], int n) -> float {
-                return __int_as_float(__builtin_amdgcn_readlane(bits[n >> 6], n & 63));
-            };
-#pragma unroll
-            for (int b = 0; b < 10; ++b) {
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int n0 = 16 * b + 4 * qd;
-                    float v0, v1, v2, v3;
-                    if (n0 < 56) {
-                        v0 = cp;
-                        v1 = fmaf(cp, cdp, -(sp * sdp));
-                        v2 = fmaf(cp, c2p, -(sp * s2p));
-                        v3 = fmaf(cp, c3p, -(sp * s3p));
-                        rotate(cp, sp, c4p, s4p);
-                    } else if (n0 < 108) {
-                        const float p1 = fmaf(cp, cdp, -(sp * sdp)), p2 = fmaf(cp, c2p, -(sp * s2p)), p3 = fmaf(cp, c3p, -(sp * s3p));
-                        const float q1 = fmaf(cc, cdc, -(sc * sdc)), q2 = fmaf(cc, c2c, -(sc * s2c)), q3 = fmaf(cc, c3c, -(sc * s3c));
-                        v0 = readw(wp_bits, n0) * cp;
-                        v1 = readw(wp_bits, n0 + 1) * p1;
-                        v2 = readw(wp_bits, n0 + 2) * p2;
-                        v3 = readw(wp_bits, n0 + 3) * p3;
-                        v0 += readw(wc_bits, n0) * cc;
-                        v1 += readw(wc_bits, n0 + 1) * q1;
-                        v2 += readw(wc_bits, n0 + 2) * q2;
-                        v3 += readw(wc_bits, n0 + 3) * q3;
-                        rotate(cp, sp, c4p, s4p);
-                        rotate(cc, sc, c4c, s4c);
-                    } else {
-                        v0 = cc;
-                        v1 = fmaf(cc, cdc, -(sc * sdc));
-                        v2 = fmaf(cc, c2c, -(sc * s2c));
-                        v3 = fmaf(cc, c3c, -(sc * s3c));
-                        rotate(cc, sc, c4c, s4c);
-                    }
-                    float* dst = &S.tr[(4 * qd) * kTrStride + lane];
-                    dst[0] = v0;
-                    dst[kTrStride] = v1;
-                    dst[2 * kTrStride] = v2;
-                    dst[3 * kTrStride] = v3;
-                }
-                flush(b);
+            v2f Ecp, Esp, Ecc, Esc;   // per-sample steps e^{i w0 n}; their error is amplified by l
+            {
+                const double pr = (double)pw0 * kInv2Pi, cr = (double)cw0 * kInv2Pi;
+                float c, d;
+                unit_phasor(pr * (double)lane, c, d);
+                Ecp.x = c;
+                Esp.x = d;
+                unit_phasor(pr * (double)(lane + 64), c, d);
+                Ecp.y = c;
+                Esp.y = d;
+                unit_phasor(cr * (double)(lane + 32), c, d);   // the -N w0 l offset is in the amplitude's phase
+                Ecc.x = c;
+                Esc.x = d;
+                unit_phasor(cr * (double)(lane + 96), c, d);
+                Ecc.y = c;
+                Esc.y = d;
             }
+            wave_lds_sync();
+            v2f Pcp = Ecp, Psp = Esp, Pcc = Ecc, Psc = Esc;   // harmonic 1
+            v2f sum_p = {0.0f, 0.0f}, sum_c = {0.0f, 0.0f}, drift_p = {0.0f, 0.0f}, drift_c = {0.0f, 0.0f};
+            const int last = uni(maxl);
+#pragma unroll 2
+            for (int l = 1; l <= last; ++l) {
+                const float4 a = S.coef_prev[l], b = S.coef_cur[l];   // wave-uniform address: LDS broadcasts
+                sum_p = __builtin_elementwise_fma(Pcp, splat(a.x), sum_p);
+                sum_p = __builtin_elementwise_fma(Psp, splat(a.y), sum_p);
+                drift_p = __builtin_elementwise_fma(Pcp, splat(a.z), drift_p);
+                drift_p = __builtin_elementwise_fma(Psp, splat(a.w), drift_p);
+                sum_c = __builtin_elementwise_fma(Pcc, splat(b.x), sum_c);
+                sum_c = __builtin_elementwise_fma(Psc, splat(b.y), sum_c);
+                drift_c = __builtin_elementwise_fma(Pcc, splat(b.z), drift_c);
+                drift_c = __builtin_elementwise_fma(Psc, splat(b.w), drift_c);
+                const v2f np = __builtin_elementwise_fma(Pcp, Ecp, -(Psp * Esp));
+                Psp = __builtin_elementwise_fma(Psp, Ecp, Pcp * Esp);
+                Pcp = np;
+                const v2f nc = __builtin_elementwise_fma(Pcc, Ecc, -(Psc * Esc));
+                Psc = __builtin_elementwise_fma(Psc, Ecc, Pcc * Esc);
+                Pcc = nc;
+            }
+            const float* Ws = T->ws;
+            const v2f wp = {Ws[lane + N], Ws[lane + 64 + N]};
+            const v2f wc = {Ws[lane + 32], Ws[lane + 96]};
+            const v2f n_p = {(float)lane, (float)(lane + 64)}, n_c = {(float)(lane + 32), (float)(lane + 96)};
+            const v2f vp = __builtin_elementwise_fma(drift_p, n_p, sum_p) * wp;
+            const v2f vc = __builtin_elementwise_fma(drift_c, n_c, sum_c) * wc;
+            const float c_lo = __shfl_xor(vc.x, 32, kWave), c_hi = __shfl_xor(vc.y, 32, kWave);
+            acc[0] += vp.x + ((lane >= 32) ? c_lo : 0.0f);
+            acc[1] += vp.y + ((lane < 32) ? c_lo : c_hi);
+            acc[2] += (lane < 32) ? c_hi : 0.0f;
+            wave_lds_sync();
         }
     }
 
@@ -753,7 +704,13 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     // (natural in, base-4 digit-reversed out), inverse is decimation in time (digit-reversed in,
     // natural out): no reordering pass.  Twiddles e^{-2 pi i m/256} come from v_sin/v_cos (their
     // argument is in revolutions, m/256 is exact), not from memory.
-    if (!(tabs.ablate & 32)) {
+    // With no unvoiced band every bin is scaled by zero, so the transform pair returns exact zeros:
+    // only the overlap with the previous frame's Uw remains.
+    const bool any_unvoiced = __ballot(lane >= 1 && lane <= cur.L && cur.Vl == 0) != 0ULL;
+    if (!any_unvoiced) {
+        cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
+    }
+    if (!(tabs.ablate & 32) && any_unvoiced) {
         auto twiddle = [](int m) -> float2 {
             const float rev = (float)(m & 255) * (1.0f / 256.0f);
             return make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev));
@@ -763,7 +720,7 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         float win[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            win[r] = win_value(lw.uv, r);
+            win[r] = T->uv_window[lane + 64 * r];
         }
         S.scale[lane] = 0.0f;
         S.scale[lane + 64] = 0.0f;
@@ -885,13 +842,13 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             cur.uw[2] = (s02 - s13) * (1.0f / 256.0f);
             cur.uw[3] = (d02 + d13y) * (1.0f / 256.0f);   // Re(d02 - i*d13)
         }
+    }
+    if (!(tabs.ablate & 32)) {
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
         // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
-        const float wprev[2] = {win_value(lw.wola, 0), win_value(lw.wola, 1)};   // w(n) is 0 from n = 106 on
-        const float wcurr[3] = {win_value(lw.wola, 2), win_value(lw.wola, 3), win_value(lw.wola2, 0)};
-        // the denominators as the reference's plan builds them (src/core/mbe_unvoiced_fft.c:165-169)
-        const float wden[3] = {(wprev[0] * wprev[0]) + (wcurr[0] * wcurr[0]), (wprev[1] * wprev[1]) + (wcurr[1] * wcurr[1]),
-                               (lane < 32) ? (wcurr[2] * wcurr[2]) : 1.0f};
+        const float wden[3] = {T->wola_denom[lane], T->wola_denom[lane + 64], (lane < 32) ? T->wola_denom[lane + 128] : 1.0f};
+        const float wprev[2] = {T->wola_w_prev[lane], T->wola_w_prev[lane + 64]};   // w(n) is 0 from n = 106 on
+        const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float give = (lane < 32) ? cur.uw[j] : ((j == 0) ? 0.0f : cur.uw[j - 1]);
@@ -963,72 +920,7 @@ __device__ __forceinline__ void store_rng(const StreamRng& r, mbx_stream_rng* p,
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent waves with an LDS-DMA prefetch of the next stream.
-//
-// A wave walks streams s = blockIdx.x, blockIdx.x + gridDim.x, ...  While it synthesises the last
-// frame of stream s, the state of stream s' = s + gridDim.x (and the parameters of its first frame)
-// is already streaming from HBM into the wave's LDS stage with global_load_lds -- no VGPR is tied up
-// by the transfer, so the memory-level parallelism no longer depends on the register-limited
-// occupancy.  The DMA is issued by the `after_loads` hook of synth_core, i.e. after the frame's last
-// ordinary vector load: vmcnt retires in order, so an ordinary load issued later would have to wait
-// for the whole prefetch.
-// ------------------------------------------------------------------------------------------
-struct StageBuf {              // one 64-dword chunk per global_load_lds instruction
-    uint32_t cur[11 * 64];     // cur_mp, dwords 0..650
-    uint32_t prev[5 * 64];     // prev_mp, dwords 0..297 (everything the decode reads)
-    uint32_t enh[5 * 64];      // prev_mp_enhanced, dwords 0..297
-    uint32_t enh_uw[2 * 64];   // prev_mp_enhanced.previousUw[128..255]
-    uint32_t fp[64];           // FrameParams of the stream's first frame
-};
-
-__device__ __forceinline__ void dma_dword(const uint32_t* gsrc, uint32_t* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
-}
-
-__device__ __forceinline__ void prefetch_stream(StageBuf& st, const mbe_parms* triplet, const FrameParams* first_frame, int lane) {
-    const uint32_t* g = reinterpret_cast<const uint32_t*>(triplet);
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        const int idx = 64 * k + lane;
-        dma_dword(g + (idx < PARMS_DWORDS ? idx : PARMS_DWORDS - 1), &st.cur[64 * k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int idx = 64 * k + lane;
-        const int c = idx < O_UW ? idx : O_UW - 1;
-        dma_dword(g + PARMS_DWORDS + c, &st.prev[64 * k]);
-        dma_dword(g + 2 * PARMS_DWORDS + c, &st.enh[64 * k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        dma_dword(g + 2 * PARMS_DWORDS + O_UW + 128 + 64 * k + lane, &st.enh_uw[64 * k]);
-    }
-    dma_dword(reinterpret_cast<const uint32_t*>(first_frame) + lane, &st.fp[0]);
-}
-
-__device__ __forceinline__ void wait_prefetch() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wave_lds_sync();
-}
-
-__device__ __forceinline__ void load_enh_view_staged(Parms& r, const StageBuf& st, int lane) {
-    const bool band = lane < MBX_BAND_SLOTS;
-    r = Parms{};
-    r.w0 = uni(__uint_as_float(st.enh[O_W0]));
-    r.L = uni((int)st.enh[O_L]);
-    r.Vl = band ? (int)st.enh[O_VL + lane] : 0;
-    r.Ml = band ? __uint_as_float(st.enh[O_ML + lane]) : 0.0f;
-    r.PHIl = band ? __uint_as_float(st.enh[O_PHI + lane]) : 0.0f;
-    r.PSIl = band ? __uint_as_float(st.enh[O_PSI + lane]) : 0.0f;
-    r.localEnergy = uni(__uint_as_float(st.enh[O_LOCALENERGY]));
-    r.amplitudeThreshold = uni((int)st.enh[O_AMPTHR]);
-    r.uw[2] = __uint_as_float(st.enh_uw[lane]);
-    r.uw[3] = __uint_as_float(st.enh_uw[64 + lane]);
-}
-
-// ------------------------------------------------------------------------------------------
-// IMBE 7200x4400 stream kernel: persistent single-wave workgroups, each walking a strided set of streams.
+// IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
 imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
@@ -1036,134 +928,102 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                    mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
-    __shared__ StageBuf stage;
-    (void)records;
-    const int lane_in = lane_id();
-    int s = blockIdx.x;
+    const int s = blockIdx.x;
     if (s >= S) {
         return;
     }
-    LaneWindows lw;
-    load_lane_windows(lw, tabs_in.t, lane_in);
-    prefetch_stream(stage, &state[3 * (size_t)s], &params[(size_t)s * (size_t)Tn], lane_in);
+    const int lane_in = lane_id();
+    // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
+    // registers for the whole launch; `prev` is only needed from the start of a frame to the
+    // snapshot and `enh` only from the snapshot to the end of synthesis, so both are parked in
+    // their own HBM/L2 slots in between (exactly the loads and stores a T = 1 launch needs anyway).
+    mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
+    mbe_parms* const slot_prev = &state[3 * (size_t)s + 1];
+    mbe_parms* const slot_enh = &state[3 * (size_t)s + 2];
+    Parms cur;
+    load_parms(cur, slot_cur, lane_in);
+    StreamRng rng;
+    load_rng(rng, &rngs[s]);
 
-    for (; s < S; s += gridDim.x) {
-        // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
-        // registers for the whole stream; `prev` is only needed from the start of a frame to the
-        // snapshot and `enh` only from there to the end of synthesis, so both are parked in their own
-        // HBM/L2 slots in between (exactly the loads and stores a T = 1 launch needs anyway).
-        mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
-        mbe_parms* const slot_prev = &state[3 * (size_t)s + 1];
-        mbe_parms* const slot_enh = &state[3 * (size_t)s + 2];
-        const int next = s + (int)gridDim.x;
-        StreamRng rng;
-        load_rng(rng, &rngs[s]);
-        wait_prefetch();   // the stage now holds this stream's state and its first frame's parameters
-        Parms cur;
-        load_parms(cur, reinterpret_cast<const mbe_parms*>(stage.cur), lane_in);
+    for (int t = 0; t < Tn; ++t) {
+        const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+        // Keep per-frame table values out of the loop-carried register set: without this the compiler
+        // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
+        // across the frame loop, which halves the occupancy.
+        DeviceTables ft = tabs_in;
+        int lane = lane_in;
+        asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
+        const DeviceTables& tabs = ft;
+        const float* fp = params[f].v;
+        const uint32_t errw = uni(__float_as_uint(fp[62]));
+        const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
+        unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
+        const int total = c0 + prot;
+        bool muted;
+        // The parts of prev_mp_enhanced that synthesis reads are requested now, together with prev_mp,
+        // so that one memory latency covers both (they are first used after the decode).
+        Parms enh;
+        load_enh_view(enh, slot_enh, lane);
+        {
+            Parms prev;
+            load_prev_view(prev, slot_prev, lane);
 
-        for (int t = 0; t < Tn; ++t) {
-            const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
-            // Keep per-frame table values out of the loop-carried register set: without this the compiler
-            // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
-            // across the frame loop, which halves the occupancy.
-            DeviceTables ft = tabs_in;
-            int lane = lane_in;
-            asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
-            const DeviceTables& tabs = ft;
-            const bool staged = (t == 0);
-            const float* fp = staged ? reinterpret_cast<const float*>(stage.fp) : params[f].v;
-            const uint32_t errw = uni(__float_as_uint(fp[62]));
-            const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
-            unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
-            const int total = c0 + prot;
-            bool muted;
-            // The parts of prev_mp_enhanced that synthesis reads are fetched now, together with prev_mp,
-            // so that one memory latency covers both (they are first used after the decode).
-            Parms enh;
-            if (staged) {
-                load_enh_view_staged(enh, stage, lane);
+            // prepare (imbe4400_prepare_process)
+            cur.errorCount4 = c4;
+            cur.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
+            cur.errorCountTotal = total;
+            cur.errorRate = uni((0.95f * prev.errorRate) + (0.000365f * (float)total));
+
+            const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, lane);
+            const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
+            const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
+            const bool repeat =
+                (bad == 1) || (c0_valid ? ((c0 >= 2) && ((float)total >= repeat_threshold)) : (total > 5));
+            if (!repeat) {
+                cur.repeatCount = 0;
             } else {
-                load_enh_view(enh, slot_enh, lane);
-            }
-            {
-                Parms prev;
-                if (staged) {
-                    load_prev_view(prev, reinterpret_cast<const mbe_parms*>(stage.prev), lane);
+                if (prev.repeatCount > (MBE_MAX_FRAME_REPEATS - 1)) {
+                    imbe_headroom_reset(cur, lane);
                 } else {
-                    load_prev_view(prev, slot_prev, lane);
+                    // cur_mp := prev_mp.  Only the prediction memory was loaded (and padded by the
+                    // decode); everything else is fetched from the slot now.
+                    load_parms(cur, slot_prev, lane);
+                    cur.Ml = prev.Ml;
+                    cur.log2Ml = prev.log2Ml;
+                    cur.repeatCount++;
                 }
-
-                // prepare (imbe4400_prepare_process)
-                cur.errorCount4 = c4;
-                cur.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
-                cur.errorCountTotal = total;
-                cur.errorRate = uni((0.95f * prev.errorRate) + (0.000365f * (float)total));
-
-                const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, lane);
-                const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
-                const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
-                const bool repeat =
-                    (bad == 1) || (c0_valid ? ((c0 >= 2) && ((float)total >= repeat_threshold)) : (total > 5));
-                if (!repeat) {
-                    cur.repeatCount = 0;
-                } else {
-                    if (prev.repeatCount > (MBE_MAX_FRAME_REPEATS - 1)) {
-                        imbe_headroom_reset(cur, lane);
-                    } else {
-                        // cur_mp := prev_mp.  Only the prediction memory was loaded (and padded by the
-                        // decode); everything else is fetched from the slot now.
-                        load_parms(cur, slot_prev, lane);
-                        cur.Ml = prev.Ml;
-                        cur.log2Ml = prev.log2Ml;
-                        cur.repeatCount++;
-                    }
-                    flags |= MBE_PROCESS_FLAG_REPEAT;
-                }
-                muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
+                flags |= MBE_PROCESS_FLAG_REPEAT;
             }
-            store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
-            float out[3] = {0.0f, 0.0f, 0.0f};
-            // During the last frame of this stream the next stream's state starts streaming into the
-            // stage (everything staged for this stream has been consumed by now).
-            bool prefetch_due = (t == Tn - 1) && (next < S);
-            auto start_prefetch = [&]() {
-                if (prefetch_due) {
-                    wave_lds_sync();
-                    prefetch_stream(stage, &state[3 * (size_t)next], &params[(size_t)next * (size_t)Tn], lane);
-                    prefetch_due = false;
-                }
-            };
-            {
-                const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
-                if (!(tabs.ablate & 128)) {
-                    synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lw, start_prefetch, lane);
-                }
-            }
-            start_prefetch();   // muted / silent frames leave the synthesiser before the hook
-            if (muted) {
-                flags |= MBE_PROCESS_FLAG_MUTE;
-            }
-            store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
-            if (t + 1 < Tn) {
-                __threadfence_block();           // the next frame of this wave reloads both slots
-            }
-
-            store_pcm(out, f, pcm16, pcmf, lane);
-            if (results && lane == 0) {
-                mbe_process_result r;
-                r.c0_errors = c0;
-                r.protected_errors = total - c0;
-                r.c4_errors = c4;
-                r.total_errors = total;
-                r.flags = flags;
-                results[f] = r;
+            muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
+        }
+        store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
+        float out[3] = {0.0f, 0.0f, 0.0f};
+        {
+            const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
+            if (!(tabs.ablate & 128)) {
+                synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane);
             }
         }
+        if (muted) {
+            flags |= MBE_PROCESS_FLAG_MUTE;
+        }
+        store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
+        __threadfence_block();               // the next frame of this wave reloads both slots
 
-        store_parms(cur, slot_cur, lane_in);
-        store_rng(rng, &rngs[s], lane_in);
+        store_pcm(out, f, pcm16, pcmf, lane);
+        if (results && lane == 0) {
+            mbe_process_result r;
+            r.c0_errors = c0;
+            r.protected_errors = total - c0;
+            r.c4_errors = c4;
+            r.total_errors = total;
+            r.flags = flags;
+            results[f] = r;
+        }
     }
+
+    store_parms(cur, slot_cur, lane_in);
+    store_rng(rng, &rngs[s], lane_in);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1378,8 +1238,6 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
     load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
     load_rng(rng, &rngs[s]);
-    LaneWindows lw;
-    load_lane_windows(lw, tabs_in.t, lane_in);
 
     for (int t = 0; t < Tn; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
@@ -1472,7 +1330,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             cur = enh;
         }
         if (action == kVoice || action == kToneFallback) {
-            synth_core(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lw, NoHook{}, lane);
+            synth_core(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane);
             store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := synthesised model
             if (action == kToneFallback) {
                 __threadfence_block();
@@ -1522,9 +1380,7 @@ synth_speech_kernel(int S, mbe_parms* __restrict__ curs, mbe_parms* __restrict__
     StreamRng rng;
     load_rng(rng, &rngs[s]);
     float out[3];
-    LaneWindows lw;
-    load_lane_windows(lw, tabs.t, lane);
-    synth_core(out, cur, prev, false, 0.0f, rng, scratch, tabs, lw, NoHook{}, lane);
+    synth_core(out, cur, prev, false, 0.0f, rng, scratch, tabs, lane);
     store_pcm(out, (size_t)s, pcm16, pcmf, lane);
     store_parms(cur, &curs[s], lane);
     store_parms(prev, &prevs[s], lane);

@@ -6,11 +6,11 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   rm -rf /tmp/pmc_d
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_d -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${1:+--workload $1} > /dev/null 2>&1
   python3 - <<'PY'
-import csv,glob,collections
+import csv,glob,collections,os
 acc=collections.defaultdict(list)
 for f in glob.glob('/tmp/pmc_d/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'stream_kernel' in r['Kernel_Name']:
+        if os.environ.get('MBX_KERNEL_FILTER', 'stream_kernel') in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value'])/float(r['Grid_Size'])*64)
 print(' '.join(f"{k[3:]}={v[-1]:.0f}" for k,v in sorted(acc.items())))
 PY
