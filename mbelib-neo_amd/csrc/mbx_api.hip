@@ -172,23 +172,9 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
         a = (uint32_t)(((uint64_t)a * 171u) % 53125u);
         c = (uint32_t)(((uint64_t)c * 171u + 11213u) % 53125u);
     }
-    for (int k = 0; k < 256; ++k) {
-        const double ang = -2.0 * M_PI * (double)k / 256.0;
-        d.twiddle[k] = make_float2((float)cos(ang), (float)sin(ang));
-    }
     for (int L = 1; L < 64; ++L) {
         d.log2_int[L] = log2f((float)L);
     }
-    memset(d.imbe_inv_bo, 255, sizeof(d.imbe_inv_bo));
-    for (int l9 = 0; l9 < 48; ++l9) {
-        for (int i = 0; i < 79; ++i) {
-            const int word = host->imbe_bo[l9][i][0], bit = host->imbe_bo[l9][i][1];
-            if (word < 58 && bit < 12) {
-                d.imbe_inv_bo[l9][word][bit] = (uint8_t)(i + 6);
-            }
-        }
-    }
-
     HIP_TRY(hipMalloc(&g_ctx.d_blob, sizeof(mbx_tables)));
     HIP_TRY(hipMalloc(&g_ctx.d_derived, sizeof(mbx::DerivedTables)));
     HIP_TRY(hipMemcpy(g_ctx.d_blob, table_blob, sizeof(mbx_tables), hipMemcpyHostToDevice));

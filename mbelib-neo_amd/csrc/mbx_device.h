@@ -17,9 +17,7 @@ constexpr int kWave = 64;
 struct DerivedTables {
     uint32_t lcg_mul[161];    // 171^k mod 53125           (unvoiced-noise LCG jump-ahead)
     uint32_t lcg_add[161];    // additive term after k steps
-    float2   twiddle[256];    // exp(-2*pi*i*k/256)
     float    log2_int[64];    // log2f((float)L) from the host libm (AMBE gain term)
-    uint8_t  imbe_inv_bo[48][58][12];   // inverse of imbe_bo: [L-9][word][bit] -> payload bit (255 = none)
 };
 
 // Output of the expand stage, input of the stream stage: 64 dwords per frame (layout in mbx_expand.hip).

@@ -24,23 +24,6 @@ constexpr int kRow = 65;   // 64 dwords + 1 pad
 
 __device__ __forceinline__ int rbit(const uint32_t w[3], int i) { return (int)((w[i >> 5] >> (31 - (i & 31))) & 1u); }
 
-// value of IMBE parameter word m: bit `pos` comes from payload bit inv[pos] (255 = not allocated).
-// The 12-byte table row is fetched with three dword loads, not bit by bit.
-__device__ __forceinline__ int imbe_word(const uint32_t w[3], const uint8_t* inv_m, int nbits) {
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(inv_m);
-    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
-    int v = 0;
-#pragma unroll
-    for (int pos = 0; pos < 12; ++pos) {
-        const uint32_t word = (pos < 4) ? q0 : ((pos < 8) ? q1 : q2);
-        const int src = (int)((word >> (8 * (pos & 3))) & 0xffu);
-        if (pos < nbits && src != 255) {
-            v |= rbit(w, src) << pos;
-        }
-    }
-    return v;
-}
-
 __device__ __forceinline__ void write_out(const float (*tile)[kRow], FrameParams* out, size_t first, size_t n) {
     __syncthreads();
     const int lane = threadIdx.x;
@@ -52,48 +35,93 @@ __device__ __forceinline__ void write_out(const float (*tile)[kRow], FrameParams
     }
 }
 
+__device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
+
 __global__ void __launch_bounds__(64)
 expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
     __shared__ float tile[kFramesPerBlock][kRow];
+    __shared__ uint32_t words[kFramesPerBlock][64];   // parameter words b_0..b_57 of each frame
+    __shared__ float gains[kFramesPerBlock][8];        // G_1..G_6
     const mbx_tables* T = tabs.t;
     const size_t first = (size_t)blockIdx.x * kFramesPerBlock;
     const int fi = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const size_t i = first + fi;
     float* row = tile[fi];
+    {
+        uint4* z = reinterpret_cast<uint4*>(&words[fi][8 * sub]);
+        z[0] = make_uint4(0u, 0u, 0u, 0u);
+        z[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    int bad = 1, L = 0, K = 0;
+    float w0 = 0.0f;
     if (i < n) {
-        const uint4 rec = *reinterpret_cast<const uint4*>(&recs[i]);
+        rec = *reinterpret_cast<const uint4*>(&recs[i]);
         const uint32_t w[3] = {rec.x, rec.y, rec.z};
         int b0 = (int)(w[0] >> 26);
         b0 = (b0 << 1) | rbit(w, 85);
         b0 = (b0 << 1) | rbit(w, 86);
-        int bad = 0, L = 0, K = 0;
-        float w0 = 0.0f;
-        if (b0 > 207) {
-            bad = 1;
-        } else {
+        if (b0 <= 207) {
             w0 = T->imbe_w0[b0];
             L = T->imbe_L[b0];
             K = T->imbe_K[b0];
-            if (L == 0) {
-                bad = 1;   // the reference has stored w0 but not L in this case
+            bad = (L == 0) ? 1 : 0;   // the reference has stored w0 but not L in this case
+        }
+    }
+    const int L9 = bad ? 0 : L - 9;
+    wave_lds_sync();
+    // Bit layout (ref src/imbe/imbe7200x4400.c:156-168): payload bit i feeds bit e[1] of word e[0].  The
+    // eight lanes of a frame scatter ten payload bits each with LDS atomic ORs.
+    if (i < n && !bad) {
+        const uint32_t w[3] = {rec.x, rec.y, rec.z};
+        const uint16_t* bo = reinterpret_cast<const uint16_t*>(&T->imbe_bo[L9][0][0]);
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const int idx = 10 * sub + t;   // payload bit idx + 6
+            if (idx < 79) {
+                const uint32_t e = bo[idx];
+                const uint32_t m = e & 0xffu, pos = e >> 8;
+                if (m < 58u && pos < 12u) {
+                    atomicOr(&words[fi][m], (uint32_t)rbit(w, idx + 6) << pos);
+                }
             }
         }
-        const int L9 = bad ? 0 : L - 9;
-        const uint8_t(*inv)[12] = tabs.d->imbe_inv_bo[L9];
+    }
+    wave_lds_sync();
+    if (i < n && !bad && sub >= 1 && sub <= 6) {   // gain G_sub (:190-209)
+        float G;
+        if (sub == 1) {
+            G = T->imbe_B2[low_bits(words[fi][2], 6)];
+        } else {
+            const float nb = T->imbe_ba[L9][sub - 2][0];
+            const float step = T->imbe_ba[L9][sub - 2][1];
+            const int inb = (int)nb;
+            const int bm = (int)low_bits(words[fi][sub + 1], inb);
+            G = (step * ((float)bm - ldexpf(1.0f, inb - 1) + 0.5f));
+        }
+        gains[fi][sub] = G;
+    }
+    wave_lds_sync();
+    if (i < n) {
         if (sub == 0) {
             uint32_t vlo = 0, vhi = 0;
             if (!bad) {   // voicing: three harmonics per band, band K-1 first
-                const int b1 = imbe_word(w, inv[1], 12);
-                for (int l = 1; l <= L; ++l) {
-                    int band = (K - 1) - ((l - 1) / 3);
-                    band = band < 0 ? 0 : band;
-                    const uint32_t v = (uint32_t)((b1 >> band) & 1);
-                    if (l <= 32) {
-                        vlo |= v << (l - 1);
-                    } else {
-                        vhi |= v << (l - 33);
+                // harmonic l takes bit max(K-1 - (l-1)/3, 0) of b1: band bit K-1-k covers l = 3k+1..3k+3,
+                // every harmonic past 3K shares bit 0 (src/imbe/imbe7200x4400.c:170-188)
+                const uint32_t b1 = low_bits(words[fi][1], 12);
+                unsigned long long v = 0ULL;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    if (k < K && ((b1 >> (K - 1 - k)) & 1u)) {
+                        v |= 7ULL << (3 * k);
                     }
                 }
+                if (b1 & 1u) {
+                    v |= ~0ULL << (3 * K);
+                }
+                v &= (L >= 64) ? ~0ULL : ((1ULL << L) - 1ULL);   // bit l-1 = harmonic l, l <= L
+                vlo = (uint32_t)v;
+                vhi = (uint32_t)(v >> 32);
             }
             row[0] = 0.0f;
             row[57] = __uint_as_float(vlo);
@@ -105,24 +133,13 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             row[63] = __int_as_float(bad);
         } else if (sub <= 6 && !bad) {
             const int blk = sub;
-            // gains (all six are needed for this block's mean Ri)
-            float Gm[7];
-            Gm[1] = T->imbe_B2[imbe_word(w, inv[2], 6)];
-#pragma unroll
-            for (int g = 2; g < 7; ++g) {
-                const float nb = T->imbe_ba[L9][g - 2][0];
-                const float step = T->imbe_ba[L9][g - 2][1];
-                const int inb = (int)nb;
-                const int bm = imbe_word(w, inv[g + 1], inb);
-                Gm[g] = (step * ((float)bm - ldexpf(1.0f, inb - 1) + 0.5f));
-            }
             float C[11];
-            {
+            {   // this block's mean: one output of the 6-point inverse DCT of the gains (:211-231)
                 float sum = 0;
 #pragma unroll
                 for (int m = 1; m <= 6; ++m) {
                     const float am = (m == 1) ? 1.0f : 2.0f;
-                    sum = sum + (am * Gm[m] * T->imbe_ri_cos[m][blk]);
+                    sum = sum + (am * gains[fi][m] * T->imbe_ri_cos[m][blk]);
                 }
                 C[1] = sum;
             }
@@ -140,7 +157,7 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
                 if (k <= ji) {
                     const int Bm = T->imbe_hoba[L9][m - 8];
                     if (Bm > 0) {
-                        const int bm = imbe_word(w, inv[m], Bm);
+                        const int bm = (int)low_bits(words[fi][m], Bm);
                         v = ((T->imbe_quantstep[Bm - 1] * T->imbe_standdev[k - 2]) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
                     }
                     ++m;

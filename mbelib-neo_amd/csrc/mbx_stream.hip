@@ -199,6 +199,7 @@ struct WaveScratch {
         struct {                       // voiced bank: complex amplitudes of harmonic l, (A, -B, -d B, -d A)
             alignas(16) float4 coef_prev[64];
             alignas(16) float4 coef_cur[64];
+            alignas(16) float4 icoef[8];   // interpolated low harmonics: (phi_prev, w0 l + dw, 2 M_prev, 2 dM)
         };
         struct {                       // unvoiced path (the coefficients are dead by then)
             float2 fft[256];           //   in-place radix-4 FFT
@@ -577,32 +578,59 @@ __device__ void synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     const bool interp = (lane < 8) && cv && pv && stable;
     float acc[3] = {0.0f, 0.0f, 0.0f};
 
-    // (1) low harmonics with a stable pitch: lane = sample, loop over the (<= 7) harmonics
+    // (1) low harmonics with a stable pitch (src/core/mbelib.c interpolated branch): amplitude linear and
+    //     phase quadratic in n, evaluated directly.  lane = sample; samples (lane, lane + 64) are packed in
+    //     one v2f, the short third block (128 + lane, lane < 32) packs two harmonics instead.  The phase
+    //     is formed with the reference's own operation order (bit-identical float theta); its cosine uses
+    //     a two-float reduction to revolutions and v_cos_f32.
     unsigned long long imask = (tabs.ablate & 16) ? 0ULL : __ballot(interp);
-    float nf[3], nfrac[3], nsq[3];   // n, n/N (exact reference quotient) and n*n for this lane's samples
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int n = lane + 64 * j;
-        nf[j] = (float)n;
-        nfrac[j] = (float)n / (float)N;
-        nsq[j] = (float)(n * n);
-    }
-    while (imask) {
-        const int l = __ffsll((long long)imask) - 1;
-        imask &= imask - 1;
-        const float pPHI = lane_get(prev.PHIl, l), cPHI = lane_get(cur.PHIl, l);
-        const float pM = lane_get(prev.Ml, l), cM = lane_get(cur.Ml, l);
-        const float pw0l = pw0 * (float)l;
-        const float dphi = cPHI - pPHI - (((pw0 + cw0) * (float)(l * N)) / 2.0f);
-        const float dw =
-            (1.0f / (float)N) * (dphi - (2.0f * (float)M_PI * floorf((dphi + (float)M_PI) / (2.0f * (float)M_PI))));
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
+    if (imask) {
+        if (lane < 8) {   // per-harmonic constants from the harmonic's own lane, broadcast through LDS
+            float4 k = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (interp) {
+                const float dphi = cur.PHIl - prev.PHIl - (((pw0 + cw0) * (float)(lane * N)) / 2.0f);
+                const float dw = (1.0f / (float)N)
+                                 * (dphi - (2.0f * (float)M_PI * floorf((dphi + (float)M_PI) / (2.0f * (float)M_PI))));
+                k = make_float4(prev.PHIl, (pw0 * (float)lane) + dw, 2.0f * prev.Ml, 2.0f * (cur.Ml - prev.Ml));
+            }
+            S.icoef[lane] = k;
+        }
+        wave_lds_sync();
+        const float dw0 = cw0 - pw0;
+        // 2 amp cos(theta) for two (harmonic, sample) combinations at once
+        auto term = [&](v2f phi, v2f a, v2f fl, v2f amp0, v2f damp, v2f nf, v2f nsq, v2f nfrac) -> v2f {
             // (float)(l*n*n) is exact below 2^24, so l * n^2 in float is the same value; the division by
             // 2N = 320 becomes a multiplication by its rounded reciprocal (<= 1 ulp of a phase term < 16 rad)
-            const float theta = pPHI + ((pw0l + dw) * nf[j]) + (((cw0 - pw0) * ((float)l * nsq[j])) * (1.0f / 320.0f));
-            const float amp = pM + (nfrac[j] * (cM - pM));
-            acc[j] += 2.0f * amp * cos_reduced(theta);
+            const v2f theta = (phi + (a * nf)) + ((splat(dw0) * (fl * nsq)) * splat(1.0f / 320.0f));
+            const v2f hi = theta * splat(0.15915494f);   // revolutions: theta / 2 pi as hi + lo
+            const v2f lo = __builtin_elementwise_fma(theta, splat(6.4206382e-9f),
+                                                     __builtin_elementwise_fma(theta, splat(0.15915494f), -hi));
+            const v2f r = v2f{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y)} + lo;
+            const v2f cs = {__builtin_amdgcn_cosf(r.x), __builtin_amdgcn_cosf(r.y)};
+            return __builtin_elementwise_fma(nfrac, damp, amp0) * cs;
+        };
+        const v2f nf01 = {(float)lane, (float)(lane + 64)};
+        const v2f nsq01 = {(float)(lane * lane), (float)((lane + 64) * (lane + 64))};
+        const v2f nfrac01 = {(float)lane / (float)N, (float)(lane + 64) / (float)N};   // the reference's quotient
+        const float nf2 = (float)(lane + 128), nsq2 = (float)((lane + 128) * (lane + 128)), nfrac2 = (float)(lane + 128) / (float)N;
+        v2f acc01 = {0.0f, 0.0f}, acc2 = {0.0f, 0.0f};
+        while (imask) {
+            const int la = __ffsll((long long)imask) - 1;
+            imask &= imask - 1;
+            const int lb = imask ? (__ffsll((long long)imask) - 1) : 0;   // slot 0 holds zero amplitudes
+            imask &= imask - 1;
+            const float4 ka = S.icoef[la], kb = S.icoef[lb];
+            acc01 += term(splat(ka.x), splat(ka.y), splat((float)la), splat(ka.z), splat(ka.w), nf01, nsq01, nfrac01);
+            if (lb) {
+                acc01 += term(splat(kb.x), splat(kb.y), splat((float)lb), splat(kb.z), splat(kb.w), nf01, nsq01, nfrac01);
+            }
+            acc2 += term(v2f{ka.x, kb.x}, v2f{ka.y, kb.y}, v2f{(float)la, (float)lb}, v2f{ka.z, kb.z}, v2f{ka.w, kb.w},
+                         splat(nf2), splat(nsq2), splat(nfrac2));
+        }
+        acc[0] += acc01.x;
+        acc[1] += acc01.y;
+        if (lane < 32) {
+            acc[2] += acc2.x + acc2.y;
         }
     }
 
@@ -996,7 +1024,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             }
             muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
         }
-        store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
+        if (!(tabs.ablate & 256)) store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
         float out[3] = {0.0f, 0.0f, 0.0f};
         {
             const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
@@ -1007,7 +1035,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         if (muted) {
             flags |= MBE_PROCESS_FLAG_MUTE;
         }
-        store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
+        if (!(tabs.ablate & 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
         __threadfence_block();               // the next frame of this wave reloads both slots
 
         store_pcm(out, f, pcm16, pcmf, lane);
@@ -1022,7 +1050,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         }
     }
 
-    store_parms(cur, slot_cur, lane_in);
+    if (!(tabs_in.ablate & 1024)) store_parms(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[s], lane_in);
 }
 
