@@ -4,7 +4,8 @@
 // parameter bits -- fundamental, voicing decisions, gain / PRBA / higher-order coefficient
 // dequantisation, the block inverse DCTs that yield the prediction residuals T_l -- is independent
 // between frames.  It runs here, 8 frames per wavefront: sub-lane 0 of a frame does the header and
-// the voicing bits, sub-lanes 1..6 (IMBE) / 1..4 (AMBE) own one inverse-DCT block each.  Sums keep the
+// the voicing bits; sub-lanes 1..6 own one inverse-DCT block each (IMBE), or all eight lanes own half
+// a block each (AMBE, four blocks of up to 17 coefficients).  Sums keep the
 // reference's sequential order inside a block, so the residuals are bit-identical to the CPU path.
 // What is left for the stream kernel is the part that needs the previous frame: the prediction.
 //
@@ -232,8 +233,8 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             w0 = (float)((double)(f0 * (float)2) * M_PI);
             L = T->ambe_L[b0];
         }
-        if (sub >= 1 && sub <= 4 && bad == 0) {
-            const int blk = sub;
+        if (bad == 0) {   // two lanes per inverse-DCT block: each takes half of the block's outputs
+            const int blk = (sub >> 1) + 1, half = sub & 1;
             const int b3 = pick(w, 12, 13, 14, 15, 16, 17, 18, 19, 40);
             const int b4 = pick(w, 20, 21, 22, 23, 41, 42, 43);
             float Gm[9];
@@ -269,7 +270,9 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             for (int k = 3; k <= 17; ++k) {
                 C[k] = (k <= 6 && k <= ji) ? hoc[k - 3] : 0.0f;
             }
-            for (int j = 1; j <= ji; ++j) {
+            const int jsplit = (ji + 1) >> 1;
+            const int j0 = half ? jsplit + 1 : 1, j1 = half ? ji : jsplit;
+            for (int j = j0; j <= j1; ++j) {
                 float sum = 0;
 #pragma unroll
                 for (int k = 1; k <= 17; ++k) {
@@ -278,7 +281,7 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
                         sum = sum + (ak * C[k] * T->ambe_idct_cos[ji][j][k]);
                     }
                 }
-                row[l++] = sum;
+                row[l + j - 1] = sum;
             }
         }
     }
@@ -289,9 +292,17 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         if (bad == 0) {
             if (!silence) {
                 const int b1 = pick(w, 4, 5, 6, 7, 35);
+                // the eight decisions of this codebook row as one bit mask (one 8-byte load, not L loads)
+                const uint2 vq = *reinterpret_cast<const uint2*>(&T->ambe_vuv[b1][0]);
+                uint32_t vmask = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t byte = ((q < 4 ? vq.x : vq.y) >> (8 * (q & 3))) & 0xffu;
+                    vmask |= (byte & 1u) << q;
+                }
                 for (int l = 1; l <= L; ++l) {
                     const int jl = (int)((float)l * (float)16.0 * f0);
-                    const uint32_t v = T->ambe_vuv[b1][jl & 7];
+                    const uint32_t v = (vmask >> (jl & 7)) & 1u;
                     if (l <= 32) {
                         vlo |= v << (l - 1);
                     } else {
