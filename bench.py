@@ -54,6 +54,24 @@ def algorithmic_bytes_per_launch(codec, S, T):
     return S * T * b_io + S * 2 * 3 * 2604
 
 
+def measured_traffic(workload, S, T):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary of this
+    workload and size (profiles/rNN/<workload>_pmc.json, written by tools/profile_round.sh: FETCH_SIZE
+    and WRITE_SIZE in separate rocprofv3 passes, each calibrated on state_copy_kernel's known byte
+    count).  PMC counters cannot be read from inside this process; None when no summary matches."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("streams_per_gpu") == S and d.get("frames_per_stream_per_step") == T and "dominant_kernel" in d:
+            best = (d["dominant_kernel"]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
+    return best
+
+
 def cpu_baseline(name, codec, T, budget_s=12.0):
     """The CPU oracle (a port of the reference path, oracle/mbx_oracle.c) on ONE host core, on a
     bounded sample of the same workload."""
@@ -182,6 +200,7 @@ def main():
     total_frames = world * n * args.steps
     value = total_frames / dt
     alg_bytes = algorithmic_bytes_per_launch(codec, S, T)
+    traffic = measured_traffic(args.workload, S, T)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     line = {
         "metric": "20ms frames/sec (whole node), " + ("IMBE 7200x4400" if codec == 0 else "AMBE+2 3600x2450"),
@@ -217,7 +236,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic[0] if traffic else None,
+            "traffic_source": traffic[1] if traffic else None,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": kernel_ms,
             "note": "algorithmic bytes = S*T*(wire frame + int16 PCM) + S*2*3*2604 state; the path is VALU/latency bound "

@@ -1,7 +1,10 @@
 #!/bin/bash
 # Collects the judged evidence for one bench workload on the GPU box:
-#   bench line (un-profiled), rocprofv3 --stats, FETCH_SIZE and WRITE_SIZE PMC passes.
-# usage: tools/profile_round.sh <tag> [workload]      -> gpurun_out/<tag>_*
+#   bench line (un-profiled), rocprofv3 --kernel-trace --stats, FETCH_SIZE and WRITE_SIZE PMC passes
+#   (separate passes), plus the same two counters on state_copy_kernel, which moves a KNOWN byte
+#   count with the stream kernels' dword-per-lane accesses (the calibration MI355X_MICROARCH.md asks
+#   for before trusting an absolute FETCH_SIZE at an access width other than 16 B/lane).
+# usage: tools/profile_round.sh <out-prefix> [workload]   -> gpurun_out/<out-prefix>_{bench.json,kernel_stats.csv,pmc.json}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-prof}
 WL=${2:-imbe_voiced}
@@ -9,24 +12,54 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 50 --warmup 5 --workload $WL > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write
+rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write /tmp/c_fetch /tmp/c_write
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --workload $WL > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $WL > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $WL > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/c_fetch -- python3 $R/tools/calibrate_fetch.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/c_write -- python3 $R/tools/calibrate_fetch.py > /dev/null 2>&1
 cp /tmp/p_stats/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
-python3 - "$OUT/${TAG}_pmc.json" <<'PY'
-import csv,glob,collections,json,sys
-out=[]
-for name,d in (("FETCH_SIZE","/tmp/p_fetch"),("WRITE_SIZE","/tmp/p_write")):
-    acc=collections.defaultdict(list)
-    for f in glob.glob(d+"/*/*_counter_collection.csv"):
+python3 - "$OUT/${TAG}_pmc.json" "$OUT/${TAG}_bench.json" "$WL" <<'PY'
+import csv, glob, collections, json, sys
+
+def mean_kb(d):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
-    for k,v in acc.items():
-        out.append({"counter":name,"kernel":k,"dispatches":len(v),"mean_value_KB":sum(v)/len(v)})
-json.dump(out,open(sys.argv[1],"w"),indent=1)
+            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+known = 65536 * 3 * 2604  # bytes each way per state_copy_kernel dispatch (tools/calibrate_fetch.py)
+fetch, write = mean_kb("/tmp/p_fetch"), mean_kb("/tmp/p_write")
+cf, cw = mean_kb("/tmp/c_fetch"), mean_kb("/tmp/c_write")
+k_copy = [k for k in cf if "state_copy" in k][0]
+f_fac = known / (cf[k_copy][0] * 1024.0)
+w_fac = known / (cw[k_copy][0] * 1024.0)
+bench = json.load(open(sys.argv[2]))
+kern = bench["roofline"]["kernel"]
+out = {
+    "workload": sys.argv[3],
+    "streams_per_gpu": bench["config"]["streams_per_gpu"],
+    "frames_per_stream_per_step": bench["config"]["frames_per_stream_per_step"],
+    "unit": "KB per dispatch (rocprofv3 Counter_Value), mean over dispatches",
+    "counters": [{"counter": n, "kernel": k, "dispatches": v[1], "mean_value_KB": v[0]}
+                 for n, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)) for k, v in d.items()],
+    "calibration": {
+        "kernel": k_copy, "known_bytes_each_way": known,
+        "FETCH_SIZE_KB": cf[k_copy][0], "WRITE_SIZE_KB": cw[k_copy][0],
+        "fetch_factor": f_fac, "write_factor": w_fac,
+        "note": "factor = known bytes / counter bytes for dword-per-lane coalesced accesses (the stream kernels' pattern)",
+    },
+}
+fk = [k for k in fetch if k.endswith(kern) or kern in k]
+if fk:
+    k = fk[0]
+    rd, wr = fetch[k][0] * 1024.0 * f_fac, write[k][0] * 1024.0 * w_fac
+    out["dominant_kernel"] = {"kernel": k, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                              "traffic_bytes_per_launch": rd + wr}
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(json.dumps(out.get("dominant_kernel")), json.dumps(out["calibration"]))
 PY
-cat $OUT/${TAG}_kernel_stats.csv | cut -c1-50,120-220
-cat $OUT/${TAG}_pmc.json | tr -d '\n' | cut -c1-900; echo
+cut -c1-60,150-230 $OUT/${TAG}_kernel_stats.csv
 python3 -c "
 import json; d=json.load(open('$OUT/${TAG}_bench.json')); print(d['value'], d['roofline'], d['cpu_baseline'])"
