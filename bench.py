@@ -5,7 +5,7 @@ Metric (BASELINE.json): 20 ms frames/s, whole job, IMBE 7200x4400.
 Workload (default, BASELINE.json configs[1]): 65,536 streams per GPU x T=1 frame per step,
 clean-encoded all-voiced IMBE frames, state warmed by one identical frame so both the
 previous and the current model are voiced.  One "step" = one pass of the hot path
-(FEC kernel + stream kernel, mbx_process_batch) over the whole batch with every input
+(FEC kernel + stream kernel = mbx_process_batch) over the whole batch with every input
 already resident in HBM.  Streams are independent, so N GPUs = N independent shards
 (weak scaling, no data-path collective); the only collective is the RCCL broadcast of the
 constant-table blob at start-up (plus timing reductions).
@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--workload", default="imbe_voiced", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-expand", action="store_true", help="run the parameter expansion as a separate launch")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (mbx_debug_set_ablation); results invalid")
     args = ap.parse_args()
 
@@ -156,15 +157,19 @@ def main():
     n = S * T
 
     def step(ev=None):
-        # mbx_process_batch() = these three launches; they are issued separately only so that the
+        # mbx_process_batch() = these launches (FEC stage, then mbx_process_records: the stream kernel,
+        # which expands the parameter records itself); they are issued separately only so that the
         # dominant (stream) kernel can be bracketed by events
         _native.check(fec(d_frames.data_ptr(), n, out["records"].data_ptr(), stream), "fec")
-        _native.check(L.mbx_expand_records(codec, out["records"].data_ptr(), n, stream), "expand")
+        run = L.mbx_process_records
+        if args.split_expand:   # development aid: expansion as its own launch, stream kernel reads the workspace
+            _native.check(L.mbx_expand_records(codec, out["records"].data_ptr(), n, stream), "expand")
+            run = L.mbx_stream_expanded
         if ev is not None:
             ev[0].record()
         _native.check(
-            L.mbx_stream_expanded(codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
-                                  out["pcm16"].data_ptr(), None, out["results"].data_ptr(), stream),
+            run(codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
+                out["pcm16"].data_ptr(), None, out["results"].data_ptr(), stream),
             "stream",
         )
         if ev is not None:

@@ -336,12 +336,31 @@ int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, v
     return check_launch("expand_kernel");
 }
 
+// Stream-stage launch.  `params` = FrameParams rows written by mbx_expand_records(), or nullptr: the
+// stream kernel then expands each record itself (one launch less, no workspace traffic).
+static int launch_stream(int codec, int S, int T, const mbx_param_record* d_records, const mbx::FrameParams* params,
+                         mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                         mbe_process_result* d_results, void* stream) {
+    if (codec == MBX_CODEC_IMBE7200X4400) {
+        hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                           params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+        return check_launch("imbe_stream_kernel");
+    }
+    hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                       params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+    return check_launch("ambe_stream_kernel");
+}
+
+static bool stream_args_ok(int codec, int S, int T, const void* d_records, const void* d_state, const void* d_rng) {
+    return d_records && d_state && d_rng && S >= 0 && T >= 0
+           && (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_AMBE3600X2450);
+}
+
 int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream) {
     REQUIRE_READY();
-    if (!d_records || !d_state || !d_rng || S < 0 || T < 0
-        || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450)) {
+    if (!stream_args_ok(codec, S, T, d_records, d_state, d_rng)) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     if (S == 0 || T == 0) {
@@ -350,27 +369,27 @@ int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_recor
     if ((size_t)S * (size_t)T > g_ctx.workspace_frames) {
         return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_stream_expanded: mbx_expand_records() has not been run for this batch");
     }
-    if (codec == MBX_CODEC_IMBE7200X4400) {
-        hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
-                           g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
-        return check_launch("imbe_stream_kernel");
-    }
-    hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
-                       g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
-    return check_launch("ambe_stream_kernel");
+    return launch_stream(codec, S, T, d_records, g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
 }
 
 int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream) {
-    if (S < 0 || T < 0) {
+    REQUIRE_READY();
+    if (!stream_args_ok(codec, S, T, d_records, d_state, d_rng)) {
         return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0 || T == 0) {
+        return 0;
+    }
+    if (codec == MBX_CODEC_IMBE7200X4400) {   // expansion fused into the stream kernel
+        return launch_stream(codec, S, T, d_records, nullptr, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
     }
     int rc = mbx_expand_records(codec, d_records, (size_t)S * (size_t)T, stream);
     if (rc < 0) {
         return rc;
     }
-    return mbx_stream_expanded(codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+    return launch_stream(codec, S, T, d_records, g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
 }
 
 int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,

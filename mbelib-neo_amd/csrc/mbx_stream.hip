@@ -201,6 +201,12 @@ struct WaveScratch {
             alignas(16) float4 coef_cur[64];
             alignas(16) float4 icoef[8];   // interpolated low harmonics: (phi_prev, w0 l + dw, 2 M_prev, 2 dM)
         };
+        struct {                       // in-wave parameter expansion (dead before synthesis starts)
+            uint32_t words[64];        //   parameter words b_0..b_57
+            float    gains[12];        //   IMBE G_1..G_6 / AMBE+2 R_1..R_8
+            float    C[84];            //   DCT coefficients C[block][k] at block * 12 + k
+            float    fp[64];           //   the frame's FrameParams row
+        } x;
         struct {                       // unvoiced path (the coefficients are dead by then)
             float2 fft[256];           //   in-place radix-4 FFT
             float  mag2[132];          //   |X(k)|^2, k = 0..128
@@ -213,6 +219,179 @@ struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
     unsigned long long cn_seed48;
     uint32_t           cn_seeded, unv_state, unv_override;
 };
+
+// ------------------------------------------------------------------------------------------
+// IMBE 7200x4400, stateless half of the parameter decode for ONE frame on the whole wave
+// (ref src/imbe/imbe7200x4400.c:117-270): fundamental, bit layout, voicing, gains, higher-order
+// coefficients, per-block inverse DCT.  Writes the FrameParams row (layout: mbx_expand.hip) to
+// S.x.fp.  lane = payload bit for the scatter, = gain / coefficient index for the dequantisation,
+// = harmonic for the inverse DCT; every sum keeps the reference's sequential order.
+//
+// The record and every wave-uniform table entry (w0/L/K of b0, the block lengths) are read with SCALAR
+// loads (constant address space): they do not queue behind the state loads the caller has in flight.
+// Every per-lane table address then depends only on those scalars and the lane, and the three small
+// codebooks (B2, quantstep) are held one entry per lane, so there is a single round of vector-memory
+// latency instead of a chain of dependent lookups.
+// ------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) mbx_tables* ConstTables;
+__device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
+
+__device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, const mbx_tables* Tg, int lane) {
+    ConstTables T = (ConstTables)Tg;
+    const __attribute__((address_space(4))) uint32_t* rq = (const __attribute__((address_space(4))) uint32_t*)rp;
+    const uint4 rec = make_uint4(rq[0], rq[1], rq[2], rq[3]);
+    int b0 = (int)(rec.x >> 26);
+    b0 = (b0 << 2) | (int)((rec.z >> 9) & 3u);   // payload bits 85, 86
+    int bad = 1, L = 0, K = 0;
+    float w0 = 0.0f;
+    if (b0 <= 207) {
+        w0 = T->imbe_w0[b0];
+        L = T->imbe_L[b0];
+        K = T->imbe_K[b0];
+        bad = (L == 0) ? 1 : 0;   // the reference has stored w0 but not L in this case
+    }
+    S.x.words[lane] = 0u;
+    S.x.fp[lane] = 0.0f;
+    if (!bad) {
+        const int L9 = L - 9;
+        int J[6];   // block lengths, wave-uniform
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            J[q] = (int)T->imbe_ji[L9][q];
+        }
+        // ---- every per-lane table value is requested here ----
+        const uint16_t* bo = reinterpret_cast<const uint16_t*>(&Tg->imbe_bo[L9][0][0]);
+        const uint32_t e0 = bo[lane], e1 = bo[lane < 15 ? lane + 64 : 78];
+        const int g = (lane >= 2 && lane <= 6) ? lane - 2 : 0;
+        const float nb = Tg->imbe_ba[L9][g][0], step = Tg->imbe_ba[L9][g][1];
+        const float b2 = Tg->imbe_B2[lane];
+        const float qs = Tg->imbe_quantstep[lane < 11 ? lane : 0];
+        int hblk = 1, hk;   // higher-order coefficient owned by this lane (word lane + 8): block, index
+        {
+            int first = 0, ji = J[0];
+#pragma unroll
+            for (int q = 1; q < 6; ++q) {
+                if (lane >= first + (ji - 1)) {
+                    first += ji - 1;
+                    hblk = q + 1;
+                    ji = J[q];
+                }
+            }
+            hk = lane - first + 2;
+        }
+        const int Bm = Tg->imbe_hoba[L9][lane < 50 ? lane : 0];
+        const float sd = Tg->imbe_standdev[(hk >= 2 && hk <= 10) ? hk - 2 : 0];
+        int iblk = 1, iji = J[0], ij;   // harmonic owned by this lane: block, block length, index in block
+        {
+            int first = 1;
+#pragma unroll
+            for (int q = 1; q < 6; ++q) {
+                if (lane >= first + iji) {
+                    first += iji;
+                    iblk = q + 1;
+                    iji = J[q];
+                }
+            }
+            ij = lane - first + 1;
+        }
+        const bool harm = lane >= 1 && lane <= L;
+        float cosr[11], ric[7];   // fetched now: loads cannot move up across the LDS fences below
+        {
+            const float* row = &Tg->imbe_idct_cos[harm ? iji : 1][harm ? ij : 1][0];
+#pragma unroll
+            for (int k = 1; k <= 10; ++k) {
+                cosr[k] = row[k];
+            }
+            const float* col = &Tg->imbe_ri_cos[0][(lane >= 1 && lane <= 6) ? lane : 0];
+#pragma unroll
+            for (int m = 1; m <= 6; ++m) {
+                ric[m] = col[7 * m];
+            }
+        }
+
+        wave_lds_sync();
+        {   // payload bit j + 6 feeds bit e[1] of word e[0] (:156-168)
+            const int i0 = lane + 6, i1 = lane + 70;
+            const uint32_t word0 = (i0 < 32) ? rec.x : ((i0 < 64) ? rec.y : rec.z);
+            const uint32_t m0 = e0 & 0xffu, p0 = e0 >> 8;
+            if (m0 < 58u && p0 < 12u) {
+                atomicOr(&S.x.words[m0], ((word0 >> (31 - (i0 & 31))) & 1u) << p0);
+            }
+            const uint32_t word1 = (i1 < 96) ? rec.z : 0u;
+            const uint32_t m1 = e1 & 0xffu, p1 = e1 >> 8;
+            if (lane < 15 && m1 < 58u && p1 < 12u) {
+                atomicOr(&S.x.words[m1], ((word1 >> (31 - (i1 & 31))) & 1u) << p1);
+            }
+        }
+        wave_lds_sync();
+        {   // gain G_lane (:190-209); B2 is held one entry per lane
+            const float g1 = lane_get(b2, (int)low_bits(S.x.words[2], 6));
+            if (lane >= 1 && lane <= 6) {
+                float G = g1;
+                if (lane != 1) {
+                    const int inb = (int)nb;
+                    const int bm = (int)low_bits(S.x.words[lane + 1], inb);
+                    G = (step * ((float)bm - ldexpf(1.0f, inb - 1) + 0.5f));
+                }
+                S.x.gains[lane] = G;
+            }
+        }
+        wave_lds_sync();
+        if (lane >= 1 && lane <= 6) {   // block mean R_lane: 6-point inverse DCT of the gains (:211-231)
+            float sum = 0;
+#pragma unroll
+            for (int m = 1; m <= 6; ++m) {
+                const float am = (m == 1) ? 1.0f : 2.0f;
+                sum = sum + (am * S.x.gains[m] * ric[m]);
+            }
+            S.x.C[lane * 12 + 1] = sum;
+        }
+        {   // higher-order coefficient of word m = lane + 8 (:233-249)
+            const float q = lane_get(qs, Bm > 0 ? Bm - 1 : 0);
+            if (lane < L - 6) {
+                float v = 0.0f;
+                if (Bm > 0) {
+                    const int bm = (int)low_bits(S.x.words[lane + 8], Bm);
+                    v = ((q * sd) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
+                }
+                S.x.C[hblk * 12 + hk] = v;
+            }
+        }
+        wave_lds_sync();
+        if (harm) {   // per-block inverse DCT (:251-270), lane = harmonic
+            const float* C = &S.x.C[iblk * 12];
+            float sum = 0;
+#pragma unroll
+            for (int k = 1; k <= 10; ++k) {
+                if (k <= iji) {
+                    const float ak = (k == 1) ? 1.0f : 2.0f;
+                    sum = sum + (ak * C[k] * cosr[k]);
+                }
+            }
+            S.x.fp[lane] = sum;
+        }
+    } else {
+        wave_lds_sync();
+    }
+    // voicing (:170-188): harmonic l = lane takes bit max(K-1 - (l-1)/3, 0) of b1; the mask is a ballot
+    unsigned long long v = 0ULL;
+    if (!bad) {
+        const uint32_t b1 = low_bits(S.x.words[1], 12);
+        const int third = ((lane - 1) * 171) >> 9;   // (lane - 1) / 3 for 1 <= lane <= 64
+        const int band = (K - 1 - third) < 0 ? 0 : (K - 1 - third);
+        v = __ballot(lane >= 1 && lane <= L && ((b1 >> band) & 1u)) >> 1;   // bit l-1 = harmonic l
+    }
+    if (lane == 0) {
+        S.x.fp[57] = __uint_as_float((uint32_t)v);
+        S.x.fp[58] = __uint_as_float((uint32_t)(v >> 32));
+        S.x.fp[59] = w0;
+        S.x.fp[60] = __int_as_float(L);
+        S.x.fp[61] = __int_as_float(K);
+        S.x.fp[62] = __uint_as_float(rec.w);
+        S.x.fp[63] = __int_as_float(bad);
+    }
+    wave_lds_sync();
+}
 
 // ------------------------------------------------------------------------------------------
 // IMBE 7200x4400 parameter decode.  Returns 0 (voice) or 1 (invalid fundamental).
@@ -982,19 +1161,29 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         int lane = lane_in;
         asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
         const DeviceTables& tabs = ft;
-        const float* fp = params[f].v;
+        // Frame parameters: expanded here from the FEC record (the normal path), or taken from the
+        // workspace row a separate mbx_expand_records() launch has written.  Either way decode reads LDS.
+        // The table requests go out BEFORE the state loads (vector memory returns in order, and the
+        // tables are L2 hits), the arithmetic runs while the state is in flight.
+        // The parts of prev_mp_enhanced that synthesis reads are requested now, together with prev_mp,
+        // so that one memory latency covers both (they are first used after the decode).
+        Parms enh;
+        load_enh_view(enh, slot_enh, lane);
+        Parms prev;
+        load_prev_view(prev, slot_prev, lane);
+        if (params) {
+            scratch.x.fp[lane] = params[f].v[lane];
+            wave_lds_sync();
+        } else {
+            expand_imbe_wave(&records[f], scratch, tabs.t, lane);
+        }
+        const float* fp = scratch.x.fp;
         const uint32_t errw = uni(__float_as_uint(fp[62]));
         const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
         unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID | C4_VALID from the FEC stage
         const int total = c0 + prot;
         bool muted;
-        // The parts of prev_mp_enhanced that synthesis reads are requested now, together with prev_mp,
-        // so that one memory latency covers both (they are first used after the decode).
-        Parms enh;
-        load_enh_view(enh, slot_enh, lane);
         {
-            Parms prev;
-            load_prev_view(prev, slot_prev, lane);
 
             // prepare (imbe4400_prepare_process)
             cur.errorCount4 = c4;

@@ -2,9 +2,9 @@
 # development aid: VALU/SALU/LDS instruction counts of the stream kernel per ablation mask
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for m in 0 1 2 4 8 16 32 64 128; do
+for m in ${MBX_MASKS:-0 1 2 4 8 16 32 64 128}; do
   rm -rf /tmp/pmc_abl
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc_abl -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --ablate $m ${1:+--workload $1} > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc_abl -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --ablate $m ${1:+--workload $1} $MBX_BENCH_ARGS > /dev/null 2>&1
   python3 - "$m" <<'PY'
 import csv,glob,sys,collections
 acc=collections.defaultdict(list)
