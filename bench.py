@@ -162,7 +162,9 @@ def main():
         # dominant (stream) kernel can be bracketed by events
         _native.check(fec(d_frames.data_ptr(), n, out["records"].data_ptr(), stream), "fec")
         run = L.mbx_process_records
-        if args.split_expand:   # development aid: expansion as its own launch, stream kernel reads the workspace
+        # IMBE: mbx_process_records is ONE launch.  AMBE+2: it is the expand launch + the stream launch;
+        # they are issued separately here so that the events bracket the stream kernel only.
+        if args.split_expand or codec == 1:
             _native.check(L.mbx_expand_records(codec, out["records"].data_ptr(), n, stream), "expand")
             run = L.mbx_stream_expanded
         if ev is not None:

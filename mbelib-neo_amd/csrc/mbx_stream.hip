@@ -1436,7 +1436,10 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
     cur.tonePhase = dual ? (p2 + 160u * s2) : p2;
 }
 
-__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+#ifndef MBX_AMBE_WAVES_PER_SIMD
+#define MBX_AMBE_WAVES_PER_SIMD 4   // the AMBE+2 kernel spills at 96 VGPRs; four spill-free waves are faster
+#endif
+__global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)
 ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                    mbe_parms* __restrict__ state,
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
