@@ -59,6 +59,13 @@ typedef struct mbe_process_result {
     unsigned flags;
 } mbe_process_result;
 
+/* One soft-decision bit (ref include/mbelib-neo/mbelib.h:148-151): hard decision + confidence in it
+ * (0 = unknown / erasure-like, 255 = highly reliable).  ABI-identical to the reference's struct. */
+typedef struct mbe_soft_bit {
+    uint8_t bit;
+    uint8_t reliability;
+} mbe_soft_bit;
+
 #define MBE_PROCESS_FLAG_SOFT_INPUT 0x0001u
 #define MBE_PROCESS_FLAG_C0_VALID   0x0002u
 #define MBE_PROCESS_FLAG_C4_VALID   0x0004u
@@ -85,6 +92,9 @@ enum { MBX_CODEC_IMBE7200X4400 = 0, MBX_CODEC_AMBE3600X2450 = 1 };
  *   AMBE: row 0 cells 23..0, row 1 cells 22..0, row 2 cells 10..0, row 3 cells 13..0 = 72 bits */
 #define MBX_IMBE_FRAME_BYTES 18
 #define MBX_AMBE_FRAME_BYTES 9
+/* soft-decision frames keep the reference's own array shapes: mbe_soft_bit[8][23] / [4][24] */
+#define MBX_IMBE_SOFT_BITS 184
+#define MBX_AMBE_SOFT_BITS 96
 
 /* One decoded-parameter record per frame, produced by the FEC stage and consumed by the
  * stream stage: 88 (IMBE) or 49 (AMBE) parameter bits, bit i at word i/32, bit 31-(i%32);

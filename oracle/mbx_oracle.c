@@ -359,6 +359,330 @@ mbxo_fec_ambe3600x2450(const uint8_t frame[MBX_AMBE_FRAME_BYTES], mbx_param_reco
     return c0 + prot;
 }
 
+/* =====================================================================================
+ * Soft-decision front end (§8(f) row 1).  Word-based restatement: a candidate is a packed
+ * code word, its cost the sum of the reliabilities of the positions where it disagrees with
+ * the hard decisions.  The reference scans the candidates in ascending data order and keeps
+ * the current best unless the new one is strictly better under
+ *     (lower cost) > (data equal to the hard decoder's output) > (fewer differing bits),
+ * src/ecc/ecc.c:50-63; that scan returns the minimum of the key
+ *     (cost, !matches_hard, differing bits, data word)           -- see soft_key().
+ * ===================================================================================== */
+mbe_soft_bit
+mbxo_soft_bit_from_hard(int bit, uint8_t reliability) { /* src/core/mbelib.c:116-122 */
+    mbe_soft_bit s;
+    s.bit = (uint8_t)(bit ? 1u : 0u);
+    s.reliability = reliability;
+    return s;
+}
+
+mbe_soft_bit
+mbxo_soft_bit_from_llr(int16_t llr) { /* src/core/mbelib.c:124-131 */
+    int mag = (llr < 0) ? -(int)llr : (int)llr;
+    mbe_soft_bit s;
+    s.bit = (uint8_t)((llr > 0) ? 1u : 0u);
+    s.reliability = (uint8_t)(mag > 255 ? 255 : mag);
+    return s;
+}
+
+int
+mbxo_soft_bits_from_hard(const char* bits, mbe_soft_bit* soft, size_t count, uint8_t reliability) {
+    if (!soft) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_bits(bits, count);
+    if (rc < 0) {
+        return rc;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        soft[i] = mbxo_soft_bit_from_hard(bits[i], reliability);
+    }
+    return 0;
+}
+
+int
+mbxo_soft_bits_from_llr(const int16_t* llr, mbe_soft_bit* soft, size_t count) {
+    if (!llr || !soft) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        soft[i] = mbxo_soft_bit_from_llr(llr[i]);
+    }
+    return 0;
+}
+
+static int
+validate_soft(const mbe_soft_bit* bits, size_t count) { /* src/internal/mbe_result.h:31-42 */
+    if (!bits) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        if (bits[i].bit > 1u) {
+            return MBE_STATUS_INVALID_BITS;
+        }
+    }
+    return 0;
+}
+
+static uint32_t
+soft_hard_word(const mbe_soft_bit* in, int n) {
+    uint32_t w = 0;
+    for (int j = n - 1; j >= 0; --j) {
+        w = (w << 1) | (uint32_t)(in[j].bit & 1u);
+    }
+    return w;
+}
+
+static uint32_t
+soft_cost(const mbe_soft_bit* in, uint32_t diff) {
+    uint32_t cost = 0;
+    while (diff) {
+        int j = __builtin_ctz(diff);
+        cost += in[j].reliability;
+        diff &= diff - 1;
+    }
+    return cost;
+}
+
+static uint64_t
+soft_key(uint32_t cost, int matches_hard, int diffs, uint32_t data) {
+    return ((uint64_t)cost << 32) | ((uint64_t)(matches_hard ? 0u : 1u) << 24) | ((uint64_t)diffs << 16) | data;
+}
+
+static uint32_t
+golay_encode(uint32_t data) { /* src/ecc/ecc.c:65-80 */
+    uint32_t ecc = 0;
+    for (int i = 0; i < 12; ++i) {
+        if ((data >> (11 - i)) & 1u) {
+            ecc ^= T->golay_gen[i];
+        }
+    }
+    return (data << 11) | ecc;
+}
+
+/* soft Golay on a packed word; *out = chosen data bits over the HARD parity bits (ecc.c:354-356) */
+static int
+golay2312_soft_word(const mbe_soft_bit* in, uint32_t* out) {
+    const uint32_t hard = soft_hard_word(in, 23);
+    uint32_t hard_fixed;
+    (void)mbxo_golay2312_word(hard, &hard_fixed);
+    const uint32_t hard_data = hard_fixed >> 11;
+    uint64_t best = ~(uint64_t)0;
+    for (uint32_t data = 0; data < 4096u; ++data) {
+        const uint32_t diff = golay_encode(data) ^ hard;
+        const uint64_t key = soft_key(soft_cost(in, diff), data == hard_data, __builtin_popcount(diff >> 11), data);
+        if (key < best) {
+            best = key;
+        }
+    }
+    const uint32_t data = (uint32_t)(best & 0xffffu);
+    *out = (data << 11) | (hard & 0x7ffu);
+    return (int)((best >> 16) & 0xffu);
+}
+
+int
+mbxo_golay2312_soft(const mbe_soft_bit* in, char* out) {
+    if (!out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_soft(in, 23u);
+    if (rc < 0) {
+        return rc;
+    }
+    uint32_t w;
+    int diffs = golay2312_soft_word(in, &w);
+    word_to_chars(w, out, 23);
+    return diffs;
+}
+
+/* Hamming(15,11) code word of an 11-bit data word: data bit i sits at position pos[i], the four
+ * parity positions are the unique values with a zero syndrome (src/ecc/ecc.c:133-155) */
+static uint32_t
+hamming_encode(uint32_t data) {
+    static const int data_pos[11] = {2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14};
+    static const int parity_pos[4] = {0, 1, 3, 7};
+    uint32_t cw = 0;
+    for (int i = 0; i < 11; ++i) {
+        cw |= ((data >> i) & 1u) << data_pos[i];
+    }
+    for (uint32_t p = 0; p < 16u; ++p) {
+        uint32_t c = cw;
+        for (int i = 0; i < 4; ++i) {
+            c |= ((p >> i) & 1u) << parity_pos[i];
+        }
+        int syndrome = 0;
+        for (int i = 0; i < 4; ++i) {
+            syndrome |= (__builtin_popcount(c & T->hamming_gen[i]) & 1) << i;
+        }
+        if (syndrome == 0) {
+            return c;
+        }
+    }
+    return 0xffffffffu; /* not reached: every data word has a code word */
+}
+
+static int
+hamming1511_soft_word(const mbe_soft_bit* in, uint32_t* out) {
+    const uint32_t hard = soft_hard_word(in, 15);
+    uint32_t hard_fixed;
+    (void)mbxo_hamming1511_word(hard, &hard_fixed);
+    uint64_t best = ~(uint64_t)0;
+    uint32_t best_cw = hard_fixed;
+    for (uint32_t data = 0; data < 2048u; ++data) {
+        const uint32_t cw = hamming_encode(data);
+        if (cw == 0xffffffffu) {
+            continue;
+        }
+        const uint32_t diff = cw ^ hard;
+        const uint64_t key = soft_key(soft_cost(in, diff), cw == hard_fixed, __builtin_popcount(diff), data);
+        if (key < best) {
+            best = key;
+            best_cw = cw;
+        }
+    }
+    *out = best_cw;
+    return (best == ~(uint64_t)0) ? __builtin_popcount(best_cw ^ hard) : (int)((best >> 16) & 0xffu);
+}
+
+int
+mbxo_hamming1511_soft(const mbe_soft_bit* in, char* out) {
+    if (!out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_soft(in, 15u);
+    if (rc < 0) {
+        return rc;
+    }
+    uint32_t w;
+    int diffs = hamming1511_soft_word(in, &w);
+    word_to_chars(w, out, 15);
+    return diffs;
+}
+
+/* ref: src/imbe/imbe7200x4400.c:445-459 (C0), :675-707 (demod), :517-560 (data ECC), :746-778 */
+int
+mbxo_fec_imbe7200x4400_soft(const mbe_soft_bit fr[8][23], mbx_param_record* rec) {
+    uint32_t row[8];
+    int c0 = golay2312_soft_word(fr[0], &row[0]);
+
+    uint8_t pr[115];
+    pr_bits(row[0] >> 11, 114, pr);
+    mbe_soft_bit work[7][23];
+    int k = 1;
+    for (int r = 1; r < 7; ++r) {
+        for (int j = imbe_row_width[r] - 1; j >= 0; --j) {
+            work[r][j].bit = (uint8_t)((fr[r][j].bit & 1u) ^ pr[k++]);
+            work[r][j].reliability = fr[r][j].reliability;
+        }
+    }
+
+    int prot = 0, c4 = 0;
+    memset(rec, 0, sizeof(*rec));
+    int at = rec_append(rec, 0, row[0], 23, 12);
+    for (int r = 1; r < 4; ++r) {
+        prot += golay2312_soft_word(work[r], &row[r]);
+        at = rec_append(rec, at, row[r], 23, 12);
+    }
+    for (int r = 4; r < 7; ++r) {
+        int e = hamming1511_soft_word(work[r], &row[r]);
+        prot += e;
+        if (r == 4) {
+            c4 = e;
+        }
+        at = rec_append(rec, at, row[r], 15, 11);
+    }
+    at = rec_append(rec, at, soft_hard_word(fr[7], 7), 7, 7);
+    rec->w[3] = (uint32_t)c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
+                | ((MBE_PROCESS_FLAG_SOFT_INPUT | MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24);
+    return c0 + prot;
+}
+
+/* ref: src/ambe/ambe_common.c:48-73 (C0 + parity), :102-124 (demod), :159-190 (data),
+ *      src/ambe/ambe3600x2450.c:684-714 */
+int
+mbxo_fec_ambe3600x2450_soft(const mbe_soft_bit fr[4][24], mbx_param_record* rec) {
+    uint32_t cw;
+    int c0 = golay2312_soft_word(&fr[0][1], &cw);
+    uint32_t row0 = (cw << 1) | (uint32_t)(fr[0][0].bit & 1u);
+    if (c0 == 0 && (__builtin_popcount(row0) & 1)) {
+        row0 ^= 1u;
+        c0 = 1;
+    }
+
+    uint8_t pr[24];
+    pr_bits((row0 >> 12) & 0xfffu, 23, pr);
+    mbe_soft_bit c1[23];
+    int k = 1;
+    for (int j = 22; j >= 0; --j) {
+        c1[j].bit = (uint8_t)((fr[1][j].bit & 1u) ^ pr[k++]);
+        c1[j].reliability = fr[1][j].reliability;
+    }
+
+    memset(rec, 0, sizeof(*rec));
+    int at = rec_append(rec, 0, row0, 24, 12);
+    uint32_t row1;
+    int prot = golay2312_soft_word(c1, &row1);
+    at = rec_append(rec, at, row1, 23, 12);
+    at = rec_append(rec, at, soft_hard_word(fr[2], 11), 11, 11);
+    at = rec_append(rec, at, soft_hard_word(fr[3], 14), 14, 14);
+    rec->w[3] = (uint32_t)c0 | ((uint32_t)prot << 8) | ((MBE_PROCESS_FLAG_SOFT_INPUT | MBE_PROCESS_FLAG_C0_VALID) << 24);
+    return c0 + prot;
+}
+
+int
+mbxo_decode_imbe7200x4400_soft_frame(const mbe_soft_bit fr[8][23], char imbe_d[88], mbe_process_result* result) {
+    if (result) {
+        memset(result, 0, sizeof(*result));
+    }
+    if (!imbe_d) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_soft(&fr[0][0], 8u * 23u);
+    if (rc < 0) {
+        return rc;
+    }
+    mbx_param_record rec;
+    int total = mbxo_fec_imbe7200x4400_soft(fr, &rec);
+    mbxo_record_to_bits(&rec, 88, imbe_d);
+    if (result) {
+        mbxo_record_to_result(&rec, result);
+    }
+    return total;
+}
+
+int
+mbxo_decode_ambe3600x2450_soft_frame(const mbe_soft_bit fr[4][24], char ambe_d[49], mbe_process_result* result) {
+    if (result) {
+        memset(result, 0, sizeof(*result));
+    }
+    if (!ambe_d) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_soft(&fr[0][0], 4u * 24u);
+    if (rc < 0) {
+        return rc;
+    }
+    mbx_param_record rec;
+    int total = mbxo_fec_ambe3600x2450_soft(fr, &rec);
+    mbxo_record_to_bits(&rec, 49, ambe_d);
+    if (result) {
+        mbxo_record_to_result(&rec, result);
+    }
+    return total;
+}
+
+int
+mbxo_fec_soft_batch(int codec, size_t n, const mbe_soft_bit* soft, mbx_param_record* records) {
+    for (size_t i = 0; i < n; ++i) {
+        if (codec == MBX_CODEC_IMBE7200X4400) {
+            mbxo_fec_imbe7200x4400_soft((const mbe_soft_bit(*)[23])(soft + i * MBX_IMBE_SOFT_BITS), &records[i]);
+        } else {
+            mbxo_fec_ambe3600x2450_soft((const mbe_soft_bit(*)[24])(soft + i * MBX_AMBE_SOFT_BITS), &records[i]);
+        }
+    }
+    return 0;
+}
+
 int
 mbxo_decode_imbe7200x4400_frame(const char fr[8][23], char imbe_d[88], mbe_process_result* result) {
     if (result) {

@@ -47,6 +47,21 @@ int mbxo_hamming1511(const char* in, char* out);
 int mbxo_fec_imbe7200x4400(const uint8_t frame[MBX_IMBE_FRAME_BYTES], mbx_param_record* rec);
 int mbxo_fec_ambe3600x2450(const uint8_t frame[MBX_AMBE_FRAME_BYTES], mbx_param_record* rec);
 /* the reference's char-array entry points, same return/validation behaviour */
+/* soft-decision front end -- ref src/ecc/ecc.c:138-215,303-357,410-413,
+ * src/imbe/imbe7200x4400.c:445-459,517-560,675-707,746-778, src/ambe/ambe_common.c:48-73,102-124,159-190,
+ * src/ambe/ambe3600x2450.c:684-714, src/core/mbelib.c:107-158 */
+mbe_soft_bit mbxo_soft_bit_from_hard(int bit, uint8_t reliability);
+mbe_soft_bit mbxo_soft_bit_from_llr(int16_t llr);
+int mbxo_soft_bits_from_hard(const char* bits, mbe_soft_bit* soft, size_t count, uint8_t reliability);
+int mbxo_soft_bits_from_llr(const int16_t* llr, mbe_soft_bit* soft, size_t count);
+int mbxo_golay2312_soft(const mbe_soft_bit* in, char* out);   /* returns data-bit differences, -1/-2 on bad input */
+int mbxo_hamming1511_soft(const mbe_soft_bit* in, char* out); /* returns bit differences */
+int mbxo_fec_imbe7200x4400_soft(const mbe_soft_bit fr[8][23], mbx_param_record* rec);
+int mbxo_fec_ambe3600x2450_soft(const mbe_soft_bit fr[4][24], mbx_param_record* rec);
+int mbxo_decode_imbe7200x4400_soft_frame(const mbe_soft_bit fr[8][23], char imbe_d[88], mbe_process_result* result);
+int mbxo_decode_ambe3600x2450_soft_frame(const mbe_soft_bit fr[4][24], char ambe_d[49], mbe_process_result* result);
+int mbxo_fec_soft_batch(int codec, size_t n, const mbe_soft_bit* soft, mbx_param_record* records);
+
 int mbxo_decode_imbe7200x4400_frame(const char fr[8][23], char imbe_d[88], mbe_process_result* result);
 int mbxo_decode_ambe3600x2450_frame(const char fr[4][24], char ambe_d[49], mbe_process_result* result);
 

@@ -6,7 +6,7 @@
  * tests/golden/.  The layouts are described in tests/golden/README.md and parsed by
  * tests/golden_io.py.
  *
- *   usage: oracle/_ref/gen_fixtures tests/golden
+ *   usage: oracle/_ref/gen_fixtures tests/golden [soft]
  *
  * All inputs are seeded (splitmix64, seed 0x9E3779B97F4A7C15 ^ tag) so the files are
  * reproducible.  Per-stream RNG seeds follow SURVEY.md §8(d): mbe_setThreadRngSeed(1234 + s).
@@ -39,6 +39,16 @@ extern int mbe_processImbe7200x4400Framef(float*, mbe_process_result*, const cha
 extern int mbe_processAmbe3600x2450Framef(float*, mbe_process_result*, const char[4][24], char[49], mbe_parms*,
                                           mbe_parms*, mbe_parms*);
 extern int mbe_processImbe4400Dataf(float*, mbe_process_result*, const char[88], mbe_parms*, mbe_parms*, mbe_parms*);
+/* soft-decision front end: include/mbelib-neo/mbelib.h:208-224, 246, 260, 437-447, 513-523 */
+extern mbe_soft_bit mbe_softBitFromLlr(int16_t);
+extern int mbe_softBitsFromLlr(const int16_t*, mbe_soft_bit*, size_t);
+extern int mbe_softBitsFromHard(const char*, mbe_soft_bit*, size_t, uint8_t);
+extern int mbe_golay2312Soft(const mbe_soft_bit*, char*);
+extern int mbe_hamming1511Soft(const mbe_soft_bit*, char*);
+extern int mbe_decodeImbe7200x4400SoftFrame(const mbe_soft_bit[8][23], char[88], mbe_process_result*);
+extern int mbe_decodeAmbe3600x2450SoftFrame(const mbe_soft_bit[4][24], char[49], mbe_process_result*);
+extern int mbe_processImbe7200x4400SoftFramef(float*, mbe_process_result*, const mbe_soft_bit[8][23], char[88], mbe_parms*,
+                                              mbe_parms*, mbe_parms*);
 
 static uint64_t sm_state;
 static uint64_t
@@ -556,13 +566,167 @@ gen_misc(const char* dir) {
     printf("misc_kat.bin written\n");
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* soft_kat.bin: the soft-decision front end.
+ *   u32 NG, NG x { soft[23] (bit, reliability), char out[23], i32 ret }      mbe_golay2312Soft
+ *   u32 NH, NH x { soft[15], char out[15], i32 ret }                          mbe_hamming1511Soft
+ *   u32 NI, NI x { soft[8][23], char d[88], i32 ret, result(20) }             mbe_decodeImbe7200x4400SoftFrame
+ *   u32 NA, NA x { soft[4][24], char d[49], i32 ret, result(20) }             mbe_decodeAmbe3600x2450SoftFrame
+ *   u32 NL, NL x { i16 llr, soft }                                            mbe_softBitFromLlr
+ *   u32 NP, NP x { soft[8][23], i32 ret, result(20), float pcm[160] }         mbe_processImbe7200x4400SoftFramef,
+ *                                                                             one stream, mbe_setThreadRngSeed(4242)
+ * Reliability profiles rotate per case: 0 uniform random, 1 all equal (tie-breaks decide),
+ * 2 two-level {3, 200}, 3 all zero, 4 random with the flipped positions weak (a clean code word
+ * with a few low-confidence errors -- the realistic case).                                  */
+static void
+soft_fill(mbe_soft_bit* s, int n, int profile) {
+    for (int i = 0; i < n; ++i) {
+        uint64_t v = splitmix64();
+        s[i].bit = (uint8_t)(v & 1u);
+        switch (profile) {
+            case 0: s[i].reliability = (uint8_t)(v >> 8); break;
+            case 1: s[i].reliability = 77; break;
+            case 2: s[i].reliability = ((v >> 8) & 1u) ? 200 : 3; break;
+            case 3: s[i].reliability = 0; break;
+            default: s[i].reliability = (uint8_t)(128u + ((v >> 8) & 127u)); break;
+        }
+    }
+}
+
+/* profile 4: overwrite a block with a valid code word (through the hard decoder) and damage it */
+static void
+soft_damage_golay(mbe_soft_bit* s) {
+    char in[23], out[23];
+    for (int i = 0; i < 23; ++i) {
+        in[i] = (char)s[i].bit;
+    }
+    mbe_golay2312(in, out);
+    /* out = corrected data + original parity: re-encode by decoding once more is not needed, a word
+     * within distance 3 of a code word is what a receiver sees */
+    for (int i = 0; i < 23; ++i) {
+        s[i].bit = (uint8_t)out[i];
+    }
+    int flips = (int)(splitmix64() % 5u);
+    for (int k = 0; k < flips; ++k) {
+        int at = (int)(splitmix64() % 23u);
+        s[at].bit ^= 1u;
+        s[at].reliability = (uint8_t)(splitmix64() % 40u);
+    }
+}
+
+static void
+gen_soft(const char* dir) {
+    FILE* f = open_out(dir, "soft_kat.bin");
+    sm_state = 0x9E3779B97F4A7C15ULL ^ 0x50F7ULL;
+    uint32_t n = 640;
+    W(f, &n, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        mbe_soft_bit s[23];
+        char out[23];
+        soft_fill(s, 23, (int)(i % 5u));
+        if ((i % 5u) == 4u) {
+            soft_damage_golay(s);
+        }
+        int32_t ret = mbe_golay2312Soft(s, out);
+        W(f, s, sizeof(s));
+        W(f, out, 23);
+        W(f, &ret, 4);
+    }
+    n = 640;
+    W(f, &n, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        mbe_soft_bit s[15];
+        char out[15];
+        soft_fill(s, 15, (int)(i % 5u));
+        int32_t ret = mbe_hamming1511Soft(s, out);
+        W(f, s, sizeof(s));
+        W(f, out, 15);
+        W(f, &ret, 4);
+    }
+    n = 160;
+    W(f, &n, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        mbe_soft_bit fr[8][23];
+        char d[88];
+        mbe_process_result r;
+        soft_fill(&fr[0][0], 184, (int)(i % 5u));
+        if ((i % 5u) == 4u) {
+            for (int row = 0; row < 4; ++row) {
+                soft_damage_golay(fr[row]);
+            }
+        }
+        int32_t ret = mbe_decodeImbe7200x4400SoftFrame((const mbe_soft_bit(*)[23])fr, d, &r);
+        W(f, fr, sizeof(fr));
+        W(f, d, 88);
+        W(f, &ret, 4);
+        W(f, &r, sizeof(r));
+    }
+    n = 320;
+    W(f, &n, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        mbe_soft_bit fr[4][24];
+        char d[49];
+        mbe_process_result r;
+        soft_fill(&fr[0][0], 96, (int)(i % 5u));
+        if ((i % 5u) == 4u) {
+            soft_damage_golay(&fr[0][1]);
+            soft_damage_golay(&fr[1][0]);
+        }
+        int32_t ret = mbe_decodeAmbe3600x2450SoftFrame((const mbe_soft_bit(*)[24])fr, d, &r);
+        W(f, fr, sizeof(fr));
+        W(f, d, 49);
+        W(f, &ret, 4);
+        W(f, &r, sizeof(r));
+    }
+    {
+        static const int16_t llr[] = {0, 1, -1, 2, -2, 100, -100, 254, -254, 255, -255, 256, -256, 1000, -1000, 32767, -32767, -32768};
+        n = (uint32_t)(sizeof(llr) / sizeof(llr[0]));
+        W(f, &n, 4);
+        for (uint32_t i = 0; i < n; ++i) {
+            mbe_soft_bit s = mbe_softBitFromLlr(llr[i]);
+            W(f, &llr[i], 2);
+            W(f, &s, sizeof(s));
+        }
+    }
+    {
+        n = 12;
+        W(f, &n, 4);
+        mbe_parms cur, prev, enh;
+        mbe_initMbeParms(&cur, &prev, &enh);
+        mbe_setThreadRngSeed(4242u);
+        for (uint32_t i = 0; i < n; ++i) {
+            mbe_soft_bit fr[8][23];
+            char d[88];
+            float out[160];
+            mbe_process_result r;
+            soft_fill(&fr[0][0], 184, (i % 3u) ? 4 : 0);
+            if (i % 3u) {
+                for (int row = 0; row < 4; ++row) {
+                    soft_damage_golay(fr[row]);
+                }
+            }
+            int32_t ret = mbe_processImbe7200x4400SoftFramef(out, &r, (const mbe_soft_bit(*)[23])fr, d, &cur, &prev, &enh);
+            W(f, fr, sizeof(fr));
+            W(f, &ret, 4);
+            W(f, &r, sizeof(r));
+            W(f, out, sizeof(out));
+        }
+    }
+    fclose(f);
+    printf("soft_kat.bin written\n");
+}
+
 int
 main(int argc, char** argv) {
-    if (argc != 2) {
-        fprintf(stderr, "usage: %s outdir\n", argv[0]);
+    if (argc != 2 && argc != 3) {
+        fprintf(stderr, "usage: %s outdir [soft]\n", argv[0]);
         return 2;
     }
     const char* dir = argv[1];
+    if (argc == 3 && strcmp(argv[2], "soft") == 0) {   /* only the soft-decision file */
+        gen_soft(dir);
+        return 0;
+    }
     gen_ecc(dir);
     gen_fec(dir, 0, 2048);
     gen_fec(dir, 1, 2048);
@@ -573,5 +737,6 @@ main(int argc, char** argv) {
     gen_f2s(dir);
     gen_params(dir);
     gen_misc(dir);
+    gen_soft(dir);
     return 0;
 }

@@ -117,3 +117,25 @@ def misc_kat():
     )
     assert d.itemsize == len(b)
     return b.view(d)[0]
+
+
+def soft_kat():
+    """soft_kat.bin (layout: oracle/tools/gen_fixtures.c gen_soft): dict of structured arrays"""
+    b = _read("soft_kat.bin")
+    out, off = {}, 0
+
+    def section(name, dt):
+        nonlocal off
+        n = int(b[off : off + 4].view("<u4")[0])
+        off += 4
+        out[name] = b[off : off + n * dt.itemsize].view(dt)
+        off += n * dt.itemsize
+
+    section("golay", np.dtype([("soft", "u1", (23, 2)), ("out", "i1", (23,)), ("ret", "<i4")]))
+    section("hamming", np.dtype([("soft", "u1", (15, 2)), ("out", "i1", (15,)), ("ret", "<i4")]))
+    section("imbe", np.dtype([("soft", "u1", (184, 2)), ("bits", "i1", (88,)), ("ret", "<i4"), ("result", RESULT_DTYPE)]))
+    section("ambe", np.dtype([("soft", "u1", (96, 2)), ("bits", "i1", (49,)), ("ret", "<i4"), ("result", RESULT_DTYPE)]))
+    section("llr", np.dtype([("llr", "<i2"), ("soft", "u1", (2,))]))
+    section("process", np.dtype([("soft", "u1", (184, 2)), ("ret", "<i4"), ("result", RESULT_DTYPE), ("pcmf", "<f4", (160,))]))
+    assert off == b.size
+    return out

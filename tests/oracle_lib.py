@@ -69,6 +69,19 @@ class Oracle:
         h.mbxo_rng_seed.argtypes = [_vp, C.c_uint32]
         h.mbxo_fnv1a32.restype = C.c_uint32
         h.mbxo_fnv1a32.argtypes = [_vp, C.c_size_t]
+        # soft-decision front end
+        for name in ("mbxo_golay2312_soft", "mbxo_hamming1511_soft"):
+            getattr(h, name).restype = C.c_int
+            getattr(h, name).argtypes = [_vp, _vp]
+        for name in ("mbxo_decode_imbe7200x4400_soft_frame", "mbxo_decode_ambe3600x2450_soft_frame"):
+            getattr(h, name).restype = C.c_int
+            getattr(h, name).argtypes = [_vp, _vp, _vp]
+        h.mbxo_fec_soft_batch.restype = C.c_int
+        h.mbxo_fec_soft_batch.argtypes = [C.c_int, C.c_size_t, _vp, _vp]
+        h.mbxo_soft_bits_from_llr.restype = C.c_int
+        h.mbxo_soft_bits_from_llr.argtypes = [_vp, _vp, C.c_size_t]
+        h.mbxo_soft_bits_from_hard.restype = C.c_int
+        h.mbxo_soft_bits_from_hard.argtypes = [_vp, _vp, C.c_size_t, C.c_uint8]
 
     # ---- small wrappers -----------------------------------------------------------------
     def golay(self, cw):
@@ -115,6 +128,40 @@ class Oracle:
         rec = np.zeros(n, dtype=RECORD_DTYPE)
         self.h.mbxo_fec_batch(codec, n, frames.ctypes.data, rec.ctypes.data)
         return rec
+
+    def fec_soft_batch(self, codec, soft):
+        """soft: [n, 184|96, 2] uint8 (bit, reliability) in the reference's array order -> records"""
+        soft = np.ascontiguousarray(soft, dtype=np.uint8)
+        n = soft.shape[0]
+        rec = np.zeros(n, dtype=RECORD_DTYPE)
+        self.h.mbxo_fec_soft_batch(codec, n, soft.ctypes.data, rec.ctypes.data)
+        return rec
+
+    def golay_soft(self, soft23):
+        soft23 = np.ascontiguousarray(soft23, dtype=np.uint8)
+        out = np.zeros(23, dtype=np.int8)
+        ret = self.h.mbxo_golay2312_soft(soft23.ctypes.data, out.ctypes.data)
+        return out, ret
+
+    def hamming_soft(self, soft15):
+        soft15 = np.ascontiguousarray(soft15, dtype=np.uint8)
+        out = np.zeros(15, dtype=np.int8)
+        ret = self.h.mbxo_hamming1511_soft(soft15.ctypes.data, out.ctypes.data)
+        return out, ret
+
+    def decode_soft_frame(self, codec, soft):
+        soft = np.ascontiguousarray(soft, dtype=np.uint8)
+        d = np.zeros(88 if codec == 0 else 49, dtype=np.int8)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        fn = self.h.mbxo_decode_imbe7200x4400_soft_frame if codec == 0 else self.h.mbxo_decode_ambe3600x2450_soft_frame
+        ret = fn(soft.ctypes.data, d.ctypes.data, res.ctypes.data)
+        return d, ret, res[0]
+
+    def soft_from_llr(self, llr):
+        llr = np.ascontiguousarray(llr, dtype=np.int16)
+        out = np.zeros((llr.size, 2), dtype=np.uint8)
+        assert self.h.mbxo_soft_bits_from_llr(llr.ctypes.data, out.ctypes.data, llr.size) == 0
+        return out
 
     def process_batch(self, codec, S, T, frames, state, rng):
         frames = np.ascontiguousarray(frames, dtype=np.uint8)

@@ -235,3 +235,34 @@ def test_misc_known_answers(oracle):
     parity.check_results(fx["hr_result"].reshape(1), res)
     parity.check_state(fx["hr_cur"].reshape(1), st[0, 0:1], rel=1e-6)
     parity.check_pcm(fx["hr_pcm"], out, rel=1e-6, worst=1e-5)
+
+
+# ---- soft-decision front end against the real reference's outputs -------
+def test_soft_golay_hamming_match_reference(oracle):
+    kat = golden_io.soft_kat()
+    for row in kat["golay"]:
+        out, ret = oracle.golay_soft(row["soft"])
+        assert ret == row["ret"] and np.array_equal(out, row["out"])
+    for row in kat["hamming"]:
+        out, ret = oracle.hamming_soft(row["soft"])
+        assert ret == row["ret"] and np.array_equal(out, row["out"])
+
+
+@pytest.mark.parametrize("codec", [0, 1])
+def test_soft_frames_match_reference(oracle, codec):
+    kat = golden_io.soft_kat()["imbe" if codec == 0 else "ambe"]
+    for row in kat:
+        bits, ret, res = oracle.decode_soft_frame(codec, row["soft"])
+        assert ret == row["ret"]
+        assert np.array_equal(bits, row["bits"])
+        for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
+            assert res[name] == row["result"][name], name
+    # the batch driver used by the GPU tests agrees with the per-frame entry
+    rec = oracle.fec_soft_batch(codec, kat["soft"])
+    nbits = 88 if codec == 0 else 49
+    assert np.array_equal(oracle_lib.records_to_bits(rec, nbits), kat["bits"])
+
+
+def test_soft_bits_from_llr(oracle):
+    kat = golden_io.soft_kat()["llr"]
+    assert np.array_equal(oracle.soft_from_llr(kat["llr"]), kat["soft"])
