@@ -73,6 +73,31 @@ int mbx_fec_imbe7200x4400(const uint8_t* d_frames /* n*18 */, size_t n, mbx_para
 int mbx_fec_ambe3600x2450(const uint8_t* d_frames /* n*9 */, size_t n, mbx_param_record* d_records /* n */,
                           void* stream);
 
+/* ---- soft-decision FEC stage: soft frames -> parameter records ------
+ * One wavefront per frame; exhaustive maximum-likelihood Golay/Hamming decode with the reference's
+ * tie rules, bit-exact.  Frames keep the reference's own shapes: n x mbe_soft_bit[8][23] (IMBE) or
+ * n x mbe_soft_bit[4][24] (AMBE+2).  Hard decisions must be 0/1 (mbx_validate_soft_bits, host); the
+ * records carry MBE_PROCESS_FLAG_SOFT_INPUT.
+ * ref: mbe_decodeImbe7200x4400SoftFrame / mbe_decodeAmbe3600x2450SoftFrame
+ *      include/mbelib-neo/mbelib.h:437-447, 513-523; src/imbe/imbe7200x4400.c:445-459,517-560,675-707,746-778;
+ *      src/ambe/ambe_common.c:48-73,102-124,159-190; src/ambe/ambe3600x2450.c:684-714;
+ *      mbe_golay2312Soft src/ecc/ecc.c:303-357, mbe_hamming1511Soft src/ecc/ecc.c:157-215,410-413 */
+int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft /* n*184 | n*96 */, size_t n, mbx_param_record* d_records,
+                 void* stream);
+/* ref: mbe_processImbe7200x4400SoftFrame[f] / mbe_processAmbe3600x2450SoftFrame[f]
+ *      src/imbe/imbe7200x4400.c:950-980, src/ambe/ambe3600x2450.c:939-969: soft FEC, then mbx_process_records */
+int mbx_process_batch_soft(int codec, int S, int T, const mbe_soft_bit* d_soft, mbe_parms* d_state, mbx_stream_rng* d_rng,
+                           int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
+                           void* stream);
+/* ref: mbe_golay2312Soft (kind 0, 23 soft bits per block) / mbe_hamming1511Soft (kind 1, 15 soft bits)
+ *      include/mbelib-neo/mbelib.h:246, 260.  out[i] bit j = corrected cell j, errs[i] = the reference's return value */
+int mbx_ecc_soft_words(int kind, const mbe_soft_bit* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream);
+/* host helpers -- ref mbe_validate_soft_bits src/internal/mbe_result.h:31-42, mbe_softBitsFromHard / mbe_softBitsFromLlr
+ * include/mbelib-neo/mbelib.h:219-224, src/core/mbelib.c:133-158 */
+int mbx_validate_soft_bits(const mbe_soft_bit* soft, size_t count); /* 0, -1 (NULL), -2 (a hard decision > 1) */
+int mbx_soft_bits_from_hard(const char* bits, mbe_soft_bit* soft, size_t count, uint8_t reliability);
+int mbx_soft_bits_from_llr(const int16_t* llr, mbe_soft_bit* soft, size_t count);
+
 /* ---- stream stage: parameter records + per-stream state -> PCM (one wavefront per stream) */
 
 /* ref: mbe_processImbe4400Dataf / mbe_processAmbe2450Dataf
@@ -136,6 +161,10 @@ int mbx_synthesize_speech_host(int S, mbe_parms* cur, mbe_parms* prev, mbx_strea
                                int16_t* pcm16);
 int mbx_floattoshort_host(const float* in, int16_t* out, size_t nframes);
 int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* records);
+int mbx_fec_soft_host(int codec, const mbe_soft_bit* soft, size_t n, mbx_param_record* records);
+int mbx_process_batch_soft_host(int codec, int S, int T, const mbe_soft_bit* soft, mbe_parms* state, mbx_stream_rng* rng,
+                                int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records);
+int mbx_ecc_soft_words_host(int kind, const mbe_soft_bit* in, size_t n, uint32_t* out, int32_t* errs);
 
 /* per-stream RNG helpers (host): ref mbe_setThreadRngSeed src/core/mbelib.c:173-181 */
 void mbx_rng_default(mbx_stream_rng* rng);

@@ -45,6 +45,15 @@ _SIGNATURES = {
     "mbx_synthesize_speech_host": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "mbx_floattoshort_host": (C.c_int, [_vp, _vp, _sz]),
     "mbx_fec_host": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "mbx_fec_soft": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
+    "mbx_process_batch_soft": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_ecc_soft_words": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "mbx_validate_soft_bits": (C.c_int, [_vp, _sz]),
+    "mbx_soft_bits_from_hard": (C.c_int, [_vp, _vp, _sz, C.c_uint8]),
+    "mbx_soft_bits_from_llr": (C.c_int, [_vp, _vp, _sz]),
+    "mbx_fec_soft_host": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "mbx_process_batch_soft_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_ecc_soft_words_host": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
     "mbx_rng_default": (None, [_vp]),
     "mbx_rng_seed": (None, [_vp, C.c_uint32]),
     "mbx_debug_set_ablation": (None, [C.c_int]),

@@ -30,6 +30,9 @@ __global__ void smoothing_kernel(int, mbe_parms*, const mbe_parms*);
 __global__ void comfort_noise_kernel(int, mbx_stream_rng*, float*, int16_t*);
 __global__ void state_copy_kernel(int, mbe_parms*);
 __global__ void ecc_words_kernel(int, const uint32_t*, size_t, uint32_t*, int32_t*, DeviceTables);
+__global__ void fec_imbe7200x4400_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
+__global__ void fec_ambe3600x2450_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
+__global__ void ecc_soft_words_kernel(int, const mbe_soft_bit*, size_t, uint32_t*, int32_t*, DeviceTables);
 }  // namespace mbx
 
 namespace {
@@ -175,6 +178,39 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     for (int L = 1; L < 64; ++L) {
         d.log2_int[L] = log2f((float)L);
     }
+    {   // x_k = 173 x_{k-1} + 13849 (mod 2^16)  =>  x_k = pr_mul[k] x_0 + pr_add[k]
+        uint32_t m = 1u, a = 0u;
+        for (int k = 0; k < 116; ++k) {
+            d.pr_mul[k] = m;
+            d.pr_add[k] = a;
+            m = (173u * m) & 0xffffu;
+            a = (173u * a + 13849u) & 0xffffu;
+        }
+    }
+    for (int i = 0; i < 11; ++i) {
+        // code word of data bit i: data bits at positions {2,4,5,6,8..14}, parity at {0,1,3,7} chosen
+        // for a zero syndrome (ref src/ecc/ecc.c:128-155)
+        static const int data_pos[11] = {2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14};
+        static const int parity_pos[4] = {0, 1, 3, 7};
+        uint32_t found = 0xffffffffu;
+        for (uint32_t p = 0; p < 16u && found == 0xffffffffu; ++p) {
+            uint32_t c = 1u << data_pos[i];
+            for (int q = 0; q < 4; ++q) {
+                c |= ((p >> q) & 1u) << parity_pos[q];
+            }
+            int syndrome = 0;
+            for (int q = 0; q < 4; ++q) {
+                syndrome |= (__builtin_popcount(c & host->hamming_gen[q]) & 1) << q;
+            }
+            if (syndrome == 0) {
+                found = c;
+            }
+        }
+        if (found == 0xffffffffu) {
+            return fail(MBX_EBADTABLE, "mbx_init: Hamming generator rows admit no code word for a data bit");
+        }
+        d.ham_basis[i] = found;
+    }
     HIP_TRY(hipMalloc(&g_ctx.d_blob, sizeof(mbx_tables)));
     HIP_TRY(hipMalloc(&g_ctx.d_derived, sizeof(mbx::DerivedTables)));
     HIP_TRY(hipMemcpy(g_ctx.d_blob, table_blob, sizeof(mbx_tables), hipMemcpyHostToDevice));
@@ -313,6 +349,80 @@ int mbx_fec_ambe3600x2450(const uint8_t* d_frames, size_t n, mbx_param_record* d
     return check_launch("fec_ambe3600x2450_kernel");
 }
 
+int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft, size_t n, mbx_param_record* d_records, void* stream) {
+    REQUIRE_READY();
+    if (!d_soft || !d_records || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    if (n > 0x7fffffffu) {
+        return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_fec_soft: more than 2^31-1 frames in one launch");
+    }
+    if (codec == MBX_CODEC_IMBE7200X4400) {   // one wavefront per frame
+        hipLaunchKernelGGL(mbx::fec_imbe7200x4400_soft_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_soft, n,
+                           d_records, g_ctx.tabs);
+    } else {
+        hipLaunchKernelGGL(mbx::fec_ambe3600x2450_soft_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_soft, n,
+                           d_records, g_ctx.tabs);
+    }
+    return check_launch("fec_soft_kernel");
+}
+
+int mbx_ecc_soft_words(int kind, const mbe_soft_bit* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream) {
+    REQUIRE_READY();
+    if (!d_in || !d_out || (kind != 0 && kind != 1) || n > 0x7fffffffu) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::ecc_soft_words_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, kind, d_in, n, d_out,
+                       d_errs, g_ctx.tabs);
+    return check_launch("ecc_soft_words_kernel");
+}
+
+int mbx_validate_soft_bits(const mbe_soft_bit* soft, size_t count) {
+    if (!soft) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        if (soft[i].bit > 1u) {
+            return MBE_STATUS_INVALID_BITS;
+        }
+    }
+    return 0;
+}
+
+int mbx_soft_bits_from_hard(const char* bits, mbe_soft_bit* soft, size_t count, uint8_t reliability) {
+    if (!soft || !bits) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        if ((unsigned char)bits[i] > 1u) {
+            return MBE_STATUS_INVALID_BITS;
+        }
+    }
+    for (size_t i = 0; i < count; ++i) {
+        soft[i].bit = (uint8_t)(bits[i] ? 1u : 0u);
+        soft[i].reliability = reliability;
+    }
+    return 0;
+}
+
+int mbx_soft_bits_from_llr(const int16_t* llr, mbe_soft_bit* soft, size_t count) {
+    if (!llr || !soft) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        const int v = llr[i], mag = v < 0 ? -v : v;
+        soft[i].bit = (uint8_t)(v > 0 ? 1u : 0u);
+        soft[i].reliability = (uint8_t)(mag > 255 ? 255 : mag);
+    }
+    return 0;
+}
+
 int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream) {
     REQUIRE_READY();
     if (!d_records || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450)) {
@@ -402,6 +512,20 @@ int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parm
     const size_t n = (size_t)S * (size_t)T;
     int rc = (codec == MBX_CODEC_IMBE7200X4400) ? mbx_fec_imbe7200x4400(d_frames, n, d_records, stream)
                                                 : mbx_fec_ambe3600x2450(d_frames, n, d_records, stream);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbx_process_records(codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+}
+
+int mbx_process_batch_soft(int codec, int S, int T, const mbe_soft_bit* d_soft, mbe_parms* d_state, mbx_stream_rng* d_rng,
+                           int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
+                           void* stream) {
+    REQUIRE_READY();
+    if (!d_soft || !d_records || S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = mbx_fec_soft(codec, d_soft, (size_t)S * (size_t)T, d_records, stream);
     if (rc < 0) {
         return rc;
     }
@@ -526,28 +650,28 @@ int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* r
     return 0;
 }
 
-int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
-                           int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
-    REQUIRE_READY();
-    if (!frames || !state || !rng || S < 0 || T < 0) {
-        return MBE_STATUS_INVALID_ARGUMENT;
-    }
+// frames in (hard: packed bytes, soft: mbe_soft_bit arrays), everything else as mbx_process_batch
+static int process_batch_host_impl(int codec, int S, int T, const void* frames, size_t frame_bytes, bool soft, mbe_parms* state,
+                                   mbx_stream_rng* rng, int16_t* pcm16, float* pcmf, mbe_process_result* results,
+                                   mbx_param_record* records) {
     const size_t n = (size_t)S * (size_t)T;
-    const size_t fb = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES;
     DevBuf df, ds, dg, d16, dfl, dres, drec;
-    HIP_TRY(df.alloc(n * fb));
+    HIP_TRY(df.alloc(n * frame_bytes));
     HIP_TRY(ds.alloc((size_t)S * 3 * sizeof(mbe_parms)));
     HIP_TRY(dg.alloc((size_t)S * sizeof(mbx_stream_rng)));
     HIP_TRY(d16.alloc(n * 160 * sizeof(int16_t)));
     HIP_TRY(dfl.alloc(n * 160 * sizeof(float)));
     HIP_TRY(dres.alloc(n * sizeof(mbe_process_result)));
     HIP_TRY(drec.alloc(n * sizeof(mbx_param_record)));
-    HIP_TRY(hipMemcpy(df.p, frames, n * fb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(df.p, frames, n * frame_bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ds.p, state, (size_t)S * 3 * sizeof(mbe_parms), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dg.p, rng, (size_t)S * sizeof(mbx_stream_rng), hipMemcpyHostToDevice));
-    int rc = mbx_process_batch(codec, S, T, df.as<uint8_t>(), ds.as<mbe_parms>(), dg.as<mbx_stream_rng>(),
-                               pcm16 ? d16.as<int16_t>() : nullptr, pcmf ? dfl.as<float>() : nullptr,
-                               results ? dres.as<mbe_process_result>() : nullptr, drec.as<mbx_param_record>(), nullptr);
+    int rc = soft ? mbx_process_batch_soft(codec, S, T, df.as<mbe_soft_bit>(), ds.as<mbe_parms>(), dg.as<mbx_stream_rng>(),
+                                           pcm16 ? d16.as<int16_t>() : nullptr, pcmf ? dfl.as<float>() : nullptr,
+                                           results ? dres.as<mbe_process_result>() : nullptr, drec.as<mbx_param_record>(), nullptr)
+                  : mbx_process_batch(codec, S, T, df.as<uint8_t>(), ds.as<mbe_parms>(), dg.as<mbx_stream_rng>(),
+                                      pcm16 ? d16.as<int16_t>() : nullptr, pcmf ? dfl.as<float>() : nullptr,
+                                      results ? dres.as<mbe_process_result>() : nullptr, drec.as<mbx_param_record>(), nullptr);
     if (rc < 0) {
         return rc;
     }
@@ -565,6 +689,79 @@ int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_p
     }
     if (records) {
         HIP_TRY(hipMemcpy(records, drec.p, n * sizeof(mbx_param_record), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
+                           int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
+    REQUIRE_READY();
+    if (!frames || !state || !rng || S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    const size_t fb = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES;
+    return process_batch_host_impl(codec, S, T, frames, fb, false, state, rng, pcm16, pcmf, results, records);
+}
+
+int mbx_process_batch_soft_host(int codec, int S, int T, const mbe_soft_bit* soft, mbe_parms* state, mbx_stream_rng* rng,
+                                int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
+    REQUIRE_READY();
+    if (!soft || !state || !rng || S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    const size_t cells = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_SOFT_BITS : MBX_AMBE_SOFT_BITS;
+    int rc = mbx_validate_soft_bits(soft, (size_t)S * (size_t)T * cells);
+    if (rc < 0) {
+        return rc;
+    }
+    return process_batch_host_impl(codec, S, T, soft, cells * sizeof(mbe_soft_bit), true, state, rng, pcm16, pcmf, results,
+                                   records);
+}
+
+int mbx_fec_soft_host(int codec, const mbe_soft_bit* soft, size_t n, mbx_param_record* records) {
+    REQUIRE_READY();
+    if (!soft || !records) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    const size_t cells = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_SOFT_BITS : MBX_AMBE_SOFT_BITS;
+    int rc = mbx_validate_soft_bits(soft, n * cells);
+    if (rc < 0) {
+        return rc;
+    }
+    DevBuf df, dr;
+    HIP_TRY(df.alloc(n * cells * sizeof(mbe_soft_bit)));
+    HIP_TRY(dr.alloc(n * sizeof(mbx_param_record)));
+    HIP_TRY(hipMemcpy(df.p, soft, n * cells * sizeof(mbe_soft_bit), hipMemcpyHostToDevice));
+    rc = mbx_fec_soft(codec, df.as<mbe_soft_bit>(), n, dr.as<mbx_param_record>(), nullptr);
+    if (rc < 0) {
+        return rc;
+    }
+    HIP_TRY(hipMemcpy(records, dr.p, n * sizeof(mbx_param_record), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mbx_ecc_soft_words_host(int kind, const mbe_soft_bit* in, size_t n, uint32_t* out, int32_t* errs) {
+    REQUIRE_READY();
+    if (!in || !out || (kind != 0 && kind != 1)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    const size_t width = kind == 0 ? 23 : 15;
+    int rc = mbx_validate_soft_bits(in, n * width);
+    if (rc < 0) {
+        return rc;
+    }
+    DevBuf di, dout, de;
+    HIP_TRY(di.alloc(n * width * sizeof(mbe_soft_bit) + 2));
+    HIP_TRY(dout.alloc(n * sizeof(uint32_t)));
+    HIP_TRY(de.alloc(n * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(di.p, in, n * width * sizeof(mbe_soft_bit), hipMemcpyHostToDevice));
+    rc = mbx_ecc_soft_words(kind, di.as<mbe_soft_bit>(), n, dout.as<uint32_t>(), de.as<int32_t>(), nullptr);
+    if (rc < 0) {
+        return rc;
+    }
+    HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (errs) {
+        HIP_TRY(hipMemcpy(errs, de.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
     return 0;
 }

@@ -18,6 +18,9 @@ struct DerivedTables {
     uint32_t lcg_mul[161];    // 171^k mod 53125           (unvoiced-noise LCG jump-ahead)
     uint32_t lcg_add[161];    // additive term after k steps
     float    log2_int[64];    // log2f((float)L) from the host libm (AMBE gain term)
+    uint32_t pr_mul[116];     // 173^k mod 2^16             (demodulation sequence jump-ahead, k = 0..115)
+    uint32_t pr_add[116];     // additive term after k steps
+    uint32_t ham_basis[11];   // Hamming(15,11) code word of data bit i (soft-decision candidates)
 };
 
 // Output of the expand stage, input of the stream stage: 64 dwords per frame (layout in mbx_expand.hip).

@@ -234,4 +234,277 @@ ecc_words_kernel(int kind, const uint32_t* __restrict__ in, size_t n, uint32_t* 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Soft-decision front end.  ONE WAVEFRONT PER FRAME (or per code word).
+//
+//   ref src/ecc/ecc.c:36-63 (cost, tie rules), :65-80 (Golay encoder), :303-357 (mbe_golay2312Soft),
+//       :128-215 (Hamming candidates, mbe_hamming1511Soft);
+//       src/imbe/imbe7200x4400.c:445-459, :517-560, :675-707, :746-778;
+//       src/ambe/ambe_common.c:48-73, :102-124, :159-190; src/ambe/ambe3600x2450.c:684-714
+//
+// The reference scores all 4096 (2048) code words against the 23 (15) soft bits -- the cost of a
+// candidate is the sum of the reliabilities of the positions where it disagrees with the hard
+// decisions -- scanning data words in ascending order and replacing the best only when the new one
+// is strictly better under (lower cost) > (equals the hard decoder's output) > (fewer differing
+// bits).  That scan returns the minimum of the packed key
+//     cost << 17 | !matches_hard << 16 | differing_bits << 12 | data          (Golay; cost <= 5865)
+// so here every lane scores 64 (32) candidates with three (two) LDS byte-tables of partial costs and
+// the wave takes the minimum key.  Integer work: results are bit-exact.
+// ------------------------------------------------------------------------------------------
+struct SoftScratch {
+    uint32_t cell[192];       // the frame's soft bits: bit | reliability << 8
+    uint16_t cost[3][256];    // partial cost of the byte-k pattern of (candidate ^ hard decisions)
+};
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, m, kWave);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// cost tables for a block of `nbits` soft bits whose reliability j is held by lane j (0 elsewhere)
+__device__ __forceinline__ void build_cost_tables(SoftScratch& S, int rel_lane, int ntables, int lane) {
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < ntables) {
+            uint32_t p6 = 0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(rel_lane, 8 * k + b);
+                p6 += ((lane >> b) & 1) ? r : 0u;
+            }
+            const uint32_t r6 = (uint32_t)__builtin_amdgcn_readlane(rel_lane, 8 * k + 6);
+            const uint32_t r7 = (uint32_t)__builtin_amdgcn_readlane(rel_lane, 8 * k + 7);
+            S.cost[k][lane] = (uint16_t)p6;
+            S.cost[k][lane + 64] = (uint16_t)(p6 + r6);
+            S.cost[k][lane + 128] = (uint16_t)(p6 + r7);
+            S.cost[k][lane + 192] = (uint16_t)(p6 + r6 + r7);
+        }
+    }
+    wave_lds_sync();
+}
+
+// Soft Golay(23,12).  `hard` = the 23 hard decisions (bit j = cell j, wave-uniform), lane j holds
+// reliability j.  Returns the chosen data bits over the HARD parity bits (ecc.c:354-356); `diffs` =
+// data-bit differences between the hard decisions and the chosen code word (the return value of
+// mbe_golay2312Soft).
+__device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int rel_lane, SoftScratch& S, int lane, int& diffs) {
+    uint32_t hard_fixed;
+    (void)golay2312(T, hard, hard_fixed);
+    const uint32_t hard_data = hard_fixed >> 11;
+    build_cost_tables(S, rel_lane, 3, lane);
+    // parity of data word d: XOR of generator rows, row i belongs to data bit 11 - i.  The lane's six
+    // low data bits and (for lane = j) the six high data bits of round j are encoded once.
+    uint32_t ecc_lo = 0, ecc_hi_lane = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const uint32_t glo = (uint32_t)T->golay_gen[11 - b], ghi = (uint32_t)T->golay_gen[5 - b];
+        ecc_lo ^= ((lane >> b) & 1) ? glo : 0u;
+        ecc_hi_lane ^= ((lane >> b) & 1) ? ghi : 0u;
+    }
+    uint32_t best = 0xffffffffu;
+#pragma unroll 4
+    for (int j = 0; j < 64; ++j) {
+        const uint32_t data = (uint32_t)(64 * j + lane);
+        const uint32_t ecc = ecc_lo ^ (uint32_t)__builtin_amdgcn_readlane((int)ecc_hi_lane, j);
+        const uint32_t x = ((data << 11) | ecc) ^ hard;
+        const uint32_t cost = (uint32_t)S.cost[0][x & 255u] + (uint32_t)S.cost[1][(x >> 8) & 255u] + (uint32_t)S.cost[2][x >> 16];
+        const uint32_t key = (cost << 17) | ((data != hard_data) ? 0x10000u : 0u) | ((uint32_t)__popc(x >> 11) << 12) | data;
+        best = key < best ? key : best;
+    }
+    best = wave_min_u32(best);
+    diffs = (int)((best >> 12) & 0xfu);
+    return ((best & 0xfffu) << 11) | (hard & 0x7ffu);
+}
+
+// Soft Hamming(15,11): returns the chosen code word, `diffs` = differing bits (all 15 positions).
+__device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, int rel_lane, SoftScratch& S, int lane, int& diffs) {
+    uint32_t hard_fixed;
+    (void)hamming1511(tabs.t, hard, hard_fixed);
+    build_cost_tables(S, rel_lane, 2, lane);
+    uint32_t cw_lo = 0, cw_hi_lane = 0;   // linear code: code word of a data word = XOR of basis words
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        cw_lo ^= ((lane >> b) & 1) ? tabs.d->ham_basis[b] : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        cw_hi_lane ^= ((lane >> b) & 1) ? tabs.d->ham_basis[6 + b] : 0u;
+    }
+    uint32_t best = 0xffffffffu;
+#pragma unroll 4
+    for (int j = 0; j < 32; ++j) {
+        const uint32_t data = (uint32_t)(64 * j + lane);
+        const uint32_t cw = cw_lo ^ (uint32_t)__builtin_amdgcn_readlane((int)cw_hi_lane, j);
+        const uint32_t x = cw ^ hard;
+        const uint32_t cost = (uint32_t)S.cost[0][x & 255u] + (uint32_t)S.cost[1][x >> 8];
+        const uint32_t key = (cost << 16) | ((cw != hard_fixed) ? 0x8000u : 0u) | ((uint32_t)__popc(x) << 11) | data;
+        best = key < best ? key : best;
+    }
+    best = wave_min_u32(best);
+    diffs = (int)((best >> 11) & 0xfu);
+    const uint32_t data = best & 0x7ffu;
+    uint32_t cw = 0;
+#pragma unroll
+    for (int b = 0; b < 11; ++b) {
+        cw ^= ((data >> b) & 1u) ? tabs.d->ham_basis[b] : 0u;
+    }
+    return cw;
+}
+
+// cells [first, first + width) of the frame as a block: hard word (bit j = cell first + j, optionally
+// demodulated with the PR sequence, whose bit for cell j is number k_first + (width - 1 - j)) and the
+// reliability of cell j in lane j
+__device__ __forceinline__ uint32_t soft_block(const SoftScratch& S, const DeviceTables& tabs, int first, int width, int k_first,
+                                               uint32_t pr_x0, int lane, int& rel_lane) {
+    uint32_t bit = 0;
+    rel_lane = 0;
+    if (lane < width) {
+        const uint32_t c = S.cell[first + lane];
+        bit = c & 1u;
+        rel_lane = (int)(c >> 8);
+        if (k_first > 0) {
+            const int k = k_first + (width - 1 - lane);
+            const uint32_t x = (tabs.d->pr_mul[k] * pr_x0 + tabs.d->pr_add[k]) & 0xffffu;
+            bit ^= x >> 15;
+        }
+    }
+    return (uint32_t)__ballot(bit != 0u);
+}
+
+__device__ __forceinline__ void load_soft_cells(SoftScratch& S, const mbe_soft_bit* frame, int count, int lane) {
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(frame);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < count) {
+            const uint32_t v = src[idx];
+            S.cell[idx] = (v & 1u) | (v & 0xff00u);   // the reference masks the hard decision with & 1
+        }
+    }
+    wave_lds_sync();
+}
+
+__global__ void __launch_bounds__(64)
+fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, mbx_param_record* __restrict__ out,
+                              DeviceTables tabs) {
+    __shared__ SoftScratch S;
+    const size_t i = blockIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const int lane = lane_id();
+    load_soft_cells(S, soft + i * MBX_IMBE_SOFT_BITS, MBX_IMBE_SOFT_BITS, lane);
+    int rel, diffs;
+    uint32_t row[8];
+    {
+        const uint32_t hard = soft_block(S, tabs, 0, 23, 0, 0u, lane, rel);
+        row[0] = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    }
+    const int c0 = diffs;
+    const uint32_t x0 = (16u * (row[0] >> 11)) & 0xffffu;
+    int prot = 0, c4 = 0, k = 1;
+#pragma unroll 1
+    for (int r = 1; r < 4; ++r) {
+        const uint32_t hard = soft_block(S, tabs, 23 * r, 23, k, x0, lane, rel);
+        row[r] = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+        prot += diffs;
+        k += 23;
+    }
+#pragma unroll 1
+    for (int r = 4; r < 7; ++r) {
+        const uint32_t hard = soft_block(S, tabs, 23 * r, 15, k, x0, lane, rel);
+        row[r] = hamming_soft_wave(tabs, hard, rel, S, lane, diffs);
+        prot += diffs;
+        if (r == 4) {
+            c4 = diffs;
+        }
+        k += 15;
+    }
+    row[7] = soft_block(S, tabs, 23 * 7, 7, 0, 0u, lane, rel);
+    if (lane == 0) {
+        RecordWriter rw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rw.push(row[r], 23, 12);
+        }
+#pragma unroll
+        for (int r = 4; r < 7; ++r) {
+            rw.push(row[r], 15, 11);
+        }
+        rw.push(row[7], 7, 7);
+        *reinterpret_cast<uint4*>(&out[i]) =
+            make_uint4((uint32_t)(rw.hi >> 32), (uint32_t)rw.hi, (uint32_t)(rw.lo >> 32),
+                       (uint32_t)c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
+                           | ((MBE_PROCESS_FLAG_SOFT_INPUT | MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24));
+    }
+}
+
+__global__ void __launch_bounds__(64)
+fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, mbx_param_record* __restrict__ out,
+                              DeviceTables tabs) {
+    __shared__ SoftScratch S;
+    const size_t i = blockIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const int lane = lane_id();
+    load_soft_cells(S, soft + i * MBX_AMBE_SOFT_BITS, MBX_AMBE_SOFT_BITS, lane);
+    int rel, diffs;
+    // C0: cells 1..23 of row 0 are the Golay block, cell 0 the overall parity bit
+    uint32_t hard = soft_block(S, tabs, 1, 23, 0, 0u, lane, rel);
+    const uint32_t cw = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    int c0 = diffs;
+    uint32_t row0 = (cw << 1) | (S.cell[0] & 1u);
+    if (c0 == 0 && (__popc(row0) & 1)) {
+        row0 ^= 1u;
+        c0 = 1;
+    }
+    const uint32_t x0 = (16u * ((row0 >> 12) & 0xfffu)) & 0xffffu;
+    hard = soft_block(S, tabs, 24, 23, 1, x0, lane, rel);
+    const uint32_t row1 = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    const int prot = diffs;
+    const uint32_t row2 = soft_block(S, tabs, 48, 11, 0, 0u, lane, rel);
+    const uint32_t row3 = soft_block(S, tabs, 72, 14, 0, 0u, lane, rel);
+    if (lane == 0) {
+        RecordWriter rw;
+        rw.push(row0, 24, 12);
+        rw.push(row1, 23, 12);
+        rw.push(row2, 11, 11);
+        rw.push(row3, 14, 14);
+        *reinterpret_cast<uint4*>(&out[i]) =
+            make_uint4((uint32_t)(rw.hi >> 32), (uint32_t)rw.hi, (uint32_t)(rw.lo >> 32),
+                       (uint32_t)c0 | ((uint32_t)prot << 8) | ((MBE_PROCESS_FLAG_SOFT_INPUT | MBE_PROCESS_FLAG_C0_VALID) << 24));
+    }
+}
+
+// Code-word level soft ECC, batched: kind 0 = Golay (23 soft bits per block), 1 = Hamming (15).
+// out = corrected word in the cell order of the hard helpers, errs = the reference's return value.
+__global__ void __launch_bounds__(64)
+ecc_soft_words_kernel(int kind, const mbe_soft_bit* __restrict__ in, size_t n, uint32_t* __restrict__ out, int32_t* __restrict__ errs,
+                      DeviceTables tabs) {
+    __shared__ SoftScratch S;
+    const size_t i = blockIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const int lane = lane_id();
+    const int width = (kind == 0) ? 23 : 15;
+    load_soft_cells(S, in + i * (size_t)width, width, lane);
+    int rel, diffs;
+    const uint32_t hard = soft_block(S, tabs, 0, width, 0, 0u, lane, rel);
+    const uint32_t w = (kind == 0) ? golay_soft_wave(tabs.t, hard, rel, S, lane, diffs) : hamming_soft_wave(tabs, hard, rel, S, lane, diffs);
+    if (lane == 0) {
+        out[i] = w;
+        if (errs) {
+            errs[i] = diffs;
+        }
+    }
+}
+
 }  // namespace mbx

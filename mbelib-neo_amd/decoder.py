@@ -175,3 +175,65 @@ def process_batch_host(codec, S, T, frames, state, rng, device=0):
     )
     _native.check(rc, "mbx_process_batch_host")
     return {"pcm16": pcm16, "pcmf": pcmf, "results": results, "records": records, "state": state, "rng": rng}
+
+
+# ---- soft-decision front end (mbe_soft_bit arrays: uint8 [..., 2] = (bit, reliability)) ------------
+SOFT_CELLS = {0: 184, 1: 96}
+
+
+def _soft_array(codec, soft, n):
+    soft = np.ascontiguousarray(soft, dtype=np.uint8)
+    if soft.size != n * SOFT_CELLS[codec] * 2:
+        raise ValueError(f"expected {n} soft frames of {SOFT_CELLS[codec]} (bit, reliability) pairs")
+    return soft
+
+
+def fec_soft_host(codec, soft, device=0):
+    """mbe_decode*SoftFrame for a batch: soft [n, 184|96, 2] uint8 -> parameter records."""
+    ensure_init(device)
+    soft = np.ascontiguousarray(soft, dtype=np.uint8)
+    n = soft.size // (SOFT_CELLS[codec] * 2)
+    soft = _soft_array(codec, soft, n)
+    records = np.empty(n, dtype=RECORD_DTYPE)
+    _native.check(_native.lib().mbx_fec_soft_host(codec, soft.ctypes.data, n, records.ctypes.data), "mbx_fec_soft_host")
+    return records
+
+
+def process_batch_soft_host(codec, S, T, soft, state, rng, device=0):
+    """mbe_process*SoftFramef for S streams x T frames on host buffers."""
+    ensure_init(device)
+    n = S * T
+    soft = _soft_array(codec, soft, n)
+    state = np.ascontiguousarray(state).copy()
+    rng = np.ascontiguousarray(rng).copy()
+    pcm16 = np.empty((n, 160), dtype=np.int16)
+    pcmf = np.empty((n, 160), dtype=np.float32)
+    results = np.empty(n, dtype=RESULT_DTYPE)
+    records = np.empty(n, dtype=RECORD_DTYPE)
+    rc = _native.lib().mbx_process_batch_soft_host(
+        codec, S, T, soft.ctypes.data, state.ctypes.data, rng.ctypes.data, pcm16.ctypes.data, pcmf.ctypes.data,
+        results.ctypes.data, records.ctypes.data,
+    )
+    _native.check(rc, "mbx_process_batch_soft_host")
+    return {"pcm16": pcm16, "pcmf": pcmf, "results": results, "records": records, "state": state, "rng": rng}
+
+
+def ecc_soft_words_host(kind, soft, device=0):
+    """mbe_golay2312Soft (kind 0, soft [n, 23, 2]) / mbe_hamming1511Soft (kind 1, soft [n, 15, 2]):
+    returns (corrected words, return values)."""
+    ensure_init(device)
+    width = 23 if kind == 0 else 15
+    soft = np.ascontiguousarray(soft, dtype=np.uint8)
+    n = soft.size // (width * 2)
+    out = np.empty(n, dtype=np.uint32)
+    errs = np.empty(n, dtype=np.int32)
+    rc = _native.lib().mbx_ecc_soft_words_host(kind, soft.ctypes.data, n, out.ctypes.data, errs.ctypes.data)
+    _native.check(rc, "mbx_ecc_soft_words_host")
+    return out, errs
+
+
+def soft_bits_from_llr(llr):
+    llr = np.ascontiguousarray(llr, dtype=np.int16)
+    soft = np.empty(llr.shape + (2,), dtype=np.uint8)
+    _native.check(_native.lib().mbx_soft_bits_from_llr(llr.ctypes.data, soft.ctypes.data, llr.size), "mbx_soft_bits_from_llr")
+    return soft

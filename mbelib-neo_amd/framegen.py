@@ -176,3 +176,17 @@ def ambe_voice_param_bits(n, rng):
 
 def ambe_noisy_voice_frames(n, rng, ber=0.01):
     return flip_bits(encode_ambe3600x2450(ambe_voice_param_bits(n, rng)), CODEC_AMBE3600X2450, ber, rng)
+
+
+def soft_frames(codec, n, rng, snr_like=2.0):
+    """Soft-decision test frames in the reference's array shape, uint8 [n, 184|96, 2] = (bit, reliability):
+    random-bit frames observed through additive noise, reliability = clamped |observation| -- so wrong
+    hard decisions tend to carry low confidence, plus a share of exact ties (quantised confidences)."""
+    cells = 184 if codec == CODEC_IMBE7200X4400 else 96
+    bits = rng.integers(0, 2, size=(n, cells), dtype=np.int64)
+    obs = (2.0 * bits - 1.0) * snr_like + rng.normal(0.0, 1.0, size=(n, cells))
+    hard = (obs > 0).astype(np.uint8)
+    rel = np.clip(np.abs(obs) * 40.0, 0, 255).astype(np.uint8)
+    coarse = rng.integers(0, 4, size=(n, 1)) == 0          # a quarter of the frames: 3-level confidences
+    rel = np.where(coarse, (rel // 96) * 96, rel).astype(np.uint8)
+    return np.stack([hard, rel], axis=-1)
