@@ -33,6 +33,9 @@ WORKLOADS = {
     "imbe_mixed": (0, 65536, 16, "BASELINE configs[3]: 65,536 IMBE streams x T=16 random-bit frames (mixed voiced/unvoiced)"),
     "ambe_fec": (1, 65536, 1, "BASELINE configs[2]: 65,536 AMBE+2 streams x T=1, clean voice frames + 1% bit flips"),
     "ambe_stream": (1, 8192, 128, "BASELINE configs[4] per-GPU shard: 8,192 AMBE+2 streams x T=128 random-bit frames, int16 out"),
+    # SURVEY.md §8(f) row 1 (not a BASELINE config): the soft-decision front end in front of the same path
+    "imbe_soft": (0, 65536, 1, "65,536 IMBE 7200x4400 streams x T=1, soft-decision frames (noisy observations of random bits)"),
+    "ambe_soft": (1, 65536, 1, "65,536 AMBE+2 3600x2450 streams x T=1, soft-decision frames (noisy observations of random bits)"),
 }
 
 
@@ -44,6 +47,8 @@ def make_frames(name, codec, S, T, rank):
         return framegen.imbe_clean_voiced_frames(S * T, rng)
     if name == "ambe_fec":
         return framegen.ambe_noisy_voice_frames(S * T, rng, ber=0.01)
+    if name.endswith("_soft"):
+        return framegen.soft_frames(codec, S * T, rng)
     return framegen.random_frames(codec, S * T, rng)
 
 
@@ -79,15 +84,16 @@ def cpu_baseline(name, codec, T, budget_s=12.0):
     import oracle_lib
 
     o = oracle_lib.load()
-    S = 4096 if T == 1 else max(64, 4096 // T)
+    soft = name.endswith("_soft")
+    S = (512 if soft else 4096) if T == 1 else max(64, 4096 // T)
     frames = make_frames(name, codec, S, T, rank=0)
     seeds = np.arange(S) + 1234
     state, rng = o.init_state(S), o.rng_seeded(seeds)
-    out = o.process_batch(codec, S, T, frames, state, rng)  # warm-up pass (also warms the state)
+    out = o.process_batch(codec, S, T, frames, state, rng, soft=soft)  # warm-up pass (also warms the state)
     state, rng = out["state"], out["rng"]
     done, t0 = 0, time.perf_counter()
     while True:
-        out = o.process_batch(codec, S, T, frames, state, rng)
+        out = o.process_batch(codec, S, T, frames, state, rng, soft=soft)
         state, rng = out["state"], out["rng"]
         done += S * T
         dt = time.perf_counter() - t0
@@ -153,7 +159,12 @@ def main():
     L.mbx_debug_set_ablation(0)
     _native.check(L.mbx_reserve(S * T), "mbx_reserve")  # launches below never allocate
     stream = torch.cuda.current_stream().cuda_stream
-    fec = L.mbx_fec_imbe7200x4400 if codec == 0 else L.mbx_fec_ambe3600x2450
+    soft = args.workload.endswith("_soft")
+    if soft:
+        def fec(frames_ptr, count, records_ptr, strm):
+            return L.mbx_fec_soft(codec, frames_ptr, count, records_ptr, strm)
+    else:
+        fec = L.mbx_fec_imbe7200x4400 if codec == 0 else L.mbx_fec_ambe3600x2450
     n = S * T
 
     def step(ev=None):

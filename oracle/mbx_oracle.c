@@ -2075,30 +2075,42 @@ mbxo_fec_batch(int codec, size_t n, const uint8_t* frames, mbx_param_record* rec
     return 0;
 }
 
-int
-mbxo_process_batch(int codec, int S, int Tn, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
+/* `soft` != 0: frames are mbe_soft_bit arrays (184 | 96 per frame) through the soft-decision FEC */
+static int
+process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_parms* state, mbx_stream_rng* rng,
                    int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
     if (!T || !frames || !state || !rng || S < 0 || Tn < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const int fb = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES;
+    const int imbe = (codec == MBX_CODEC_IMBE7200X4400);
+    const size_t fb = soft ? (size_t)(imbe ? MBX_IMBE_SOFT_BITS : MBX_AMBE_SOFT_BITS) * sizeof(mbe_soft_bit)
+                           : (size_t)(imbe ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES);
     for (int s = 0; s < S; ++s) {
         mbe_parms* cur = &state[3 * (size_t)s];
         mbe_parms* prev = cur + 1;
         mbe_parms* enh = cur + 2;
         for (int t = 0; t < Tn; ++t) {
             size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+            const uint8_t* fr = (const uint8_t*)frames + f * fb;
             mbx_param_record rec;
             mbe_process_result res;
             float pcm[160];
             char bits[88];
-            if (codec == MBX_CODEC_IMBE7200X4400) {
-                mbxo_fec_imbe7200x4400(frames + f * fb, &rec);
+            if (imbe) {
+                if (soft) {
+                    mbxo_fec_imbe7200x4400_soft((const mbe_soft_bit(*)[23])fr, &rec);
+                } else {
+                    mbxo_fec_imbe7200x4400(fr, &rec);
+                }
                 mbxo_record_to_bits(&rec, 88, bits);
                 mbxo_record_to_result(&rec, &res);
                 mbxo_process_imbe4400_dataf(pcm, &res, bits, cur, prev, enh, &rng[s]);
             } else {
-                mbxo_fec_ambe3600x2450(frames + f * fb, &rec);
+                if (soft) {
+                    mbxo_fec_ambe3600x2450_soft((const mbe_soft_bit(*)[24])fr, &rec);
+                } else {
+                    mbxo_fec_ambe3600x2450(fr, &rec);
+                }
                 mbxo_record_to_bits(&rec, 49, bits);
                 mbxo_record_to_result(&rec, &res);
                 mbxo_process_ambe2450_dataf(pcm, &res, bits, cur, prev, enh, &rng[s]);
@@ -2118,6 +2130,18 @@ mbxo_process_batch(int codec, int S, int Tn, const uint8_t* frames, mbe_parms* s
         }
     }
     return 0;
+}
+
+int
+mbxo_process_batch(int codec, int S, int Tn, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
+                   int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
+    return process_batch_impl(codec, S, Tn, frames, 0, state, rng, pcm16, pcmf, results, records);
+}
+
+int
+mbxo_process_batch_soft(int codec, int S, int Tn, const mbe_soft_bit* soft, mbe_parms* state, mbx_stream_rng* rng,
+                        int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
+    return process_batch_impl(codec, S, Tn, soft, 1, state, rng, pcm16, pcmf, results, records);
 }
 
 void

@@ -61,6 +61,8 @@ int mbxo_fec_ambe3600x2450_soft(const mbe_soft_bit fr[4][24], mbx_param_record* 
 int mbxo_decode_imbe7200x4400_soft_frame(const mbe_soft_bit fr[8][23], char imbe_d[88], mbe_process_result* result);
 int mbxo_decode_ambe3600x2450_soft_frame(const mbe_soft_bit fr[4][24], char ambe_d[49], mbe_process_result* result);
 int mbxo_fec_soft_batch(int codec, size_t n, const mbe_soft_bit* soft, mbx_param_record* records);
+int mbxo_process_batch_soft(int codec, int S, int T, const mbe_soft_bit* soft, mbe_parms* state, mbx_stream_rng* rng,
+                            int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records);
 
 int mbxo_decode_imbe7200x4400_frame(const char fr[8][23], char imbe_d[88], mbe_process_result* result);
 int mbxo_decode_ambe3600x2450_frame(const char fr[4][24], char ambe_d[49], mbe_process_result* result);

@@ -49,6 +49,8 @@ class Oracle:
             getattr(h, name).argtypes = [_vp] * 8
         h.mbxo_process_batch.restype = C.c_int
         h.mbxo_process_batch.argtypes = [C.c_int, C.c_int, C.c_int] + [_vp] * 7
+        h.mbxo_process_batch_soft.restype = C.c_int
+        h.mbxo_process_batch_soft.argtypes = [C.c_int, C.c_int, C.c_int] + [_vp] * 7
         h.mbxo_fec_batch.restype = C.c_int
         h.mbxo_fec_batch.argtypes = [C.c_int, C.c_size_t, _vp, _vp]
         h.mbxo_floattoshort_batch.restype = None
@@ -163,7 +165,8 @@ class Oracle:
         assert self.h.mbxo_soft_bits_from_llr(llr.ctypes.data, out.ctypes.data, llr.size) == 0
         return out
 
-    def process_batch(self, codec, S, T, frames, state, rng):
+    def process_batch(self, codec, S, T, frames, state, rng, soft=False):
+        """frames: packed wire frames, or with soft=True uint8 [S*T, 184|96, 2] soft-decision frames"""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         state = np.ascontiguousarray(state).copy()
         rng = np.ascontiguousarray(rng).copy()
@@ -172,7 +175,8 @@ class Oracle:
         pcmf = np.zeros((n, 160), dtype=np.float32)
         results = np.zeros(n, dtype=RESULT_DTYPE)
         records = np.zeros(n, dtype=RECORD_DTYPE)
-        rc = self.h.mbxo_process_batch(
+        fn = self.h.mbxo_process_batch_soft if soft else self.h.mbxo_process_batch
+        rc = fn(
             codec, S, T, frames.ctypes.data, state.ctypes.data, rng.ctypes.data, pcm16.ctypes.data, pcmf.ctypes.data,
             results.ctypes.data, records.ctypes.data,
         )

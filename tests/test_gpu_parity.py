@@ -307,3 +307,20 @@ def test_soft_process_matches_reference_stream(mbx, oracle):
     for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
         assert np.array_equal(res[name], kat["result"][name]), name
     parity.check_pcm(kat["pcmf"], out["pcmf"])
+
+
+@pytest.mark.parametrize("codec,S,T", [(0, 192, 4), (1, 256, 4)])
+def test_soft_pipeline_vs_oracle(mbx, oracle, codec, S, T):
+    """soft FEC + the whole stream stage against the oracle on seeded soft frames"""
+    from mbelib_neo_amd import decoder, framegen
+    from mbelib_neo_amd.layout import init_state, rng_seeded
+
+    soft = framegen.soft_frames(codec, S * T, framegen.rng_for(4200 + codec))
+    seeds = [1234 + s for s in range(S)]
+    ref = oracle.process_batch(codec, S, T, soft, oracle.init_state(S), oracle.rng_seeded(seeds), soft=True)
+    got = decoder.process_batch_soft_host(codec, S, T, soft, init_state(S), rng_seeded(seeds))
+    assert np.array_equal(got["records"]["w"], ref["records"]["w"])
+    parity.check_results(ref["results"], got["results"])
+    assert np.all((got["results"]["flags"] & 1) == 1)   # MBE_PROCESS_FLAG_SOFT_INPUT survives the stream stage
+    parity.check_pcm(ref["pcmf"], got["pcmf"], ref["pcm16"], got["pcm16"])
+    parity.check_state(ref["state"], got["state"])
