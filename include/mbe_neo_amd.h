@@ -19,6 +19,8 @@
 #ifndef MBE_NEO_AMD_H
 #define MBE_NEO_AMD_H
 
+#include <stddef.h>
+
 #include "mbx_types.h"
 
 #ifdef __cplusplus
@@ -53,6 +55,24 @@ int mbe_processImbe7200x4400Framef(float* aout_buf, mbe_process_result* result, 
 int mbe_processImbe7200x4400Frame(short* aout_buf, mbe_process_result* result, const char imbe_fr[8][23],
                                   char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp,
                                   mbe_parms* prev_mp_enhanced);                           /* :509 */
+
+/* soft-decision entry points */
+mbe_soft_bit mbe_softBitFromHard(int bit, uint8_t reliability);                           /* :208 */
+mbe_soft_bit mbe_softBitFromLlr(int16_t llr);                                             /* :214 */
+int mbe_softBitsFromHard(const char* bits, mbe_soft_bit* soft, size_t count, uint8_t reliability); /* :219 */
+int mbe_softBitsFromLlr(const int16_t* llr, mbe_soft_bit* soft, size_t count);            /* :224 */
+int mbe_golay2312Soft(const mbe_soft_bit* in, char* out);                                 /* :246 */
+int mbe_hamming1511Soft(const mbe_soft_bit* in, char* out);                               /* :260 */
+int mbe_decodeAmbe3600x2450SoftFrame(const mbe_soft_bit ambe_fr[4][24], char ambe_d[49], mbe_process_result* result); /* :403 */
+int mbe_processAmbe3600x2450SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
+                                       char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced); /* :441 */
+int mbe_processAmbe3600x2450SoftFrame(short* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
+                                      char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced); /* :445 */
+int mbe_decodeImbe7200x4400SoftFrame(const mbe_soft_bit imbe_fr[8][23], char imbe_d[88], mbe_process_result* result); /* :479 */
+int mbe_processImbe7200x4400SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[8][23],
+                                       char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced); /* :517 */
+int mbe_processImbe7200x4400SoftFrame(short* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[8][23],
+                                      char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced); /* :521 */
 
 const char* mbe_versionString(void);                                                      /* :588 */
 void mbe_setThreadRngSeed(uint32_t seed);                                                 /* :596 */

@@ -77,6 +77,7 @@ struct Slot {
     int16_t*          pcm16 = nullptr;    // 160
     mbe_process_result* res = nullptr;
     uint32_t*         words = nullptr;    // 4: in, out, errs
+    mbe_soft_bit*     soft = nullptr;     // one soft frame (184 cells)
     Slot() {
         std::call_once(g_once, init_once);
         HIP_OK(hipStreamCreate(&stream));
@@ -88,6 +89,7 @@ struct Slot {
         HIP_OK(hipMalloc(&pcm16, 160 * sizeof(int16_t)));
         HIP_OK(hipMalloc(&res, sizeof(mbe_process_result)));
         HIP_OK(hipMalloc(&words, 4 * sizeof(uint32_t)));
+        HIP_OK(hipMalloc(&soft, MBX_IMBE_SOFT_BITS * sizeof(mbe_soft_bit)));
     }
     void up(void* dst, const void* src, size_t n) { HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream)); }
     void down(void* dst, const void* src, size_t n) { HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream)); }
@@ -281,6 +283,45 @@ int ecc_word(int kind, uint32_t in, uint32_t* out) {
     return (int)back[1];
 }
 
+// soft-decision code word (kind 0: 23 soft bits, kind 1: 15): one-wave launch
+int ecc_soft_word(int kind, const mbe_soft_bit* in, uint32_t* out) {
+    Slot& s = slot();
+    const size_t width = kind == 0 ? 23 : 15;
+    s.up(s.soft, in, width * sizeof(mbe_soft_bit));
+    must(mbx_ecc_soft_words(kind, s.soft, 1, &s.words[1], reinterpret_cast<int32_t*>(&s.words[2]), s.stream), "mbx_ecc_soft_words");
+    uint32_t back[2];
+    s.down(back, &s.words[1], 8);
+    s.sync();
+    *out = back[0];
+    return (int)back[1];
+}
+
+// mbe_decode*SoftFrame: ref src/imbe/imbe7200x4400.c:746-778, src/ambe/ambe3600x2450.c:684-714
+int decode_soft_frame(int codec, const mbe_soft_bit* cells, int ncell, int nbits, char* bits_out, mbe_process_result* result) {
+    if (result) {
+        memset(result, 0, sizeof(*result));
+    }
+    if (!bits_out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = mbx_validate_soft_bits(cells, (size_t)ncell);
+    if (rc < 0) {
+        return rc;
+    }
+    Slot& s = slot();
+    s.up(s.soft, cells, (size_t)ncell * sizeof(mbe_soft_bit));
+    must(mbx_fec_soft(codec, s.soft, 1, s.rec, s.stream), "mbx_fec_soft");
+    mbx_param_record rec;
+    s.down(&rec, s.rec, sizeof(rec));
+    s.sync();
+    mbe_process_result r;
+    mbx_unpack_records(&rec, 1, nbits, bits_out, &r);
+    if (result) {
+        *result = r;
+    }
+    return r.total_errors;
+}
+
 }  // namespace
 
 extern "C" {
@@ -392,6 +433,73 @@ int mbe_hamming1511(const char* in, char* out) {
         out[j] = (char)((fixed >> j) & 1u);
     }
     return errs;
+}
+
+// ---- soft-decision helpers: ref src/core/mbelib.c:107-158, src/ecc/ecc.c:303-357, 410-413 -----
+mbe_soft_bit mbe_softBitFromHard(int bit, uint8_t reliability) {
+    mbe_soft_bit s;
+    s.bit = (uint8_t)(bit ? 1u : 0u);
+    s.reliability = reliability;
+    return s;
+}
+
+mbe_soft_bit mbe_softBitFromLlr(int16_t llr) {
+    mbe_soft_bit s;
+    (void)mbx_soft_bits_from_llr(&llr, &s, 1);
+    return s;
+}
+
+int mbe_softBitsFromHard(const char* bits, mbe_soft_bit* soft, size_t count, uint8_t reliability) {
+    if (!soft) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_bits(bits, count);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbx_soft_bits_from_hard(bits, soft, count, reliability);
+}
+
+int mbe_softBitsFromLlr(const int16_t* llr, mbe_soft_bit* soft, size_t count) { return mbx_soft_bits_from_llr(llr, soft, count); }
+
+int mbe_golay2312Soft(const mbe_soft_bit* in, char* out) {
+    if (!out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = mbx_validate_soft_bits(in, 23u);
+    if (rc < 0) {
+        return rc;
+    }
+    uint32_t w;
+    const int diffs = ecc_soft_word(0, in, &w);
+    for (int j = 0; j < 23; ++j) {
+        out[j] = (char)((w >> j) & 1u);
+    }
+    return diffs;
+}
+
+int mbe_hamming1511Soft(const mbe_soft_bit* in, char* out) {
+    if (!out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = mbx_validate_soft_bits(in, 15u);
+    if (rc < 0) {
+        return rc;
+    }
+    uint32_t w;
+    const int diffs = ecc_soft_word(1, in, &w);
+    for (int j = 0; j < 15; ++j) {
+        out[j] = (char)((w >> j) & 1u);
+    }
+    return diffs;
+}
+
+int mbe_decodeImbe7200x4400SoftFrame(const mbe_soft_bit imbe_fr[8][23], char imbe_d[88], mbe_process_result* result) {
+    return decode_soft_frame(MBX_CODEC_IMBE7200X4400, reinterpret_cast<const mbe_soft_bit*>(imbe_fr), 184, 88, imbe_d, result);
+}
+
+int mbe_decodeAmbe3600x2450SoftFrame(const mbe_soft_bit ambe_fr[4][24], char ambe_d[49], mbe_process_result* result) {
+    return decode_soft_frame(MBX_CODEC_AMBE3600X2450, reinterpret_cast<const mbe_soft_bit*>(ambe_fr), 96, 49, ambe_d, result);
 }
 
 // ---- frame decode ---------------------------------------------------------------------------
@@ -568,6 +676,65 @@ void mbe_synthesizeComfortNoise(short* aout_buf) {
     s.down(aout_buf, s.pcm16, 160 * sizeof(int16_t));
     s.down(&t_rng.r, s.rng, sizeof(mbx_stream_rng));
     s.sync();
+}
+
+// ---- soft frames -> PCM: ref src/imbe/imbe7200x4400.c:950-980, src/ambe/ambe3600x2450.c:939-969 --------
+int mbe_processImbe7200x4400SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[8][23],
+                                       char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeImbe7200x4400SoftFrame(imbe_fr, imbe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processImbe4400Dataf(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processImbe7200x4400SoftFrame(short* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[8][23],
+                                      char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (!aout_buf) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeImbe7200x4400SoftFrame(imbe_fr, imbe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processImbe4400Data(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processAmbe3600x2450SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
+                                       char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeAmbe3600x2450SoftFrame(ambe_fr, ambe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processAmbe2450Dataf(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processAmbe3600x2450SoftFrame(short* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
+                                      char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (!aout_buf) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeAmbe3600x2450SoftFrame(ambe_fr, ambe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processAmbe2450Data(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 }  // extern "C"

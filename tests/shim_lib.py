@@ -38,6 +38,20 @@ def load():
     for name in ("mbe_golay2312", "mbe_hamming1511"):
         getattr(h, name).restype = C.c_int
         getattr(h, name).argtypes = [_vp, _vp]
+    for name in ("mbe_processImbe7200x4400SoftFramef", "mbe_processImbe7200x4400SoftFrame",
+                 "mbe_processAmbe3600x2450SoftFramef", "mbe_processAmbe3600x2450SoftFrame"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 7
+    for name in ("mbe_decodeImbe7200x4400SoftFrame", "mbe_decodeAmbe3600x2450SoftFrame"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 3
+    for name in ("mbe_golay2312Soft", "mbe_hamming1511Soft"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp, _vp]
+    h.mbe_softBitsFromLlr.restype = C.c_int
+    h.mbe_softBitsFromLlr.argtypes = [_vp, _vp, C.c_size_t]
+    h.mbe_softBitsFromHard.restype = C.c_int
+    h.mbe_softBitsFromHard.argtypes = [_vp, _vp, C.c_size_t, C.c_uint8]
     h.mbe_checkGolayBlock.restype = C.c_int
     h.mbe_checkGolayBlock.argtypes = [C.POINTER(C.c_long)]
     h.mbe_setThreadRngSeed.argtypes = [C.c_uint32]

@@ -379,3 +379,55 @@ def test_streams_frame_by_frame_match_reference_goldens(mbe):
             parity.check_pcm(fx["frames"][s]["pcmf"], np.array(got))
             st = np.concatenate([cur, prev, enh])
             parity.check_state(fx["final"][s], st)
+
+
+# ---- soft-decision entry points (reference tests/test_soft_decision.c style: per-frame API) -------
+def test_soft_entry_points_match_reference_fixture(mbe):
+    kat = golden_io.soft_kat()
+    for row in kat["golay"][:60]:
+        out = np.zeros(23, dtype=np.int8)
+        soft = np.ascontiguousarray(row["soft"])
+        assert mbe.mbe_golay2312Soft(p(soft), p(out)) == row["ret"]
+        assert np.array_equal(out, row["out"])
+    for row in kat["hamming"][:60]:
+        out = np.zeros(15, dtype=np.int8)
+        soft = np.ascontiguousarray(row["soft"])
+        assert mbe.mbe_hamming1511Soft(p(soft), p(out)) == row["ret"]
+        assert np.array_equal(out, row["out"])
+    for name, fn, nbits in (("imbe", mbe.mbe_decodeImbe7200x4400SoftFrame, 88), ("ambe", mbe.mbe_decodeAmbe3600x2450SoftFrame, 49)):
+        for row in kat[name][:40]:
+            bits = np.zeros(nbits, dtype=np.int8)
+            res = np.zeros(1, dtype=RESULT_DTYPE)
+            soft = np.ascontiguousarray(row["soft"])
+            assert fn(p(soft), p(bits), p(res)) == row["ret"]
+            assert np.array_equal(bits, row["bits"])
+            assert res[0]["flags"] == row["result"]["flags"] and res[0]["total_errors"] == row["result"]["total_errors"]
+    llr = np.ascontiguousarray(kat["llr"]["llr"])
+    soft = np.zeros((llr.size, 2), dtype=np.uint8)
+    assert mbe.mbe_softBitsFromLlr(p(llr), p(soft), llr.size) == 0
+    assert np.array_equal(soft, kat["llr"]["soft"])
+
+
+def test_soft_frame_rejects_bad_hard_decision(mbe):
+    soft = np.zeros((184, 2), dtype=np.uint8)
+    soft[17, 0] = 2
+    bits = np.zeros(88, dtype=np.int8)
+    assert mbe.mbe_decodeImbe7200x4400SoftFrame(p(soft), p(bits), None) == -2   # MBE_STATUS_INVALID_BITS
+    assert mbe.mbe_decodeImbe7200x4400SoftFrame(p(soft), None, None) == -1
+
+
+def test_soft_process_stream_matches_reference(mbe):
+    """12 frames through mbe_processImbe7200x4400SoftFramef, one stream, seed 4242 (reference fixture)."""
+    kat = golden_io.soft_kat()["process"]
+    cur, prev, enh = (np.zeros(1, dtype=PARMS_DTYPE) for _ in range(3))
+    mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))
+    mbe.mbe_setThreadRngSeed(4242)
+    pcm = np.zeros((len(kat), 160), dtype=np.float32)
+    for t, row in enumerate(kat):
+        bits = np.zeros(88, dtype=np.int8)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        soft = np.ascontiguousarray(row["soft"])
+        ret = mbe.mbe_processImbe7200x4400SoftFramef(p(pcm[t]), p(res), p(soft), p(bits), p(cur), p(prev), p(enh))
+        assert ret == row["ret"]
+        assert res[0]["flags"] == row["result"]["flags"]
+    parity.check_pcm(kat["pcmf"], pcm)
