@@ -253,8 +253,9 @@ ecc_words_kernel(int kind, const uint32_t* __restrict__ in, size_t n, uint32_t* 
 // the wave takes the minimum key.  Integer work: results are bit-exact.
 // ------------------------------------------------------------------------------------------
 struct SoftScratch {
-    uint32_t cell[192];       // the frame's soft bits: bit | reliability << 8
-    uint16_t cost[3][256];    // partial cost of the byte-k pattern of (candidate ^ hard decisions)
+    uint32_t cell[192];      // the frame's soft bits: bit | reliability << 8
+    uint32_t parity[2048];   // key contribution of a parity pattern: cost << shift (+ differing bits, Hamming)
+    uint2    round[64];      // per-round constants: (table offset, key contribution) of the high bits j of u
 };
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -266,87 +267,155 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return v;
 }
 
-// cost tables for a block of `nbits` soft bits whose reliability j is held by lane j (0 elsewhere)
-__device__ __forceinline__ void build_cost_tables(SoftScratch& S, int rel_lane, int ntables, int lane) {
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (k < ntables) {
-            uint32_t p6 = 0;
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(rel_lane, 8 * k + b);
-                p6 += ((lane >> b) & 1) ? r : 0u;
-            }
-            const uint32_t r6 = (uint32_t)__builtin_amdgcn_readlane(rel_lane, 8 * k + 6);
-            const uint32_t r7 = (uint32_t)__builtin_amdgcn_readlane(rel_lane, 8 * k + 7);
-            S.cost[k][lane] = (uint16_t)p6;
-            S.cost[k][lane + 64] = (uint16_t)(p6 + r6);
-            S.cost[k][lane + 128] = (uint16_t)(p6 + r7);
-            S.cost[k][lane + 192] = (uint16_t)(p6 + r6 + r7);
-        }
-    }
-    wave_lds_sync();
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane_index) {   // wave-uniform lane index
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_index);
 }
+
+// How the candidate search is organised (both codes).  Let hd / hp be the data / parity part of the
+// hard decisions.  The candidates are walked in u = data ^ hd instead of data:
+//   * the data-part cost and the number of differing data bits depend on u only and split into a
+//     lane part (six low bits of u = lane) and a round part (high bits of u = j);
+//   * the code is linear, parity(data) = parity(u) ^ parity(hd), so the parity-part cost is a table
+//     look-up at parity_lo(lane) ^ parity_hi(j) ^ s with s = parity(hd) ^ hp -- the table holds the
+//     cost already shifted into its key position;
+//   * data = u ^ hd splits into lane and round bits as well.
+// Every field of the key is therefore a SUM of a per-lane constant, a per-round constant (held one per
+// lane, fetched with v_readlane) and one LDS word: per candidate one XOR, one ds_read_b32, one
+// v_add3 and one v_min.  All candidates are scored as "does not match the hard decoder"; the single
+// one that does is re-scored after the loop with that bit cleared (it can only win then).
 
 // Soft Golay(23,12).  `hard` = the 23 hard decisions (bit j = cell j, wave-uniform), lane j holds
 // reliability j.  Returns the chosen data bits over the HARD parity bits (ecc.c:354-356); `diffs` =
 // data-bit differences between the hard decisions and the chosen code word (the return value of
-// mbe_golay2312Soft).
+// mbe_golay2312Soft).  Key: cost << 17 | !matches_hard << 16 | differing data bits << 12 | data.
 __device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int rel_lane, SoftScratch& S, int lane, int& diffs) {
     uint32_t hard_fixed;
     (void)golay2312(T, hard, hard_fixed);
-    const uint32_t hard_data = hard_fixed >> 11;
-    build_cost_tables(S, rel_lane, 3, lane);
-    // parity of data word d: XOR of generator rows, row i belongs to data bit 11 - i.  The lane's six
-    // low data bits and (for lane = j) the six high data bits of round j are encoded once.
-    uint32_t ecc_lo = 0, ecc_hi_lane = 0;
+    const uint32_t hd = hard >> 11, hp = hard & 0x7ffu;
+    const uint32_t rel = (uint32_t)rel_lane;
+    // per-lane pieces: bit b of the lane index selects position ...
+    uint32_t par_lo = 0, par_hi = 0, par_hd = 0;   // parity of data bits 0..5 / 6..11 (pattern = lane) / of hd
+    uint32_t a_lo = 0, a_hi = 0;                    // data-part cost: cells 11..16 / 17..22
+    uint32_t b_lo = 0, b_hi = 0;                    // parity-part cost: cells 0..5 / 6..10 (pattern = lane, < 32)
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-        const uint32_t glo = (uint32_t)T->golay_gen[11 - b], ghi = (uint32_t)T->golay_gen[5 - b];
-        ecc_lo ^= ((lane >> b) & 1) ? glo : 0u;
-        ecc_hi_lane ^= ((lane >> b) & 1) ? ghi : 0u;
+        const uint32_t bit = (uint32_t)(lane >> b) & 1u;
+        const uint32_t glo = (uint32_t)T->golay_gen[11 - b], ghi = (uint32_t)T->golay_gen[5 - b];   // row i <-> data bit 11 - i
+        par_lo ^= bit ? glo : 0u;
+        par_hi ^= bit ? ghi : 0u;
+        par_hd ^= ((hd >> b) & 1u) ? glo : 0u;
+        par_hd ^= ((hd >> (b + 6)) & 1u) ? ghi : 0u;
+        a_lo += bit ? rl(rel, 11 + b) : 0u;
+        a_hi += bit ? rl(rel, 17 + b) : 0u;
+        b_lo += bit ? rl(rel, b) : 0u;
+        if (b < 5) {
+            b_hi += bit ? rl(rel, 6 + b) : 0u;
+        }
     }
+    const uint32_t s = par_hd ^ hp;
+    wave_lds_sync();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {   // parity table: pattern lane + 64 k
+        S.parity[lane + 64 * k] = (b_lo + rl(b_hi, k)) << 17;
+    }
+    const uint32_t addr_lane = par_lo << 2;                                         // byte offsets into S.parity
+    const uint32_t addr_round = (par_hi ^ s) << 2;                                  // for round j = lane
+    const uint32_t key_lane = (a_lo << 17) + 0x10000u + ((uint32_t)__popc(lane) << 12) + ((uint32_t)lane ^ (hd & 63u));
+    const uint32_t key_round = (a_hi << 17) + ((uint32_t)__popc(lane) << 12) + ((((uint32_t)lane ^ (hd >> 6)) & 63u) << 6);
+    S.round[lane] = make_uint2(addr_round, key_round);   // read back wave-uniformly: LDS broadcasts, no VALU
+    wave_lds_sync();
+    const char* table = reinterpret_cast<const char*>(S.parity);
     uint32_t best = 0xffffffffu;
-#pragma unroll 4
+#pragma unroll 8
     for (int j = 0; j < 64; ++j) {
-        const uint32_t data = (uint32_t)(64 * j + lane);
-        const uint32_t ecc = ecc_lo ^ (uint32_t)__builtin_amdgcn_readlane((int)ecc_hi_lane, j);
-        const uint32_t x = ((data << 11) | ecc) ^ hard;
-        const uint32_t cost = (uint32_t)S.cost[0][x & 255u] + (uint32_t)S.cost[1][(x >> 8) & 255u] + (uint32_t)S.cost[2][x >> 16];
-        const uint32_t key = (cost << 17) | ((data != hard_data) ? 0x10000u : 0u) | ((uint32_t)__popc(x >> 11) << 12) | data;
+        const uint2 r = S.round[j];
+        const uint32_t val = *reinterpret_cast<const uint32_t*>(table + (addr_lane ^ r.x));
+        const uint32_t key = val + key_lane + r.y;
         best = key < best ? key : best;
     }
     best = wave_min_u32(best);
+    {   // the candidate whose data equals the hard decoder's output
+        const uint32_t ut = (hard_fixed >> 11) ^ hd;
+        const int lt = (int)(ut & 63u), jt = (int)(ut >> 6);
+        const uint32_t val = *reinterpret_cast<const uint32_t*>(table + (rl(addr_lane, lt) ^ rl(addr_round, jt)));
+        const uint32_t key = val + rl(key_lane, lt) + rl(key_round, jt) - 0x10000u;
+        best = key < best ? key : best;
+    }
     diffs = (int)((best >> 12) & 0xfu);
-    return ((best & 0xfffu) << 11) | (hard & 0x7ffu);
+    return ((best & 0xfffu) << 11) | hp;
 }
 
-// Soft Hamming(15,11): returns the chosen code word, `diffs` = differing bits (all 15 positions).
+// Soft Hamming(15,11): returns the chosen code word, `diffs` = differing bits over all 15 positions.
+// Data bit i sits at cell kHamData[i], parity bit q at cell kHamParity[q] (ecc.c:128-131).
+// Key: cost << 16 | !matches_hard << 15 | differing bits << 11 | data.
 __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, int rel_lane, SoftScratch& S, int lane, int& diffs) {
+    constexpr int kHamData[11] = {2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14};
+    constexpr int kHamParity[4] = {0, 1, 3, 7};
     uint32_t hard_fixed;
     (void)hamming1511(tabs.t, hard, hard_fixed);
-    build_cost_tables(S, rel_lane, 2, lane);
-    uint32_t cw_lo = 0, cw_hi_lane = 0;   // linear code: code word of a data word = XOR of basis words
+    const uint32_t rel = (uint32_t)rel_lane;
+    auto gather_data = [&](uint32_t cw) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            d |= ((cw >> kHamData[i]) & 1u) << i;
+        }
+        return d;
+    };
+    auto gather_parity = [&](uint32_t cw) {
+        uint32_t q = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q |= ((cw >> kHamParity[i]) & 1u) << i;
+        }
+        return q;
+    };
+    const uint32_t hd = gather_data(hard), hp = gather_parity(hard);
+    uint32_t par_lo = 0, par_hi = 0, par_hd = 0, a_lo = 0, a_hi = 0, p_cost = 0;
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-        cw_lo ^= ((lane >> b) & 1) ? tabs.d->ham_basis[b] : 0u;
+        const uint32_t bit = (uint32_t)(lane >> b) & 1u;
+        const uint32_t plo = gather_parity(tabs.d->ham_basis[b]);
+        par_lo ^= bit ? plo : 0u;
+        par_hd ^= ((hd >> b) & 1u) ? plo : 0u;
+        a_lo += bit ? rl(rel, kHamData[b]) : 0u;
+        if (b < 5) {
+            const uint32_t phi = gather_parity(tabs.d->ham_basis[6 + b]);
+            par_hi ^= bit ? phi : 0u;
+            par_hd ^= ((hd >> (b + 6)) & 1u) ? phi : 0u;
+            a_hi += bit ? rl(rel, kHamData[6 + b]) : 0u;
+        }
+        if (b < 4) {
+            p_cost += bit ? rl(rel, kHamParity[b]) : 0u;
+        }
     }
-#pragma unroll
-    for (int b = 0; b < 5; ++b) {
-        cw_hi_lane ^= ((lane >> b) & 1) ? tabs.d->ham_basis[6 + b] : 0u;
+    const uint32_t s = par_hd ^ hp;
+    wave_lds_sync();
+    if (lane < 16) {   // parity pattern = lane: its cost and its differing-bit count, in key position
+        S.parity[lane] = (p_cost << 16) + ((uint32_t)__popc(lane) << 11);
     }
+    const uint32_t addr_lane = par_lo << 2, addr_round = (par_hi ^ s) << 2;
+    const uint32_t key_lane = (a_lo << 16) + 0x8000u + ((uint32_t)__popc(lane) << 11) + ((uint32_t)lane ^ (hd & 63u));
+    const uint32_t key_round = (a_hi << 16) + ((uint32_t)__popc(lane & 31) << 11) + ((((uint32_t)lane ^ (hd >> 6)) & 31u) << 6);
+    S.round[lane] = make_uint2(addr_round, key_round);
+    wave_lds_sync();
+    const char* table = reinterpret_cast<const char*>(S.parity);
     uint32_t best = 0xffffffffu;
-#pragma unroll 4
+#pragma unroll 8
     for (int j = 0; j < 32; ++j) {
-        const uint32_t data = (uint32_t)(64 * j + lane);
-        const uint32_t cw = cw_lo ^ (uint32_t)__builtin_amdgcn_readlane((int)cw_hi_lane, j);
-        const uint32_t x = cw ^ hard;
-        const uint32_t cost = (uint32_t)S.cost[0][x & 255u] + (uint32_t)S.cost[1][x >> 8];
-        const uint32_t key = (cost << 16) | ((cw != hard_fixed) ? 0x8000u : 0u) | ((uint32_t)__popc(x) << 11) | data;
+        const uint2 r = S.round[j];
+        const uint32_t val = *reinterpret_cast<const uint32_t*>(table + (addr_lane ^ r.x));
+        const uint32_t key = val + key_lane + r.y;
         best = key < best ? key : best;
     }
     best = wave_min_u32(best);
+    {   // the candidate that equals the hard decoder's output
+        const uint32_t ut = gather_data(hard_fixed) ^ hd;
+        const int lt = (int)(ut & 63u), jt = (int)(ut >> 6);
+        const uint32_t val = *reinterpret_cast<const uint32_t*>(table + (rl(addr_lane, lt) ^ rl(addr_round, jt)));
+        const uint32_t key = val + rl(key_lane, lt) + rl(key_round, jt) - 0x8000u;
+        best = key < best ? key : best;
+    }
     diffs = (int)((best >> 11) & 0xfu);
     const uint32_t data = best & 0x7ffu;
     uint32_t cw = 0;
