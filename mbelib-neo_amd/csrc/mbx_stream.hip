@@ -252,6 +252,10 @@ __device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, con
     }
     S.x.words[lane] = 0u;
     S.x.fp[lane] = 0.0f;
+    S.x.C[lane] = 0.0f;   // coefficients past a block's length stay zero: the inverse DCT below adds
+    if (lane < 20) {      // them unconditionally (x + 0*c == x for every x this sum can take)
+        S.x.C[64 + lane] = 0.0f;
+    }
     if (!bad) {
         const int L9 = L - 9;
         int J[6];   // block lengths, wave-uniform
@@ -363,10 +367,8 @@ __device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, con
             float sum = 0;
 #pragma unroll
             for (int k = 1; k <= 10; ++k) {
-                if (k <= iji) {
-                    const float ak = (k == 1) ? 1.0f : 2.0f;
-                    sum = sum + (ak * C[k] * cosr[k]);
-                }
+                const float ak = (k == 1) ? 1.0f : 2.0f;
+                sum = sum + (ak * C[k] * cosr[k]);
             }
             S.x.fp[lane] = sum;
         }
@@ -537,7 +539,7 @@ __device__ float enhance(Parms& cur, int lane) {
         return 0.0f;
     }
     float s_step, c_step;
-    sincosf(cur.w0, &s_step, &c_step);
+    unit_phasor((double)cur.w0 * 0.15915494309189533577, c_step, s_step);
     // cos(l*w0) for lane = l.  The reference rotates (1, 0) l times by w0 (src/core/mbelib.c:412-424);
     // here the lane multiplies the powers (c,s)^(2^b) selected by the bits of l -- 6 squarings
     // instead of up to 56 dependent steps, same quantity to ~1e-7.
@@ -560,9 +562,12 @@ __device__ float enhance(Parms& cur, int lane) {
     const float R2m0 = Rm0 * Rm0;
     const float R2m1 = Rm1 * Rm1;
     if (in && cur.Ml != 0.0f) {
-        const float Wl = sqrtf(cur.Ml)
-                         * sqrtf(sqrtf(((float)0.96 * (float)M_PI * ((R2m0 + R2m1) - ((float)2 * Rm0 * Rm1 * cw)))
-                                       / (cur.w0 * Rm0 * (R2m0 - R2m1))));
+        // The weight is continuous across its own thresholds (the clamp values equal the weight there),
+        // so v_sqrt_f32 / v_rcp_f32 (1 ulp) are accurate enough: no decision can flip visibly.
+        const float Wl = __builtin_amdgcn_sqrtf(cur.Ml)
+                         * __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(
+                             ((float)0.96 * (float)M_PI * ((R2m0 + R2m1) - ((float)2 * Rm0 * Rm1 * cw)))
+                             * __builtin_amdgcn_rcpf(cur.w0 * Rm0 * (R2m0 - R2m1))));
         if ((8 * lane) <= L) {
         } else if (Wl > 1.2f) {
             cur.Ml = 1.2f * cur.Ml;
@@ -1225,7 +1230,9 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             flags |= MBE_PROCESS_FLAG_MUTE;
         }
         if (!(tabs.ablate & 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
-        __threadfence_block();               // the next frame of this wave reloads both slots
+        if (t + 1 < Tn) {
+            __threadfence_block();           // the next frame of this wave reloads both slots
+        }
 
         store_pcm(out, f, pcm16, pcmf, lane);
         if (results && lane == 0) {
@@ -1566,7 +1573,9 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             store_parms(cur, slot_prev, lane);
             store_parms(cur, slot_enh, lane);
         }
-        __threadfence_block();   // the next frame of this wave reloads the parked structs
+        if (t + 1 < Tn) {
+            __threadfence_block();   // the next frame of this wave reloads the parked structs
+        }
 
         store_pcm(out, f, pcm16, pcmf, lane);
         if (results && lane == 0) {
