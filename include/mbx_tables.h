@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define MBX_TABLES_MAGIC   0x3154584Du /* "MXT1" */
-#define MBX_TABLES_VERSION 2u
+#define MBX_TABLES_VERSION 3u
 
 typedef struct mbx_tables {
     uint32_t magic;
@@ -72,6 +72,10 @@ typedef struct mbx_tables {
     float    wola_w_prev[160];
     float    wola_w_curr[160];
     float    wola_denom[160];
+
+    /* ---- IMBE 7100x4400 (§8(f) row 4): its own Hamming(15,11) bit mapping, ref src/ecc/ecc.c:422-464 ---- */
+    uint16_t hamming7100_gen[4];   /* parity-check row masks                              */
+    uint16_t hamming7100_fix[16];  /* syndrome -> single-bit flip mask                    */
     uint8_t  pad_[4];
 } mbx_tables;
 

@@ -84,7 +84,11 @@ typedef struct mbe_soft_bit {
 /* ---- batch-side additions (no counterpart in the reference) ------------------------ */
 
 /* Codec selector for the batch entry points. */
-enum { MBX_CODEC_IMBE7200X4400 = 0, MBX_CODEC_AMBE3600X2450 = 1 };
+enum {
+    MBX_CODEC_IMBE7200X4400 = 0,
+    MBX_CODEC_AMBE3600X2450 = 1,
+    MBX_CODEC_IMBE7100X4400 = 2 /* own FEC/demodulation front end, then the 7200x4400 path */
+};
 
 /* Channel-frame wire size handed to the launcher: the 0/1 chars of the reference's
  * imbe_fr[8][23] / ambe_fr[4][24] with the meaningful cells packed MSB-first.
@@ -92,6 +96,7 @@ enum { MBX_CODEC_IMBE7200X4400 = 0, MBX_CODEC_AMBE3600X2450 = 1 };
  *   AMBE: row 0 cells 23..0, row 1 cells 22..0, row 2 cells 10..0, row 3 cells 13..0 = 72 bits */
 #define MBX_IMBE_FRAME_BYTES 18
 #define MBX_AMBE_FRAME_BYTES 9
+#define MBX_IMBE7100_FRAME_BYTES 18 /* 142 channel bits: rows of 19, 24, 23, 23, 15, 15, 23 cells, MSB-first */
 /* soft-decision frames keep the reference's own array shapes: mbe_soft_bit[8][23] / [4][24] */
 #define MBX_IMBE_SOFT_BITS 184
 #define MBX_AMBE_SOFT_BITS 96

@@ -7,10 +7,15 @@ import numpy as np
 
 CODEC_IMBE7200X4400 = 0
 CODEC_AMBE3600X2450 = 1
-FRAME_BYTES = {CODEC_IMBE7200X4400: 18, CODEC_AMBE3600X2450: 9}
-PARAM_BITS = {CODEC_IMBE7200X4400: 88, CODEC_AMBE3600X2450: 49}
-FRAME_CELLS = {CODEC_IMBE7200X4400: (8, 23), CODEC_AMBE3600X2450: (4, 24)}
-ROW_WIDTHS = {CODEC_IMBE7200X4400: (23, 23, 23, 23, 15, 15, 15, 7), CODEC_AMBE3600X2450: (24, 23, 11, 14)}
+CODEC_IMBE7100X4400 = 2  # own FEC / demodulation front end, then the 7200x4400 path
+FRAME_BYTES = {CODEC_IMBE7200X4400: 18, CODEC_AMBE3600X2450: 9, CODEC_IMBE7100X4400: 18}
+PARAM_BITS = {CODEC_IMBE7200X4400: 88, CODEC_AMBE3600X2450: 49, CODEC_IMBE7100X4400: 88}
+FRAME_CELLS = {CODEC_IMBE7200X4400: (8, 23), CODEC_AMBE3600X2450: (4, 24), CODEC_IMBE7100X4400: (7, 24)}
+ROW_WIDTHS = {
+    CODEC_IMBE7200X4400: (23, 23, 23, 23, 15, 15, 15, 7),
+    CODEC_AMBE3600X2450: (24, 23, 11, 14),
+    CODEC_IMBE7100X4400: (19, 24, 23, 23, 15, 15, 23),
+}
 
 FLAG_SOFT_INPUT = 0x01
 FLAG_C0_VALID = 0x02
@@ -169,5 +174,7 @@ def table_views(blob):
     take("wola_w_prev", "<f4", (160,))
     take("wola_w_curr", "<f4", (160,))
     take("wola_denom", "<f4", (160,))
+    take("hamming7100_gen", "<u2", (4,))
+    take("hamming7100_fix", "<u2", (16,))
     assert off + 4 == len(b), (off, len(b))
     return out

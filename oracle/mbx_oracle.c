@@ -58,6 +58,7 @@ mbxo_load_tables(const void* blob, size_t n) {
 
 static const int imbe_row_width[8] = {23, 23, 23, 23, 15, 15, 15, 7};
 static const int ambe_row_width[4] = {24, 23, 11, 14};
+static const int imbe7100_row_width[7] = {19, 24, 23, 23, 15, 15, 23};
 
 /* ref: src/internal/mbe_result.h:18-29 (mbe_validate_bits) */
 static int
@@ -357,6 +358,187 @@ mbxo_fec_ambe3600x2450(const uint8_t frame[MBX_AMBE_FRAME_BYTES], mbx_param_reco
     at = rec_append(rec, at, row[3], 14, 14);
     rec->w[3] = (uint32_t)c0 | ((uint32_t)prot << 8) | (MBE_PROCESS_FLAG_C0_VALID << 24);
     return c0 + prot;
+}
+
+/* =====================================================================================
+ * IMBE 7100x4400 front end (§8(f) row 4): its own C0 (Golay shortened to 18 cells), demodulation
+ * seed (7 bits), Hamming bit mapping and parameter-bit order; after mbe_convertImbe7100to7200 the
+ * 88 bits are those of the 7200x4400 path.
+ * ===================================================================================== */
+int
+mbxo_pack_imbe7100_frame(const char fr[7][24], uint8_t out[MBX_IMBE7100_FRAME_BYTES]) {
+    int rc = validate_bits((const char*)fr, 7u * 24u);
+    if (rc < 0) {
+        return rc;
+    }
+    if (!out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    memset(out, 0, MBX_IMBE7100_FRAME_BYTES);
+    int pos = 0;
+    for (int r = 0; r < 7; ++r) {
+        for (int j = imbe7100_row_width[r] - 1; j >= 0; --j) {
+            put_bit(out, pos++, fr[r][j]);
+        }
+    }
+    return 0;
+}
+
+void
+mbxo_unpack_imbe7100_frame(const uint8_t in[MBX_IMBE7100_FRAME_BYTES], char fr[7][24]) {
+    memset(fr, 0, 7 * 24);
+    int pos = 0;
+    for (int r = 0; r < 7; ++r) {
+        for (int j = imbe7100_row_width[r] - 1; j >= 0; --j) {
+            fr[r][j] = (char)get_bit(in, pos++);
+        }
+    }
+}
+
+/* ref: src/ecc/ecc.c:422-464 */
+int
+mbxo_hamming1511_7100_word(uint32_t cw, uint32_t* fixed) {
+    int syndrome = 0;
+    for (int i = 0; i < 4; ++i) {
+        syndrome |= (__builtin_popcount(cw & T->hamming7100_gen[i]) & 1) << i;
+    }
+    *fixed = (syndrome > 0) ? (cw ^ T->hamming7100_fix[syndrome]) : cw;
+    return syndrome > 0;
+}
+
+int
+mbxo_hamming1511_7100(const char* in, char* out) {
+    if (!out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_bits(in, 15u);
+    if (rc < 0) {
+        return rc;
+    }
+    uint32_t fixed;
+    int errs = mbxo_hamming1511_7100_word(chars_to_word(in, 15), &fixed);
+    word_to_chars(fixed, out, 15);
+    return errs;
+}
+
+/* ref: src/imbe/imbe7100x4400.c:381-438 -- a permutation of the 88 bits that depends on K(b0) */
+int
+mbxo_convert_imbe7100to7200(char* d) {
+    int rc = validate_bits(d, 88u);
+    if (rc < 0) {
+        return rc;
+    }
+    static const int b0_index[8] = {1, 2, 3, 4, 5, 6, 86, 87};
+    int b0 = 0;
+    for (int i = 0; i < 8; ++i) {
+        b0 = (b0 << 1) | d[b0_index[i]];
+    }
+    float w0 = ((float)(4 * M_PI) / (float)((float)b0 + 39.5));
+    int L = (int)(0.9254 * (int)((M_PI / w0) + 0.25));
+    int K = (L < 37) ? (int)((float)(L + 2) / (float)3) : 12;
+    char tmp[88];
+    tmp[87] = d[0];
+    tmp[48 + K] = d[42];
+    tmp[49 + K] = d[43];
+    for (int i = 0; i < K; ++i) {
+        tmp[48 + i] = d[44 + i];
+    }
+    int j = 0, k = 1;
+    while (j < 87) {
+        tmp[j] = d[k];
+        if (++j == 48) {
+            j += K + 2;
+        }
+        if (++k == 42) {
+            k += K + 2;
+        }
+    }
+    memcpy(d, tmp, 88);
+    return 0;
+}
+
+int
+mbxo_fec_imbe7100x4400(const uint8_t frame[MBX_IMBE7100_FRAME_BYTES], mbx_param_record* rec) {
+    uint32_t row[7];
+    int pos = 0;
+    for (int r = 0; r < 7; ++r) {
+        row[r] = take_bits(frame, pos, imbe7100_row_width[r]);
+        pos += imbe7100_row_width[r];
+    }
+    /* C0: cells 1..18 are the low 18 positions of a Golay block whose top five positions are zero */
+    uint32_t fixed;
+    int c0 = mbxo_golay2312_word((row[0] >> 1) & 0x3ffffu, &fixed);
+    row[0] = ((fixed & 0x3ffffu) << 1) | (row[0] & 1u);
+
+    uint8_t pr[101];
+    pr_bits((row[0] >> 12) & 0x7fu, 100, pr);
+    int k = 1;
+    for (int r = 1; r < 6; ++r) {
+        for (int j = imbe7100_row_width[r] - 1; j >= 0; --j) {
+            row[r] ^= (uint32_t)pr[k++] << j;
+        }
+    }
+
+    char d[88];
+    int at = 0, prot = 0, c4 = 0;
+    for (int j = 18; j > 11; --j) {
+        d[at++] = (char)((row[0] >> j) & 1u);
+    }
+    uint32_t w;
+    prot += mbxo_golay2312_word(row[1] >> 1, &w); /* C1: cells 1..23 */
+    for (int j = 22; j > 10; --j) {
+        d[at++] = (char)((w >> j) & 1u);
+    }
+    for (int r = 2; r < 4; ++r) {
+        prot += mbxo_golay2312_word(row[r], &w);
+        for (int j = 22; j > 10; --j) {
+            d[at++] = (char)((w >> j) & 1u);
+        }
+    }
+    for (int r = 4; r < 6; ++r) {
+        int e = mbxo_hamming1511_7100_word(row[r], &w);
+        prot += e;
+        if (r == 4) {
+            c4 = e;
+        }
+        for (int j = 14; j >= 4; --j) {
+            d[at++] = (char)((w >> j) & 1u);
+        }
+    }
+    for (int j = 22; j >= 0; --j) {
+        d[at++] = (char)((row[6] >> j) & 1u);
+    }
+    mbxo_convert_imbe7100to7200(d);
+
+    memset(rec, 0, sizeof(*rec));
+    for (int i = 0; i < 88; ++i) {
+        rec_put(rec, i, d[i]);
+    }
+    rec->w[3] = (uint32_t)c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
+                | ((MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24);
+    return c0 + prot;
+}
+
+int
+mbxo_decode_imbe7100x4400_frame(const char fr[7][24], char imbe_d[88], mbe_process_result* result) {
+    if (result) {
+        memset(result, 0, sizeof(*result));
+    }
+    if (!imbe_d) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    uint8_t packed[MBX_IMBE7100_FRAME_BYTES];
+    int rc = mbxo_pack_imbe7100_frame(fr, packed);
+    if (rc < 0) {
+        return rc;
+    }
+    mbx_param_record rec;
+    int total = mbxo_fec_imbe7100x4400(packed, &rec);
+    mbxo_record_to_bits(&rec, 88, imbe_d);
+    if (result) {
+        mbxo_record_to_result(&rec, result);
+    }
+    return total;
 }
 
 /* =====================================================================================
@@ -2068,6 +2250,8 @@ mbxo_fec_batch(int codec, size_t n, const uint8_t* frames, mbx_param_record* rec
     for (size_t i = 0; i < n; ++i) {
         if (codec == MBX_CODEC_IMBE7200X4400) {
             mbxo_fec_imbe7200x4400(frames + i * MBX_IMBE_FRAME_BYTES, &records[i]);
+        } else if (codec == MBX_CODEC_IMBE7100X4400) {
+            mbxo_fec_imbe7100x4400(frames + i * MBX_IMBE7100_FRAME_BYTES, &records[i]);
         } else {
             mbxo_fec_ambe3600x2450(frames + i * MBX_AMBE_FRAME_BYTES, &records[i]);
         }
@@ -2082,7 +2266,10 @@ process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_p
     if (!T || !frames || !state || !rng || S < 0 || Tn < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const int imbe = (codec == MBX_CODEC_IMBE7200X4400);
+    const int imbe = (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400);
+    if (soft && codec == MBX_CODEC_IMBE7100X4400) {
+        return MBE_STATUS_INVALID_ARGUMENT; /* soft 7100x4400 frames: not restated yet */
+    }
     const size_t fb = soft ? (size_t)(imbe ? MBX_IMBE_SOFT_BITS : MBX_AMBE_SOFT_BITS) * sizeof(mbe_soft_bit)
                            : (size_t)(imbe ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES);
     for (int s = 0; s < S; ++s) {
@@ -2099,6 +2286,8 @@ process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_p
             if (imbe) {
                 if (soft) {
                     mbxo_fec_imbe7200x4400_soft((const mbe_soft_bit(*)[23])fr, &rec);
+                } else if (codec == MBX_CODEC_IMBE7100X4400) {
+                    mbxo_fec_imbe7100x4400(fr, &rec);
                 } else {
                     mbxo_fec_imbe7200x4400(fr, &rec);
                 }

@@ -47,6 +47,17 @@ int mbxo_hamming1511(const char* in, char* out);
 int mbxo_fec_imbe7200x4400(const uint8_t frame[MBX_IMBE_FRAME_BYTES], mbx_param_record* rec);
 int mbxo_fec_ambe3600x2450(const uint8_t frame[MBX_AMBE_FRAME_BYTES], mbx_param_record* rec);
 /* the reference's char-array entry points, same return/validation behaviour */
+/* IMBE 7100x4400 front end -- ref src/imbe/imbe7100x4400.c:100-122 (C0), :153-212
+ * (data ECC), :292-334 (demodulation), :381-438 (mbe_convertImbe7100to7200), :440-479 (frame decode),
+ * src/ecc/ecc.c:422-464 (mbe_7100x4400hamming1511).  The record holds the 88 bits AFTER the conversion. */
+int mbxo_pack_imbe7100_frame(const char fr[7][24], uint8_t out[MBX_IMBE7100_FRAME_BYTES]); /* 0 / -1 / -2 */
+void mbxo_unpack_imbe7100_frame(const uint8_t in[MBX_IMBE7100_FRAME_BYTES], char fr[7][24]);
+int mbxo_hamming1511_7100_word(uint32_t cw, uint32_t* fixed);
+int mbxo_hamming1511_7100(const char* in, char* out);
+int mbxo_convert_imbe7100to7200(char* imbe_d);
+int mbxo_fec_imbe7100x4400(const uint8_t frame[MBX_IMBE7100_FRAME_BYTES], mbx_param_record* rec);
+int mbxo_decode_imbe7100x4400_frame(const char fr[7][24], char imbe_d[88], mbe_process_result* result);
+
 /* soft-decision front end -- ref src/ecc/ecc.c:138-215,303-357,410-413,
  * src/imbe/imbe7200x4400.c:445-459,517-560,675-707,746-778, src/ambe/ambe_common.c:48-73,102-124,159-190,
  * src/ambe/ambe3600x2450.c:684-714, src/core/mbelib.c:107-158 */

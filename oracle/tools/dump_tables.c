@@ -75,6 +75,11 @@ main(int argc, char** argv) {
         t->hamming_fix[hamming_syndrome(1u << b, hammingGenerator)] = (uint16_t)(1u << b);
     }
 
+    NARROW(t->hamming7100_gen, imbe7100x4400hammingGenerator, 4, 32767);
+    for (int b = 0; b < 15; ++b) {
+        t->hamming7100_fix[hamming_syndrome(1u << b, imbe7100x4400hammingGenerator)] = (uint16_t)(1u << b);
+    }
+
     /* IMBE fundamental: same expressions as src/imbe/imbe7200x4400.c:132-148 */
     for (int b0 = 0; b0 < 208; ++b0) {
         float w0 = ((float)(4 * M_PI) / (float)((float)b0 + 39.5));

@@ -39,6 +39,12 @@ extern int mbe_processImbe7200x4400Framef(float*, mbe_process_result*, const cha
 extern int mbe_processAmbe3600x2450Framef(float*, mbe_process_result*, const char[4][24], char[49], mbe_parms*,
                                           mbe_parms*, mbe_parms*);
 extern int mbe_processImbe4400Dataf(float*, mbe_process_result*, const char[88], mbe_parms*, mbe_parms*, mbe_parms*);
+/* IMBE 7100x4400: include/mbelib-neo/mbelib.h:267, 533-590 */
+extern int mbe_7100x4400hamming1511(const char*, char*);
+extern int mbe_convertImbe7100to7200(char*);
+extern int mbe_decodeImbe7100x4400Frame(const char[7][24], char[88], mbe_process_result*);
+extern int mbe_processImbe7100x4400Framef(float*, mbe_process_result*, const char[7][24], char[88], mbe_parms*, mbe_parms*,
+                                          mbe_parms*);
 /* soft-decision front end: include/mbelib-neo/mbelib.h:208-224, 246, 260, 437-447, 513-523 */
 extern mbe_soft_bit mbe_softBitFromLlr(int16_t);
 extern int mbe_softBitsFromLlr(const int16_t*, mbe_soft_bit*, size_t);
@@ -716,15 +722,100 @@ gen_soft(const char* dir) {
     printf("soft_kat.bin written\n");
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* imbe7100_kat.bin: the IMBE 7100x4400 front end.
+ *   u32 NH, NH x { u32 in, u32 out, i32 errs }                 mbe_7100x4400hamming1511, all 32768 words
+ *   u32 NC, NC x { char in[88], char out[88] }                 mbe_convertImbe7100to7200
+ *   u32 NF, NF x { char fr[7][24], char d[88], i32 ret, result(20) }   mbe_decodeImbe7100x4400Frame
+ *   u32 S, u32 T, per stream T x { char fr[7][24], i32 ret, result(20), float pcm[160] }, then cur (2604 B)
+ *                                                              mbe_processImbe7100x4400Framef, seeds 1234 + s */
+static void
+gen_imbe7100(const char* dir) {
+    FILE* f = open_out(dir, "imbe7100_kat.bin");
+    sm_state = 0x9E3779B97F4A7C15ULL ^ 0x7100ULL;
+    uint32_t n = 32768;
+    W(f, &n, 4);
+    for (uint32_t w = 0; w < n; ++w) {
+        char in[15], out[15];
+        for (int j = 0; j < 15; ++j) {
+            in[j] = (char)((w >> j) & 1u);
+        }
+        int32_t errs = mbe_7100x4400hamming1511(in, out);
+        uint32_t o = 0;
+        for (int j = 0; j < 15; ++j) {
+            o |= (uint32_t)(out[j] & 1) << j;
+        }
+        W(f, &w, 4);
+        W(f, &o, 4);
+        W(f, &errs, 4);
+    }
+    n = 512;
+    W(f, &n, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        char in[88], out[88];
+        for (int c = 0; c < 88; ++c) {
+            in[c] = (char)(splitmix64() & 1u);
+        }
+        memcpy(out, in, 88);
+        mbe_convertImbe7100to7200(out);
+        W(f, in, 88);
+        W(f, out, 88);
+    }
+    n = 2048;
+    W(f, &n, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        char fr[7][24], d[88];
+        mbe_process_result r;
+        int sparse = (i % 8u) == 7u;
+        for (int c = 0; c < 7 * 24; ++c) {
+            uint64_t v = splitmix64();
+            ((char*)fr)[c] = sparse ? (char)((v % 29) == 0) : (char)(v & 1);
+        }
+        int32_t ret = mbe_decodeImbe7100x4400Frame((const char(*)[24])fr, d, &r);
+        W(f, fr, sizeof(fr));
+        W(f, d, 88);
+        W(f, &ret, 4);
+        W(f, &r, sizeof(r));
+    }
+    uint32_t S = 16, T = 12;
+    W(f, &S, 4);
+    W(f, &T, 4);
+    for (uint32_t s = 0; s < S; ++s) {
+        mbe_parms cur, prev, enh;
+        mbe_initMbeParms(&cur, &prev, &enh);
+        mbe_setThreadRngSeed(1234u + s);
+        for (uint32_t t = 0; t < T; ++t) {
+            char fr[7][24], d[88];
+            float out[160];
+            mbe_process_result r;
+            for (int c = 0; c < 7 * 24; ++c) {
+                ((char*)fr)[c] = (char)(splitmix64() & 1u);
+            }
+            int32_t ret = mbe_processImbe7100x4400Framef(out, &r, (const char(*)[24])fr, d, &cur, &prev, &enh);
+            W(f, fr, sizeof(fr));
+            W(f, &ret, 4);
+            W(f, &r, sizeof(r));
+            W(f, out, sizeof(out));
+        }
+        W(f, &cur, sizeof(cur));
+    }
+    fclose(f);
+    printf("imbe7100_kat.bin written\n");
+}
+
 int
 main(int argc, char** argv) {
     if (argc != 2 && argc != 3) {
-        fprintf(stderr, "usage: %s outdir [soft]\n", argv[0]);
+        fprintf(stderr, "usage: %s outdir [soft|imbe7100]\n", argv[0]);
         return 2;
     }
     const char* dir = argv[1];
     if (argc == 3 && strcmp(argv[2], "soft") == 0) {   /* only the soft-decision file */
         gen_soft(dir);
+        return 0;
+    }
+    if (argc == 3 && strcmp(argv[2], "imbe7100") == 0) {
+        gen_imbe7100(dir);
         return 0;
     }
     gen_ecc(dir);
@@ -738,5 +829,6 @@ main(int argc, char** argv) {
     gen_params(dir);
     gen_misc(dir);
     gen_soft(dir);
+    gen_imbe7100(dir);
     return 0;
 }

@@ -139,3 +139,28 @@ def soft_kat():
     section("process", np.dtype([("soft", "u1", (184, 2)), ("ret", "<i4"), ("result", RESULT_DTYPE), ("pcmf", "<f4", (160,))]))
     assert off == b.size
     return out
+
+
+def imbe7100_kat():
+    """imbe7100_kat.bin (layout: oracle/tools/gen_fixtures.c gen_imbe7100)"""
+    b = _read("imbe7100_kat.bin")
+    out, off = {}, 0
+
+    def section(name, dt):
+        nonlocal off
+        n = int(b[off : off + 4].view("<u4")[0])
+        off += 4
+        out[name] = b[off : off + n * dt.itemsize].view(dt)
+        off += n * dt.itemsize
+
+    section("hamming", np.dtype([("inp", "<u4"), ("out", "<u4"), ("errs", "<i4")]))
+    section("convert", np.dtype([("inp", "i1", (88,)), ("out", "i1", (88,))]))
+    section("fec", np.dtype([("cells", "i1", (168,)), ("bits", "i1", (88,)), ("ret", "<i4"), ("result", RESULT_DTYPE)]))
+    S, T = (int(x) for x in b[off : off + 8].view("<u4"))
+    off += 8
+    frame = np.dtype([("cells", "i1", (168,)), ("ret", "<i4"), ("result", RESULT_DTYPE), ("pcmf", "<f4", (160,))])
+    per_stream = np.dtype([("frames", frame, (T,)), ("final", PARMS_DTYPE)])
+    out["stream"] = b[off : off + S * per_stream.itemsize].view(per_stream)
+    off += S * per_stream.itemsize
+    assert off == b.size
+    return out

@@ -71,6 +71,15 @@ class Oracle:
         h.mbxo_rng_seed.argtypes = [_vp, C.c_uint32]
         h.mbxo_fnv1a32.restype = C.c_uint32
         h.mbxo_fnv1a32.argtypes = [_vp, C.c_size_t]
+        # IMBE 7100x4400 front end
+        h.mbxo_pack_imbe7100_frame.restype = C.c_int
+        h.mbxo_pack_imbe7100_frame.argtypes = [_vp, _vp]
+        h.mbxo_hamming1511_7100_word.restype = C.c_int
+        h.mbxo_hamming1511_7100_word.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
+        h.mbxo_convert_imbe7100to7200.restype = C.c_int
+        h.mbxo_convert_imbe7100to7200.argtypes = [_vp]
+        h.mbxo_decode_imbe7100x4400_frame.restype = C.c_int
+        h.mbxo_decode_imbe7100x4400_frame.argtypes = [_vp, _vp, _vp]
         # soft-decision front end
         for name in ("mbxo_golay2312_soft", "mbxo_hamming1511_soft"):
             getattr(h, name).restype = C.c_int
@@ -120,7 +129,7 @@ class Oracle:
         cells = np.ascontiguousarray(cells, dtype=np.int8)
         n = cells.shape[0]
         out = np.zeros((n, FRAME_BYTES[codec]), dtype=np.uint8)
-        fn = self.h.mbxo_pack_imbe_frame if codec == 0 else self.h.mbxo_pack_ambe_frame
+        fn = {0: self.h.mbxo_pack_imbe_frame, 1: self.h.mbxo_pack_ambe_frame, 2: self.h.mbxo_pack_imbe7100_frame}[codec]
         rcs = [fn(cells[i].ctypes.data, out[i].ctypes.data) for i in range(n)]
         return rcs, out
 
@@ -130,6 +139,23 @@ class Oracle:
         rec = np.zeros(n, dtype=RECORD_DTYPE)
         self.h.mbxo_fec_batch(codec, n, frames.ctypes.data, rec.ctypes.data)
         return rec
+
+    def hamming7100(self, cw):
+        out = C.c_uint32(0)
+        errs = self.h.mbxo_hamming1511_7100_word(int(cw), C.byref(out))
+        return out.value, errs
+
+    def convert7100(self, bits88):
+        d = np.ascontiguousarray(bits88, dtype=np.int8).copy()
+        assert self.h.mbxo_convert_imbe7100to7200(d.ctypes.data) == 0
+        return d
+
+    def decode_imbe7100_frame(self, cells168):
+        cells = np.ascontiguousarray(cells168, dtype=np.int8)
+        d = np.zeros(88, dtype=np.int8)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        ret = self.h.mbxo_decode_imbe7100x4400_frame(cells.ctypes.data, d.ctypes.data, res.ctypes.data)
+        return d, ret, res[0]
 
     def fec_soft_batch(self, codec, soft):
         """soft: [n, 184|96, 2] uint8 (bit, reliability) in the reference's array order -> records"""

@@ -266,3 +266,40 @@ def test_soft_frames_match_reference(oracle, codec):
 def test_soft_bits_from_llr(oracle):
     kat = golden_io.soft_kat()["llr"]
     assert np.array_equal(oracle.soft_from_llr(kat["llr"]), kat["soft"])
+
+
+# ---- IMBE 7100x4400 front end against the real reference's outputs -------
+def test_imbe7100_hamming_and_convert_match_reference(oracle):
+    kat = golden_io.imbe7100_kat()
+    for row in kat["hamming"][::7]:
+        out, errs = oracle.hamming7100(row["inp"])
+        assert out == row["out"] and errs == row["errs"]
+    for row in kat["convert"]:
+        assert np.array_equal(oracle.convert7100(row["inp"]), row["out"])
+
+
+def test_imbe7100_frames_match_reference(oracle):
+    kat = golden_io.imbe7100_kat()
+    for row in kat["fec"]:
+        bits, ret, res = oracle.decode_imbe7100_frame(row["cells"])
+        assert ret == row["ret"]
+        assert np.array_equal(bits, row["bits"])
+        for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
+            assert res[name] == row["result"][name], name
+    rcs, packed = oracle.pack(2, kat["fec"]["cells"])
+    assert all(rc == 0 for rc in rcs)
+    rec = oracle.fec_batch(2, packed)
+    assert np.array_equal(oracle_lib.records_to_bits(rec, 88), kat["fec"]["bits"])
+
+
+def test_imbe7100_stream_matches_reference(oracle):
+    st = golden_io.imbe7100_kat()["stream"]
+    S, T = st.shape[0], st["frames"].shape[1]
+    cells = st["frames"]["cells"].reshape(S * T, 168)
+    rcs, packed = oracle.pack(2, cells)
+    assert all(rc == 0 for rc in rcs)
+    out = oracle.process_batch(2, S, T, packed, oracle.init_state(S), oracle.rng_seeded([1234 + s for s in range(S)]))
+    ref = st["frames"].reshape(-1)
+    parity.check_results(ref["result"], out["results"])
+    parity.check_pcm(ref["pcmf"], out["pcmf"], rel=2e-6, worst=2e-5)
+    parity.check_state(st["final"], out["state"][:, 0])
