@@ -56,6 +56,8 @@ int mbx_reserve(size_t max_frames);
  * NULL -> MBE_STATUS_INVALID_ARGUMENT, any cell outside {0,1} -> MBE_STATUS_INVALID_BITS
  * and nothing is written. */
 int mbx_pack_imbe7200x4400(const char* frames /* n*8*23 */, size_t n, uint8_t* packed /* n*18 */);
+/* IMBE 7100x4400: char[7][24] cells, rows of 19, 24, 23, 23, 15, 15, 23 -> 142 bits in 18 bytes */
+int mbx_pack_imbe7100x4400(const char* frames /* n*7*24 */, size_t n, uint8_t* packed /* n*18 */);
 int mbx_pack_ambe3600x2450(const char* frames /* n*4*24 */, size_t n, uint8_t* packed /* n*9 */);
 /* parameter record -> the reference's imbe_d[88] / ambe_d[49] chars and mbe_process_result */
 void mbx_unpack_records(const mbx_param_record* rec, size_t n, int nbits /* 88|49 */, char* bits /* n*nbits, or NULL */,
@@ -71,6 +73,13 @@ int mbx_fec_imbe7200x4400(const uint8_t* d_frames /* n*18 */, size_t n, mbx_para
 /* ref: mbe_decodeAmbe3600x2450Frame  include/mbelib-neo/mbelib.h:395, src/ambe/ambe3600x2450.c:649-682,
  *      src/ambe/ambe_common.c:22-46, 75-100, 127-157 */
 int mbx_fec_ambe3600x2450(const uint8_t* d_frames /* n*9 */, size_t n, mbx_param_record* d_records /* n */,
+                          void* stream);
+
+/* ref: mbe_decodeImbe7100x4400Frame  include/mbelib-neo/mbelib.h:545, src/imbe/imbe7100x4400.c:440-479 (C0 :100-122,
+ *      demodulation :292-334, data ECC :153-212, mbe_convertImbe7100to7200 :381-438; mbe_7100x4400hamming1511
+ *      src/ecc/ecc.c:422-464).  The records hold the converted bits: feed them to mbx_process_records with
+ *      MBX_CODEC_IMBE7200X4400, or call mbx_process_batch with MBX_CODEC_IMBE7100X4400. */
+int mbx_fec_imbe7100x4400(const uint8_t* d_frames /* n*18 */, size_t n, mbx_param_record* d_records /* n */,
                           void* stream);
 
 /* ---- soft-decision FEC stage: soft frames -> parameter records ------

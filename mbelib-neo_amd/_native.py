@@ -45,6 +45,8 @@ _SIGNATURES = {
     "mbx_synthesize_speech_host": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "mbx_floattoshort_host": (C.c_int, [_vp, _vp, _sz]),
     "mbx_fec_host": (C.c_int, [C.c_int, _vp, _sz, _vp]),
+    "mbx_pack_imbe7100x4400": (C.c_int, [_vp, _sz, _vp]),
+    "mbx_fec_imbe7100x4400": (C.c_int, [_vp, _sz, _vp, _vp]),
     "mbx_fec_soft": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
     "mbx_process_batch_soft": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_ecc_soft_words": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp]),

@@ -17,6 +17,7 @@ namespace mbx {
 // kernels (mbx_fec.hip, mbx_stream.hip)
 __global__ void fec_imbe7200x4400_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
 __global__ void fec_ambe3600x2450_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
+__global__ void fec_imbe7100x4400_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
 __global__ void floattoshort_kernel(const float*, int16_t*, size_t);
 __global__ void expand_imbe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void expand_ambe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
@@ -250,6 +251,21 @@ int mbx_pack_imbe7200x4400(const char* frames, size_t n, uint8_t* packed) {
     return 0;
 }
 
+int mbx_pack_imbe7100x4400(const char* frames, size_t n, uint8_t* packed) {
+    static const int width[7] = {19, 24, 23, 23, 15, 15, 23};
+    int rc = validate_bits(frames, n * 168u);
+    if (rc < 0) {
+        return rc;
+    }
+    if (!packed) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        pack_rows(frames + i * 168u, 7, 24, width, packed + i * MBX_IMBE7100_FRAME_BYTES, MBX_IMBE7100_FRAME_BYTES);
+    }
+    return 0;
+}
+
 int mbx_pack_ambe3600x2450(const char* frames, size_t n, uint8_t* packed) {
     static const int width[4] = {24, 23, 11, 14};
     int rc = validate_bits(frames, n * 96u);
@@ -347,6 +363,20 @@ int mbx_fec_ambe3600x2450(const uint8_t* d_frames, size_t n, mbx_param_record* d
     hipLaunchKernelGGL(mbx::fec_ambe3600x2450_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, n,
                        d_records, g_ctx.tabs);
     return check_launch("fec_ambe3600x2450_kernel");
+}
+
+int mbx_fec_imbe7100x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d_records, void* stream) {
+    REQUIRE_READY();
+    if (!d_frames || !d_records) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(mbx::fec_imbe7100x4400_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, n,
+                       d_records, g_ctx.tabs);
+    return check_launch("fec_imbe7100x4400_kernel");
 }
 
 int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft, size_t n, mbx_param_record* d_records, void* stream) {
@@ -510,8 +540,17 @@ int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parm
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     const size_t n = (size_t)S * (size_t)T;
-    int rc = (codec == MBX_CODEC_IMBE7200X4400) ? mbx_fec_imbe7200x4400(d_frames, n, d_records, stream)
-                                                : mbx_fec_ambe3600x2450(d_frames, n, d_records, stream);
+    int rc;
+    if (codec == MBX_CODEC_IMBE7200X4400) {
+        rc = mbx_fec_imbe7200x4400(d_frames, n, d_records, stream);
+    } else if (codec == MBX_CODEC_IMBE7100X4400) {   // own front end; the records are in 7200x4400 order
+        rc = mbx_fec_imbe7100x4400(d_frames, n, d_records, stream);
+        codec = MBX_CODEC_IMBE7200X4400;
+    } else if (codec == MBX_CODEC_AMBE3600X2450) {
+        rc = mbx_fec_ambe3600x2450(d_frames, n, d_records, stream);
+    } else {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
     if (rc < 0) {
         return rc;
     }
@@ -636,13 +675,15 @@ int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* r
     if (!frames || !records) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const size_t fb = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES;
+    const size_t fb = (codec == MBX_CODEC_AMBE3600X2450) ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;
     DevBuf df, dr;
     HIP_TRY(df.alloc(n * fb));
     HIP_TRY(dr.alloc(n * sizeof(mbx_param_record)));
     HIP_TRY(hipMemcpy(df.p, frames, n * fb, hipMemcpyHostToDevice));
-    int rc = (codec == MBX_CODEC_IMBE7200X4400) ? mbx_fec_imbe7200x4400(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
-                                                : mbx_fec_ambe3600x2450(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr);
+    int rc = (codec == MBX_CODEC_IMBE7200X4400)   ? mbx_fec_imbe7200x4400(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
+             : (codec == MBX_CODEC_IMBE7100X4400) ? mbx_fec_imbe7100x4400(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
+             : (codec == MBX_CODEC_AMBE3600X2450) ? mbx_fec_ambe3600x2450(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
+                                                  : MBE_STATUS_INVALID_ARGUMENT;
     if (rc < 0) {
         return rc;
     }
@@ -699,7 +740,7 @@ int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_p
     if (!frames || !state || !rng || S < 0 || T < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const size_t fb = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES;
+    const size_t fb = (codec == MBX_CODEC_AMBE3600X2450) ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;   // 7100: 18 bytes too
     return process_batch_host_impl(codec, S, T, frames, fb, false, state, rng, pcm16, pcmf, results, records);
 }
 

@@ -186,6 +186,116 @@ fec_ambe3600x2450_kernel(const uint8_t* __restrict__ frames, size_t n, mbx_param
                    (uint32_t)c0 | ((uint32_t)prot << 8) | (MBE_PROCESS_FLAG_C0_VALID << 24));
 }
 
+// ------------------------------------------------------------------------------------------
+// IMBE 7100x4400 front end: rows of 19, 24, 23, 23, 15, 15, 23 cells.
+//   ref src/imbe/imbe7100x4400.c:100-122 (C0: Golay shortened to 18 cells), :292-334 (demodulation, 7-bit
+//       seed), :153-212 (Golay on C1..C3, Hamming with the 7100 bit mapping on C4/C5, raw C6),
+//       :381-438 (mbe_convertImbe7100to7200: a permutation of the 88 bits that depends on K(b0)),
+//       :440-479 (frame decode); src/ecc/ecc.c:422-464 (mbe_7100x4400hamming1511)
+// The record holds the 88 bits AFTER the conversion, i.e. in 7200x4400 order: the stream stage is the
+// 7200x4400 one.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int hamming1511_7100(const mbx_tables* T, uint32_t cw, uint32_t& fixed) {
+    int syndrome = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        syndrome |= (__popc(cw & (uint32_t)T->hamming7100_gen[i]) & 1) << i;
+    }
+    fixed = syndrome ? (cw ^ (uint32_t)T->hamming7100_fix[syndrome]) : cw;
+    return syndrome != 0;
+}
+
+struct Bits88 {   // bit i (0 = first parameter bit) at bit 127 - i of hi:lo
+    uint64_t hi = 0, lo = 0;
+    __device__ int get(int i) const { return (int)(((i < 64) ? (hi >> (63 - i)) : (lo >> (127 - i))) & 1ull); }
+    __device__ void put(int i, int b) {
+        if (i < 64) {
+            hi |= (uint64_t)b << (63 - i);
+        } else {
+            lo |= (uint64_t)b << (127 - i);
+        }
+    }
+};
+
+__global__ void __launch_bounds__(256)
+fec_imbe7100x4400_kernel(const uint8_t* __restrict__ frames, size_t n, mbx_param_record* __restrict__ out,
+                         DeviceTables tabs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const mbx_tables* T = tabs.t;
+    const uint8_t* f = frames + i * MBX_IMBE7100_FRAME_BYTES;
+    BitReader br;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        br.w[k] = (load_be16(f + 4 * k) << 16) | load_be16(f + 4 * k + 2);
+    }
+    br.w[4] = load_be16(f + 16) << 16;
+
+    uint32_t row[7];
+    row[0] = br.take(0, 19);
+    row[1] = br.take(19, 24);
+    row[2] = br.take(43, 23);
+    row[3] = br.take(66, 23);
+    row[4] = br.take(89, 15);
+    row[5] = br.take(104, 15);
+    row[6] = br.take(119, 23);
+
+    uint32_t w;
+    const int c0 = golay2312(T, (row[0] >> 1) & 0x3ffffu, w);   // the five missing positions are zeros
+    row[0] = ((w & 0x3ffffu) << 1) | (row[0] & 1u);
+    PrSequence pr((row[0] >> 12) & 0x7fu);
+    row[1] ^= pr.mask_for(24);
+    row[2] ^= pr.mask_for(23);
+    row[3] ^= pr.mask_for(23);
+    row[4] ^= pr.mask_for(15);
+    row[5] ^= pr.mask_for(15);
+
+    int prot = 0, c4 = 0;
+    RecordWriter rw;                       // 7100 order: 7 + 12 + 12 + 12 + 11 + 11 + 23 bits
+    rw.push(row[0] >> 12, 7, 7);
+    prot += golay2312(T, row[1] >> 1, w);   // C1 = cells 1..23
+    rw.push(w, 23, 12);
+    prot += golay2312(T, row[2], w);
+    rw.push(w, 23, 12);
+    prot += golay2312(T, row[3], w);
+    rw.push(w, 23, 12);
+    c4 = hamming1511_7100(T, row[4], w);
+    prot += c4;
+    rw.push(w, 15, 11);
+    prot += hamming1511_7100(T, row[5], w);
+    rw.push(w, 15, 11);
+    rw.push(row[6], 23, 23);
+
+    Bits88 d, t;
+    d.hi = rw.hi;
+    d.lo = rw.lo;
+    // mbe_convertImbe7100to7200
+    const int b0 = (int)(((d.hi >> 56) & 0x7eull) << 1) | (d.get(86) << 1) | d.get(87);   // bits 1..6, 86, 87
+    const int K = (b0 < 208) ? (int)T->imbe_K[b0] : 12;   // the reference's expression gives 12 for every b0 >= 208
+    t.put(87, d.get(0));
+    t.put(48 + K, d.get(42));
+    t.put(49 + K, d.get(43));
+    for (int q = 0; q < K; ++q) {
+        t.put(48 + q, d.get(44 + q));
+    }
+    int j = 0, k = 1;
+    while (j < 87) {
+        t.put(j, d.get(k));
+        if (++j == 48) {
+            j += K + 2;
+        }
+        if (++k == 42) {
+            k += K + 2;
+        }
+    }
+    *reinterpret_cast<uint4*>(&out[i]) =
+        make_uint4((uint32_t)(t.hi >> 32), (uint32_t)t.hi, (uint32_t)(t.lo >> 32),
+                   (uint32_t)c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
+                       | ((MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24));
+}
+
 // float -> int16 (a21): ref src/core/mbelib.c:1148-1177.  One thread per sample.
 __device__ __forceinline__ int16_t float_to_pcm16(float x) {
     const float top = 32767.0f * 0.95f;

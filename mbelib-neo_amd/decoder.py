@@ -87,7 +87,7 @@ class BatchDecoder:
         n = d_frames.numel() // FRAME_BYTES[self.codec]
         rec = torch.empty((n, 4), dtype=torch.int32, device=self.device)
         L = _native.lib()
-        fn = L.mbx_fec_imbe7200x4400 if self.codec == CODEC_IMBE7200X4400 else L.mbx_fec_ambe3600x2450
+        fn = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400}[self.codec]
         _native.check(fn(d_frames.data_ptr(), n, rec.data_ptr(), torch.cuda.current_stream().cuda_stream), "mbx_fec")
         return rec
 

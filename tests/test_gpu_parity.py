@@ -324,3 +324,46 @@ def test_soft_pipeline_vs_oracle(mbx, oracle, codec, S, T):
     assert np.all((got["results"]["flags"] & 1) == 1)   # MBE_PROCESS_FLAG_SOFT_INPUT survives the stream stage
     parity.check_pcm(ref["pcmf"], got["pcmf"], ref["pcm16"], got["pcm16"])
     parity.check_state(ref["state"], got["state"])
+
+
+# ---- IMBE 7100x4400 front end ---------------------------------------------
+def test_imbe7100_fec_bit_exact(mbx, oracle):
+    from mbelib_neo_amd import decoder, framegen
+
+    kat = golden_io.imbe7100_kat()["fec"]
+    rcs, packed = oracle.pack(2, kat["cells"])
+    assert all(rc == 0 for rc in rcs)
+    dec = decoder.BatchDecoder(2, 1)
+    got = decoder.records_numpy(dec.fec(packed))
+    assert np.array_equal(oracle_lib.records_to_bits(got, 88), kat["bits"])            # the reference's own outputs
+    res = oracle_lib.records_to_results(got)
+    for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
+        assert np.array_equal(res[name], kat["result"][name]), name
+    n = 65536
+    frames = framegen.random_frames(2, n, framegen.rng_for(7100))
+    frames[::3] &= framegen.random_frames(2, (n + 2) // 3, framegen.rng_for(7101)) & framegen.random_frames(2, (n + 2) // 3, framegen.rng_for(7102))
+    assert np.array_equal(decoder.records_numpy(dec.fec(frames))["w"], oracle.fec_batch(2, frames)["w"])
+
+
+def test_imbe7100_stream_matches_reference_and_oracle(mbx, oracle):
+    from mbelib_neo_amd import framegen
+    from mbelib_neo_amd.layout import init_state, rng_seeded
+
+    st = golden_io.imbe7100_kat()["stream"]
+    S, T = st.shape[0], st["frames"].shape[1]
+    rcs, packed = oracle.pack(2, st["frames"]["cells"].reshape(S * T, 168))
+    out = _host_batch(mbx, 2, S, T, packed, init_state(S), rng_seeded([1234 + s for s in range(S)]))
+    ref = st["frames"].reshape(-1)
+    parity.check_results(ref["result"], out["results"])
+    parity.check_pcm(ref["pcmf"], out["pcmf"])
+    parity.check_state(st["final"], out["state"][:, 0])
+    # a larger seeded batch against the oracle
+    S, T = 512, 6
+    frames = framegen.random_frames(2, S * T, framegen.rng_for(7110))
+    seeds = [1234 + s for s in range(S)]
+    ref = oracle.process_batch(2, S, T, frames, oracle.init_state(S), oracle.rng_seeded(seeds))
+    got = _host_batch(mbx, 2, S, T, frames, init_state(S), rng_seeded(seeds))
+    assert np.array_equal(got["records"]["w"], ref["records"]["w"])
+    parity.check_results(ref["results"], got["results"])
+    parity.check_pcm(ref["pcmf"], got["pcmf"], ref["pcm16"], got["pcm16"])
+    parity.check_state(ref["state"], got["state"])
