@@ -56,6 +56,16 @@ int mbe_processImbe7200x4400Frame(short* aout_buf, mbe_process_result* result, c
                                   char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp,
                                   mbe_parms* prev_mp_enhanced);                           /* :509 */
 
+/* IMBE 7100x4400 */
+int mbe_7100x4400hamming1511(const char* in, char* out);                                  /* :267 */
+int mbe_decodeImbe7100x4400Frame(const char imbe_fr[7][24], char imbe_d[88], mbe_process_result* result); /* :545 */
+int mbe_processImbe7100x4400Framef(float* aout_buf, mbe_process_result* result, const char imbe_fr[7][24],
+                                   char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp,
+                                   mbe_parms* prev_mp_enhanced);                          /* :564 */
+int mbe_processImbe7100x4400Frame(short* aout_buf, mbe_process_result* result, const char imbe_fr[7][24],
+                                  char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp,
+                                  mbe_parms* prev_mp_enhanced);                           /* :568 */
+
 /* soft-decision entry points */
 mbe_soft_bit mbe_softBitFromHard(int bit, uint8_t reliability);                           /* :208 */
 mbe_soft_bit mbe_softBitFromLlr(int16_t llr);                                             /* :214 */

@@ -155,7 +155,8 @@ int mbx_spectral_amp_enhance(int S, mbe_parms* d_parms, void* stream);
 int mbx_adaptive_smoothing(int S, mbe_parms* d_cur, const mbe_parms* d_prev, void* stream);
 /* ref: mbe_synthesizeComfortNoisef / mbe_synthesizeComfortNoise  include/mbelib-neo/mbelib.h:706-712 */
 int mbx_comfort_noise(int S, mbx_stream_rng* d_rng, float* d_pcmf, int16_t* d_pcm16, void* stream);
-/* ref: mbe_golay2312 / mbe_checkGolayBlock (kind 0), mbe_hamming1511 (kind 1)  include/mbelib-neo/mbelib.h:231-253.
+/* ref: mbe_golay2312 / mbe_checkGolayBlock (kind 0), mbe_hamming1511 (kind 1), mbe_7100x4400hamming1511 (kind 2)
+ *      include/mbelib-neo/mbelib.h:231-267.
  * One code word per element: bit j of in[i] is cell j; out[i] is the corrected word (Golay parity bits
  * pass through like the reference), errs[i] the corrected-bit count (may be NULL). */
 int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream);

@@ -186,15 +186,18 @@ int decode_frame(int codec, const char* cells, int ncell, int nbits, char* bits_
         return rc;
     }
     uint8_t packed[MBX_IMBE_FRAME_BYTES];
-    rc = (codec == MBX_CODEC_IMBE7200X4400) ? mbx_pack_imbe7200x4400(cells, 1, packed) : mbx_pack_ambe3600x2450(cells, 1, packed);
+    rc = (codec == MBX_CODEC_IMBE7200X4400)   ? mbx_pack_imbe7200x4400(cells, 1, packed)
+         : (codec == MBX_CODEC_IMBE7100X4400) ? mbx_pack_imbe7100x4400(cells, 1, packed)
+                                              : mbx_pack_ambe3600x2450(cells, 1, packed);
     if (rc < 0) {
         return rc;
     }
     Slot& s = slot();
-    const size_t fb = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES;
+    const size_t fb = (codec == MBX_CODEC_AMBE3600X2450) ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;
     s.up(s.frame, packed, fb);
-    must((codec == MBX_CODEC_IMBE7200X4400) ? mbx_fec_imbe7200x4400(s.frame, 1, s.rec, s.stream)
-                                            : mbx_fec_ambe3600x2450(s.frame, 1, s.rec, s.stream),
+    must((codec == MBX_CODEC_IMBE7200X4400)   ? mbx_fec_imbe7200x4400(s.frame, 1, s.rec, s.stream)
+         : (codec == MBX_CODEC_IMBE7100X4400) ? mbx_fec_imbe7100x4400(s.frame, 1, s.rec, s.stream)
+                                              : mbx_fec_ambe3600x2450(s.frame, 1, s.rec, s.stream),
          "mbx_fec");
     mbx_param_record rec;
     s.down(&rec, s.rec, sizeof(rec));
@@ -433,6 +436,59 @@ int mbe_hamming1511(const char* in, char* out) {
         out[j] = (char)((fixed >> j) & 1u);
     }
     return errs;
+}
+
+// ---- IMBE 7100x4400: ref src/ecc/ecc.c:422-464, src/imbe/imbe7100x4400.c:381-479, 527-592 -------
+int mbe_7100x4400hamming1511(const char* in, char* out) {
+    if (!out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_bits(in, 15u);
+    if (rc < 0) {
+        return rc;
+    }
+    uint32_t cw = 0, fixed;
+    for (int j = 14; j >= 0; --j) {
+        cw = (cw << 1) | (uint32_t)(in[j] & 1);
+    }
+    const int errs = ecc_word(2, cw, &fixed);
+    for (int j = 0; j < 15; ++j) {
+        out[j] = (char)((fixed >> j) & 1u);
+    }
+    return errs;
+}
+
+int mbe_decodeImbe7100x4400Frame(const char imbe_fr[7][24], char imbe_d[88], mbe_process_result* result) {
+    return decode_frame(MBX_CODEC_IMBE7100X4400, reinterpret_cast<const char*>(imbe_fr), 168, 88, imbe_d, result);
+}
+
+int mbe_processImbe7100x4400Framef(float* aout_buf, mbe_process_result* result, const char imbe_fr[7][24], char imbe_d[88],
+                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeImbe7100x4400Frame(imbe_fr, imbe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processImbe4400Dataf(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processImbe7100x4400Frame(short* aout_buf, mbe_process_result* result, const char imbe_fr[7][24], char imbe_d[88],
+                                  mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (!aout_buf) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeImbe7100x4400Frame(imbe_fr, imbe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processImbe4400Data(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 // ---- soft-decision helpers: ref src/core/mbelib.c:107-158, src/ecc/ecc.c:303-357, 410-413 -----

@@ -650,7 +650,7 @@ int mbx_state_copy(int S, mbe_parms* d_state, void* stream) {
 
 int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream) {
     REQUIRE_READY();
-    if (!d_in || !d_out || (kind != 0 && kind != 1)) {
+    if (!d_in || !d_out || kind < 0 || kind > 2) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     if (n == 0) {

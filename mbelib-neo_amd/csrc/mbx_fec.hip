@@ -327,7 +327,8 @@ floattoshort_kernel(const float* __restrict__ in, int16_t* __restrict__ out, siz
 }
 
 
-// Code-word level ECC (the public per-word helpers, batched): kind 0 = Golay(23,12), 1 = Hamming(15,11).
+// Code-word level ECC (the public per-word helpers, batched): kind 0 = Golay(23,12), 1 = Hamming(15,11),
+// 2 = Hamming(15,11) with the IMBE 7100x4400 bit mapping (mbe_7100x4400hamming1511, src/ecc/ecc.c:422-464).
 //   ref mbe_golay2312 / mbe_checkGolayBlock src/ecc/ecc.c:221-301, mbe_hamming1511 src/ecc/ecc.c:366-408
 __global__ void __launch_bounds__(256)
 ecc_words_kernel(int kind, const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ out, int32_t* __restrict__ errs,
@@ -337,7 +338,9 @@ ecc_words_kernel(int kind, const uint32_t* __restrict__ in, size_t n, uint32_t* 
         return;
     }
     uint32_t fixed;
-    const int e = (kind == 0) ? golay2312(tabs.t, in[i] & 0x7fffffu, fixed) : hamming1511(tabs.t, in[i] & 0x7fffu, fixed);
+    const int e = (kind == 0)   ? golay2312(tabs.t, in[i] & 0x7fffffu, fixed)
+                  : (kind == 1) ? hamming1511(tabs.t, in[i] & 0x7fffu, fixed)
+                                : hamming1511_7100(tabs.t, in[i] & 0x7fffu, fixed);
     out[i] = fixed;
     if (errs) {
         errs[i] = e;

@@ -45,6 +45,13 @@ def load():
     for name in ("mbe_decodeImbe7200x4400SoftFrame", "mbe_decodeAmbe3600x2450SoftFrame"):
         getattr(h, name).restype = C.c_int
         getattr(h, name).argtypes = [_vp] * 3
+    for name in ("mbe_processImbe7100x4400Framef", "mbe_processImbe7100x4400Frame"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 7
+    h.mbe_decodeImbe7100x4400Frame.restype = C.c_int
+    h.mbe_decodeImbe7100x4400Frame.argtypes = [_vp] * 3
+    h.mbe_7100x4400hamming1511.restype = C.c_int
+    h.mbe_7100x4400hamming1511.argtypes = [_vp, _vp]
     for name in ("mbe_golay2312Soft", "mbe_hamming1511Soft"):
         getattr(h, name).restype = C.c_int
         getattr(h, name).argtypes = [_vp, _vp]

@@ -431,3 +431,34 @@ def test_soft_process_stream_matches_reference(mbe):
         assert ret == row["ret"]
         assert res[0]["flags"] == row["result"]["flags"]
     parity.check_pcm(kat["pcmf"], pcm)
+
+
+# ---- IMBE 7100x4400 entry points ------------------------------------------------------------------
+def test_imbe7100_entry_points_match_reference_fixture(mbe):
+    kat = golden_io.imbe7100_kat()
+    for row in kat["hamming"][::257]:
+        cells = np.array([(int(row["inp"]) >> j) & 1 for j in range(15)], dtype=np.int8)
+        out = np.zeros(15, dtype=np.int8)
+        assert mbe.mbe_7100x4400hamming1511(p(cells), p(out)) == row["errs"]
+        assert sum(int(out[j]) << j for j in range(15)) == int(row["out"])
+    for row in kat["fec"][:48]:
+        bits = np.zeros(88, dtype=np.int8)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        cells = np.ascontiguousarray(row["cells"])
+        assert mbe.mbe_decodeImbe7100x4400Frame(p(cells), p(bits), p(res)) == row["ret"]
+        assert np.array_equal(bits, row["bits"])
+        assert res[0]["flags"] == row["result"]["flags"] and res[0]["c4_errors"] == row["result"]["c4_errors"]
+    st = kat["stream"][0]
+    cur, prev, enh = (np.zeros(1, dtype=PARMS_DTYPE) for _ in range(3))
+    mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))
+    mbe.mbe_setThreadRngSeed(1234)
+    T = len(st["frames"])
+    pcm = np.zeros((T, 160), dtype=np.float32)
+    for t, row in enumerate(st["frames"]):
+        bits = np.zeros(88, dtype=np.int8)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        cells = np.ascontiguousarray(row["cells"])
+        assert mbe.mbe_processImbe7100x4400Framef(p(pcm[t]), p(res), p(cells), p(bits), p(cur), p(prev), p(enh)) == row["ret"]
+        assert res[0]["flags"] == row["result"]["flags"]
+    parity.check_pcm(st["frames"]["pcmf"], pcm)
+    parity.check_state(st["final"].reshape(1), cur)
