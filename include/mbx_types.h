@@ -100,6 +100,7 @@ enum {
 /* soft-decision frames keep the reference's own array shapes: mbe_soft_bit[8][23] / [4][24] */
 #define MBX_IMBE_SOFT_BITS 184
 #define MBX_AMBE_SOFT_BITS 96
+#define MBX_IMBE7100_SOFT_BITS 168 /* mbe_soft_bit[7][24] */
 
 /* One decoded-parameter record per frame, produced by the FEC stage and consumed by the
  * stream stage: 88 (IMBE) or 49 (AMBE) parameter bits, bit i at word i/32, bit 31-(i%32);

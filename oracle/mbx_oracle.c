@@ -678,11 +678,15 @@ mbxo_golay2312_soft(const mbe_soft_bit* in, char* out) {
 }
 
 /* Hamming(15,11) code word of an 11-bit data word: data bit i sits at position pos[i], the four
- * parity positions are the unique values with a zero syndrome (src/ecc/ecc.c:133-155) */
+ * parity positions are the unique values with a zero syndrome (src/ecc/ecc.c:128-155).  variant7100
+ * selects the IMBE 7100x4400 bit mapping and generator. */
 static uint32_t
-hamming_encode(uint32_t data) {
-    static const int data_pos[11] = {2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14};
-    static const int parity_pos[4] = {0, 1, 3, 7};
+hamming_encode(uint32_t data, int variant7100) {
+    static const int std_data[11] = {2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14}, std_parity[4] = {0, 1, 3, 7};
+    static const int v71_data[11] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14}, v71_parity[4] = {0, 1, 2, 3};
+    const int* data_pos = variant7100 ? v71_data : std_data;
+    const int* parity_pos = variant7100 ? v71_parity : std_parity;
+    const uint16_t* gen = variant7100 ? T->hamming7100_gen : T->hamming_gen;
     uint32_t cw = 0;
     for (int i = 0; i < 11; ++i) {
         cw |= ((data >> i) & 1u) << data_pos[i];
@@ -694,7 +698,7 @@ hamming_encode(uint32_t data) {
         }
         int syndrome = 0;
         for (int i = 0; i < 4; ++i) {
-            syndrome |= (__builtin_popcount(c & T->hamming_gen[i]) & 1) << i;
+            syndrome |= (__builtin_popcount(c & gen[i]) & 1) << i;
         }
         if (syndrome == 0) {
             return c;
@@ -704,14 +708,18 @@ hamming_encode(uint32_t data) {
 }
 
 static int
-hamming1511_soft_word(const mbe_soft_bit* in, uint32_t* out) {
+hamming1511_soft_word(const mbe_soft_bit* in, uint32_t* out, int variant7100) {
     const uint32_t hard = soft_hard_word(in, 15);
     uint32_t hard_fixed;
-    (void)mbxo_hamming1511_word(hard, &hard_fixed);
+    if (variant7100) {
+        (void)mbxo_hamming1511_7100_word(hard, &hard_fixed);
+    } else {
+        (void)mbxo_hamming1511_word(hard, &hard_fixed);
+    }
     uint64_t best = ~(uint64_t)0;
     uint32_t best_cw = hard_fixed;
     for (uint32_t data = 0; data < 2048u; ++data) {
-        const uint32_t cw = hamming_encode(data);
+        const uint32_t cw = hamming_encode(data, variant7100);
         if (cw == 0xffffffffu) {
             continue;
         }
@@ -726,8 +734,8 @@ hamming1511_soft_word(const mbe_soft_bit* in, uint32_t* out) {
     return (best == ~(uint64_t)0) ? __builtin_popcount(best_cw ^ hard) : (int)((best >> 16) & 0xffu);
 }
 
-int
-mbxo_hamming1511_soft(const mbe_soft_bit* in, char* out) {
+static int
+hamming1511_soft_chars(const mbe_soft_bit* in, char* out, int variant7100) {
     if (!out) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -736,9 +744,19 @@ mbxo_hamming1511_soft(const mbe_soft_bit* in, char* out) {
         return rc;
     }
     uint32_t w;
-    int diffs = hamming1511_soft_word(in, &w);
+    int diffs = hamming1511_soft_word(in, &w, variant7100);
     word_to_chars(w, out, 15);
     return diffs;
+}
+
+int
+mbxo_hamming1511_7100_soft(const mbe_soft_bit* in, char* out) {
+    return hamming1511_soft_chars(in, out, 1);
+}
+
+int
+mbxo_hamming1511_soft(const mbe_soft_bit* in, char* out) {
+    return hamming1511_soft_chars(in, out, 0);
 }
 
 /* ref: src/imbe/imbe7200x4400.c:445-459 (C0), :675-707 (demod), :517-560 (data ECC), :746-778 */
@@ -766,7 +784,7 @@ mbxo_fec_imbe7200x4400_soft(const mbe_soft_bit fr[8][23], mbx_param_record* rec)
         at = rec_append(rec, at, row[r], 23, 12);
     }
     for (int r = 4; r < 7; ++r) {
-        int e = hamming1511_soft_word(work[r], &row[r]);
+        int e = hamming1511_soft_word(work[r], &row[r], 0);
         prot += e;
         if (r == 4) {
             c4 = e;
@@ -809,6 +827,91 @@ mbxo_fec_ambe3600x2450_soft(const mbe_soft_bit fr[4][24], mbx_param_record* rec)
     at = rec_append(rec, at, soft_hard_word(fr[3], 14), 14, 14);
     rec->w[3] = (uint32_t)c0 | ((uint32_t)prot << 8) | ((MBE_PROCESS_FLAG_SOFT_INPUT | MBE_PROCESS_FLAG_C0_VALID) << 24);
     return c0 + prot;
+}
+
+/* ref: src/imbe/imbe7100x4400.c:124-150 (C0: the five missing positions are certain zeros), :336-378
+ *      (demodulation), :214-274 (data ECC), :481-525 (frame decode) */
+int
+mbxo_fec_imbe7100x4400_soft(const mbe_soft_bit fr[7][24], mbx_param_record* rec) {
+    mbe_soft_bit blk[23];
+    for (int j = 0; j < 18; ++j) {
+        blk[j] = fr[0][j + 1];
+    }
+    for (int j = 18; j < 23; ++j) {
+        blk[j] = mbxo_soft_bit_from_hard(0, 255u);
+    }
+    uint32_t w;
+    int c0 = golay2312_soft_word(blk, &w);
+    uint32_t row0 = ((w & 0x3ffffu) << 1) | (uint32_t)(fr[0][0].bit & 1u);
+
+    uint8_t pr[101];
+    pr_bits((row0 >> 12) & 0x7fu, 100, pr);
+    mbe_soft_bit work[6][24];
+    int k = 1;
+    for (int r = 1; r < 6; ++r) {
+        for (int j = imbe7100_row_width[r] - 1; j >= 0; --j) {
+            work[r][j].bit = (uint8_t)((fr[r][j].bit & 1u) ^ pr[k++]);
+            work[r][j].reliability = fr[r][j].reliability;
+        }
+    }
+
+    char d[88];
+    int at = 0, prot = 0, c4 = 0;
+    for (int j = 18; j > 11; --j) {
+        d[at++] = (char)((row0 >> j) & 1u);
+    }
+    prot += golay2312_soft_word(&work[1][1], &w); /* C1: cells 1..23 */
+    for (int j = 22; j > 10; --j) {
+        d[at++] = (char)((w >> j) & 1u);
+    }
+    for (int r = 2; r < 4; ++r) {
+        prot += golay2312_soft_word(work[r], &w);
+        for (int j = 22; j > 10; --j) {
+            d[at++] = (char)((w >> j) & 1u);
+        }
+    }
+    for (int r = 4; r < 6; ++r) {
+        int e = hamming1511_soft_word(work[r], &w, 1);
+        prot += e;
+        if (r == 4) {
+            c4 = e;
+        }
+        for (int j = 14; j >= 4; --j) {
+            d[at++] = (char)((w >> j) & 1u);
+        }
+    }
+    for (int j = 22; j >= 0; --j) {
+        d[at++] = (char)(fr[6][j].bit & 1u);
+    }
+    mbxo_convert_imbe7100to7200(d);
+    memset(rec, 0, sizeof(*rec));
+    for (int i = 0; i < 88; ++i) {
+        rec_put(rec, i, d[i]);
+    }
+    rec->w[3] = (uint32_t)c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
+                | ((MBE_PROCESS_FLAG_SOFT_INPUT | MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24);
+    return c0 + prot;
+}
+
+int
+mbxo_decode_imbe7100x4400_soft_frame(const mbe_soft_bit fr[7][24], char imbe_d[88], mbe_process_result* result) {
+    if (result) {
+        memset(result, 0, sizeof(*result));
+    }
+    if (!imbe_d) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_soft(&fr[0][0], 7u * 24u);
+    if (rc < 0) {
+        return rc;
+    }
+    mbx_param_record rec;
+    int total = mbxo_fec_imbe7100x4400_soft(fr, &rec);
+    mbxo_record_to_bits(&rec, 88, imbe_d);
+    if (result) {
+        mbxo_record_to_result(&rec, result);
+    }
+    return total;
 }
 
 int
@@ -858,6 +961,8 @@ mbxo_fec_soft_batch(int codec, size_t n, const mbe_soft_bit* soft, mbx_param_rec
     for (size_t i = 0; i < n; ++i) {
         if (codec == MBX_CODEC_IMBE7200X4400) {
             mbxo_fec_imbe7200x4400_soft((const mbe_soft_bit(*)[23])(soft + i * MBX_IMBE_SOFT_BITS), &records[i]);
+        } else if (codec == MBX_CODEC_IMBE7100X4400) {
+            mbxo_fec_imbe7100x4400_soft((const mbe_soft_bit(*)[24])(soft + i * MBX_IMBE7100_SOFT_BITS), &records[i]);
         } else {
             mbxo_fec_ambe3600x2450_soft((const mbe_soft_bit(*)[24])(soft + i * MBX_AMBE_SOFT_BITS), &records[i]);
         }
@@ -2267,11 +2372,10 @@ process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_p
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     const int imbe = (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400);
-    if (soft && codec == MBX_CODEC_IMBE7100X4400) {
-        return MBE_STATUS_INVALID_ARGUMENT; /* soft 7100x4400 frames: not restated yet */
-    }
-    const size_t fb = soft ? (size_t)(imbe ? MBX_IMBE_SOFT_BITS : MBX_AMBE_SOFT_BITS) * sizeof(mbe_soft_bit)
-                           : (size_t)(imbe ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES);
+    const size_t cells = (codec == MBX_CODEC_IMBE7200X4400)   ? MBX_IMBE_SOFT_BITS
+                         : (codec == MBX_CODEC_IMBE7100X4400) ? MBX_IMBE7100_SOFT_BITS
+                                                              : MBX_AMBE_SOFT_BITS;
+    const size_t fb = soft ? cells * sizeof(mbe_soft_bit) : (size_t)(imbe ? MBX_IMBE_FRAME_BYTES : MBX_AMBE_FRAME_BYTES);
     for (int s = 0; s < S; ++s) {
         mbe_parms* cur = &state[3 * (size_t)s];
         mbe_parms* prev = cur + 1;
@@ -2284,7 +2388,9 @@ process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_p
             float pcm[160];
             char bits[88];
             if (imbe) {
-                if (soft) {
+                if (soft && codec == MBX_CODEC_IMBE7100X4400) {
+                    mbxo_fec_imbe7100x4400_soft((const mbe_soft_bit(*)[24])fr, &rec);
+                } else if (soft) {
                     mbxo_fec_imbe7200x4400_soft((const mbe_soft_bit(*)[23])fr, &rec);
                 } else if (codec == MBX_CODEC_IMBE7100X4400) {
                     mbxo_fec_imbe7100x4400(fr, &rec);

@@ -67,6 +67,9 @@ int mbxo_soft_bits_from_hard(const char* bits, mbe_soft_bit* soft, size_t count,
 int mbxo_soft_bits_from_llr(const int16_t* llr, mbe_soft_bit* soft, size_t count);
 int mbxo_golay2312_soft(const mbe_soft_bit* in, char* out);   /* returns data-bit differences, -1/-2 on bad input */
 int mbxo_hamming1511_soft(const mbe_soft_bit* in, char* out); /* returns bit differences */
+int mbxo_hamming1511_7100_soft(const mbe_soft_bit* in, char* out); /* 7100x4400 bit mapping, src/ecc/ecc.c:466-469 */
+int mbxo_fec_imbe7100x4400_soft(const mbe_soft_bit fr[7][24], mbx_param_record* rec); /* src/imbe/imbe7100x4400.c:124-150,214-274,336-378,481-525 */
+int mbxo_decode_imbe7100x4400_soft_frame(const mbe_soft_bit fr[7][24], char imbe_d[88], mbe_process_result* result);
 int mbxo_fec_imbe7200x4400_soft(const mbe_soft_bit fr[8][23], mbx_param_record* rec);
 int mbxo_fec_ambe3600x2450_soft(const mbe_soft_bit fr[4][24], mbx_param_record* rec);
 int mbxo_decode_imbe7200x4400_soft_frame(const mbe_soft_bit fr[8][23], char imbe_d[88], mbe_process_result* result);

@@ -43,6 +43,8 @@ extern int mbe_processImbe4400Dataf(float*, mbe_process_result*, const char[88],
 extern int mbe_7100x4400hamming1511(const char*, char*);
 extern int mbe_convertImbe7100to7200(char*);
 extern int mbe_decodeImbe7100x4400Frame(const char[7][24], char[88], mbe_process_result*);
+extern int mbe_7100x4400hamming1511Soft(const mbe_soft_bit*, char*);
+extern int mbe_decodeImbe7100x4400SoftFrame(const mbe_soft_bit[7][24], char[88], mbe_process_result*);
 extern int mbe_processImbe7100x4400Framef(float*, mbe_process_result*, const char[7][24], char[88], mbe_parms*, mbe_parms*,
                                           mbe_parms*);
 /* soft-decision front end: include/mbelib-neo/mbelib.h:208-224, 246, 260, 437-447, 513-523 */
@@ -798,6 +800,37 @@ gen_imbe7100(const char* dir) {
             W(f, out, sizeof(out));
         }
         W(f, &cur, sizeof(cur));
+    }
+    /* soft-decision 7100x4400: u32 NHS, NHS x { soft[15], char out[15], i32 ret }   mbe_7100x4400hamming1511Soft
+     *                           u32 NFS, NFS x { soft[7][24], char d[88], i32 ret, result(20) }  mbe_decodeImbe7100x4400SoftFrame */
+    n = 320;
+    W(f, &n, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        mbe_soft_bit sb[15];
+        char out[15];
+        soft_fill(sb, 15, (int)(i % 5u));
+        int32_t ret = mbe_7100x4400hamming1511Soft(sb, out);
+        W(f, sb, sizeof(sb));
+        W(f, out, 15);
+        W(f, &ret, 4);
+    }
+    n = 160;
+    W(f, &n, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        mbe_soft_bit fr[7][24];
+        char d[88];
+        mbe_process_result r;
+        soft_fill(&fr[0][0], 168, (int)(i % 5u));
+        if ((i % 5u) == 4u) {
+            soft_damage_golay(&fr[1][1]);
+            soft_damage_golay(&fr[2][0]);
+            soft_damage_golay(&fr[3][0]);
+        }
+        int32_t ret = mbe_decodeImbe7100x4400SoftFrame((const mbe_soft_bit(*)[24])fr, d, &r);
+        W(f, fr, sizeof(fr));
+        W(f, d, 88);
+        W(f, &ret, 4);
+        W(f, &r, sizeof(r));
     }
     fclose(f);
     printf("imbe7100_kat.bin written\n");

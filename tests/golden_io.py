@@ -162,5 +162,7 @@ def imbe7100_kat():
     per_stream = np.dtype([("frames", frame, (T,)), ("final", PARMS_DTYPE)])
     out["stream"] = b[off : off + S * per_stream.itemsize].view(per_stream)
     off += S * per_stream.itemsize
+    section("hamming_soft", np.dtype([("soft", "u1", (15, 2)), ("out", "i1", (15,)), ("ret", "<i4")]))
+    section("fec_soft", np.dtype([("soft", "u1", (168, 2)), ("bits", "i1", (88,)), ("ret", "<i4"), ("result", RESULT_DTYPE)]))
     assert off == b.size
     return out

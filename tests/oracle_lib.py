@@ -81,7 +81,9 @@ class Oracle:
         h.mbxo_decode_imbe7100x4400_frame.restype = C.c_int
         h.mbxo_decode_imbe7100x4400_frame.argtypes = [_vp, _vp, _vp]
         # soft-decision front end
-        for name in ("mbxo_golay2312_soft", "mbxo_hamming1511_soft"):
+        h.mbxo_decode_imbe7100x4400_soft_frame.restype = C.c_int
+        h.mbxo_decode_imbe7100x4400_soft_frame.argtypes = [_vp, _vp, _vp]
+        for name in ("mbxo_golay2312_soft", "mbxo_hamming1511_soft", "mbxo_hamming1511_7100_soft"):
             getattr(h, name).restype = C.c_int
             getattr(h, name).argtypes = [_vp, _vp]
         for name in ("mbxo_decode_imbe7200x4400_soft_frame", "mbxo_decode_ambe3600x2450_soft_frame"):
@@ -171,17 +173,19 @@ class Oracle:
         ret = self.h.mbxo_golay2312_soft(soft23.ctypes.data, out.ctypes.data)
         return out, ret
 
-    def hamming_soft(self, soft15):
+    def hamming_soft(self, soft15, variant7100=False):
         soft15 = np.ascontiguousarray(soft15, dtype=np.uint8)
         out = np.zeros(15, dtype=np.int8)
-        ret = self.h.mbxo_hamming1511_soft(soft15.ctypes.data, out.ctypes.data)
+        fn = self.h.mbxo_hamming1511_7100_soft if variant7100 else self.h.mbxo_hamming1511_soft
+        ret = fn(soft15.ctypes.data, out.ctypes.data)
         return out, ret
 
     def decode_soft_frame(self, codec, soft):
         soft = np.ascontiguousarray(soft, dtype=np.uint8)
-        d = np.zeros(88 if codec == 0 else 49, dtype=np.int8)
+        d = np.zeros(49 if codec == 1 else 88, dtype=np.int8)
         res = np.zeros(1, dtype=RESULT_DTYPE)
-        fn = self.h.mbxo_decode_imbe7200x4400_soft_frame if codec == 0 else self.h.mbxo_decode_ambe3600x2450_soft_frame
+        fn = {0: self.h.mbxo_decode_imbe7200x4400_soft_frame, 1: self.h.mbxo_decode_ambe3600x2450_soft_frame,
+              2: self.h.mbxo_decode_imbe7100x4400_soft_frame}[codec]
         ret = fn(soft.ctypes.data, d.ctypes.data, res.ctypes.data)
         return d, ret, res[0]
 

@@ -303,3 +303,18 @@ def test_imbe7100_stream_matches_reference(oracle):
     parity.check_results(ref["result"], out["results"])
     parity.check_pcm(ref["pcmf"], out["pcmf"], rel=2e-6, worst=2e-5)
     parity.check_state(st["final"], out["state"][:, 0])
+
+
+def test_imbe7100_soft_matches_reference(oracle):
+    kat = golden_io.imbe7100_kat()
+    for row in kat["hamming_soft"]:
+        out, ret = oracle.hamming_soft(row["soft"], variant7100=True)
+        assert ret == row["ret"] and np.array_equal(out, row["out"])
+    for row in kat["fec_soft"]:
+        bits, ret, res = oracle.decode_soft_frame(2, row["soft"])
+        assert ret == row["ret"]
+        assert np.array_equal(bits, row["bits"])
+        for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
+            assert res[name] == row["result"][name], name
+    rec = oracle.fec_soft_batch(2, kat["fec_soft"]["soft"])
+    assert np.array_equal(oracle_lib.records_to_bits(rec, 88), kat["fec_soft"]["bits"])
