@@ -66,6 +66,13 @@ int mbe_processImbe7100x4400Frame(short* aout_buf, mbe_process_result* result, c
                                   char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp,
                                   mbe_parms* prev_mp_enhanced);                           /* :568 */
 
+int mbe_7100x4400hamming1511Soft(const mbe_soft_bit* in, char* out);                      /* :274 */
+int mbe_decodeImbe7100x4400SoftFrame(const mbe_soft_bit imbe_fr[7][24], char imbe_d[88], mbe_process_result* result); /* :553 */
+int mbe_processImbe7100x4400SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[7][24],
+                                       char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced); /* :576 */
+int mbe_processImbe7100x4400SoftFrame(short* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[7][24],
+                                      char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced); /* :580 */
+
 /* soft-decision entry points */
 mbe_soft_bit mbe_softBitFromHard(int bit, uint8_t reliability);                           /* :208 */
 mbe_soft_bit mbe_softBitFromLlr(int16_t llr);                                             /* :214 */

@@ -89,7 +89,7 @@ struct Slot {
         HIP_OK(hipMalloc(&pcm16, 160 * sizeof(int16_t)));
         HIP_OK(hipMalloc(&res, sizeof(mbe_process_result)));
         HIP_OK(hipMalloc(&words, 4 * sizeof(uint32_t)));
-        HIP_OK(hipMalloc(&soft, MBX_IMBE_SOFT_BITS * sizeof(mbe_soft_bit)));
+        HIP_OK(hipMalloc(&soft, MBX_IMBE_SOFT_BITS * sizeof(mbe_soft_bit)));   // the largest soft frame (184 cells)
     }
     void up(void* dst, const void* src, size_t n) { HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream)); }
     void down(void* dst, const void* src, size_t n) { HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream)); }
@@ -289,7 +289,7 @@ int ecc_word(int kind, uint32_t in, uint32_t* out) {
 // soft-decision code word (kind 0: 23 soft bits, kind 1: 15): one-wave launch
 int ecc_soft_word(int kind, const mbe_soft_bit* in, uint32_t* out) {
     Slot& s = slot();
-    const size_t width = kind == 0 ? 23 : 15;
+    const size_t width = kind == 0 ? 23 : 15;   // kind 2: Hamming with the 7100x4400 mapping
     s.up(s.soft, in, width * sizeof(mbe_soft_bit));
     must(mbx_ecc_soft_words(kind, s.soft, 1, &s.words[1], reinterpret_cast<int32_t*>(&s.words[2]), s.stream), "mbx_ecc_soft_words");
     uint32_t back[2];
@@ -732,6 +732,56 @@ void mbe_synthesizeComfortNoise(short* aout_buf) {
     s.down(aout_buf, s.pcm16, 160 * sizeof(int16_t));
     s.down(&t_rng.r, s.rng, sizeof(mbx_stream_rng));
     s.sync();
+}
+
+// ---- soft IMBE 7100x4400: ref src/ecc/ecc.c:466-469, src/imbe/imbe7100x4400.c:481-525, 542-576 -------------
+int mbe_7100x4400hamming1511Soft(const mbe_soft_bit* in, char* out) {
+    if (!out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = mbx_validate_soft_bits(in, 15u);
+    if (rc < 0) {
+        return rc;
+    }
+    uint32_t w;
+    const int diffs = ecc_soft_word(2, in, &w);
+    for (int j = 0; j < 15; ++j) {
+        out[j] = (char)((w >> j) & 1u);
+    }
+    return diffs;
+}
+
+int mbe_decodeImbe7100x4400SoftFrame(const mbe_soft_bit imbe_fr[7][24], char imbe_d[88], mbe_process_result* result) {
+    return decode_soft_frame(MBX_CODEC_IMBE7100X4400, reinterpret_cast<const mbe_soft_bit*>(imbe_fr), 168, 88, imbe_d, result);
+}
+
+int mbe_processImbe7100x4400SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[7][24],
+                                       char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeImbe7100x4400SoftFrame(imbe_fr, imbe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processImbe4400Dataf(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processImbe7100x4400SoftFrame(short* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[7][24],
+                                      char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (!aout_buf) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeImbe7100x4400SoftFrame(imbe_fr, imbe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processImbe4400Data(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 // ---- soft frames -> PCM: ref src/imbe/imbe7200x4400.c:950-980, src/ambe/ambe3600x2450.c:939-969 --------

@@ -33,6 +33,7 @@ __global__ void state_copy_kernel(int, mbe_parms*);
 __global__ void ecc_words_kernel(int, const uint32_t*, size_t, uint32_t*, int32_t*, DeviceTables);
 __global__ void fec_imbe7200x4400_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
 __global__ void fec_ambe3600x2450_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
+__global__ void fec_imbe7100x4400_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
 __global__ void ecc_soft_words_kernel(int, const mbe_soft_bit*, size_t, uint32_t*, int32_t*, DeviceTables);
 }  // namespace mbx
 
@@ -188,30 +189,34 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
             a = (173u * a + 13849u) & 0xffffu;
         }
     }
-    for (int i = 0; i < 11; ++i) {
-        // code word of data bit i: data bits at positions {2,4,5,6,8..14}, parity at {0,1,3,7} chosen
-        // for a zero syndrome (ref src/ecc/ecc.c:128-155)
-        static const int data_pos[11] = {2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14};
-        static const int parity_pos[4] = {0, 1, 3, 7};
-        uint32_t found = 0xffffffffu;
-        for (uint32_t p = 0; p < 16u && found == 0xffffffffu; ++p) {
-            uint32_t c = 1u << data_pos[i];
-            for (int q = 0; q < 4; ++q) {
-                c |= ((p >> q) & 1u) << parity_pos[q];
+    for (int variant = 0; variant < 2; ++variant) {
+        // code word of data bit i: data bits at positions {2,4,5,6,8..14} (7100x4400 mapping: {4..14}), parity
+        // at {0,1,3,7} ({0,1,2,3}) chosen for a zero syndrome (ref src/ecc/ecc.c:128-155)
+        static const int data_pos[2][11] = {{2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14}, {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14}};
+        static const int parity_pos[2][4] = {{0, 1, 3, 7}, {0, 1, 2, 3}};
+        const uint16_t* gen = variant ? host->hamming7100_gen : host->hamming_gen;
+        for (int i = 0; i < 11; ++i) {
+            uint32_t found = 0xffffffffu;
+            for (uint32_t p = 0; p < 16u && found == 0xffffffffu; ++p) {
+                uint32_t c = 1u << data_pos[variant][i];
+                for (int q = 0; q < 4; ++q) {
+                    c |= ((p >> q) & 1u) << parity_pos[variant][q];
+                }
+                int syndrome = 0;
+                for (int q = 0; q < 4; ++q) {
+                    syndrome |= (__builtin_popcount(c & gen[q]) & 1) << q;
+                }
+                if (syndrome == 0) {
+                    found = c;
+                }
             }
-            int syndrome = 0;
-            for (int q = 0; q < 4; ++q) {
-                syndrome |= (__builtin_popcount(c & host->hamming_gen[q]) & 1) << q;
+            if (found == 0xffffffffu) {
+                return fail(MBX_EBADTABLE, "mbx_init: Hamming generator rows admit no code word for a data bit");
             }
-            if (syndrome == 0) {
-                found = c;
-            }
+            (variant ? d.ham7100_basis : d.ham_basis)[i] = found;
         }
-        if (found == 0xffffffffu) {
-            return fail(MBX_EBADTABLE, "mbx_init: Hamming generator rows admit no code word for a data bit");
-        }
-        d.ham_basis[i] = found;
     }
+
     HIP_TRY(hipMalloc(&g_ctx.d_blob, sizeof(mbx_tables)));
     HIP_TRY(hipMalloc(&g_ctx.d_derived, sizeof(mbx::DerivedTables)));
     HIP_TRY(hipMemcpy(g_ctx.d_blob, table_blob, sizeof(mbx_tables), hipMemcpyHostToDevice));
@@ -381,7 +386,7 @@ int mbx_fec_imbe7100x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d
 
 int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft, size_t n, mbx_param_record* d_records, void* stream) {
     REQUIRE_READY();
-    if (!d_soft || !d_records || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450)) {
+    if (!d_soft || !d_records || codec < MBX_CODEC_IMBE7200X4400 || codec > MBX_CODEC_IMBE7100X4400) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     if (n == 0) {
@@ -393,6 +398,9 @@ int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft, size_t n, mbx_param_reco
     if (codec == MBX_CODEC_IMBE7200X4400) {   // one wavefront per frame
         hipLaunchKernelGGL(mbx::fec_imbe7200x4400_soft_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_soft, n,
                            d_records, g_ctx.tabs);
+    } else if (codec == MBX_CODEC_IMBE7100X4400) {
+        hipLaunchKernelGGL(mbx::fec_imbe7100x4400_soft_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_soft, n,
+                           d_records, g_ctx.tabs);
     } else {
         hipLaunchKernelGGL(mbx::fec_ambe3600x2450_soft_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_soft, n,
                            d_records, g_ctx.tabs);
@@ -402,7 +410,7 @@ int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft, size_t n, mbx_param_reco
 
 int mbx_ecc_soft_words(int kind, const mbe_soft_bit* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream) {
     REQUIRE_READY();
-    if (!d_in || !d_out || (kind != 0 && kind != 1) || n > 0x7fffffffu) {
+    if (!d_in || !d_out || kind < 0 || kind > 2 || n > 0x7fffffffu) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     if (n == 0) {
@@ -568,6 +576,9 @@ int mbx_process_batch_soft(int codec, int S, int T, const mbe_soft_bit* d_soft, 
     if (rc < 0) {
         return rc;
     }
+    if (codec == MBX_CODEC_IMBE7100X4400) {   // the records are in 7200x4400 order
+        codec = MBX_CODEC_IMBE7200X4400;
+    }
     return mbx_process_records(codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
 }
 
@@ -691,6 +702,10 @@ int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* r
     return 0;
 }
 
+static size_t soft_cells(int codec) {
+    return codec == MBX_CODEC_IMBE7200X4400 ? MBX_IMBE_SOFT_BITS : (codec == MBX_CODEC_IMBE7100X4400 ? MBX_IMBE7100_SOFT_BITS : MBX_AMBE_SOFT_BITS);
+}
+
 // frames in (hard: packed bytes, soft: mbe_soft_bit arrays), everything else as mbx_process_batch
 static int process_batch_host_impl(int codec, int S, int T, const void* frames, size_t frame_bytes, bool soft, mbe_parms* state,
                                    mbx_stream_rng* rng, int16_t* pcm16, float* pcmf, mbe_process_result* results,
@@ -750,7 +765,7 @@ int mbx_process_batch_soft_host(int codec, int S, int T, const mbe_soft_bit* sof
     if (!soft || !state || !rng || S < 0 || T < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const size_t cells = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_SOFT_BITS : MBX_AMBE_SOFT_BITS;
+    const size_t cells = soft_cells(codec);
     int rc = mbx_validate_soft_bits(soft, (size_t)S * (size_t)T * cells);
     if (rc < 0) {
         return rc;
@@ -764,7 +779,7 @@ int mbx_fec_soft_host(int codec, const mbe_soft_bit* soft, size_t n, mbx_param_r
     if (!soft || !records) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const size_t cells = (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_SOFT_BITS : MBX_AMBE_SOFT_BITS;
+    const size_t cells = soft_cells(codec);
     int rc = mbx_validate_soft_bits(soft, n * cells);
     if (rc < 0) {
         return rc;
@@ -783,7 +798,7 @@ int mbx_fec_soft_host(int codec, const mbe_soft_bit* soft, size_t n, mbx_param_r
 
 int mbx_ecc_soft_words_host(int kind, const mbe_soft_bit* in, size_t n, uint32_t* out, int32_t* errs) {
     REQUIRE_READY();
-    if (!in || !out || (kind != 0 && kind != 1)) {
+    if (!in || !out || kind < 0 || kind > 2) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     const size_t width = kind == 0 ? 23 : 15;

@@ -21,6 +21,7 @@ struct DerivedTables {
     uint32_t pr_mul[116];     // 173^k mod 2^16             (demodulation sequence jump-ahead, k = 0..115)
     uint32_t pr_add[116];     // additive term after k steps
     uint32_t ham_basis[11];   // Hamming(15,11) code word of data bit i (soft-decision candidates)
+    uint32_t ham7100_basis[11];   // the same for the IMBE 7100x4400 bit mapping
 };
 
 // Output of the expand stage, input of the stream stage: 64 dwords per frame (layout in mbx_expand.hip).

@@ -461,11 +461,17 @@ __device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int rel_
 // Soft Hamming(15,11): returns the chosen code word, `diffs` = differing bits over all 15 positions.
 // Data bit i sits at cell kHamData[i], parity bit q at cell kHamParity[q] (ecc.c:128-131).
 // Key: cost << 16 | !matches_hard << 15 | differing bits << 11 | data.
+template <bool k7100>   // k7100: the IMBE 7100x4400 bit mapping (data at cells 4..14, parity at 0..3), ecc.c:130-131
 __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, int rel_lane, SoftScratch& S, int lane, int& diffs) {
-    constexpr int kHamData[11] = {2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14};
-    constexpr int kHamParity[4] = {0, 1, 3, 7};
+    constexpr int kHamData[11] = {k7100 ? 4 : 2, k7100 ? 5 : 4, k7100 ? 6 : 5, k7100 ? 7 : 6, 8, 9, 10, 11, 12, 13, 14};
+    constexpr int kHamParity[4] = {0, 1, k7100 ? 2 : 3, k7100 ? 3 : 7};
+    const uint32_t* basis = k7100 ? tabs.d->ham7100_basis : tabs.d->ham_basis;
     uint32_t hard_fixed;
-    (void)hamming1511(tabs.t, hard, hard_fixed);
+    if (k7100) {
+        (void)hamming1511_7100(tabs.t, hard, hard_fixed);
+    } else {
+        (void)hamming1511(tabs.t, hard, hard_fixed);
+    }
     const uint32_t rel = (uint32_t)rel_lane;
     auto gather_data = [&](uint32_t cw) {
         uint32_t d = 0;
@@ -488,12 +494,12 @@ __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, i
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
         const uint32_t bit = (uint32_t)(lane >> b) & 1u;
-        const uint32_t plo = gather_parity(tabs.d->ham_basis[b]);
+        const uint32_t plo = gather_parity(basis[b]);
         par_lo ^= bit ? plo : 0u;
         par_hd ^= ((hd >> b) & 1u) ? plo : 0u;
         a_lo += bit ? rl(rel, kHamData[b]) : 0u;
         if (b < 5) {
-            const uint32_t phi = gather_parity(tabs.d->ham_basis[6 + b]);
+            const uint32_t phi = gather_parity(basis[6 + b]);
             par_hi ^= bit ? phi : 0u;
             par_hd ^= ((hd >> (b + 6)) & 1u) ? phi : 0u;
             a_hi += bit ? rl(rel, kHamData[6 + b]) : 0u;
@@ -534,7 +540,7 @@ __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, i
     uint32_t cw = 0;
 #pragma unroll
     for (int b = 0; b < 11; ++b) {
-        cw ^= ((data >> b) & 1u) ? tabs.d->ham_basis[b] : 0u;
+        cw ^= ((data >> b) & 1u) ? basis[b] : 0u;
     }
     return cw;
 }
@@ -601,7 +607,7 @@ fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
 #pragma unroll 1
     for (int r = 4; r < 7; ++r) {
         const uint32_t hard = soft_block(S, tabs, 23 * r, 15, k, x0, lane, rel);
-        row[r] = hamming_soft_wave(tabs, hard, rel, S, lane, diffs);
+        row[r] = hamming_soft_wave<false>(tabs, hard, rel, S, lane, diffs);
         prot += diffs;
         if (r == 4) {
             c4 = diffs;
@@ -665,7 +671,96 @@ fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     }
 }
 
-// Code-word level soft ECC, batched: kind 0 = Golay (23 soft bits per block), 1 = Hamming (15).
+// IMBE 7100x4400 soft frames, mbe_soft_bit[7][24] (ref src/imbe/imbe7100x4400.c:124-150, 214-274, 336-378, 481-525):
+// C0 = cells 1..18 of row 0 completed by five certain zeros, 7-bit demodulation seed, C1 = cells 1..23 of
+// row 1, the 7100 Hamming mapping on rows 4/5, then mbe_convertImbe7100to7200.
+__global__ void __launch_bounds__(64)
+fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, mbx_param_record* __restrict__ out,
+                              DeviceTables tabs) {
+    __shared__ SoftScratch S;
+    const size_t i = blockIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const int lane = lane_id();
+    load_soft_cells(S, soft + i * MBX_IMBE7100_SOFT_BITS, MBX_IMBE7100_SOFT_BITS, lane);
+    // C0 is cells 1..18 of row 0 completed by five certain zeros, mbe_softBitFromHard(0, 255): they go into
+    // the (unused) cells 19..23 of the row, so the block is simply cells 1..23
+    if (lane >= 19 && lane < 24) {
+        S.cell[lane] = 255u << 8;
+    }
+    wave_lds_sync();
+    int rel, diffs;
+    uint32_t hard = soft_block(S, tabs, 1, 23, 0, 0u, lane, rel);
+    uint32_t w = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    const int c0 = diffs;
+    const uint32_t row0 = ((w & 0x3ffffu) << 1) | (S.cell[0] & 1u);
+    const uint32_t x0 = (16u * ((row0 >> 12) & 0x7fu)) & 0xffffu;
+    // demodulation bit numbers: row 1 (24 cells) uses 1..24 with cell j <- 1 + (23 - j); its Golay block is
+    // cells 1..23, i.e. a 23-wide block whose cell c uses number 1 + (22 - c)
+    int prot = 0, c4 = 0;
+    Bits88 d;
+    int at = 0;
+    auto push = [&](uint32_t value, int width, int count) {   // top `count` bits of a `width`-bit value
+        for (int q = 0; q < count; ++q) {
+            d.put(at++, (int)((value >> (width - 1 - q)) & 1u));
+        }
+    };
+    push(row0 >> 12, 7, 7);
+    hard = soft_block(S, tabs, 24 + 1, 23, 1, x0, lane, rel);
+    w = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    prot += diffs;
+    push(w, 23, 12);
+    int k = 25;
+#pragma unroll 1
+    for (int r = 2; r < 4; ++r) {
+        hard = soft_block(S, tabs, 24 * r, 23, k, x0, lane, rel);
+        w = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+        prot += diffs;
+        push(w, 23, 12);
+        k += 23;
+    }
+#pragma unroll 1
+    for (int r = 4; r < 6; ++r) {
+        hard = soft_block(S, tabs, 24 * r, 15, k, x0, lane, rel);
+        w = hamming_soft_wave<true>(tabs, hard, rel, S, lane, diffs);
+        prot += diffs;
+        if (r == 4) {
+            c4 = diffs;
+        }
+        push(w, 15, 11);
+        k += 15;
+    }
+    push(soft_block(S, tabs, 24 * 6, 23, 0, 0u, lane, rel), 23, 23);
+    if (lane == 0) {
+        Bits88 t;
+        const int b0 = (int)(((d.hi >> 56) & 0x7eull) << 1) | (d.get(86) << 1) | d.get(87);
+        const int K = (b0 < 208) ? (int)tabs.t->imbe_K[b0] : 12;
+        t.put(87, d.get(0));
+        t.put(48 + K, d.get(42));
+        t.put(49 + K, d.get(43));
+        for (int q = 0; q < K; ++q) {
+            t.put(48 + q, d.get(44 + q));
+        }
+        int j = 0, kk = 1;
+        while (j < 87) {
+            t.put(j, d.get(kk));
+            if (++j == 48) {
+                j += K + 2;
+            }
+            if (++kk == 42) {
+                kk += K + 2;
+            }
+        }
+        *reinterpret_cast<uint4*>(&out[i]) =
+            make_uint4((uint32_t)(t.hi >> 32), (uint32_t)t.hi, (uint32_t)(t.lo >> 32),
+                       (uint32_t)c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
+                           | ((MBE_PROCESS_FLAG_SOFT_INPUT | MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24));
+    }
+}
+
+// Code-word level soft ECC, batched: kind 0 = Golay (23 soft bits per block), 1 = Hamming (15), 2 = Hamming
+// with the IMBE 7100x4400 bit mapping (mbe_7100x4400hamming1511Soft).
 // out = corrected word in the cell order of the hard helpers, errs = the reference's return value.
 __global__ void __launch_bounds__(64)
 ecc_soft_words_kernel(int kind, const mbe_soft_bit* __restrict__ in, size_t n, uint32_t* __restrict__ out, int32_t* __restrict__ errs,
@@ -680,7 +775,9 @@ ecc_soft_words_kernel(int kind, const mbe_soft_bit* __restrict__ in, size_t n, u
     load_soft_cells(S, in + i * (size_t)width, width, lane);
     int rel, diffs;
     const uint32_t hard = soft_block(S, tabs, 0, width, 0, 0u, lane, rel);
-    const uint32_t w = (kind == 0) ? golay_soft_wave(tabs.t, hard, rel, S, lane, diffs) : hamming_soft_wave(tabs, hard, rel, S, lane, diffs);
+    const uint32_t w = (kind == 0)   ? golay_soft_wave(tabs.t, hard, rel, S, lane, diffs)
+                       : (kind == 1) ? hamming_soft_wave<false>(tabs, hard, rel, S, lane, diffs)
+                                     : hamming_soft_wave<true>(tabs, hard, rel, S, lane, diffs);
     if (lane == 0) {
         out[i] = w;
         if (errs) {

@@ -178,7 +178,7 @@ def process_batch_host(codec, S, T, frames, state, rng, device=0):
 
 
 # ---- soft-decision front end (mbe_soft_bit arrays: uint8 [..., 2] = (bit, reliability)) ------------
-SOFT_CELLS = {0: 184, 1: 96}
+SOFT_CELLS = {0: 184, 1: 96, 2: 168}
 
 
 def _soft_array(codec, soft, n):
@@ -219,7 +219,8 @@ def process_batch_soft_host(codec, S, T, soft, state, rng, device=0):
 
 
 def ecc_soft_words_host(kind, soft, device=0):
-    """mbe_golay2312Soft (kind 0, soft [n, 23, 2]) / mbe_hamming1511Soft (kind 1, soft [n, 15, 2]):
+    """mbe_golay2312Soft (kind 0, soft [n, 23, 2]) / mbe_hamming1511Soft (kind 1, soft [n, 15, 2]) /
+    mbe_7100x4400hamming1511Soft (kind 2):
     returns (corrected words, return values)."""
     ensure_init(device)
     width = 23 if kind == 0 else 15

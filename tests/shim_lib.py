@@ -52,7 +52,12 @@ def load():
     h.mbe_decodeImbe7100x4400Frame.argtypes = [_vp] * 3
     h.mbe_7100x4400hamming1511.restype = C.c_int
     h.mbe_7100x4400hamming1511.argtypes = [_vp, _vp]
-    for name in ("mbe_golay2312Soft", "mbe_hamming1511Soft"):
+    for name in ("mbe_processImbe7100x4400SoftFramef", "mbe_processImbe7100x4400SoftFrame"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 7
+    h.mbe_decodeImbe7100x4400SoftFrame.restype = C.c_int
+    h.mbe_decodeImbe7100x4400SoftFrame.argtypes = [_vp] * 3
+    for name in ("mbe_golay2312Soft", "mbe_hamming1511Soft", "mbe_7100x4400hamming1511Soft"):
         getattr(h, name).restype = C.c_int
         getattr(h, name).argtypes = [_vp, _vp]
     h.mbe_softBitsFromLlr.restype = C.c_int

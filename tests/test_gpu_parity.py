@@ -367,3 +367,19 @@ def test_imbe7100_stream_matches_reference_and_oracle(mbx, oracle):
     parity.check_results(ref["results"], got["results"])
     parity.check_pcm(ref["pcmf"], got["pcmf"], ref["pcm16"], got["pcm16"])
     parity.check_state(ref["state"], got["state"])
+
+
+def test_imbe7100_soft_matches_reference_and_oracle(mbx, oracle):
+    from mbelib_neo_amd import decoder, framegen
+
+    kat = golden_io.imbe7100_kat()
+    words, errs = decoder.ecc_soft_words_host(2, kat["hamming_soft"]["soft"])
+    expect = (kat["hamming_soft"]["out"].astype(np.uint32) << np.arange(15, dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+    assert np.array_equal(words, expect) and np.array_equal(errs, kat["hamming_soft"]["ret"])
+    rec = decoder.fec_soft_host(2, kat["fec_soft"]["soft"])
+    assert np.array_equal(oracle_lib.records_to_bits(rec, 88), kat["fec_soft"]["bits"])
+    res = oracle_lib.records_to_results(rec)
+    for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
+        assert np.array_equal(res[name], kat["fec_soft"]["result"][name]), name
+    soft = framegen.soft_frames(2, 2048, framegen.rng_for(7120))
+    assert np.array_equal(decoder.fec_soft_host(2, soft)["w"], oracle.fec_soft_batch(2, soft)["w"])

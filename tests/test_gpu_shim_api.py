@@ -462,3 +462,18 @@ def test_imbe7100_entry_points_match_reference_fixture(mbe):
         assert res[0]["flags"] == row["result"]["flags"]
     parity.check_pcm(st["frames"]["pcmf"], pcm)
     parity.check_state(st["final"].reshape(1), cur)
+
+
+def test_imbe7100_soft_entry_points(mbe):
+    kat = golden_io.imbe7100_kat()
+    for row in kat["hamming_soft"][:50]:
+        out = np.zeros(15, dtype=np.int8)
+        soft = np.ascontiguousarray(row["soft"])
+        assert mbe.mbe_7100x4400hamming1511Soft(p(soft), p(out)) == row["ret"]
+        assert np.array_equal(out, row["out"])
+    for row in kat["fec_soft"][:40]:
+        bits = np.zeros(88, dtype=np.int8)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        soft = np.ascontiguousarray(row["soft"])
+        assert mbe.mbe_decodeImbe7100x4400SoftFrame(p(soft), p(bits), p(res)) == row["ret"]
+        assert np.array_equal(bits, row["bits"]) and res[0]["flags"] == row["result"]["flags"]
