@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define MBX_TABLES_MAGIC   0x3154584Du /* "MXT1" */
-#define MBX_TABLES_VERSION 3u
+#define MBX_TABLES_VERSION 4u
 
 typedef struct mbx_tables {
     uint32_t magic;
@@ -76,6 +76,19 @@ typedef struct mbx_tables {
     /* ---- IMBE 7100x4400 (§8(f) row 4): its own Hamming(15,11) bit mapping, ref src/ecc/ecc.c:422-464 ---- */
     uint16_t hamming7100_gen[4];   /* parity-check row masks                              */
     uint16_t hamming7100_fix[16];  /* syndrome -> single-bit flip mask                    */
+
+    /* ---- AMBE 3600x2400 parameter decode (§8(f) row 4), ref src/internal/ambe3600x2400_const.h.
+     *      The 8-point / per-block DCT cosines are those of AMBE+2 (ambe_ri_cos, ambe_idct_cos). ---- */
+    float    ambep_dg[64];
+    float    ambep_prba24[512][3];
+    float    ambep_prba58[128][4];
+    float    ambep_hoc_b5[16][4];
+    float    ambep_hoc_b6[16][4];
+    float    ambep_hoc_b7[16][4];
+    float    ambep_hoc_b8[16][4];
+    uint8_t  ambep_L[128];         /* b0 -> L (b0 <= 125)                                   */
+    uint8_t  ambep_vuv[16][8];
+    uint8_t  ambep_lmprbl[57][4];
     uint8_t  pad_[4];
 } mbx_tables;
 

@@ -87,7 +87,8 @@ typedef struct mbe_soft_bit {
 enum {
     MBX_CODEC_IMBE7200X4400 = 0,
     MBX_CODEC_AMBE3600X2450 = 1,
-    MBX_CODEC_IMBE7100X4400 = 2 /* own FEC/demodulation front end, then the 7200x4400 path */
+    MBX_CODEC_IMBE7100X4400 = 2, /* own FEC/demodulation front end, then the 7200x4400 path */
+    MBX_CODEC_AMBE3600X2400 = 3  /* D-STAR: the AMBE FEC front end of 3600x2450, its own parameter decode and frame policy */
 };
 
 /* Channel-frame wire size handed to the launcher: the 0/1 chars of the reference's

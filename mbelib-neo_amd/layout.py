@@ -8,13 +8,15 @@ import numpy as np
 CODEC_IMBE7200X4400 = 0
 CODEC_AMBE3600X2450 = 1
 CODEC_IMBE7100X4400 = 2  # own FEC / demodulation front end, then the 7200x4400 path
-FRAME_BYTES = {CODEC_IMBE7200X4400: 18, CODEC_AMBE3600X2450: 9, CODEC_IMBE7100X4400: 18}
-PARAM_BITS = {CODEC_IMBE7200X4400: 88, CODEC_AMBE3600X2450: 49, CODEC_IMBE7100X4400: 88}
-FRAME_CELLS = {CODEC_IMBE7200X4400: (8, 23), CODEC_AMBE3600X2450: (4, 24), CODEC_IMBE7100X4400: (7, 24)}
+CODEC_AMBE3600X2400 = 3  # D-STAR: the AMBE FEC front end, its own parameter decode and frame policy
+FRAME_BYTES = {CODEC_IMBE7200X4400: 18, CODEC_AMBE3600X2450: 9, CODEC_IMBE7100X4400: 18, CODEC_AMBE3600X2400: 9}
+PARAM_BITS = {CODEC_IMBE7200X4400: 88, CODEC_AMBE3600X2450: 49, CODEC_IMBE7100X4400: 88, CODEC_AMBE3600X2400: 49}
+FRAME_CELLS = {CODEC_IMBE7200X4400: (8, 23), CODEC_AMBE3600X2450: (4, 24), CODEC_IMBE7100X4400: (7, 24), CODEC_AMBE3600X2400: (4, 24)}
 ROW_WIDTHS = {
     CODEC_IMBE7200X4400: (23, 23, 23, 23, 15, 15, 15, 7),
     CODEC_AMBE3600X2450: (24, 23, 11, 14),
     CODEC_IMBE7100X4400: (19, 24, 23, 23, 15, 15, 23),
+    CODEC_AMBE3600X2400: (24, 23, 11, 14),
 }
 
 FLAG_SOFT_INPUT = 0x01
@@ -176,5 +178,15 @@ def table_views(blob):
     take("wola_denom", "<f4", (160,))
     take("hamming7100_gen", "<u2", (4,))
     take("hamming7100_fix", "<u2", (16,))
+    take("ambep_dg", "<f4", (64,))
+    take("ambep_prba24", "<f4", (512, 3))
+    take("ambep_prba58", "<f4", (128, 4))
+    take("ambep_hoc_b5", "<f4", (16, 4))
+    take("ambep_hoc_b6", "<f4", (16, 4))
+    take("ambep_hoc_b7", "<f4", (16, 4))
+    take("ambep_hoc_b8", "<f4", (16, 4))
+    take("ambep_L", "u1", (128,))
+    take("ambep_vuv", "u1", (16, 8))
+    take("ambep_lmprbl", "u1", (57, 4))
     assert off + 4 == len(b), (off, len(b))
     return out

@@ -1579,6 +1579,156 @@ mbxo_decode_ambe2450_parms(const char* d, mbe_parms* cur, mbe_parms* prev, int t
 }
 
 /* =====================================================================================
+ * AMBE 3600x2400 (D-STAR) parameter decode  ref: src/ambe/ambe3600x2400.c:164-551
+ * Returns 0 voice, 3 tone-class frame without a usable index (a silence model may have been set),
+ * or the tone index 5..122.
+ * ===================================================================================== */
+int
+mbxo_decode_ambe2400_parms(const char* d, mbe_parms* cur, mbe_parms* prev) {
+    if (!cur || !prev) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_bits(d, 49u);
+    if (rc < 0) {
+        return rc;
+    }
+    static const int ib0[7] = {0, 1, 2, 3, 4, 5, 48};
+    const int b0 = bits_msb(d, ib0, 7);
+    int L = 0;
+
+    if ((b0 & 0x7E) == 0x7E) { /* tone class (:212-234) */
+        static const int t7[8] = {1, 0, 0, 0, 0, 1, 1, 1}, t6[8] = {0, 0, 0, 1, 1, 1, 1, 0}, t5[8] = {0, 0, 1, 0, 1, 1, 0, 1};
+        const int def = (d[6] << 2) | (d[7] << 1) | d[8];
+        const int tone = (t7[def] << 7) | (t6[def] << 6) | (t5[def] << 5) | (d[9] << 4) | (d[42] << 3) | (d[43] << 2)
+                         | (d[10] << 1) | d[11];
+        if (tone >= 5 && tone <= 122) {
+            return tone;
+        }
+        if (!(tone >= 128 && tone <= 163)) { /* silence model (:202-210) */
+            cur->w0 = ((float)2 * M_PI) / (float)32;
+            cur->L = 14;
+            for (int l = 1; l <= 14; ++l) {
+                cur->Vl[l] = 0;
+            }
+        }
+        return 3;
+    }
+
+    const float f0 = exp2f(-4.311767578125f - (2.1336e-2f * ((float)b0 + 0.5f)));
+    cur->w0 = f0 * (float)2 * M_PI;
+    L = T->ambep_L[b0];
+    cur->L = L;
+    const float unvc = (float)0.2046 / sqrtf(cur->w0);
+
+    static const int ib1[4] = {38, 39, 40, 41};
+    const int b1 = bits_msb(d, ib1, 4);
+    for (int l = 1; l <= L; ++l) {
+        int jl = (int)((float)l * (float)16.0 * f0);
+        cur->Vl[l] = T->ambep_vuv[b1][jl];
+    }
+
+    static const int ib2[6] = {6, 7, 8, 9, 42, 43};
+    cur->gamma = T->ambep_dg[bits_msb(d, ib2, 6)] + ((float)0.5 * prev->gamma);
+
+    static const int ib3[9] = {10, 11, 12, 13, 14, 15, 16, 44, 45};
+    static const int ib4[7] = {17, 18, 19, 20, 21, 46, 47};
+    const int b3 = bits_msb(d, ib3, 9), b4 = bits_msb(d, ib4, 7);
+    float Gm[9];
+    Gm[1] = 0;
+    Gm[2] = T->ambep_prba24[b3][0];
+    Gm[3] = T->ambep_prba24[b3][1];
+    Gm[4] = T->ambep_prba24[b3][2];
+    Gm[5] = T->ambep_prba58[b4][0];
+    Gm[6] = T->ambep_prba58[b4][1];
+    Gm[7] = T->ambep_prba58[b4][2];
+    Gm[8] = T->ambep_prba58[b4][3];
+    float Ri[9];
+    for (int i = 1; i <= 8; ++i) {
+        float sum = 0;
+        for (int m = 1; m <= 8; ++m) {
+            int am = (m == 1) ? 1 : 2;
+            sum = sum + ((float)am * Gm[m] * T->ambe_ri_cos[m][i]);
+        }
+        Ri[i] = sum;
+    }
+
+    float Cik[5][18];
+    memset(Cik, 0, sizeof(Cik));
+    const float rconst = ((float)1 / ((float)2 * M_SQRT2));
+    for (int i = 1; i <= 4; ++i) {
+        Cik[i][1] = (float)0.5 * (Ri[2 * i - 1] + Ri[2 * i]);
+        Cik[i][2] = rconst * (Ri[2 * i - 1] - Ri[2 * i]);
+    }
+    static const int ib5[4] = {22, 23, 25, 26};
+    static const int ib6[4] = {27, 28, 29, 30};
+    static const int ib7[4] = {31, 32, 33, 34};
+    const int b8 = (d[35] << 3) | (d[36] << 2) | (d[37] << 1);
+    const float* hoc[5] = {NULL, T->ambep_hoc_b5[bits_msb(d, ib5, 4)], T->ambep_hoc_b6[bits_msb(d, ib6, 4)],
+                           T->ambep_hoc_b7[bits_msb(d, ib7, 4)], T->ambep_hoc_b8[b8]};
+    int Ji[5];
+    for (int i = 1; i <= 4; ++i) {
+        Ji[i] = T->ambep_lmprbl[L][i - 1];
+        for (int k = 3; k <= Ji[i]; ++k) {
+            Cik[i][k] = (k > 6) ? 0.0f : hoc[i][k - 3];
+        }
+    }
+
+    float Tl[57];
+    memset(Tl, 0, sizeof(Tl));
+    int l = 1;
+    for (int i = 1; i <= 4; ++i) {
+        int ji = Ji[i];
+        for (int j = 1; j <= ji; ++j) {
+            float sum = 0;
+            for (int k = 1; k <= ji; ++k) {
+                int ak = (k == 1) ? 1 : 2;
+                sum = sum + ((float)ak * Cik[i][k] * T->ambe_idct_cos[ji][j][k]);
+            }
+            Tl[l++] = sum;
+        }
+    }
+
+    /* log-magnitude prediction (:427-497): identical to AMBE+2 */
+    int prev_L = clampL(prev->L);
+    cur->L = clampL(cur->L);
+    if (cur->L > prev_L) {
+        for (int q = prev_L + 1; q <= cur->L; ++q) {
+            prev->Ml[q] = prev->Ml[prev_L];
+            prev->log2Ml[q] = prev->log2Ml[prev_L];
+        }
+    }
+    prev->log2Ml[0] = prev->log2Ml[1];
+    prev->Ml[0] = prev->Ml[1];
+    int lo[57];
+    float frac[57];
+    float Sum43 = 0;
+    for (int q = 1; q <= cur->L; ++q) {
+        float pos = ((float)prev_L / (float)cur->L) * (float)q;
+        lo[q] = (int)pos;
+        frac[q] = pos - (float)lo[q];
+        Sum43 = Sum43 + ((((float)1 - frac[q]) * log2ml_at(prev, lo[q])) + (frac[q] * log2ml_at(prev, lo[q] + 1)));
+    }
+    Sum43 = (((float)0.65 / (float)cur->L) * Sum43);
+    float Sum42 = 0;
+    for (int q = 1; q <= cur->L; ++q) {
+        Sum42 += Tl[q];
+    }
+    Sum42 = Sum42 / (float)cur->L;
+    float BigGamma = cur->gamma - (0.5f * log2f((float)cur->L)) - Sum42;
+    for (int q = 1; q <= cur->L; ++q) {
+        float c1 = ((float)0.65 * ((float)1 - frac[q]) * log2ml_at(prev, lo[q]));
+        float c2 = ((float)0.65 * frac[q] * log2ml_at(prev, lo[q] + 1));
+        cur->log2Ml[q] = Tl[q] + c1 + c2 - Sum43 + BigGamma;
+        if (cur->Vl[q] == 1) {
+            cur->Ml[q] = exp2f(cur->log2Ml[q]);
+        } else {
+            cur->Ml[q] = unvc * exp2f(cur->log2Ml[q]);
+        }
+    }
+    return 0;
+}
+
+/* =====================================================================================
  * Spectral amplitude enhancement (a13)  ref: src/core/mbelib.c:412-666
  * ===================================================================================== */
 float
@@ -2133,6 +2283,39 @@ mbxo_tonef(float* out, const char* d, mbe_parms* cur) {
     cur->tonePhase = p2;
 }
 
+/* ref: src/core/mbelib.c:813-856 (mbe_synthesizeTonefdstar) + :708-736 (mbe_renderTonef): a single tone of
+ * 156.25 Hz (index 5), 187.5 Hz (6) or 31.25 Hz x index (7..122) at the fixed amplitude 103 */
+void
+mbxo_tone_dstarf(float* out, mbe_parms* cur, int id1) {
+    if (!out) {
+        return;
+    }
+    memset(out, 0, 160 * sizeof(float));
+    if (!cur) {
+        return;
+    }
+    float f1 = 0.0f;
+    if (id1 == 5) {
+        f1 = 156.25f;
+    } else if (id1 == 6) {
+        f1 = 187.5f;
+    } else if (id1 >= 7 && id1 <= 122) {
+        f1 = 31.25f * (float)id1;
+    }
+    if (f1 <= 0.0f) {
+        return;
+    }
+    const float clip = (32767.0f * 0.95f) / 7.0f;
+    const float gain = ((float)103 / 127.0f) * clip;
+    const uint32_t s1 = tone_step((double)f1);
+    uint32_t p1 = (uint32_t)cur->swn;
+    for (int n = 0; n < 160; ++n) {
+        p1 += s1;
+        out[n] = gain * tone_sample(p1);
+    }
+    cur->swn = (int)p1;
+}
+
 /* =====================================================================================
  * IMBE stream stage (a10)  ref: src/imbe/imbe7200x4400.c:56-81, 780-909
  * ===================================================================================== */
@@ -2317,6 +2500,82 @@ mbxo_process_ambe2450_dataf(float* out, mbe_process_result* result, const char d
     return result->total_errors;
 }
 
+/* =====================================================================================
+ * AMBE 3600x2400 stream stage  ref: src/ambe/ambe3600x2400.c:629-763
+ * ===================================================================================== */
+int
+mbxo_process_ambe2400_dataf(float* out, mbe_process_result* result, const char d[49], mbe_parms* cur, mbe_parms* prev,
+                            mbe_parms* prev_enh, mbx_stream_rng* rng) {
+    mbe_process_result local;
+    if (!result) {
+        memset(&local, 0, sizeof(local));
+        result = &local;
+    }
+    if (!out || !cur || !prev || !prev_enh) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int total;
+    int rc = resolve_total_errors(result, &total);
+    if (rc < 0) {
+        return rc;
+    }
+    rc = validate_bits(d, 49u);
+    if (rc < 0) {
+        return rc;
+    }
+    const int c0 = ((result->flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? result->c0_errors : 0;
+    result_prepare_synthesis(result, total);
+
+    if (fabsf(prev->mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f) {
+        init_ambe_parms(cur, prev, prev_enh);
+    }
+    cur->mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
+    cur->errorCountTotal = total;
+    cur->errorCount4 = 0;
+    cur->errorRate = (0.95f * prev->errorRate) + (0.001064f * (float)cur->errorCountTotal);
+
+    int bad = mbxo_decode_ambe2400_parms(d, cur, prev);
+    if (bad < 0) {
+        return bad;
+    }
+    const int valid_tone = (bad >= 7) && (bad <= 122) && (c0 < 2) && (total < 3);
+
+    /* decode state (:661-686) */
+    if (bad == 3) {
+        result->flags |= MBE_PROCESS_FLAG_TONE;
+        cur->repeatCount = 0;
+    } else if (valid_tone) {
+        /* nothing */
+    } else if (total > 3) {
+        *cur = *prev;
+        cur->repeatCount++;
+        result->flags |= MBE_PROCESS_FLAG_REPEAT;
+    } else {
+        cur->repeatCount = 0;
+    }
+
+    /* synthesize (:688-731) */
+    if (valid_tone) {
+        mbxo_tone_dstarf(out, cur, bad);
+        *prev = *cur;
+    } else if (bad == 0) {
+        if (cur->repeatCount < MBE_MAX_FRAME_REPEATS) {
+            *prev = *cur;
+            float rm0 = mbxo_spectral_amp_enhance(cur);
+            synth_core(out, cur, prev_enh, 1, rm0, rng);
+            *prev_enh = *cur;
+        } else {
+            result->flags |= MBE_PROCESS_FLAG_MUTE;
+            mbxo_comfort_noisef(out, rng);
+            init_ambe_parms(cur, prev, prev_enh);
+        }
+    } else {
+        mbxo_comfort_noisef(out, rng);
+        init_ambe_parms(cur, prev, prev_enh);
+    }
+    return result->total_errors;
+}
+
 /* frame-level entries  ref: src/imbe/imbe7200x4400.c:935-948, src/ambe/ambe3600x2450.c:924-937 */
 int
 mbxo_process_imbe7200x4400_framef(float* out, mbe_process_result* result, const char fr[8][23], char imbe_d[88],
@@ -2346,6 +2605,21 @@ mbxo_process_ambe3600x2450_framef(float* out, mbe_process_result* result, const 
     return mbxo_process_ambe2450_dataf(out, result, ambe_d, cur, prev, prev_enh, rng);
 }
 
+/* ref: src/ambe/ambe3600x2400.c:563-596, 788-802: the AMBE FEC front end is shared with 3600x2450 */
+int
+mbxo_process_ambe3600x2400_framef(float* out, mbe_process_result* result, const char fr[4][24], char ambe_d[49],
+                                  mbe_parms* cur, mbe_parms* prev, mbe_parms* prev_enh, mbx_stream_rng* rng) {
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    int rc = mbxo_decode_ambe3600x2450_frame(fr, ambe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbxo_process_ambe2400_dataf(out, result, ambe_d, cur, prev, prev_enh, rng);
+}
+
 /* =====================================================================================
  * Batch drivers -- same contract as the HIP launcher (include/mbx.h): S streams x T frames,
  * stream-major; state[3*s + {0,1,2}] = {cur, prev, prev_enhanced}.
@@ -2357,7 +2631,7 @@ mbxo_fec_batch(int codec, size_t n, const uint8_t* frames, mbx_param_record* rec
             mbxo_fec_imbe7200x4400(frames + i * MBX_IMBE_FRAME_BYTES, &records[i]);
         } else if (codec == MBX_CODEC_IMBE7100X4400) {
             mbxo_fec_imbe7100x4400(frames + i * MBX_IMBE7100_FRAME_BYTES, &records[i]);
-        } else {
+        } else { /* both AMBE codecs share the FEC front end */
             mbxo_fec_ambe3600x2450(frames + i * MBX_AMBE_FRAME_BYTES, &records[i]);
         }
     }
@@ -2408,7 +2682,11 @@ process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_p
                 }
                 mbxo_record_to_bits(&rec, 49, bits);
                 mbxo_record_to_result(&rec, &res);
-                mbxo_process_ambe2450_dataf(pcm, &res, bits, cur, prev, enh, &rng[s]);
+                if (codec == MBX_CODEC_AMBE3600X2400) {
+                    mbxo_process_ambe2400_dataf(pcm, &res, bits, cur, prev, enh, &rng[s]);
+                } else {
+                    mbxo_process_ambe2450_dataf(pcm, &res, bits, cur, prev, enh, &rng[s]);
+                }
             }
             if (records) {
                 records[f] = rec;

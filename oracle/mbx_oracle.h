@@ -58,6 +58,17 @@ int mbxo_convert_imbe7100to7200(char* imbe_d);
 int mbxo_fec_imbe7100x4400(const uint8_t frame[MBX_IMBE7100_FRAME_BYTES], mbx_param_record* rec);
 int mbxo_decode_imbe7100x4400_frame(const char fr[7][24], char imbe_d[88], mbe_process_result* result);
 
+/* AMBE 3600x2400 (D-STAR) -- FEC / demodulation are the AMBE+2 ones (ambe_common.c), the
+ * parameter decode and the frame policy are its own: ref src/ambe/ambe3600x2400.c:164-551 (decode), :629-763
+ * (policy), src/core/mbelib.c:813-856 (D-STAR tones).  mbxo_decode returns 0 voice, 3 tone/silence class, or the
+ * tone index 5..122. */
+int mbxo_decode_ambe2400_parms(const char* ambe_d, mbe_parms* cur, mbe_parms* prev);
+int mbxo_process_ambe2400_dataf(float* out, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur,
+                                mbe_parms* prev, mbe_parms* prev_enh, mbx_stream_rng* rng);
+int mbxo_process_ambe3600x2400_framef(float* out, mbe_process_result* result, const char fr[4][24], char ambe_d[49],
+                                      mbe_parms* cur, mbe_parms* prev, mbe_parms* prev_enh, mbx_stream_rng* rng);
+void mbxo_tone_dstarf(float* out, mbe_parms* cur, int id1);
+
 /* soft-decision front end -- ref src/ecc/ecc.c:138-215,303-357,410-413,
  * src/imbe/imbe7200x4400.c:445-459,517-560,675-707,746-778, src/ambe/ambe_common.c:48-73,102-124,159-190,
  * src/ambe/ambe3600x2450.c:684-714, src/core/mbelib.c:107-158 */

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "ambe3600x2400_const.h"  /* reference: src/internal */
 #include "ambe3600x2450_const.h"  /* reference: src/internal */
 #include "ecc_const.h"            /* reference: src/internal (extern; defined in libmbe_ref) */
 #include "imbe7200x4400_const.h"  /* reference: src/internal */
@@ -121,6 +122,18 @@ main(int argc, char** argv) {
     memcpy(t->ambe_hoc_b6, AmbeHOCb6, sizeof(t->ambe_hoc_b6));
     memcpy(t->ambe_hoc_b7, AmbeHOCb7, sizeof(t->ambe_hoc_b7));
     memcpy(t->ambe_hoc_b8, AmbeHOCb8, sizeof(t->ambe_hoc_b8));
+    /* AMBE 3600x2400 (D-STAR) */
+    memcpy(t->ambep_dg, AmbePlusDg, sizeof(t->ambep_dg));
+    memcpy(t->ambep_prba24, AmbePlusPRBA24, sizeof(t->ambep_prba24));
+    memcpy(t->ambep_prba58, AmbePlusPRBA58, sizeof(t->ambep_prba58));
+    memcpy(t->ambep_hoc_b5, AmbePlusHOCb5, sizeof(t->ambep_hoc_b5));
+    memcpy(t->ambep_hoc_b6, AmbePlusHOCb6, sizeof(t->ambep_hoc_b6));
+    memcpy(t->ambep_hoc_b7, AmbePlusHOCb7, sizeof(t->ambep_hoc_b7));
+    memcpy(t->ambep_hoc_b8, AmbePlusHOCb8, sizeof(t->ambep_hoc_b8));
+    NARROW(t->ambep_L, AmbePlusLtable, 126, 56);
+    NARROW(&t->ambep_vuv[0][0], &AmbePlusVuv[0][0], 16 * 8, 1);
+    NARROW(&t->ambep_lmprbl[0][0], &AmbePlusLmprbl[0][0], 57 * 4, 255);
+
     for (int m = 1; m <= 8; m++) {
         for (int i = 1; i <= 8; i++) {
             t->ambe_ri_cos[m][i] = cosf((M_PI * (float)(m - 1) * ((float)i - 0.5f)) / 8.0f);

@@ -39,6 +39,11 @@ extern int mbe_processImbe7200x4400Framef(float*, mbe_process_result*, const cha
 extern int mbe_processAmbe3600x2450Framef(float*, mbe_process_result*, const char[4][24], char[49], mbe_parms*,
                                           mbe_parms*, mbe_parms*);
 extern int mbe_processImbe4400Dataf(float*, mbe_process_result*, const char[88], mbe_parms*, mbe_parms*, mbe_parms*);
+/* AMBE 3600x2400 (D-STAR): include/mbelib-neo/mbelib.h:315-375 */
+extern int mbe_processAmbe3600x2400Framef(float*, mbe_process_result*, const char[4][24], char[49], mbe_parms*, mbe_parms*,
+                                          mbe_parms*);
+extern int mbe_processAmbe2400Dataf(float*, mbe_process_result*, const char[49], mbe_parms*, mbe_parms*, mbe_parms*);
+extern void mbe_initProcessResult(mbe_process_result*);
 /* IMBE 7100x4400: include/mbelib-neo/mbelib.h:267, 533-590 */
 extern int mbe_7100x4400hamming1511(const char*, char*);
 extern int mbe_convertImbe7100to7200(char*);
@@ -836,10 +841,112 @@ gen_imbe7100(const char* dir) {
     printf("imbe7100_kat.bin written\n");
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* ambe2400_kat.bin: AMBE 3600x2400 / D-STAR.
+ *   u32 S, u32 T, per stream T x { char fr[4][24], char d[49], i32 ret, result(20), float pcm[160] },
+ *                 then cur, prev, prev_enh (3 x 2604 B)        mbe_processAmbe3600x2400Framef, random cells,
+ *                                                              seeds 1234 + s
+ *   u32 S2, u32 T2, per stream T2 x { char d[49], i32 total_in, i32 ret, result(20), float pcm[160] },
+ *                 then cur, prev, prev_enh                      mbe_processAmbe2400Dataf on scripted parameter
+ *                                                              bits: voice, valid tones, silence / invalid tone
+ *                                                              classes, with a given total error count; seeds 5000 + s */
+static void
+put_bits_msb(char* d, const int* idx, int n, int value) {
+    for (int i = 0; i < n; ++i) {
+        d[idx[i]] = (char)((value >> (n - 1 - i)) & 1);
+    }
+}
+
+static void
+gen_ambe2400(const char* dir) {
+    FILE* f = open_out(dir, "ambe2400_kat.bin");
+    sm_state = 0x9E3779B97F4A7C15ULL ^ 0x2400ULL;
+    uint32_t S = 32, T = 24;
+    W(f, &S, 4);
+    W(f, &T, 4);
+    for (uint32_t s = 0; s < S; ++s) {
+        mbe_parms cur, prev, enh;
+        mbe_initMbeParms(&cur, &prev, &enh);
+        mbe_setThreadRngSeed(1234u + s);
+        for (uint32_t t = 0; t < T; ++t) {
+            char fr[4][24], d[49];
+            float out[160];
+            mbe_process_result r;
+            int clean = (s % 4u) == 3u; /* a quarter of the streams: few channel errors */
+            for (int c = 0; c < 96; ++c) {
+                uint64_t v = splitmix64();
+                ((char*)fr)[c] = clean ? (char)((v % 23) == 0) : (char)(v & 1);
+            }
+            int32_t ret = mbe_processAmbe3600x2400Framef(out, &r, (const char(*)[24])fr, d, &cur, &prev, &enh);
+            W(f, fr, sizeof(fr));
+            W(f, d, 49);
+            W(f, &ret, 4);
+            W(f, &r, sizeof(r));
+            W(f, out, sizeof(out));
+        }
+        W(f, &cur, sizeof(cur));
+        W(f, &prev, sizeof(prev));
+        W(f, &enh, sizeof(enh));
+    }
+    S = 24;
+    T = 24;
+    W(f, &S, 4);
+    W(f, &T, 4);
+    static const int tone_list[12] = {5, 6, 7, 20, 64, 122, 123, 4, 130, 163, 164, 255};
+    static const int totals[8] = {0, 0, 0, 0, 1, 2, 4, 5};
+    static const int i_tone_hi[3] = {6, 7, 8};
+    for (uint32_t s = 0; s < S; ++s) {
+        mbe_parms cur, prev, enh;
+        mbe_initMbeParms(&cur, &prev, &enh);
+        mbe_setThreadRngSeed(5000u + s);
+        for (uint32_t t = 0; t < T; ++t) {
+            char d[49];
+            float out[160];
+            for (int c = 0; c < 49; ++c) {
+                d[c] = (char)(splitmix64() & 1u);
+            }
+            uint64_t pick = splitmix64() % 10u;
+            if (pick < 7) { /* voice: b0 (bits 0..5, 48) must not be 126/127 */
+                if (d[0] && d[1] && d[2] && d[3] && d[4] && d[5]) {
+                    d[(int)(splitmix64() % 6u)] = 0;
+                }
+            } else { /* tone class with a chosen index */
+                for (int c = 0; c < 6; ++c) {
+                    d[c] = 1;
+                }
+                int idx = tone_list[splitmix64() % 12u];
+                /* index bits: 7..5 through the def tables (inverse: def with (t7,t6,t5) = top three bits) */
+                static const int def_of[8] = {1, 2, 3, 4, 0, 7, 6, 5}; /* (t7 t6 t5) as a number -> def */
+                put_bits_msb(d, i_tone_hi, 3, def_of[(idx >> 5) & 7]);
+                d[9] = (char)((idx >> 4) & 1);
+                d[42] = (char)((idx >> 3) & 1);
+                d[43] = (char)((idx >> 2) & 1);
+                d[10] = (char)((idx >> 1) & 1);
+                d[11] = (char)(idx & 1);
+            }
+            mbe_process_result r;
+            mbe_initProcessResult(&r);
+            int32_t total_in = totals[splitmix64() % 8u];
+            r.total_errors = total_in;
+            int32_t ret = mbe_processAmbe2400Dataf(out, &r, d, &cur, &prev, &enh);
+            W(f, d, 49);
+            W(f, &total_in, 4);
+            W(f, &ret, 4);
+            W(f, &r, sizeof(r));
+            W(f, out, sizeof(out));
+        }
+        W(f, &cur, sizeof(cur));
+        W(f, &prev, sizeof(prev));
+        W(f, &enh, sizeof(enh));
+    }
+    fclose(f);
+    printf("ambe2400_kat.bin written\n");
+}
+
 int
 main(int argc, char** argv) {
     if (argc != 2 && argc != 3) {
-        fprintf(stderr, "usage: %s outdir [soft|imbe7100]\n", argv[0]);
+        fprintf(stderr, "usage: %s outdir [soft|imbe7100|ambe2400]\n", argv[0]);
         return 2;
     }
     const char* dir = argv[1];
@@ -849,6 +956,10 @@ main(int argc, char** argv) {
     }
     if (argc == 3 && strcmp(argv[2], "imbe7100") == 0) {
         gen_imbe7100(dir);
+        return 0;
+    }
+    if (argc == 3 && strcmp(argv[2], "ambe2400") == 0) {
+        gen_ambe2400(dir);
         return 0;
     }
     gen_ecc(dir);
@@ -863,5 +974,6 @@ main(int argc, char** argv) {
     gen_misc(dir);
     gen_soft(dir);
     gen_imbe7100(dir);
+    gen_ambe2400(dir);
     return 0;
 }

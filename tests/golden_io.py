@@ -166,3 +166,23 @@ def imbe7100_kat():
     section("fec_soft", np.dtype([("soft", "u1", (168, 2)), ("bits", "i1", (88,)), ("ret", "<i4"), ("result", RESULT_DTYPE)]))
     assert off == b.size
     return out
+
+
+def ambe2400_kat():
+    """ambe2400_kat.bin (layout: oracle/tools/gen_fixtures.c gen_ambe2400): (frame-level streams, data-level streams)"""
+    b = _read("ambe2400_kat.bin")
+    off = 0
+    S, T = (int(x) for x in b[off : off + 8].view("<u4"))
+    off += 8
+    frame = np.dtype([("cells", "i1", (96,)), ("bits", "i1", (49,)), ("ret", "<i4"), ("result", RESULT_DTYPE), ("pcmf", "<f4", (160,))])
+    per_stream = np.dtype([("frames", frame, (T,)), ("final", PARMS_DTYPE, (3,))])
+    framed = b[off : off + S * per_stream.itemsize].view(per_stream)
+    off += S * per_stream.itemsize
+    S2, T2 = (int(x) for x in b[off : off + 8].view("<u4"))
+    off += 8
+    dframe = np.dtype([("bits", "i1", (49,)), ("total_in", "<i4"), ("ret", "<i4"), ("result", RESULT_DTYPE), ("pcmf", "<f4", (160,))])
+    per_stream2 = np.dtype([("frames", dframe, (T2,)), ("final", PARMS_DTYPE, (3,))])
+    data = b[off : off + S2 * per_stream2.itemsize].view(per_stream2)
+    off += S2 * per_stream2.itemsize
+    assert off == b.size
+    return framed, data

@@ -41,7 +41,7 @@ class Oracle:
             getattr(h, name).argtypes = [_vp, _vp, _vp]
         h.mbxo_decode_ambe2450_parms.restype = C.c_int
         h.mbxo_decode_ambe2450_parms.argtypes = [_vp, _vp, _vp, C.c_int]
-        for name in ("mbxo_process_imbe4400_dataf", "mbxo_process_ambe2450_dataf"):
+        for name in ("mbxo_process_imbe4400_dataf", "mbxo_process_ambe2450_dataf", "mbxo_process_ambe2400_dataf"):
             getattr(h, name).restype = C.c_int
             getattr(h, name).argtypes = [_vp] * 7
         for name in ("mbxo_process_imbe7200x4400_framef", "mbxo_process_ambe3600x2450_framef"):
@@ -131,7 +131,8 @@ class Oracle:
         cells = np.ascontiguousarray(cells, dtype=np.int8)
         n = cells.shape[0]
         out = np.zeros((n, FRAME_BYTES[codec]), dtype=np.uint8)
-        fn = {0: self.h.mbxo_pack_imbe_frame, 1: self.h.mbxo_pack_ambe_frame, 2: self.h.mbxo_pack_imbe7100_frame}[codec]
+        fn = {0: self.h.mbxo_pack_imbe_frame, 1: self.h.mbxo_pack_ambe_frame, 2: self.h.mbxo_pack_imbe7100_frame,
+              3: self.h.mbxo_pack_ambe_frame}[codec]
         rcs = [fn(cells[i].ctypes.data, out[i].ctypes.data) for i in range(n)]
         return rcs, out
 
@@ -158,6 +159,18 @@ class Oracle:
         res = np.zeros(1, dtype=RESULT_DTYPE)
         ret = self.h.mbxo_decode_imbe7100x4400_frame(cells.ctypes.data, d.ctypes.data, res.ctypes.data)
         return d, ret, res[0]
+
+    def process_ambe2400_data(self, bits49, total_errors, state3, rng1):
+        """one mbe_processAmbe2400Dataf call: state3 = (cur, prev, enh) array of 3, updated in place"""
+        d = np.ascontiguousarray(bits49, dtype=np.int8)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        res[0]["total_errors"] = int(total_errors)
+        pcm = np.zeros(160, dtype=np.float32)
+        ret = self.h.mbxo_process_ambe2400_dataf(
+            pcm.ctypes.data, res.ctypes.data, d.ctypes.data, state3[0:1].ctypes.data, state3[1:2].ctypes.data,
+            state3[2:3].ctypes.data, rng1.ctypes.data,
+        )
+        return pcm, ret, res[0]
 
     def fec_soft_batch(self, codec, soft):
         """soft: [n, 184|96, 2] uint8 (bit, reliability) in the reference's array order -> records"""

@@ -318,3 +318,36 @@ def test_imbe7100_soft_matches_reference(oracle):
             assert res[name] == row["result"][name], name
     rec = oracle.fec_soft_batch(2, kat["fec_soft"]["soft"])
     assert np.array_equal(oracle_lib.records_to_bits(rec, 88), kat["fec_soft"]["bits"])
+
+
+# ---- AMBE 3600x2400 / D-STAR against the real reference's outputs ----------
+def test_ambe2400_frame_streams_match_reference(oracle):
+    framed, _ = golden_io.ambe2400_kat()
+    S, T = framed.shape[0], framed["frames"].shape[1]
+    rcs, packed = oracle.pack(3, framed["frames"]["cells"].reshape(S * T, 96))
+    assert all(rc == 0 for rc in rcs)
+    out = oracle.process_batch(3, S, T, packed, oracle.init_state(S), oracle.rng_seeded([1234 + s for s in range(S)]))
+    ref = framed["frames"].reshape(-1)
+    assert np.array_equal(oracle_lib.records_to_bits(out["records"], 49), ref["bits"])
+    parity.check_results(ref["result"], out["results"])
+    parity.check_pcm(ref["pcmf"], out["pcmf"], rel=2e-6, worst=2e-5)
+    parity.check_state(framed["final"], out["state"])
+
+
+def test_ambe2400_scripted_data_streams_match_reference(oracle):
+    """voice, valid D-STAR tones, silence / invalid tone classes and error-count driven repeats"""
+    _, data = golden_io.ambe2400_kat()
+    seen = set()
+    for s, stream in enumerate(data):
+        state = oracle.init_state(1)[0]
+        rng = oracle.rng_seeded([5000 + s])
+        pcm = np.zeros((len(stream["frames"]), 160), dtype=np.float32)
+        for t, fr in enumerate(stream["frames"]):
+            pcm[t], ret, res = oracle.process_ambe2400_data(fr["bits"], fr["total_in"], state, rng)
+            assert ret == fr["ret"]
+            for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
+                assert res[name] == fr["result"][name], (s, t, name)
+            seen.add(int(res["flags"]))
+        parity.check_pcm(stream["frames"]["pcmf"], pcm, rel=2e-6, worst=2e-5)
+        parity.check_state(stream["final"].reshape(1, 3), state.reshape(1, 3))
+    assert any(f & 0x10 for f in seen) and any(f & 0x40 for f in seen)   # tone class and repeats both occurred
