@@ -21,9 +21,12 @@ __global__ void fec_imbe7100x4400_kernel(const uint8_t*, size_t, mbx_param_recor
 __global__ void floattoshort_kernel(const float*, int16_t*, size_t);
 __global__ void expand_imbe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void expand_ambe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
+__global__ void expand_ambe2400_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                   int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe2400_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void synth_speech_kernel(int, mbe_parms*, mbe_parms*, mbx_stream_rng*, float*, int16_t*, DeviceTables);
 __global__ void enhance_kernel(int, mbe_parms*);
@@ -179,6 +182,9 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     }
     for (int L = 1; L < 64; ++L) {
         d.log2_int[L] = log2f((float)L);
+    }
+    for (int b0 = 0; b0 < 128; ++b0) {   // ref src/ambe/ambe3600x2400.c:238 (same expression, host libm)
+        d.ambep_f0[b0] = exp2f(-4.311767578125f - (2.1336e-2f * ((float)b0 + 0.5f)));
     }
     {   // x_k = 173 x_{k-1} + 13849 (mod 2^16)  =>  x_k = pr_mul[k] x_0 + pr_add[k]
         uint32_t m = 1u, a = 0u;
@@ -386,7 +392,7 @@ int mbx_fec_imbe7100x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d
 
 int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft, size_t n, mbx_param_record* d_records, void* stream) {
     REQUIRE_READY();
-    if (!d_soft || !d_records || codec < MBX_CODEC_IMBE7200X4400 || codec > MBX_CODEC_IMBE7100X4400) {
+    if (!d_soft || !d_records || codec < MBX_CODEC_IMBE7200X4400 || codec > MBX_CODEC_AMBE3600X2400) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     if (n == 0) {
@@ -463,7 +469,7 @@ int mbx_soft_bits_from_llr(const int16_t* llr, mbe_soft_bit* soft, size_t count)
 
 int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream) {
     REQUIRE_READY();
-    if (!d_records || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450)) {
+    if (!d_records || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450 && codec != MBX_CODEC_AMBE3600X2400)) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     if (n == 0) {
@@ -476,6 +482,9 @@ int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, v
     const unsigned egrid = (unsigned)((n + 7) / 8);   // 8 frames per 64-lane workgroup
     if (codec == MBX_CODEC_IMBE7200X4400) {
         hipLaunchKernelGGL(mbx::expand_imbe_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
+                           g_ctx.workspace, g_ctx.tabs);
+    } else if (codec == MBX_CODEC_AMBE3600X2400) {
+        hipLaunchKernelGGL(mbx::expand_ambe2400_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
                            g_ctx.workspace, g_ctx.tabs);
     } else {
         hipLaunchKernelGGL(mbx::expand_ambe_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
@@ -494,6 +503,11 @@ static int launch_stream(int codec, int S, int T, const mbx_param_record* d_reco
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
         return check_launch("imbe_stream_kernel");
     }
+    if (codec == MBX_CODEC_AMBE3600X2400) {
+        hipLaunchKernelGGL(mbx::ambe2400_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                           params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+        return check_launch("ambe2400_stream_kernel");
+    }
     hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                        params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
     return check_launch("ambe_stream_kernel");
@@ -501,7 +515,7 @@ static int launch_stream(int codec, int S, int T, const mbx_param_record* d_reco
 
 static bool stream_args_ok(int codec, int S, int T, const void* d_records, const void* d_state, const void* d_rng) {
     return d_records && d_state && d_rng && S >= 0 && T >= 0
-           && (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_AMBE3600X2450);
+           && (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400);
 }
 
 int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
@@ -554,7 +568,7 @@ int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parm
     } else if (codec == MBX_CODEC_IMBE7100X4400) {   // own front end; the records are in 7200x4400 order
         rc = mbx_fec_imbe7100x4400(d_frames, n, d_records, stream);
         codec = MBX_CODEC_IMBE7200X4400;
-    } else if (codec == MBX_CODEC_AMBE3600X2450) {
+    } else if (codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400) {   // shared AMBE FEC front end
         rc = mbx_fec_ambe3600x2450(d_frames, n, d_records, stream);
     } else {
         return MBE_STATUS_INVALID_ARGUMENT;
@@ -675,7 +689,8 @@ int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int
 void mbx_debug_set_ablation(int mask) { g_ctx.tabs.ablate = mask; }
 
 const char* mbx_stream_kernel_name(int codec) {
-    return codec == MBX_CODEC_IMBE7200X4400 ? "imbe_stream_kernel" : "ambe_stream_kernel";
+    return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? "imbe_stream_kernel"
+           : (codec == MBX_CODEC_AMBE3600X2400 ? "ambe2400_stream_kernel" : "ambe_stream_kernel");
 }
 
 // ---- host-buffer conveniences ------------------------------------------------------------
@@ -686,15 +701,16 @@ int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* r
     if (!frames || !records) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const size_t fb = (codec == MBX_CODEC_AMBE3600X2450) ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;
+    const size_t fb = (codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400) ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;
     DevBuf df, dr;
     HIP_TRY(df.alloc(n * fb));
     HIP_TRY(dr.alloc(n * sizeof(mbx_param_record)));
     HIP_TRY(hipMemcpy(df.p, frames, n * fb, hipMemcpyHostToDevice));
     int rc = (codec == MBX_CODEC_IMBE7200X4400)   ? mbx_fec_imbe7200x4400(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
              : (codec == MBX_CODEC_IMBE7100X4400) ? mbx_fec_imbe7100x4400(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
-             : (codec == MBX_CODEC_AMBE3600X2450) ? mbx_fec_ambe3600x2450(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
-                                                  : MBE_STATUS_INVALID_ARGUMENT;
+             : (codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400)
+                 ? mbx_fec_ambe3600x2450(df.as<uint8_t>(), n, dr.as<mbx_param_record>(), nullptr)
+                 : MBE_STATUS_INVALID_ARGUMENT;
     if (rc < 0) {
         return rc;
     }
@@ -703,7 +719,7 @@ int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* r
 }
 
 static size_t soft_cells(int codec) {
-    return codec == MBX_CODEC_IMBE7200X4400 ? MBX_IMBE_SOFT_BITS : (codec == MBX_CODEC_IMBE7100X4400 ? MBX_IMBE7100_SOFT_BITS : MBX_AMBE_SOFT_BITS);
+    return codec == MBX_CODEC_IMBE7200X4400 ? MBX_IMBE_SOFT_BITS : (codec == MBX_CODEC_IMBE7100X4400 ? MBX_IMBE7100_SOFT_BITS : MBX_AMBE_SOFT_BITS);   // both AMBE codecs: 96
 }
 
 // frames in (hard: packed bytes, soft: mbe_soft_bit arrays), everything else as mbx_process_batch
@@ -755,7 +771,7 @@ int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_p
     if (!frames || !state || !rng || S < 0 || T < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const size_t fb = (codec == MBX_CODEC_AMBE3600X2450) ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;   // 7100: 18 bytes too
+    const size_t fb = (codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400) ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;
     return process_batch_host_impl(codec, S, T, frames, fb, false, state, rng, pcm16, pcmf, results, records);
 }
 

@@ -22,6 +22,7 @@ struct DerivedTables {
     uint32_t pr_add[116];     // additive term after k steps
     uint32_t ham_basis[11];   // Hamming(15,11) code word of data bit i (soft-decision candidates)
     uint32_t ham7100_basis[11];   // the same for the IMBE 7100x4400 bit mapping
+    float    ambep_f0[128];       // AMBE 3600x2400: exp2f(-4.311767578125f - 2.1336e-2f * (b0 + 0.5f)) from the host libm
 };
 
 // Output of the expand stage, input of the stream stage: 64 dwords per frame (layout in mbx_expand.hip).

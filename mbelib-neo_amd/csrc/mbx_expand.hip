@@ -194,8 +194,11 @@ __device__ __forceinline__ int pick(const uint32_t w[3], int i0, int i1, int i2,
     return v;
 }
 
-__global__ void __launch_bounds__(64)
-expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
+// k2400: AMBE 3600x2400 (D-STAR, ref src/ambe/ambe3600x2400.c:164-425): other bit positions, codebooks and frame
+// classes (0 voice, 3 tone class without a usable index, 5..122 tone index); the arithmetic is the same.
+template <bool k2400>
+__device__ __forceinline__ void expand_ambe_body(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out,
+                                                 const DeviceTables& tabs) {
     __shared__ float tile[kFramesPerBlock][kRow];
     const mbx_tables* T = tabs.t;
     const size_t first = (size_t)blockIdx.x * kFramesPerBlock;
@@ -218,34 +221,51 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         const unsigned long long two = ((unsigned long long)w[0] << 32) | w[1];
         const int u3 = (int)((two >> 15) & 0x3fffu);
         const bool tone_sig = (((u0 >> 6) & 0x3f) == 63) && (((u3 & 0xf) == 0) || (((u1 >> 8) & 0xf) == (u1 & 0xf)));
-        const int b0 = pick(w, 0, 1, 2, 3, 37, 38, 39);
-        if (tone_sig && total_errors < 6) {
-            bad = 7;
-        } else if ((b0 >= 120 && b0 <= 123) || b0 == 126 || b0 == 127) {
-            bad = 2;
-        } else if (b0 == 124 || b0 == 125) {
-            silence = true;
-            f0 = (float)M_PI / 32.0f;
-            w0 = f0 * (float)(2.0 * M_PI);
-            L = (b0 == 124) ? 15 : 14;
+        if (k2400) {
+            const int b0 = pick(w, 0, 1, 2, 3, 4, 5, 48);
+            if ((b0 & 0x7E) == 0x7E) {   // tone class (:212-234); a silence model set here is wiped by the policy
+                const uint32_t t7 = 0xE1u, t6 = 0x78u, t5 = 0xB4u;   // the three 8-entry tables as bit masks
+                const int def = pick(w, 6, 7, 8);
+                const int tone = (int)(((t7 >> def) & 1u) << 7 | ((t6 >> def) & 1u) << 6 | ((t5 >> def) & 1u) << 5)
+                                 | (rbit(w, 9) << 4) | (rbit(w, 42) << 3) | (rbit(w, 43) << 2) | (rbit(w, 10) << 1) | rbit(w, 11);
+                bad = (tone >= 5 && tone <= 122) ? tone : 3;
+            } else {
+                f0 = tabs.d->ambep_f0[b0];
+                w0 = (float)((double)(f0 * (float)2) * M_PI);
+                L = T->ambep_L[b0];
+            }
         } else {
-            f0 = T->ambe_w0[b0];
-            w0 = (float)((double)(f0 * (float)2) * M_PI);
-            L = T->ambe_L[b0];
+            const int b0 = pick(w, 0, 1, 2, 3, 37, 38, 39);
+            if (tone_sig && total_errors < 6) {
+                bad = 7;
+            } else if ((b0 >= 120 && b0 <= 123) || b0 == 126 || b0 == 127) {
+                bad = 2;
+            } else if (b0 == 124 || b0 == 125) {
+                silence = true;
+                f0 = (float)M_PI / 32.0f;
+                w0 = f0 * (float)(2.0 * M_PI);
+                L = (b0 == 124) ? 15 : 14;
+            } else {
+                f0 = T->ambe_w0[b0];
+                w0 = (float)((double)(f0 * (float)2) * M_PI);
+                L = T->ambe_L[b0];
+            }
         }
         if (bad == 0) {   // two lanes per inverse-DCT block: each takes half of the block's outputs
             const int blk = (sub >> 1) + 1, half = sub & 1;
-            const int b3 = pick(w, 12, 13, 14, 15, 16, 17, 18, 19, 40);
-            const int b4 = pick(w, 20, 21, 22, 23, 41, 42, 43);
+            const int b3 = k2400 ? pick(w, 10, 11, 12, 13, 14, 15, 16, 44, 45) : pick(w, 12, 13, 14, 15, 16, 17, 18, 19, 40);
+            const int b4 = k2400 ? pick(w, 17, 18, 19, 20, 21, 46, 47) : pick(w, 20, 21, 22, 23, 41, 42, 43);
+            const float(*prba24)[3] = k2400 ? T->ambep_prba24 : T->ambe_prba24;
+            const float(*prba58)[4] = k2400 ? T->ambep_prba58 : T->ambe_prba58;
             float Gm[9];
             Gm[1] = 0.0f;
-            Gm[2] = T->ambe_prba24[b3][0];
-            Gm[3] = T->ambe_prba24[b3][1];
-            Gm[4] = T->ambe_prba24[b3][2];
-            Gm[5] = T->ambe_prba58[b4][0];
-            Gm[6] = T->ambe_prba58[b4][1];
-            Gm[7] = T->ambe_prba58[b4][2];
-            Gm[8] = T->ambe_prba58[b4][3];
+            Gm[2] = prba24[b3][0];
+            Gm[3] = prba24[b3][1];
+            Gm[4] = prba24[b3][2];
+            Gm[5] = prba58[b4][0];
+            Gm[6] = prba58[b4][1];
+            Gm[7] = prba58[b4][2];
+            Gm[8] = prba58[b4][3];
             float Ra = 0, Rb = 0;   // Ri[2*blk-1], Ri[2*blk]
 #pragma unroll
             for (int m = 1; m <= 8; ++m) {
@@ -254,15 +274,25 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
                 Rb = Rb + (am * Gm[m] * T->ambe_ri_cos[m][2 * blk]);
             }
             const float rconst = (float)(1.0 / (2.0 * M_SQRT2));
-            const int hbits = (blk == 1) ? pick(w, 24, 25, 26, 27, 44)
-                                         : ((blk == 2) ? pick(w, 28, 29, 30, 45) : ((blk == 3) ? pick(w, 31, 32, 33, 46) : pick(w, 34, 47, 48)));
-            const float* hoc = (blk == 1) ? T->ambe_hoc_b5[hbits]
-                                          : ((blk == 2) ? T->ambe_hoc_b6[hbits] : ((blk == 3) ? T->ambe_hoc_b7[hbits] : T->ambe_hoc_b8[hbits]));
+            int hbits;
+            const float* hoc;
+            if (k2400) {   // (:362-401); bit 24 is not used, b8 is the three bits 35..37 shifted up by one
+                hbits = (blk == 1) ? pick(w, 22, 23, 25, 26)
+                                   : ((blk == 2) ? pick(w, 27, 28, 29, 30) : ((blk == 3) ? pick(w, 31, 32, 33, 34) : (pick(w, 35, 36, 37) << 1)));
+                hoc = (blk == 1) ? T->ambep_hoc_b5[hbits]
+                                 : ((blk == 2) ? T->ambep_hoc_b6[hbits] : ((blk == 3) ? T->ambep_hoc_b7[hbits] : T->ambep_hoc_b8[hbits]));
+            } else {
+                hbits = (blk == 1) ? pick(w, 24, 25, 26, 27, 44)
+                                   : ((blk == 2) ? pick(w, 28, 29, 30, 45) : ((blk == 3) ? pick(w, 31, 32, 33, 46) : pick(w, 34, 47, 48)));
+                hoc = (blk == 1) ? T->ambe_hoc_b5[hbits]
+                                 : ((blk == 2) ? T->ambe_hoc_b6[hbits] : ((blk == 3) ? T->ambe_hoc_b7[hbits] : T->ambe_hoc_b8[hbits]));
+            }
+            const uint8_t(*lmprbl)[4] = k2400 ? T->ambep_lmprbl : T->ambe_lmprbl;
             int l = 1;
             for (int q = 1; q < blk; ++q) {
-                l += T->ambe_lmprbl[L][q - 1];
+                l += lmprbl[L][q - 1];
             }
-            const int ji = T->ambe_lmprbl[L][blk - 1];
+            const int ji = lmprbl[L][blk - 1];
             float C[18];
             C[1] = (float)0.5 * (Ra + Rb);
             C[2] = rconst * (Ra - Rb);
@@ -291,9 +321,9 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         float dg = 0.0f, sum42 = 0.0f;
         if (bad == 0) {
             if (!silence) {
-                const int b1 = pick(w, 4, 5, 6, 7, 35);
+                const int b1 = k2400 ? pick(w, 38, 39, 40, 41) : pick(w, 4, 5, 6, 7, 35);
                 // the eight decisions of this codebook row as one bit mask (one 8-byte load, not L loads)
-                const uint2 vq = *reinterpret_cast<const uint2*>(&T->ambe_vuv[b1][0]);
+                const uint2 vq = *reinterpret_cast<const uint2*>(k2400 ? &T->ambep_vuv[b1][0] : &T->ambe_vuv[b1][0]);
                 uint32_t vmask = 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -310,7 +340,7 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
                     }
                 }
             }
-            dg = T->ambe_dg[pick(w, 8, 9, 10, 11, 36)];
+            dg = k2400 ? T->ambep_dg[pick(w, 6, 7, 8, 9, 42, 43)] : T->ambe_dg[pick(w, 8, 9, 10, 11, 36)];
             float tsum = 0.0f;   // Sum42 in the reference's order (l ascending)
             for (int l = 1; l <= L; ++l) {
                 tsum += row[l];
@@ -327,6 +357,16 @@ expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         row[63] = __int_as_float(bad);
     }
     write_out(tile, out, first, n);
+}
+
+__global__ void __launch_bounds__(64)
+expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
+    expand_ambe_body<false>(recs, n, out, tabs);
+}
+
+__global__ void __launch_bounds__(64)
+expand_ambe2400_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
+    expand_ambe_body<true>(recs, n, out, tabs);
 }
 
 }  // namespace mbx

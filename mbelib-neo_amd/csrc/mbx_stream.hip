@@ -1446,11 +1446,40 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
 #ifndef MBX_AMBE_WAVES_PER_SIMD
 #define MBX_AMBE_WAVES_PER_SIMD 4   // the AMBE+2 kernel spills at 96 VGPRs; four spill-free waves are faster
 #endif
-__global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)
-ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
-                   mbe_parms* __restrict__ state,
-                   mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                   mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+// D-STAR single tone (ref src/core/mbelib.c:813-856 + :708-736): 156.25 Hz (index 5), 187.5 Hz (6) or 31.25 Hz x index
+// (7..122) at the fixed amplitude 103
+__device__ void tone_dstar_frame(float out[3], int id1, Parms& cur, int lane) {
+    out[0] = out[1] = out[2] = 0.0f;
+    float f1 = 0.0f;
+    if (id1 == 5) {
+        f1 = 156.25f;
+    } else if (id1 == 6) {
+        f1 = 187.5f;
+    } else if (id1 >= 7 && id1 <= 122) {
+        f1 = 31.25f * (float)id1;
+    }
+    if (f1 <= 0.0f) {
+        return;
+    }
+    const float clip = (32767.0f * 0.95f) / 7.0f;
+    const float gain = ((float)103 / 127.0f) * clip;
+    const uint32_t s1 = tone_step((double)f1);
+    const uint32_t p1 = (uint32_t)cur.swn;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        out[j] = gain * tone_sample(p1 + (uint32_t)(lane + 64 * j + 1) * s1);
+    }
+    cur.swn = (int)(p1 + 160u * s1);
+}
+
+// k2400: AMBE 3600x2400 (D-STAR) frame policy, ref src/ambe/ambe3600x2400.c:629-763 -- no erasure class, D-STAR
+// tones, repeats decided by the total error count alone.  The prediction (decode_ambe) is common.
+template <bool k2400>
+__device__ __forceinline__ void
+ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                 mbe_parms* __restrict__ state,
+                 mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                 mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
     const int s = blockIdx.x;
     if (s >= S) {
@@ -1481,7 +1510,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID
         const int total = c0 + prot;
         int bad;
-        bool prev_max_repeat;
+        bool prev_max_repeat, valid_tone = false;
         {
             Parms prev;
             load_prev_view(prev, slot_prev, lane);
@@ -1501,7 +1530,25 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
 
             bad = decode_ambe(fp, cur, prev, tabs, lane);
             prev_max_repeat = prev.repeatCount >= MBE_MAX_FRAME_REPEATS;
-            if (bad == 2) {
+            if (k2400) {   // ambe2400_update_decode_state (:661-686)
+                const int c0v = ((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? c0 : 0;
+                valid_tone = (bad >= 7) && (bad <= 122) && (c0v < 2) && (total < 3);
+                if (bad == 3) {
+                    flags |= MBE_PROCESS_FLAG_TONE;
+                    cur.repeatCount = 0;
+                } else if (valid_tone) {
+                } else if (total > 3) {
+                    load_parms(cur, slot_prev, lane);   // cur_mp := prev_mp
+                    if (bad == 0) {                     // (the decode padded the prediction memory in registers)
+                        cur.Ml = prev.Ml;
+                        cur.log2Ml = prev.log2Ml;
+                    }
+                    cur.repeatCount++;
+                    flags |= MBE_PROCESS_FLAG_REPEAT;
+                } else {
+                    cur.repeatCount = 0;
+                }
+            } else if (bad == 2) {
                 flags |= MBE_PROCESS_FLAG_ERASURE;
                 cur.repeatCount = 0;
                 load_continuity(prev, slot_prev, lane);   // phases, overlap-add and noise state of prev_mp
@@ -1522,9 +1569,11 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
 
         // One call site each for the synthesiser and the noise generator (code size: the synthesiser is
         // ~20 KB of instructions and the instruction cache holds 64 KB).
-        enum { kVoice, kToneFallback, kTone, kNoiseReinit, kNoiseErasure } action;
+        enum { kVoice, kToneFallback, kTone, kToneDstar, kNoiseReinit, kNoiseErasure } action;
         uint32_t tw[3] = {0u, 0u, 0u};
-        if (bad == 0) {
+        if (k2400 && bad != 0) {   // ambe2400_synthesize_frame (:711-731)
+            action = valid_tone ? kToneDstar : kNoiseReinit;
+        } else if (bad == 0) {
             action = (cur.repeatCount < MBE_MAX_FRAME_REPEATS) ? kVoice : kNoiseReinit;
             if (action == kNoiseReinit) {
                 flags |= MBE_PROCESS_FLAG_MUTE;
@@ -1565,6 +1614,9 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             }
         } else if (action == kTone) {
             tone_frame(out, tw, cur, lane);
+        } else if (action == kToneDstar) {
+            tone_dstar_frame(out, bad, cur, lane);
+            store_parms(cur, slot_prev, lane);   // mbe_moveMbeParms(cur_mp, prev_mp)
         } else {
             comfort_noise(out, rng, lane);
             if (action == kNoiseReinit) {   // mbe_initAmbeParms_common(cur, prev, prev_enhanced)
@@ -1594,6 +1646,21 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
 }
 
 // mbe_synthesizeSpeechf for S independent (cur, prev) pairs.
+
+__global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)
+ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                   mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                   float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+__global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)
+ambe2400_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                       mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                       float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
 __global__ void __launch_bounds__(64)
 synth_speech_kernel(int S, mbe_parms* __restrict__ curs, mbe_parms* __restrict__ prevs, mbx_stream_rng* __restrict__ rngs,
                     float* __restrict__ pcmf, int16_t* __restrict__ pcm16, DeviceTables tabs) {

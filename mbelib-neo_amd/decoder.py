@@ -87,7 +87,8 @@ class BatchDecoder:
         n = d_frames.numel() // FRAME_BYTES[self.codec]
         rec = torch.empty((n, 4), dtype=torch.int32, device=self.device)
         L = _native.lib()
-        fn = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400}[self.codec]
+        fn = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400,
+              3: L.mbx_fec_ambe3600x2450}[self.codec]   # both AMBE codecs share the FEC front end
         _native.check(fn(d_frames.data_ptr(), n, rec.data_ptr(), torch.cuda.current_stream().cuda_stream), "mbx_fec")
         return rec
 
@@ -178,7 +179,7 @@ def process_batch_host(codec, S, T, frames, state, rng, device=0):
 
 
 # ---- soft-decision front end (mbe_soft_bit arrays: uint8 [..., 2] = (bit, reliability)) ------------
-SOFT_CELLS = {0: 184, 1: 96, 2: 168}
+SOFT_CELLS = {0: 184, 1: 96, 2: 168, 3: 96}
 
 
 def _soft_array(codec, soft, n):
@@ -238,3 +239,43 @@ def soft_bits_from_llr(llr):
     soft = np.empty(llr.shape + (2,), dtype=np.uint8)
     _native.check(_native.lib().mbx_soft_bits_from_llr(llr.ctypes.data, soft.ctypes.data, llr.size), "mbx_soft_bits_from_llr")
     return soft
+
+
+def records_from_bits(bits, total_errors=None, c0_errors=None, flags=0):
+    """Parameter records from bit arrays [n, 88|49] (0/1) -- the mbe_process*Data entry of the batch API.
+    total_errors goes into the protected-error field unless c0_errors is given (then flags should carry
+    MBE_PROCESS_FLAG_C0_VALID = 2)."""
+    bits = np.asarray(bits, dtype=np.uint8)
+    n, nb = bits.shape
+    padded = np.zeros((n, 96), dtype=np.uint8)
+    padded[:, :nb] = bits
+    words = np.packbits(padded, axis=1).reshape(n, 3, 4)
+    rec = np.zeros(n, dtype=RECORD_DTYPE)
+    rec["w"][:, :3] = (words[:, :, 0].astype(np.uint32) << 24) | (words[:, :, 1].astype(np.uint32) << 16) | (
+        words[:, :, 2].astype(np.uint32) << 8) | words[:, :, 3].astype(np.uint32)
+    tot = np.zeros(n, dtype=np.uint32) if total_errors is None else np.asarray(total_errors, dtype=np.uint32)
+    c0 = np.zeros(n, dtype=np.uint32) if c0_errors is None else np.asarray(c0_errors, dtype=np.uint32)
+    rec["w"][:, 3] = c0 | ((tot - c0) << 8) | (np.uint32(flags) << 24)
+    return rec
+
+
+def process_records_host(codec, S, T, records, state, rng, device=0):
+    """mbx_process_records on host buffers: records [S*T] stream-major; returns dict like process_batch_host."""
+    torch = _torch()
+    ensure_init(device)
+    dev = torch.device("cuda", int(device))
+    n = S * T
+    d_rec = torch.from_numpy(np.ascontiguousarray(records).view(np.uint8).reshape(-1)).to(dev)
+    d_state = torch.from_numpy(np.ascontiguousarray(state).view(np.uint8).reshape(-1).copy()).to(dev)
+    d_rng = torch.from_numpy(np.ascontiguousarray(rng).view(np.uint8).reshape(-1).copy()).to(dev)
+    pcm16 = torch.empty((n, 160), dtype=torch.int16, device=dev)
+    pcmf = torch.empty((n, 160), dtype=torch.float32, device=dev)
+    results = torch.empty((n, 5), dtype=torch.int32, device=dev)
+    rc = _native.lib().mbx_process_records(codec, S, T, d_rec.data_ptr(), d_state.data_ptr(), d_rng.data_ptr(), pcm16.data_ptr(),
+                                           pcmf.data_ptr(), results.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "mbx_process_records")
+    torch.cuda.synchronize()
+    return {
+        "pcm16": pcm16.cpu().numpy(), "pcmf": pcmf.cpu().numpy(), "results": results_numpy(results),
+        "state": d_state.cpu().numpy().view(PARMS_DTYPE).reshape(S, 3), "rng": d_rng.cpu().numpy().view(RNG_DTYPE),
+    }

@@ -182,7 +182,7 @@ def soft_frames(codec, n, rng, snr_like=2.0):
     """Soft-decision test frames in the reference's array shape, uint8 [n, 184|96, 2] = (bit, reliability):
     random-bit frames observed through additive noise, reliability = clamped |observation| -- so wrong
     hard decisions tend to carry low confidence, plus a share of exact ties (quantised confidences)."""
-    cells = {0: 184, 1: 96, 2: 168}[int(codec)]
+    cells = {0: 184, 1: 96, 2: 168, 3: 96}[int(codec)]
     bits = rng.integers(0, 2, size=(n, cells), dtype=np.int64)
     obs = (2.0 * bits - 1.0) * snr_like + rng.normal(0.0, 1.0, size=(n, cells))
     hard = (obs > 0).astype(np.uint8)

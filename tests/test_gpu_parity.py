@@ -383,3 +383,51 @@ def test_imbe7100_soft_matches_reference_and_oracle(mbx, oracle):
         assert np.array_equal(res[name], kat["fec_soft"]["result"][name]), name
     soft = framegen.soft_frames(2, 2048, framegen.rng_for(7120))
     assert np.array_equal(decoder.fec_soft_host(2, soft)["w"], oracle.fec_soft_batch(2, soft)["w"])
+
+
+# ---- AMBE 3600x2400 / D-STAR -----------------------------------------------
+def test_ambe2400_frame_streams_match_reference_and_oracle(mbx, oracle):
+    from mbelib_neo_amd import framegen
+    from mbelib_neo_amd.layout import init_state, rng_seeded
+
+    framed, _ = golden_io.ambe2400_kat()
+    S, T = framed.shape[0], framed["frames"].shape[1]
+    rcs, packed = oracle.pack(3, framed["frames"]["cells"].reshape(S * T, 96))
+    out = _host_batch(mbx, 3, S, T, packed, init_state(S), rng_seeded([1234 + s for s in range(S)]))
+    ref = framed["frames"].reshape(-1)
+    assert np.array_equal(oracle_lib.records_to_bits(out["records"], 49), ref["bits"])
+    parity.check_results(ref["result"], out["results"])
+    parity.check_pcm(ref["pcmf"], out["pcmf"])
+    parity.check_state(framed["final"], out["state"])
+    # larger seeded batches against the oracle: random bits, and mostly clean channels
+    for S, T, clean in ((512, 8, False), (256, 16, True)):
+        rng = framegen.rng_for(2400 + T)
+        frames = framegen.random_frames(3, S * T, rng)
+        if clean:
+            frames &= framegen.random_frames(3, S * T, rng) & framegen.random_frames(3, S * T, rng) & framegen.random_frames(3, S * T, rng)
+        seeds = [1234 + s for s in range(S)]
+        ref = oracle.process_batch(3, S, T, frames, oracle.init_state(S), oracle.rng_seeded(seeds))
+        got = _host_batch(mbx, 3, S, T, frames, init_state(S), rng_seeded(seeds))
+        assert np.array_equal(got["records"]["w"], ref["records"]["w"])
+        parity.check_results(ref["results"], got["results"])
+        parity.check_pcm(ref["pcmf"], got["pcmf"], ref["pcm16"], got["pcm16"])
+        parity.check_state(ref["state"], got["state"])
+        assert np.array_equal(ref["rng"], got["rng"])
+
+
+def test_ambe2400_scripted_data_streams_match_reference(mbx):
+    """mbe_processAmbe2400Dataf through mbx_process_records: voice, valid D-STAR tones, silence / invalid tone
+    classes, repeats driven by the error count (fixture from the real reference)"""
+    from mbelib_neo_amd import decoder
+    from mbelib_neo_amd.layout import init_state, rng_seeded
+
+    _, data = golden_io.ambe2400_kat()
+    S, T = data.shape[0], data["frames"].shape[1]
+    fr = data["frames"].reshape(-1)
+    rec = decoder.records_from_bits(fr["bits"], total_errors=fr["total_in"])
+    out = decoder.process_records_host(3, S, T, rec, init_state(S), rng_seeded([5000 + s for s in range(S)]))
+    parity.check_results(fr["result"], out["results"])
+    parity.check_pcm(fr["pcmf"], out["pcmf"])
+    parity.check_state(data["final"], out["state"])
+    flags = fr["result"]["flags"]
+    assert np.any(flags & 0x10) and np.any(flags & 0x40)
