@@ -56,6 +56,24 @@ int mbe_processImbe7200x4400Frame(short* aout_buf, mbe_process_result* result, c
                                   char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp,
                                   mbe_parms* prev_mp_enhanced);                           /* :509 */
 
+/* AMBE 3600x2400 / D-STAR */
+int mbe_decodeAmbe3600x2400Frame(const char ambe_fr[4][24], char ambe_d[49], mbe_process_result* result);   /* :315 */
+int mbe_decodeAmbe3600x2400SoftFrame(const mbe_soft_bit ambe_fr[4][24], char ambe_d[49], mbe_process_result* result); /* :323 */
+int mbe_processAmbe2400Dataf(float* aout_buf, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur_mp,
+                             mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced);            /* :335 */
+int mbe_processAmbe2400Data(short* aout_buf, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur_mp,
+                            mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced);             /* :341 */
+int mbe_processAmbe3600x2400Framef(float* aout_buf, mbe_process_result* result, const char ambe_fr[4][24],
+                                   char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp,
+                                   mbe_parms* prev_mp_enhanced);                          /* :352 */
+int mbe_processAmbe3600x2400Frame(short* aout_buf, mbe_process_result* result, const char ambe_fr[4][24],
+                                  char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp,
+                                  mbe_parms* prev_mp_enhanced);                           /* :359 */
+int mbe_processAmbe3600x2400SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
+                                       char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced); /* :367 */
+int mbe_processAmbe3600x2400SoftFrame(short* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
+                                      char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced); /* :371 */
+
 /* IMBE 7100x4400 */
 int mbe_7100x4400hamming1511(const char* in, char* out);                                  /* :267 */
 int mbe_decodeImbe7100x4400Frame(const char imbe_fr[7][24], char imbe_d[88], mbe_process_result* result); /* :545 */

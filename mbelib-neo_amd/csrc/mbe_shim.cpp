@@ -784,6 +784,86 @@ int mbe_processImbe7100x4400SoftFrame(short* aout_buf, mbe_process_result* resul
     return mbe_processImbe4400Data(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
+// ---- AMBE 3600x2400 (D-STAR): ref src/ambe/ambe3600x2400.c:563-627 (frame decode = the AMBE+2 one), :733-852 --
+int mbe_decodeAmbe3600x2400Frame(const char ambe_fr[4][24], char ambe_d[49], mbe_process_result* result) {
+    return decode_frame(MBX_CODEC_AMBE3600X2450, reinterpret_cast<const char*>(ambe_fr), 96, 49, ambe_d, result);
+}
+
+int mbe_decodeAmbe3600x2400SoftFrame(const mbe_soft_bit ambe_fr[4][24], char ambe_d[49], mbe_process_result* result) {
+    return decode_soft_frame(MBX_CODEC_AMBE3600X2450, reinterpret_cast<const mbe_soft_bit*>(ambe_fr), 96, 49, ambe_d, result);
+}
+
+int mbe_processAmbe2400Dataf(float* aout_buf, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur_mp,
+                             mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    return process_data(MBX_CODEC_AMBE3600X2400, aout_buf, nullptr, result, ambe_d, 49, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processAmbe2400Data(short* aout_buf, mbe_process_result* result, const char ambe_d[49], mbe_parms* cur_mp,
+                            mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (!aout_buf) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    return process_data(MBX_CODEC_AMBE3600X2400, nullptr, aout_buf, result, ambe_d, 49, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processAmbe3600x2400Framef(float* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
+                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeAmbe3600x2400Frame(ambe_fr, ambe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processAmbe2400Dataf(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processAmbe3600x2400Frame(short* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
+                                  mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (!aout_buf) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeAmbe3600x2400Frame(ambe_fr, ambe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processAmbe2400Data(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processAmbe3600x2400SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
+                                       char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeAmbe3600x2400SoftFrame(ambe_fr, ambe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processAmbe2400Dataf(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
+int mbe_processAmbe3600x2400SoftFrame(short* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],
+                                      char ambe_d[49], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (!aout_buf) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbe_process_result local;
+    if (!result) {
+        result = &local;
+    }
+    const int rc = mbe_decodeAmbe3600x2400SoftFrame(ambe_fr, ambe_d, result);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbe_processAmbe2400Data(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+}
+
 // ---- soft frames -> PCM: ref src/imbe/imbe7200x4400.c:950-980, src/ambe/ambe3600x2450.c:939-969 --------
 int mbe_processImbe7200x4400SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit imbe_fr[8][23],
                                        char imbe_d[88], mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {

@@ -52,6 +52,16 @@ def load():
     h.mbe_decodeImbe7100x4400Frame.argtypes = [_vp] * 3
     h.mbe_7100x4400hamming1511.restype = C.c_int
     h.mbe_7100x4400hamming1511.argtypes = [_vp, _vp]
+    for name in ("mbe_processAmbe3600x2400Framef", "mbe_processAmbe3600x2400Frame", "mbe_processAmbe3600x2400SoftFramef",
+                 "mbe_processAmbe3600x2400SoftFrame"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 7
+    for name in ("mbe_processAmbe2400Dataf", "mbe_processAmbe2400Data"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 6
+    for name in ("mbe_decodeAmbe3600x2400Frame", "mbe_decodeAmbe3600x2400SoftFrame"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp] * 3
     for name in ("mbe_processImbe7100x4400SoftFramef", "mbe_processImbe7100x4400SoftFrame"):
         getattr(h, name).restype = C.c_int
         getattr(h, name).argtypes = [_vp] * 7

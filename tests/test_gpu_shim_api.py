@@ -477,3 +477,36 @@ def test_imbe7100_soft_entry_points(mbe):
         soft = np.ascontiguousarray(row["soft"])
         assert mbe.mbe_decodeImbe7100x4400SoftFrame(p(soft), p(bits), p(res)) == row["ret"]
         assert np.array_equal(bits, row["bits"]) and res[0]["flags"] == row["result"]["flags"]
+
+
+# ---- AMBE 3600x2400 / D-STAR entry points ---------------------------------------------------------------
+def test_ambe2400_entry_points_match_reference_fixture(mbe):
+    framed, data = golden_io.ambe2400_kat()
+    for s in (0, 3):   # a random-bit stream and a mostly clean one, frame by frame
+        st = framed[s]
+        cur, prev, enh = (np.zeros(1, dtype=PARMS_DTYPE) for _ in range(3))
+        mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))
+        mbe.mbe_setThreadRngSeed(1234 + s)
+        T = len(st["frames"])
+        pcm = np.zeros((T, 160), dtype=np.float32)
+        for t, row in enumerate(st["frames"]):
+            bits = np.zeros(49, dtype=np.int8)
+            res = np.zeros(1, dtype=RESULT_DTYPE)
+            cells = np.ascontiguousarray(row["cells"])
+            assert mbe.mbe_processAmbe3600x2400Framef(p(pcm[t]), p(res), p(cells), p(bits), p(cur), p(prev), p(enh)) == row["ret"]
+            assert np.array_equal(bits, row["bits"]) and res[0]["flags"] == row["result"]["flags"]
+        parity.check_pcm(st["frames"]["pcmf"], pcm)
+        parity.check_state(st["final"].reshape(1, 3), np.concatenate([cur, prev, enh]).reshape(1, 3))
+    st = data[1]   # scripted parameter-bit stream: tones, silence classes, repeats
+    cur, prev, enh = (np.zeros(1, dtype=PARMS_DTYPE) for _ in range(3))
+    mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))
+    mbe.mbe_setThreadRngSeed(5001)
+    pcm = np.zeros((len(st["frames"]), 160), dtype=np.float32)
+    for t, row in enumerate(st["frames"]):
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        res[0]["total_errors"] = row["total_in"]
+        bits = np.ascontiguousarray(row["bits"])
+        assert mbe.mbe_processAmbe2400Dataf(p(pcm[t]), p(res), p(bits), p(cur), p(prev), p(enh)) == row["ret"]
+        assert res[0]["flags"] == row["result"]["flags"]
+    parity.check_pcm(st["frames"]["pcmf"], pcm)
+    parity.check_state(st["final"].reshape(1, 3), np.concatenate([cur, prev, enh]).reshape(1, 3))
