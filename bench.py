@@ -33,6 +33,9 @@ WORKLOADS = {
     "imbe_mixed": (0, 65536, 16, "BASELINE configs[3]: 65,536 IMBE streams x T=16 random-bit frames (mixed voiced/unvoiced)"),
     "ambe_fec": (1, 65536, 1, "BASELINE configs[2]: 65,536 AMBE+2 streams x T=1, clean voice frames + 1% bit flips"),
     "ambe_stream": (1, 8192, 128, "BASELINE configs[4] per-GPU shard: 8,192 AMBE+2 streams x T=128 random-bit frames, int16 out"),
+    # SURVEY.md §8(f) row 4 (not BASELINE configs): the other two codecs of the reference
+    "imbe7100_mixed": (2, 65536, 16, "65,536 IMBE 7100x4400 streams x T=16 random-bit frames"),
+    "ambe2400_mixed": (3, 65536, 16, "65,536 AMBE 3600x2400 (D-STAR) streams x T=16 random-bit frames"),
     # SURVEY.md §8(f) row 1 (not a BASELINE config): the soft-decision front end in front of the same path
     "imbe_soft": (0, 65536, 1, "65,536 IMBE 7200x4400 streams x T=1, soft-decision frames (noisy observations of random bits)"),
     "ambe_soft": (1, 65536, 1, "65,536 AMBE+2 3600x2450 streams x T=1, soft-decision frames (noisy observations of random bits)"),
@@ -55,7 +58,7 @@ def make_frames(name, codec, S, T, rank):
 def algorithmic_bytes_per_launch(codec, S, T):
     """B_io = packed channel bits in + int16 PCM out per frame; B_state = load +
     store of the three-struct state per stream per launch."""
-    b_io = (18 if codec == 0 else 9) + 320
+    b_io = (18 if codec in (0, 2) else 9) + 320
     return S * T * b_io + S * 2 * 3 * 2604
 
 
@@ -164,7 +167,7 @@ def main():
         def fec(frames_ptr, count, records_ptr, strm):
             return L.mbx_fec_soft(codec, frames_ptr, count, records_ptr, strm)
     else:
-        fec = L.mbx_fec_imbe7200x4400 if codec == 0 else L.mbx_fec_ambe3600x2450
+        fec = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400, 3: L.mbx_fec_ambe3600x2450}[codec]
     n = S * T
 
     def step(ev=None):
@@ -173,15 +176,16 @@ def main():
         # dominant (stream) kernel can be bracketed by events
         _native.check(fec(d_frames.data_ptr(), n, out["records"].data_ptr(), stream), "fec")
         run = L.mbx_process_records
+        stream_codec = 0 if codec == 2 else codec   # 7100x4400 records are in 7200x4400 order after its FEC stage
         # IMBE: mbx_process_records is ONE launch.  AMBE+2: it is the expand launch + the stream launch;
         # they are issued separately here so that the events bracket the stream kernel only.
-        if args.split_expand or codec == 1:
-            _native.check(L.mbx_expand_records(codec, out["records"].data_ptr(), n, stream), "expand")
+        if args.split_expand or codec in (1, 3):
+            _native.check(L.mbx_expand_records(stream_codec, out["records"].data_ptr(), n, stream), "expand")
             run = L.mbx_stream_expanded
         if ev is not None:
             ev[0].record()
         _native.check(
-            run(codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
+            run(stream_codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
                 out["pcm16"].data_ptr(), None, out["results"].data_ptr(), stream),
             "stream",
         )
@@ -221,7 +225,7 @@ def main():
     traffic = measured_traffic(args.workload, S, T)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     line = {
-        "metric": "20ms frames/sec (whole node), " + ("IMBE 7200x4400" if codec == 0 else "AMBE+2 3600x2450"),
+        "metric": "20ms frames/sec (whole node), " + {0: "IMBE 7200x4400", 1: "AMBE+2 3600x2450", 2: "IMBE 7100x4400", 3: "AMBE 3600x2400"}[codec],
         "value": value,
         "unit": "frames/s",
         "n_gpus": world,
