@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Development aid (GPU box): long seeded comparison of the HIP path with the CPU oracle over all codecs --
+random-bit frames, mostly-clean frames and (where it exists) the soft-decision front end."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib  # noqa: E402
+import parity  # noqa: E402
+
+from mbelib_neo_amd import decoder, framegen  # noqa: E402
+from mbelib_neo_amd.layout import init_state, rng_seeded  # noqa: E402
+
+
+def main():
+    o = oracle_lib.load()
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    worst = {}
+    for r in range(rounds):
+        for codec in (0, 1, 2, 3):
+            for kind in ("random", "clean", "soft"):
+                S, T = (2048, 8) if kind != "soft" else (256, 4)
+                rng = framegen.rng_for(90000 + 1000 * r + 10 * codec + len(kind))
+                seeds = [77 + 13 * s + r for s in range(S)]
+                t0 = time.perf_counter()
+                if kind == "soft":
+                    frames = framegen.soft_frames(codec, S * T, rng, snr_like=1.0 + r)
+                    ref = o.process_batch(codec, S, T, frames, o.init_state(S), o.rng_seeded(seeds), soft=True)
+                    got = decoder.process_batch_soft_host(codec, S, T, frames, init_state(S), rng_seeded(seeds))
+                else:
+                    frames = framegen.random_frames(codec, S * T, rng)
+                    if kind == "clean":
+                        for _ in range(3):
+                            frames &= framegen.random_frames(codec, S * T, rng)
+                    ref = o.process_batch(codec, S, T, frames, o.init_state(S), o.rng_seeded(seeds))
+                    got = decoder.process_batch_host(codec, S, T, frames, init_state(S), rng_seeded(seeds))
+                assert np.array_equal(got["records"]["w"], ref["records"]["w"]), (codec, kind, "records")
+                parity.check_results(ref["results"], got["results"])
+                m = parity.check_pcm(ref["pcmf"], got["pcmf"], ref["pcm16"], got["pcm16"])
+                parity.check_state(ref["state"], got["state"])
+                assert np.array_equal(ref["rng"], got["rng"])
+                key = (codec, kind)
+                w = worst.setdefault(key, {"rel_rms": 0, "worst_frame": 0, "int16_max": 0})
+                for k in w:
+                    w[k] = max(w[k], m[k])
+                print(f"round {r} codec {codec} {kind:6s}: {S*T} frames ok  rel_rms {m['rel_rms']:.2e} worst {m['worst_frame']:.2e} "
+                      f"int16_max {m['int16_max']}  ({time.perf_counter()-t0:.1f} s)", flush=True)
+    print("worst over all rounds:", worst)
+
+
+if __name__ == "__main__":
+    main()
