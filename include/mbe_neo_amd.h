@@ -28,6 +28,7 @@ extern "C" {
 #endif
 
 void mbe_initProcessResult(mbe_process_result* result);                                   /* mbelib.h:194 */
+void mbe_formatProcessResult(char* str, size_t size, const mbe_process_result* result);    /* :202 */
 int mbe_checkGolayBlock(long int* block);                                                 /* :231 */
 int mbe_golay2312(const char* in, char* out);                                             /* :238 */
 int mbe_hamming1511(const char* in, char* out);                                           /* :253 */
@@ -115,6 +116,8 @@ void mbe_moveMbeParms(const mbe_parms* source_mp, mbe_parms* destination_mp);   
 void mbe_useLastMbeParms(mbe_parms* cur_mp, const mbe_parms* prev_mp);                    /* :608 */
 void mbe_initMbeParms(mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced);/* :615 */
 void mbe_spectralAmpEnhance(mbe_parms* cur_mp);                                           /* :623 */
+void mbe_synthesizeTonef(float* aout_buf, const char* ambe_d, mbe_parms* cur_mp);          /* :630 */
+void mbe_synthesizeTonefdstar(float* aout_buf, const char* ambe_d, mbe_parms* cur_mp, int ID1); /* :638 */
 void mbe_synthesizeSilencef(float* aout_buf);                                             /* :640 */
 void mbe_synthesizeSilence(short* aout_buf);                                              /* :642 */
 void mbe_synthesizeSpeechf(float* aout_buf, mbe_parms* cur_mp, mbe_parms* prev_mp);       /* :652 */

@@ -160,6 +160,11 @@ int mbx_comfort_noise(int S, mbx_stream_rng* d_rng, float* d_pcmf, int16_t* d_pc
  * One code word per element: bit j of in[i] is cell j; out[i] is the corrected word (Golay parity bits
  * pass through like the reference), errs[i] the corrected-bit count (may be NULL). */
 int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream);
+/* ref: mbe_synthesizeTonef (d_dstar_ids == NULL: AMBE+2 tone from the parameter bits of d_records[s]) /
+ *      mbe_synthesizeTonefdstar (d_dstar_ids[s] = tone index)  include/mbelib-neo/mbelib.h:630, 638;
+ *      src/core/mbelib.c:691-856.  One struct per element; the tone phases in d_cur[s] advance; invalid tones give silence. */
+int mbx_synthesize_tone(int S, const mbx_param_record* d_records, const int32_t* d_dstar_ids, mbe_parms* d_cur, float* d_pcmf,
+                        int16_t* d_pcm16, void* stream);
 /* Loads and stores the state triplet of S streams without touching it: the HBM-traffic floor of the
  * stream stage (used by bench.py --calibrate to price the access pattern; not a reference function). */
 int mbx_state_copy(int S, mbe_parms* d_state, void* stream);

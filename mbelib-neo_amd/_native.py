@@ -40,6 +40,7 @@ _SIGNATURES = {
     "mbx_adaptive_smoothing": (C.c_int, [C.c_int, _vp, _vp, _vp]),
     "mbx_comfort_noise": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),
     "mbx_ecc_words": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "mbx_synthesize_tone": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_state_copy": (C.c_int, [C.c_int, _vp, _vp]),
     "mbx_process_batch_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_synthesize_speech_host": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -491,6 +491,66 @@ int mbe_processImbe7100x4400Frame(short* aout_buf, mbe_process_result* result, c
     return mbe_processImbe4400Data(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
+// ---- tones and the status trace: ref src/core/mbelib.c:68-104 (format documented in mbelib.h:195-202), :745-856 ----
+void mbe_formatProcessResult(char* str, size_t size, const mbe_process_result* result) {
+    if (!str || size == 0u) {
+        return;
+    }
+    size_t pos = 0u;
+    const int total = (result && result->total_errors > 0) ? result->total_errors : 0;
+    while (pos + 1u < size && (int)pos < total) {
+        str[pos++] = '=';
+    }
+    if (result) {
+        const unsigned order[4] = {MBE_PROCESS_FLAG_ERASURE, MBE_PROCESS_FLAG_TONE, MBE_PROCESS_FLAG_REPEAT, MBE_PROCESS_FLAG_MUTE};
+        const char mark[4] = {'E', 'T', 'R', 'M'};
+        for (int i = 0; i < 4 && pos + 1u < size; ++i) {
+            if (result->flags & order[i]) {
+                str[pos++] = mark[i];
+            }
+        }
+    }
+    str[pos] = '\0';
+}
+
+static void tone_call(float* aout_buf, const char* ambe_d, mbe_parms* cur_mp, const int* dstar_id) {
+    if (!aout_buf) {
+        return;
+    }
+    memset(aout_buf, 0, 160 * sizeof(float));
+    if (!cur_mp) {
+        return;
+    }
+    Slot& s = slot();
+    int32_t id = 0;
+    if (dstar_id) {
+        id = *dstar_id;
+        s.up(&s.words[0], &id, sizeof(id));
+    } else {
+        if (validate_bits(ambe_d, 49u) < 0) {
+            return;
+        }
+        mbe_process_result none;
+        memset(&none, 0, sizeof(none));
+        const mbx_param_record rec = make_record(ambe_d, 49, &none, 0);
+        s.up(s.rec, &rec, sizeof(rec));
+    }
+    s.up(&s.state[0], cur_mp, sizeof(mbe_parms));
+    must(mbx_synthesize_tone(1, dstar_id ? nullptr : s.rec, dstar_id ? reinterpret_cast<const int32_t*>(&s.words[0]) : nullptr,
+                             &s.state[0], s.pcmf, nullptr, s.stream),
+         "mbx_synthesize_tone");
+    s.down(aout_buf, s.pcmf, 160 * sizeof(float));
+    s.down(cur_mp, &s.state[0], sizeof(mbe_parms));
+    s.sync();
+}
+
+void mbe_synthesizeTonef(float* aout_buf, const char* ambe_d, mbe_parms* cur_mp) { tone_call(aout_buf, ambe_d, cur_mp, nullptr); }
+
+void mbe_synthesizeTonefdstar(float* aout_buf, const char* ambe_d, mbe_parms* cur_mp, int ID1) {
+    (void)ambe_d;
+    tone_call(aout_buf, nullptr, cur_mp, &ID1);
+}
+
 // ---- soft-decision helpers: ref src/core/mbelib.c:107-158, src/ecc/ecc.c:303-357, 410-413 -----
 mbe_soft_bit mbe_softBitFromHard(int bit, uint8_t reliability) {
     mbe_soft_bit s;

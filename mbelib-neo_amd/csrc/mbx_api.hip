@@ -33,6 +33,7 @@ __global__ void enhance_kernel(int, mbe_parms*);
 __global__ void smoothing_kernel(int, mbe_parms*, const mbe_parms*);
 __global__ void comfort_noise_kernel(int, mbx_stream_rng*, float*, int16_t*);
 __global__ void state_copy_kernel(int, mbe_parms*);
+__global__ void tone_kernel(int, const mbx_param_record*, const int32_t*, mbe_parms*, float*, int16_t*);
 __global__ void ecc_words_kernel(int, const uint32_t*, size_t, uint32_t*, int32_t*, DeviceTables);
 __global__ void fec_imbe7200x4400_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
 __global__ void fec_ambe3600x2450_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
@@ -659,6 +660,20 @@ int mbx_comfort_noise(int S, mbx_stream_rng* d_rng, float* d_pcmf, int16_t* d_pc
     hipLaunchKernelGGL(mbx::comfort_noise_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_rng, d_pcmf,
                        d_pcm16);
     return check_launch("comfort_noise_kernel");
+}
+
+int mbx_synthesize_tone(int S, const mbx_param_record* d_records, const int32_t* d_dstar_ids, mbe_parms* d_cur, float* d_pcmf,
+                        int16_t* d_pcm16, void* stream) {
+    REQUIRE_READY();
+    if (!d_cur || S < 0 || (!d_records && !d_dstar_ids)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::tone_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_records, d_dstar_ids, d_cur,
+                       d_pcmf, d_pcm16);
+    return check_launch("tone_kernel");
 }
 
 int mbx_state_copy(int S, mbe_parms* d_state, void* stream) {

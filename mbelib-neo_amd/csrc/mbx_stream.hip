@@ -1684,6 +1684,30 @@ synth_speech_kernel(int S, mbe_parms* __restrict__ curs, mbe_parms* __restrict__
 }
 
 
+// mbe_synthesizeTonef (ids == nullptr: AMBE+2 tone from the 49 parameter bits of the record, ref src/core/mbelib.c:745-804)
+// / mbe_synthesizeTonefdstar (ids[s] = D-STAR tone index, ref :813-856), batched: one wavefront per struct
+__global__ void __launch_bounds__(64)
+tone_kernel(int S, const mbx_param_record* __restrict__ records, const int32_t* __restrict__ ids, mbe_parms* __restrict__ curs,
+            float* __restrict__ pcmf, int16_t* __restrict__ pcm16) {
+    const int s = blockIdx.x;
+    if (s >= S) {
+        return;
+    }
+    const int lane = lane_id();
+    Parms cur;
+    load_parms(cur, &curs[s], lane);
+    float out[3];
+    if (ids) {
+        tone_dstar_frame(out, ids[s], cur, lane);
+    } else {
+        const uint4 rec = *reinterpret_cast<const uint4*>(&records[s]);
+        const uint32_t w[3] = {rec.x, rec.y, rec.z};
+        tone_frame(out, w, cur, lane);
+    }
+    store_pcm(out, (size_t)s, pcm16, pcmf, lane);
+    store_parms(cur, &curs[s], lane);
+}
+
 // ------------------------------------------------------------------------------------------
 // Single-stage entry points of the public API, batched: one wavefront per struct.
 //   mbe_spectralAmpEnhance       ref src/core/mbelib.c:663-666

@@ -39,6 +39,9 @@ extern int mbe_processImbe7200x4400Framef(float*, mbe_process_result*, const cha
 extern int mbe_processAmbe3600x2450Framef(float*, mbe_process_result*, const char[4][24], char[49], mbe_parms*,
                                           mbe_parms*, mbe_parms*);
 extern int mbe_processImbe4400Dataf(float*, mbe_process_result*, const char[88], mbe_parms*, mbe_parms*, mbe_parms*);
+/* tones: include/mbelib-neo/mbelib.h:630, 638 */
+extern void mbe_synthesizeTonef(float*, const char*, mbe_parms*);
+extern void mbe_synthesizeTonefdstar(float*, const char*, mbe_parms*, int);
 /* AMBE 3600x2400 (D-STAR): include/mbelib-neo/mbelib.h:315-375 */
 extern int mbe_processAmbe3600x2400Framef(float*, mbe_process_result*, const char[4][24], char[49], mbe_parms*, mbe_parms*,
                                           mbe_parms*);
@@ -943,10 +946,63 @@ gen_ambe2400(const char* dir) {
     printf("ambe2400_kat.bin written\n");
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* tone_kat.bin: mbe_synthesizeTonef / mbe_synthesizeTonefdstar on one evolving mbe_parms each.
+ *   u32 N1, N1 x { char d[49], float pcm[160], i32 swn, u32 tonePhase }     AMBE+2 tones from parameter bits
+ *   u32 N2, N2 x { i32 id, float pcm[160], i32 swn, u32 tonePhase }         D-STAR tone indices              */
+static void
+gen_tones(const char* dir) {
+    FILE* f = open_out(dir, "tone_kat.bin");
+    static const int ids[16] = {5, 6, 7, 64, 122, 123, 128, 129, 143, 144, 150, 163, 164, 255, 4, 0};
+    static const int ads[3] = {127, 64, 3};
+    mbe_parms cur, prev, enh;
+    mbe_initMbeParms(&cur, &prev, &enh);
+    uint32_t n = 16 * 3;
+    W(f, &n, 4);
+    for (int i = 0; i < 16; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            char d[49];
+            float out[160];
+            memset(d, 0, sizeof(d));
+            const int AD = ads[a], id = ids[i];
+            for (int b = 0; b < 6; ++b) {
+                d[b] = 1; /* tone signature in the top six bits of u0 */
+            }
+            for (int b = 0; b < 6; ++b) {
+                d[6 + b] = (char)(((AD >> 1) >> (5 - b)) & 1); /* AD bits 6..1 */
+            }
+            for (int b = 0; b < 8; ++b) {
+                d[12 + b] = (char)((id >> (7 - b)) & 1); /* ID1 = bits 11..4 of u1 */
+            }
+            d[35 + 9] = (char)(AD & 1); /* u3 bit 4 = AD bit 0 (u3 = d[35..48], bit 13 first) */
+            mbe_synthesizeTonef(out, d, &cur);
+            W(f, d, 49);
+            W(f, out, sizeof(out));
+            W(f, &cur.swn, 4);
+            W(f, &cur.tonePhase, 4);
+        }
+    }
+    static const int dids[10] = {5, 6, 7, 50, 50, 122, 123, 0, 4, 100};
+    mbe_initMbeParms(&cur, &prev, &enh);
+    n = 10;
+    W(f, &n, 4);
+    for (int i = 0; i < 10; ++i) {
+        float out[160];
+        int32_t id = dids[i];
+        mbe_synthesizeTonefdstar(out, NULL, &cur, id);
+        W(f, &id, 4);
+        W(f, out, sizeof(out));
+        W(f, &cur.swn, 4);
+        W(f, &cur.tonePhase, 4);
+    }
+    fclose(f);
+    printf("tone_kat.bin written\n");
+}
+
 int
 main(int argc, char** argv) {
     if (argc != 2 && argc != 3) {
-        fprintf(stderr, "usage: %s outdir [soft|imbe7100|ambe2400]\n", argv[0]);
+        fprintf(stderr, "usage: %s outdir [soft|imbe7100|ambe2400|tones]\n", argv[0]);
         return 2;
     }
     const char* dir = argv[1];
@@ -962,6 +1018,10 @@ main(int argc, char** argv) {
         gen_ambe2400(dir);
         return 0;
     }
+    if (argc == 3 && strcmp(argv[2], "tones") == 0) {
+        gen_tones(dir);
+        return 0;
+    }
     gen_ecc(dir);
     gen_fec(dir, 0, 2048);
     gen_fec(dir, 1, 2048);
@@ -975,5 +1035,6 @@ main(int argc, char** argv) {
     gen_soft(dir);
     gen_imbe7100(dir);
     gen_ambe2400(dir);
+    gen_tones(dir);
     return 0;
 }

@@ -186,3 +186,17 @@ def ambe2400_kat():
     off += S2 * per_stream2.itemsize
     assert off == b.size
     return framed, data
+
+
+def tone_kat():
+    """tone_kat.bin (layout: oracle/tools/gen_fixtures.c gen_tones): (AMBE+2 tone frames, D-STAR tone frames)"""
+    b = _read("tone_kat.bin")
+    d1 = np.dtype([("bits", "i1", (49,)), ("pcmf", "<f4", (160,)), ("swn", "<i4"), ("tonePhase", "<u4")])
+    d2 = np.dtype([("id", "<i4"), ("pcmf", "<f4", (160,)), ("swn", "<i4"), ("tonePhase", "<u4")])
+    n1 = int(b[:4].view("<u4")[0])
+    a = b[4 : 4 + n1 * d1.itemsize].view(d1)
+    off = 4 + n1 * d1.itemsize
+    n2 = int(b[off : off + 4].view("<u4")[0])
+    c = b[off + 4 : off + 4 + n2 * d2.itemsize].view(d2)
+    assert off + 4 + n2 * d2.itemsize == b.size
+    return a, c

@@ -71,6 +71,10 @@ class Oracle:
         h.mbxo_rng_seed.argtypes = [_vp, C.c_uint32]
         h.mbxo_fnv1a32.restype = C.c_uint32
         h.mbxo_fnv1a32.argtypes = [_vp, C.c_size_t]
+        h.mbxo_tonef.restype = None
+        h.mbxo_tonef.argtypes = [_vp, _vp, _vp]
+        h.mbxo_tone_dstarf.restype = None
+        h.mbxo_tone_dstarf.argtypes = [_vp, _vp, C.c_int]
         # IMBE 7100x4400 front end
         h.mbxo_pack_imbe7100_frame.restype = C.c_int
         h.mbxo_pack_imbe7100_frame.argtypes = [_vp, _vp]

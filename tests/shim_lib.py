@@ -87,6 +87,12 @@ def load():
     for name in ("mbe_requiresMuting", "mbe_isMaxFrameRepeat", "mbe_requiresAdaptiveSmoothing"):
         getattr(h, name).restype = C.c_int
         getattr(h, name).argtypes = [_vp]
+    h.mbe_synthesizeTonef.restype = None
+    h.mbe_synthesizeTonef.argtypes = [_vp, _vp, _vp]
+    h.mbe_synthesizeTonefdstar.restype = None
+    h.mbe_synthesizeTonefdstar.argtypes = [_vp, _vp, _vp, C.c_int]
+    h.mbe_formatProcessResult.restype = None
+    h.mbe_formatProcessResult.argtypes = [C.c_char_p, C.c_size_t, _vp]
     h.mbe_versionString.restype = C.c_char_p
     return h
 

@@ -510,3 +510,31 @@ def test_ambe2400_entry_points_match_reference_fixture(mbe):
         assert res[0]["flags"] == row["result"]["flags"]
     parity.check_pcm(st["frames"]["pcmf"], pcm)
     parity.check_state(st["final"].reshape(1, 3), np.concatenate([cur, prev, enh]).reshape(1, 3))
+
+
+def test_tone_and_format_entry_points(mbe):
+    import ctypes as C
+
+    ambe, dstar = golden_io.tone_kat()
+    cur, prev, enh = (np.zeros(1, dtype=PARMS_DTYPE) for _ in range(3))
+    mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))
+    for row in ambe:
+        pcm = np.zeros(160, dtype=np.float32)
+        bits = np.ascontiguousarray(row["bits"])
+        mbe.mbe_synthesizeTonef(p(pcm), p(bits), p(cur))
+        assert np.max(np.abs(pcm - row["pcmf"])) <= 2e-3   # sinf of the device libm vs glibc on a 4400-peak tone
+        assert int(cur["swn"][0]) == row["swn"] and int(cur["tonePhase"][0]) == row["tonePhase"]
+    mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))
+    for row in dstar:
+        pcm = np.zeros(160, dtype=np.float32)
+        mbe.mbe_synthesizeTonefdstar(p(pcm), None, p(cur), int(row["id"]))
+        assert np.max(np.abs(pcm - row["pcmf"])) <= 2e-3
+        assert int(cur["swn"][0]) == row["swn"]
+    res = np.zeros(1, dtype=RESULT_DTYPE)
+    res[0]["total_errors"] = 3
+    res[0]["flags"] = 0x20 | 0x40
+    buf = C.create_string_buffer(16)
+    mbe.mbe_formatProcessResult(buf, 16, p(res))
+    assert buf.value == b"===ER"
+    mbe.mbe_formatProcessResult(buf, 4, p(res))
+    assert buf.value == b"==="

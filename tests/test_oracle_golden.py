@@ -351,3 +351,21 @@ def test_ambe2400_scripted_data_streams_match_reference(oracle):
         parity.check_pcm(stream["frames"]["pcmf"], pcm, rel=2e-6, worst=2e-5)
         parity.check_state(stream["final"].reshape(1, 3), state.reshape(1, 3))
     assert any(f & 0x10 for f in seen) and any(f & 0x40 for f in seen)   # tone class and repeats both occurred
+
+
+def test_tone_frames_match_reference(oracle):
+    """mbe_synthesizeTonef / mbe_synthesizeTonefdstar with their phase continuity across frames"""
+    ambe, dstar = golden_io.tone_kat()
+    cur = oracle.init_state(1)[0, 0:1].copy()
+    for row in ambe:
+        pcm = np.zeros(160, dtype=np.float32)
+        bits = np.ascontiguousarray(row["bits"])
+        oracle.h.mbxo_tonef(pcm.ctypes.data, bits.ctypes.data, cur.ctypes.data)
+        assert np.array_equal(pcm, row["pcmf"])
+        assert int(cur["swn"][0]) == row["swn"] and int(cur["tonePhase"][0]) == row["tonePhase"]
+    cur = oracle.init_state(1)[0, 0:1].copy()
+    for row in dstar:
+        pcm = np.zeros(160, dtype=np.float32)
+        oracle.h.mbxo_tone_dstarf(pcm.ctypes.data, cur.ctypes.data, int(row["id"]))
+        assert np.array_equal(pcm, row["pcmf"])
+        assert int(cur["swn"][0]) == row["swn"] and int(cur["tonePhase"][0]) == row["tonePhase"]
