@@ -679,8 +679,10 @@ __device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
 // samples are recomputed from the seed.  Returns true when the frame was synthesised (cur.uw / cur.ov / cur.PHIl /
 // cur.PSIl are new), false when it left early (silence, comfort noise): the per-lane state is then still what
 // the snapshot holds.
+template <bool kSnap>
 __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
-                           WaveScratch& S, const DeviceTables& tabs, int lane, const mbe_parms* snap = nullptr) {
+                           WaveScratch& S, const DeviceTables& tabs, int lane, const mbe_parms* snap_ptr = nullptr) {
+    const mbe_parms* const snap = kSnap ? snap_ptr : nullptr;
     const mbx_tables* T = tabs.t;
     const DerivedTables* D = tabs.d;
     constexpr int N = 160;
@@ -1258,7 +1260,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         {
             const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
             if (!(tabs.ablate & 128)) {
-                fresh = synth_core(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
+                fresh = synth_core<true>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
             }
         }
         {
@@ -1646,6 +1648,8 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         if (action == kVoice) {
             store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
             load_enh_view(enh, slot_enh, lane);
+            cur.log2Ml = 0.0f;                   // read back from the snapshot after the synthesiser (see the IMBE kernel)
+            cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
             rm0 = enhance(cur, lane);
         } else if (action == kToneFallback) {
             // invalid tone id: run the synthesiser on a copy of the enhanced model.  `cur` is parked in
@@ -1654,9 +1658,27 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             __threadfence_block();
             load_parms(enh, slot_enh, lane);
             cur = enh;
+            cur.log2Ml = 0.0f;   // slot_enh itself is the snapshot of this copy
+            cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
         }
         if (action == kVoice || action == kToneFallback) {
-            synth_core(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane);
+            const mbe_parms* snap = (action == kVoice) ? slot_prev : slot_enh;
+            const bool fresh = synth_core<true>(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane, snap);
+            {
+                __threadfence_block();
+                const float* f = reinterpret_cast<const float*>(snap);
+                if (lane < MBX_BAND_SLOTS) {
+                    cur.log2Ml = f[O_LOG2ML + lane];
+                }
+                if (!fresh) {   // silence / comfort noise: previousUw and the noise overlap are unchanged
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        cur.uw[j] = f[O_UW + lane + 64 * j];
+                    }
+                    cur.ov[0] = f[O_OVERLAP + lane];
+                    cur.ov[1] = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
+                }
+            }
             store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := synthesised model
             if (action == kToneFallback) {
                 __threadfence_block();
@@ -1726,7 +1748,7 @@ synth_speech_kernel(int S, mbe_parms* __restrict__ curs, mbe_parms* __restrict__
     StreamRng rng;
     load_rng(rng, &rngs[s]);
     float out[3];
-    synth_core(out, cur, prev, false, 0.0f, rng, scratch, tabs, lane);
+    synth_core<false>(out, cur, prev, false, 0.0f, rng, scratch, tabs, lane);
     store_pcm(out, (size_t)s, pcm16, pcmf, lane);
     store_parms(cur, &curs[s], lane);
     store_parms(prev, &prevs[s], lane);
