@@ -184,6 +184,40 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     for (int L = 1; L < 64; ++L) {
         d.log2_int[L] = log2f((float)L);
     }
+    for (int l9 = 0; l9 < 48; ++l9) {   // who owns what in the IMBE parameter expansion (ref src/imbe/imbe7200x4400.c:233-270)
+        const uint8_t* J = host->imbe_ji[l9];
+        const int L = l9 + 9;
+        for (int lane = 0; lane < 64; ++lane) {
+            int hblk = 1, first = 0, ji = J[0];   // higher-order coefficient of word lane + 8
+            for (int q = 1; q < 6; ++q) {
+                if (lane >= first + (ji - 1)) {
+                    first += ji - 1;
+                    hblk = q + 1;
+                    ji = J[q];
+                }
+            }
+            const int hk = lane - first + 2;
+            int iblk = 1, ifirst = 1, iji = J[0];   // harmonic `lane`
+            for (int q = 1; q < 6; ++q) {
+                if (lane >= ifirst + iji) {
+                    ifirst += iji;
+                    iblk = q + 1;
+                    iji = J[q];
+                }
+            }
+            const int ij = lane - ifirst + 1;
+            const bool harm = lane >= 1 && lane <= L && iji >= 1 && iji <= 10 && ij >= 1 && ij <= 10;
+            d.imbe_lane_map[l9][lane] = (uint32_t)hblk | ((uint32_t)(hk & 15) << 3) | ((uint32_t)iblk << 7)
+                                        | ((uint32_t)(iji & 15) << 10) | ((uint32_t)(ij & 15) << 14);
+            d.imbe_hoc_sd[l9][lane] = (hk >= 2 && hk <= 10) ? host->imbe_standdev[hk - 2] : 0.0f;
+            for (int k = 1; k <= 10; ++k) {
+                d.imbe_idct_rows[l9][lane][k - 1] = harm ? host->imbe_idct_cos[iji][ij][k] : 0.0f;
+            }
+        }
+    }
+    for (int n = 0; n < 160; ++n) {
+        d.wola_inv[n] = (host->wola_denom[n] > 1e-10f) ? (1.0f / host->wola_denom[n]) : 0.0f;
+    }
     for (int b0 = 0; b0 < 128; ++b0) {   // ref src/ambe/ambe3600x2400.c:238 (same expression, host libm)
         d.ambep_f0[b0] = exp2f(-4.311767578125f - (2.1336e-2f * ((float)b0 + 0.5f)));
     }

@@ -22,6 +22,11 @@ struct DerivedTables {
     uint32_t pr_add[116];     // additive term after k steps
     uint32_t ham_basis[11];   // Hamming(15,11) code word of data bit i (soft-decision candidates)
     uint32_t ham7100_basis[11];   // the same for the IMBE 7100x4400 bit mapping
+    // IMBE parameter expansion, per L (index L - 9) and lane: which block / position a lane owns
+    uint32_t imbe_lane_map[48][64];       // hoc block | hoc index k << 3 | harmonic's block << 7 | block length << 10 | index j << 14
+    float    imbe_hoc_sd[48][64];         // standdev[k - 2] of the higher-order coefficient in word lane + 8
+    float    imbe_idct_rows[48][64][10];  // idct_cos[ji][j][1..10] of harmonic `lane`
+    float    wola_inv[160];       // 1 / wola_denom[n] (0 where the reference skips the sample: denom <= 1e-10)
     float    ambep_f0[128];       // AMBE 3600x2400: exp2f(-4.311767578125f - 2.1336e-2f * (b0 + 0.5f)) from the host libm
 };
 

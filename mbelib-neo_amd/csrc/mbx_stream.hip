@@ -236,7 +236,7 @@ struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
 typedef const __attribute__((address_space(4))) mbx_tables* ConstTables;
 __device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
 
-__device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, const mbx_tables* Tg, int lane) {
+__device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, const mbx_tables* Tg, const DerivedTables* Dg, int lane) {
     ConstTables T = (ConstTables)Tg;
     const __attribute__((address_space(4))) uint32_t* rq = (const __attribute__((address_space(4))) uint32_t*)rp;
     const uint4 rec = make_uint4(rq[0], rq[1], rq[2], rq[3]);
@@ -258,11 +258,6 @@ __device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, con
     }
     if (!bad) {
         const int L9 = L - 9;
-        int J[6];   // block lengths, wave-uniform
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            J[q] = (int)T->imbe_ji[L9][q];
-        }
         // ---- every per-lane table value is requested here ----
         const uint16_t* bo = reinterpret_cast<const uint16_t*>(&Tg->imbe_bo[L9][0][0]);
         const uint32_t e0 = bo[lane], e1 = bo[lane < 15 ? lane + 64 : 78];
@@ -270,41 +265,19 @@ __device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, con
         const float nb = Tg->imbe_ba[L9][g][0], step = Tg->imbe_ba[L9][g][1];
         const float b2 = Tg->imbe_B2[lane];
         const float qs = Tg->imbe_quantstep[lane < 11 ? lane : 0];
-        int hblk = 1, hk;   // higher-order coefficient owned by this lane (word lane + 8): block, index
-        {
-            int first = 0, ji = J[0];
-#pragma unroll
-            for (int q = 1; q < 6; ++q) {
-                if (lane >= first + (ji - 1)) {
-                    first += ji - 1;
-                    hblk = q + 1;
-                    ji = J[q];
-                }
-            }
-            hk = lane - first + 2;
-        }
+        // which higher-order coefficient / harmonic a lane owns depends on L only: host-made tables (mbx_init)
+        const uint32_t own = Dg->imbe_lane_map[L9][lane];
+        const int hblk = (int)(own & 7u), hk = (int)((own >> 3) & 15u);
+        const int iblk = (int)((own >> 7) & 7u);
         const int Bm = Tg->imbe_hoba[L9][lane < 50 ? lane : 0];
-        const float sd = Tg->imbe_standdev[(hk >= 2 && hk <= 10) ? hk - 2 : 0];
-        int iblk = 1, iji = J[0], ij;   // harmonic owned by this lane: block, block length, index in block
-        {
-            int first = 1;
-#pragma unroll
-            for (int q = 1; q < 6; ++q) {
-                if (lane >= first + iji) {
-                    first += iji;
-                    iblk = q + 1;
-                    iji = J[q];
-                }
-            }
-            ij = lane - first + 1;
-        }
+        const float sd = Dg->imbe_hoc_sd[L9][lane];
         const bool harm = lane >= 1 && lane <= L;
         float cosr[11], ric[7];   // fetched now: loads cannot move up across the LDS fences below
         {
-            const float* row = &Tg->imbe_idct_cos[harm ? iji : 1][harm ? ij : 1][0];
+            const float* row = &Dg->imbe_idct_rows[L9][lane][0];
 #pragma unroll
             for (int k = 1; k <= 10; ++k) {
-                cosr[k] = row[k];
+                cosr[k] = row[k - 1];
             }
             const float* col = &Tg->imbe_ri_cos[0][(lane >= 1 && lane <= 6) ? lane : 0];
 #pragma unroll
@@ -1088,7 +1061,8 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     if (!(tabs.ablate & 32)) {
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
         // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
-        const float wden[3] = {T->wola_denom[lane], T->wola_denom[lane + 64], (lane < 32) ? T->wola_denom[lane + 128] : 1.0f};
+        // the division by w(n)^2 + w(n-160)^2 is a multiplication by its rounded reciprocal (<= 1 ulp of the unvoiced part)
+        const float winv[3] = {D->wola_inv[lane], D->wola_inv[lane + 64], (lane < 32) ? D->wola_inv[lane + 128] : 0.0f};
         const float wprev[2] = {T->wola_w_prev[lane], T->wola_w_prev[lane + 64]};   // w(n) is 0 from n = 106 on
         const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
 #pragma unroll
@@ -1097,8 +1071,8 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const float cs = __shfl_xor(give, 32, kWave);
             const float ps = (j == 0) ? prev.uw[2] : ((j == 1) ? prev.uw[3] : 0.0f);
             const float wp = (j < 2) ? wprev[j] : 0.0f;
-            if ((lane + 64 * j) < N && wden[j] > 1e-10f) {
-                acc[j] += ((wp * ps) + (wcurr[j] * cs)) / wden[j];
+            if ((lane + 64 * j) < N) {
+                acc[j] += ((wp * ps) + (wcurr[j] * cs)) * winv[j];
             }
         }
         wave_lds_sync();
@@ -1211,7 +1185,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             scratch.x.fp[lane] = params[f].v[lane];
             wave_lds_sync();
         } else {
-            expand_imbe_wave(&records[f], scratch, tabs.t, lane);
+            expand_imbe_wave(&records[f], scratch, tabs.t, tabs.d, lane);
         }
         const float* fp = scratch.x.fp;
         const uint32_t errw = uni(__float_as_uint(fp[62]));
