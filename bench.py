@@ -177,9 +177,11 @@ def main():
         _native.check(fec(d_frames.data_ptr(), n, out["records"].data_ptr(), stream), "fec")
         run = L.mbx_process_records
         stream_codec = 0 if codec == 2 else codec   # 7100x4400 records are in 7200x4400 order after its FEC stage
-        # IMBE: mbx_process_records is ONE launch.  AMBE+2: it is the expand launch + the stream launch;
-        # they are issued separately here so that the events bracket the stream kernel only.
-        if args.split_expand or codec in (1, 3):
+        # mbx_process_records is ONE launch for IMBE at T > 1 (expansion fused into the stream kernel); otherwise
+        # it is the expand launch + the stream launch, issued separately here so that the events bracket the
+        # stream kernel only.  --split-expand forces the separate launch for IMBE at T > 1 (development aid).
+        split = (codec in (1, 3)) or (T == 1) or args.split_expand
+        if split:
             _native.check(L.mbx_expand_records(stream_codec, out["records"].data_ptr(), n, stream), "expand")
             run = L.mbx_stream_expanded
         if ev is not None:

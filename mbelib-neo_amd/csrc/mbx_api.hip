@@ -579,7 +579,12 @@ int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_recor
     if (S == 0 || T == 0) {
         return 0;
     }
-    if (codec == MBX_CODEC_IMBE7200X4400) {   // expansion fused into the stream kernel
+    // IMBE: the stream kernel can expand the records itself.  With several frames per stream that saves the
+    // workspace round trip and a launch (+4 % at T = 16).  With ONE frame per stream the whole-job rate is the same
+    // either way (measured 0.364 vs 0.363 ms per 65,536 frames): the table look-ups of the expansion are a latency
+    // chain a one-frame wave cannot hide, and the 8-lanes-per-frame expand kernel costs as much as it saves -- there
+    // the expansion stays a separate launch, which keeps the dominant kernel to the stream stage proper.
+    if (codec == MBX_CODEC_IMBE7200X4400 && T > 1) {
         return launch_stream(codec, S, T, d_records, nullptr, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
     }
     int rc = mbx_expand_records(codec, d_records, (size_t)S * (size_t)T, stream);
