@@ -1630,8 +1630,8 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             // its slot meanwhile so that still only two structs are live.
             store_parms(cur, slot_cur, lane);
             __threadfence_block();
-            load_parms(enh, slot_enh, lane);
-            cur = enh;
+            load_parms(cur, slot_enh, lane);     // the copy that is synthesised ...
+            load_enh_view(enh, slot_enh, lane);  // ... against the enhanced model itself (only the fields synthesis reads)
             cur.log2Ml = 0.0f;   // slot_enh itself is the snapshot of this copy
             cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
         }
