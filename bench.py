@@ -80,9 +80,70 @@ def measured_traffic(workload, S, T):
     return best
 
 
+def unpack_cells(codec, frames):
+    """packed wire frames [n, 18|9] -> the reference's char cell arrays [n, rows*cols] (int8)"""
+    from mbelib_neo_amd.layout import FRAME_CELLS, ROW_WIDTHS
+
+    rows, cols = FRAME_CELLS[codec]
+    bits = np.unpackbits(np.ascontiguousarray(frames, dtype=np.uint8), axis=1)
+    cells = np.zeros((frames.shape[0], rows, cols), dtype=np.int8)
+    off = 0
+    for r, w in enumerate(ROW_WIDTHS[codec]):
+        cells[:, r, :w] = bits[:, off:off + w][:, ::-1]   # the first wire bit of a row is its highest cell
+        off += w
+    return cells.reshape(frames.shape[0], rows * cols)
+
+
+def reference_baseline(name, codec, T, budget_s=12.0):
+    """The REAL reference (oracle/_ref/libmbe_ref.so, IEEE scalar build made by oracle/Makefile from the reference's
+    own sources) through oracle/tools/ref_bench.c, ONE host core, bounded sample.  None when the library is absent."""
+    import ctypes as C
+
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_bench.so")
+    if not os.path.exists(path) or name.endswith("_soft"):
+        return None
+    try:
+        lib = C.CDLL(path)
+    except OSError:
+        return None
+    from mbelib_neo_amd.layout import FRAME_CELLS, init_state
+
+    lib.ref_process_batch.restype = C.c_int
+    lib.ref_process_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+    S = 4096 if T == 1 else max(64, 4096 // T)
+    cells = np.ascontiguousarray(unpack_cells(codec, make_frames(name, codec, S, T, rank=0)))
+    ncell = FRAME_CELLS[codec][0] * FRAME_CELLS[codec][1]
+    state = np.ascontiguousarray(init_state(S))
+    pcm = np.zeros((S * T, 160), dtype=np.int16)
+
+    def once():
+        rc = lib.ref_process_batch(codec, S, T, cells.ctypes.data, ncell, state.ctypes.data, 1234, pcm.ctypes.data)
+        assert rc == 0, rc
+
+    once()   # warm-up pass (also warms the state, like the GPU run)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        once()
+        done += S * T
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return {
+        "value": done / dt,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "reference",
+        "sample": f"{done} frames ({S} streams x T={T}, same generator as the GPU workload) in {dt:.1f} s, single thread, "
+                  "the reference's own sources built -O2 IEEE scalar (oracle/_ref/libmbe_ref.so), int16 output",
+    }
+
+
 def cpu_baseline(name, codec, T, budget_s=12.0):
-    """The CPU oracle (a port of the reference path, oracle/mbx_oracle.c) on ONE host core, on a
-    bounded sample of the same workload."""
+    """CPU baseline on ONE host core, on a bounded sample of the same workload: the real reference when its
+    library travelled with the snapshot, else the CPU oracle (a port of the reference path, oracle/mbx_oracle.c)."""
+    ref = reference_baseline(name, codec, T, budget_s)
+    if ref is not None:
+        return ref
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
