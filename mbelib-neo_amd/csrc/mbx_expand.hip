@@ -293,19 +293,21 @@ __device__ __forceinline__ void expand_ambe_body(const mbx_param_record* __restr
                 l += lmprbl[L][q - 1];
             }
             const int ji = lmprbl[L][blk - 1];
-            float C[18];
+            // Coefficients 7..17 of a block are zero (:337-348); the reference still adds their products, which
+            // leaves every partial sum unchanged (x + 0*c == x for every x this sum can take), so only k <= 6 is done.
+            float C[7];
             C[1] = (float)0.5 * (Ra + Rb);
             C[2] = rconst * (Ra - Rb);
 #pragma unroll
-            for (int k = 3; k <= 17; ++k) {
-                C[k] = (k <= 6 && k <= ji) ? hoc[k - 3] : 0.0f;
+            for (int k = 3; k <= 6; ++k) {
+                C[k] = (k <= ji) ? hoc[k - 3] : 0.0f;
             }
             const int jsplit = (ji + 1) >> 1;
             const int j0 = half ? jsplit + 1 : 1, j1 = half ? ji : jsplit;
             for (int j = j0; j <= j1; ++j) {
                 float sum = 0;
 #pragma unroll
-                for (int k = 1; k <= 17; ++k) {
+                for (int k = 1; k <= 6; ++k) {
                     if (k <= ji) {
                         const float ak = (k == 1) ? 1.0f : 2.0f;
                         sum = sum + (ak * C[k] * T->ambe_idct_cos[ji][j][k]);
