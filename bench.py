@@ -330,7 +330,7 @@ def main():
         },
     }
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # timed at N = 1 only, on rank 0
             line["cpu_baseline"] = cpu_baseline(args.workload, codec, T)
         print(json.dumps(line), flush=True)
     if world > 1:
