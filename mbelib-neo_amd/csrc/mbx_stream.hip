@@ -481,26 +481,16 @@ __device__ __forceinline__ void unit_phasor_hw(double rev, float& c, float& s) {
     s = __builtin_amdgcn_sinf(r);
 }
 
-// The same to float accuracy (phase error <= 8.3e-8, rms 2.4e-8): quadrant reduction in double,
-// Taylor polynomials on [-pi/4, pi/4].  Used where the error is amplified afterwards.
+// The same with the rounding of the reduced argument taken back out: hardware value at the rounded argument,
+// first-order correction for the residual (phase error <= 1.3e-7, rms 5.2e-8; tools/phasor_accuracy.hip).
+// Used where the error is amplified afterwards.
 __device__ __forceinline__ void unit_phasor(double rev, float& c, float& s) {
-    const double rr = rev - floor(rev);
-    const double q = rint(rr * 4.0);
-    const float x = (float)((rr - (q * 0.25)) * 6.283185307179586);
-    const float x2 = x * x;
-    float sp = fmaf(x2, 2.7557319e-6f, -1.9841270e-4f);
-    sp = fmaf(sp, x2, 8.3333333e-3f);
-    sp = fmaf(sp, x2, -1.6666667e-1f);
-    sp = fmaf(sp * x2, x, x);
-    float cp = fmaf(x2, -2.7557319e-7f, 2.4801587e-5f);
-    cp = fmaf(cp, x2, -1.3888889e-3f);
-    cp = fmaf(cp, x2, 4.1666667e-2f);
-    cp = fmaf(cp, x2, -0.5f);
-    cp = fmaf(cp, x2, 1.0f);
-    const int k = (int)q;
-    const float ss = (k & 1) ? cp : sp, cc = (k & 1) ? sp : cp;
-    s = (k & 2) ? -ss : ss;
-    c = ((k + 1) & 2) ? -cc : cc;
+    const double rr = rev - rint(rev);
+    const float r = (float)rr;
+    const float lo = (float)((rr - (double)r) * 6.283185307179586);
+    const float c0 = __builtin_amdgcn_cosf(r), s0 = __builtin_amdgcn_sinf(r);
+    c = fmaf(-lo, s0, c0);
+    s = fmaf(lo, c0, s0);
 }
 
 // ------------------------------------------------------------------------------------------
