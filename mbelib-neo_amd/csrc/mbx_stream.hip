@@ -448,24 +448,6 @@ __device__ __forceinline__ void imbe_headroom_reset(Parms& mp, int lane) {
     mp.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
 }
 
-// One oscillator step (c, s) <- (c, s) * (cd, sd).  The reference spends 6 roundings per step
-// (src/core/mbelib.c:213-218); this uses 2 multiplies + 2 FMAs (4 roundings), which tracks the exact
-// rotation slightly better; the two recurrences stay within ~1e-6 of each other over a frame.
-__device__ __forceinline__ void rotate(float& c, float& s, float cd, float sd) {
-    const float c2 = fmaf(c, cd, -(s * sd));
-    const float s2 = fmaf(s, cd, c * sd);
-    c = c2;
-    s = s2;
-}
-
-// (c, s)^2 as a rotation
-__device__ __forceinline__ void square_rotation(float& c, float& s) {
-    const float c2 = fmaf(c, c, -(s * s));
-    const float s2 = 2.0f * (c * s);
-    c = c2;
-    s = s2;
-}
-
 // cos(2*pi*frac(x / 2*pi)) with the range reduction in double and the hardware v_cos_f32
 // (measured on gfx950 over |x| < 4000: max abs error 2.6e-7, rms 6.8e-8; tools/trig_accuracy.hip)
 __device__ __forceinline__ float cos_reduced(float x) {
@@ -501,23 +483,10 @@ __device__ float enhance(Parms& cur, int lane) {
     if (L < 1 || L > 56) {
         return 0.0f;
     }
-    float s_step, c_step;
-    unit_phasor((double)cur.w0 * 0.15915494309189533577, c_step, s_step);
-    // cos(l*w0) for lane = l.  The reference rotates (1, 0) l times by w0 (src/core/mbelib.c:412-424);
-    // here the lane multiplies the powers (c,s)^(2^b) selected by the bits of l -- 6 squarings
-    // instead of up to 56 dependent steps, same quantity to ~1e-7.
-    float cw, sw = 0.0f;
-    {
-        float pc = c_step, ps = s_step;
-        cw = 1.0f;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            if ((lane >> b) & 1) {
-                rotate(cw, sw, pc, ps);
-            }
-            square_rotation(pc, ps);
-        }
-    }
+    // cos(l*w0) for lane = l.  The reference rotates (1, 0) l times by w0 (src/core/mbelib.c:412-424, error ~ l * 6e-8);
+    // here it is one evaluation per lane: double-precision argument reduction + v_cos_f32 (2.8e-7).
+    float cw, sw_unused;
+    unit_phasor_hw(((double)cur.w0 * 0.15915494309189533577) * (double)lane, cw, sw_unused);
     const bool in = lane >= 1 && lane <= L;
     const float Ml2 = cur.Ml * cur.Ml;
     const float Rm0 = wave_sum(in ? Ml2 : 0.0f);
