@@ -448,13 +448,6 @@ __device__ __forceinline__ void imbe_headroom_reset(Parms& mp, int lane) {
     mp.mutingThreshold = MBE_MUTING_THRESHOLD_IMBE;
 }
 
-// cos(2*pi*frac(x / 2*pi)) with the range reduction in double and the hardware v_cos_f32
-// (measured on gfx950 over |x| < 4000: max abs error 2.6e-7, rms 6.8e-8; tools/trig_accuracy.hip)
-__device__ __forceinline__ float cos_reduced(float x) {
-    const double rev = (double)x * 0.15915494309189533577;
-    return __builtin_amdgcn_cosf((float)(rev - floor(rev)));
-}
-
 // e^{2 pi i rev}: double-precision reduction, hardware v_cos/v_sin (phase error <= 2.8e-7, mostly the
 // rounding of the reduced argument to float; tools/phasor_accuracy.hip)
 __device__ __forceinline__ void unit_phasor_hw(double rev, float& c, float& s) {
