@@ -1382,9 +1382,14 @@ __device__ __forceinline__ uint32_t tone_step(double hz) {
     return step <= 0.0 ? 0u : (uint32_t)(step + 0.5);
 }
 
+// sin(2 pi phase / 2^32 - pi/2) = -cos(2 pi phase / 2^32) (ref src/core/mbelib.c:697-706 takes sinf of the float
+// angle).  The 32-bit phase splits exactly into a 24-bit part, which v_cos/v_sin take as revolutions, and an 8-bit
+// residual carried to first order: ~2e-7 absolute, and none of libm sinf's registers in the rare tone paths.
 __device__ __forceinline__ float tone_sample(uint32_t phase) {
-    const float angle = (float)(((double)phase * ((2.0 * M_PI) / 4294967296.0)) - (M_PI / 2.0));
-    return sinf(angle);
+    const float r = (float)(phase >> 8) * (1.0f / 16777216.0f);
+    const float lo = (float)(phase & 255u) * (float)(6.283185307179586 / 4294967296.0);
+    const float c0 = __builtin_amdgcn_cosf(r), s0 = __builtin_amdgcn_sinf(r);
+    return -fmaf(-lo, s0, c0);
 }
 
 // mbe_synthesizeTonef with a tone id already known to be valid
