@@ -215,6 +215,23 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
             }
         }
     }
+    memset(d.imbe_blk_info, 0, sizeof(d.imbe_blk_info));
+    memset(d.imbe_blk_bm, 0, sizeof(d.imbe_blk_bm));
+    memset(d.imbe_blk_step, 0, sizeof(d.imbe_blk_step));
+    for (int l9 = 0; l9 < 48; ++l9) {   // per block: where its words / harmonics start and how its coefficients are quantised
+        int m = 8, l = 1;
+        for (int blk = 1; blk <= 6; ++blk) {
+            const int ji = host->imbe_ji[l9][blk - 1];
+            d.imbe_blk_info[l9][blk] = (uint32_t)m | ((uint32_t)l << 8) | ((uint32_t)ji << 16);
+            for (int k = 2; k <= ji && k <= 10; ++k) {
+                const int Bm = (m - 8 < 50) ? host->imbe_hoba[l9][m - 8] : 0;
+                d.imbe_blk_bm[l9][blk][k] = (uint8_t)Bm;
+                d.imbe_blk_step[l9][blk][k] = (Bm > 0 && Bm <= 11) ? (host->imbe_quantstep[Bm - 1] * host->imbe_standdev[k - 2]) : 0.0f;
+                ++m;
+            }
+            l += ji;
+        }
+    }
     for (int n = 0; n < 160; ++n) {
         d.wola_inv[n] = (host->wola_denom[n] > 1e-10f) ? (1.0f / host->wola_denom[n]) : 0.0f;
     }

@@ -26,6 +26,10 @@ struct DerivedTables {
     uint32_t imbe_lane_map[48][64];       // hoc block | hoc index k << 3 | harmonic's block << 7 | block length << 10 | index j << 14
     float    imbe_hoc_sd[48][64];         // standdev[k - 2] of the higher-order coefficient in word lane + 8
     float    imbe_idct_rows[48][64][10];  // idct_cos[ji][j][1..10] of harmonic `lane`
+    // the same per inverse-DCT block (index blk = 1..6) for the 8-lanes-per-frame expand kernel
+    uint32_t imbe_blk_info[48][8];        // first word m | first harmonic l << 8 | block length << 16
+    uint8_t  imbe_blk_bm[48][8][12];      // bit count of the higher-order coefficient k = 2..10 of the block (0 = none)
+    float    imbe_blk_step[48][8][12];    // quantstep[Bm - 1] * standdev[k - 2] of that coefficient
     float    wola_inv[160];       // 1 / wola_denom[n] (0 where the reference skips the sample: denom <= 1e-10)
     float    ambep_f0[128];       // AMBE 3600x2400: exp2f(-4.311767578125f - 2.1336e-2f * (b0 + 0.5f)) from the host libm
 };

@@ -70,18 +70,52 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         }
     }
     const int L9 = bad ? 0 : L - 9;
+    const bool live = (i < n) && !bad;
+    const bool block_lane = live && sub >= 1 && sub <= 6;
+    // ---- every table value this lane will need is requested HERE, in one round: the addresses depend only on L and
+    // the lane (host-made per-block tables, mbx_init), not on each other.  All 8,192 waves of a 65,536-frame launch are
+    // resident at once and move in step, so a chain of dependent look-ups would be paid in full.
+    const DerivedTables* D = tabs.d;
+    uint32_t e[10];                       // bit-layout entries of this lane's ten payload bits
+    {
+        const uint16_t* bo = reinterpret_cast<const uint16_t*>(&T->imbe_bo[L9][0][0]);
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const int idx = 10 * sub + t;
+            e[t] = bo[idx < 79 ? idx : 78];
+        }
+    }
+    const int blk = block_lane ? sub : 1;
+    const uint32_t info = D->imbe_blk_info[L9][blk];
+    const int g = (sub >= 2 && sub <= 6) ? sub - 2 : 0;
+    const float nb = T->imbe_ba[L9][g][0], step = T->imbe_ba[L9][g][1];
+    float ric[7];
+#pragma unroll
+    for (int m = 1; m <= 6; ++m) {
+        ric[m] = T->imbe_ri_cos[m][blk];
+    }
+    float qstep[11];
+    uint32_t bmw[3];                      // the block's bit counts, k = 0..11 as three dwords
+    {
+        const uint32_t* bp = reinterpret_cast<const uint32_t*>(&D->imbe_blk_bm[L9][blk][0]);
+        bmw[0] = bp[0];
+        bmw[1] = bp[1];
+        bmw[2] = bp[2];
+#pragma unroll
+        for (int k = 2; k <= 10; ++k) {
+            qstep[k] = D->imbe_blk_step[L9][blk][k];
+        }
+    }
     wave_lds_sync();
     // Bit layout (ref src/imbe/imbe7200x4400.c:156-168): payload bit i feeds bit e[1] of word e[0].  The
     // eight lanes of a frame scatter ten payload bits each with LDS atomic ORs.
-    if (i < n && !bad) {
+    if (live) {
         const uint32_t w[3] = {rec.x, rec.y, rec.z};
-        const uint16_t* bo = reinterpret_cast<const uint16_t*>(&T->imbe_bo[L9][0][0]);
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
             const int idx = 10 * sub + t;   // payload bit idx + 6
             if (idx < 79) {
-                const uint32_t e = bo[idx];
-                const uint32_t m = e & 0xffu, pos = e >> 8;
+                const uint32_t m = e[t] & 0xffu, pos = e[t] >> 8;
                 if (m < 58u && pos < 12u) {
                     atomicOr(&words[fi][m], (uint32_t)rbit(w, idx + 6) << pos);
                 }
@@ -89,13 +123,13 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         }
     }
     wave_lds_sync();
-    if (i < n && !bad && sub >= 1 && sub <= 6) {   // gain G_sub (:190-209)
-        float G;
-        if (sub == 1) {
-            G = T->imbe_B2[low_bits(words[fi][2], 6)];
-        } else {
-            const float nb = T->imbe_ba[L9][sub - 2][0];
-            const float step = T->imbe_ba[L9][sub - 2][1];
+    float b2v = 0.0f;
+    if (live && sub == 1) {
+        b2v = T->imbe_B2[low_bits(words[fi][2], 6)];   // the one look-up that depends on the frame's own bits
+    }
+    if (block_lane) {   // gain G_sub (:190-209)
+        float G = b2v;
+        if (sub != 1) {
             const int inb = (int)nb;
             const int bm = (int)low_bits(words[fi][sub + 1], inb);
             G = (step * ((float)bm - ldexpf(1.0f, inb - 1) + 0.5f));
@@ -132,49 +166,53 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             row[61] = __int_as_float(K);
             row[62] = __uint_as_float(rec.w);
             row[63] = __int_as_float(bad);
-        } else if (sub <= 6 && !bad) {
-            const int blk = sub;
-            float C[11];
+        } else if (block_lane) {
+            const int m0 = (int)(info & 0xffu), l0 = (int)((info >> 8) & 0xffu), ji = (int)((info >> 16) & 0xffu);
+            float C2[11];   // a_k * C[k]: the doubling is exact
             {   // this block's mean: one output of the 6-point inverse DCT of the gains (:211-231)
                 float sum = 0;
 #pragma unroll
                 for (int m = 1; m <= 6; ++m) {
                     const float am = (m == 1) ? 1.0f : 2.0f;
-                    sum = sum + (am * gains[fi][m] * T->imbe_ri_cos[m][blk]);
+                    sum = sum + (am * gains[fi][m] * ric[m]);
                 }
-                C[1] = sum;
+                C2[1] = sum;
             }
-            // where this block's coefficients and harmonics start
-            int m = 8, l = 1;
-            for (int q = 1; q < blk; ++q) {
-                const int jq = T->imbe_ji[L9][q - 1];
-                m += jq - 1;
-                l += jq;
-            }
-            const int ji = T->imbe_ji[L9][blk - 1];
 #pragma unroll
-            for (int k = 2; k <= 10; ++k) {
+            for (int k = 2; k <= 10; ++k) {   // higher-order coefficients (:233-249); zero past the block length
+                const int Bm = (int)((bmw[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 float v = 0.0f;
-                if (k <= ji) {
-                    const int Bm = T->imbe_hoba[L9][m - 8];
-                    if (Bm > 0) {
-                        const int bm = (int)low_bits(words[fi][m], Bm);
-                        v = ((T->imbe_quantstep[Bm - 1] * T->imbe_standdev[k - 2]) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
-                    }
-                    ++m;
+                if (Bm > 0) {
+                    const int bm = (int)low_bits(words[fi][m0 + k - 2], Bm);
+                    v = (qstep[k] * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
                 }
-                C[k] = v;
+                C2[k] = 2.0f * v;
+            }
+            // per-block inverse DCT (:251-270).  All ten terms are added unconditionally (x + 0*c == x for every x this
+            // sum can take); the cosines of harmonic l are one contiguous row of a host-made table, fetched one
+            // output ahead of the arithmetic.
+            const float* rows = &D->imbe_idct_rows[L9][l0][0];
+            float cosr[10], next[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                cosr[k] = rows[k];
             }
             for (int j = 1; j <= ji; ++j) {
+                const float* nr = rows + 10 * (j < ji ? j : j - 1);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    next[k] = nr[k];
+                }
                 float sum = 0;
 #pragma unroll
                 for (int k = 1; k <= 10; ++k) {
-                    if (k <= ji) {
-                        const float ak = (k == 1) ? 1.0f : 2.0f;
-                        sum = sum + (ak * C[k] * T->imbe_idct_cos[ji][j][k]);
-                    }
+                    sum = sum + (C2[k] * cosr[k - 1]);
                 }
-                row[l++] = sum;
+                row[l0 + j - 1] = sum;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    cosr[k] = next[k];
+                }
             }
         }
     }
