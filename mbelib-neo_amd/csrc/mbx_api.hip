@@ -215,6 +215,12 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
             }
         }
     }
+    memset(d.imbe_blk_rows, 0, sizeof(d.imbe_blk_rows));
+    for (int b0 = 0; b0 < 208; ++b0) {
+        uint32_t wbits;
+        memcpy(&wbits, &host->imbe_w0[b0], 4);
+        d.imbe_b0[b0] = make_uint2(wbits, (uint32_t)host->imbe_L[b0] | ((uint32_t)host->imbe_K[b0] << 8));
+    }
     memset(d.imbe_blk_info, 0, sizeof(d.imbe_blk_info));
     memset(d.imbe_blk_bm, 0, sizeof(d.imbe_blk_bm));
     memset(d.imbe_blk_step, 0, sizeof(d.imbe_blk_step));
@@ -228,6 +234,11 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
                 d.imbe_blk_bm[l9][blk][k] = (uint8_t)Bm;
                 d.imbe_blk_step[l9][blk][k] = (Bm > 0 && Bm <= 11) ? (host->imbe_quantstep[Bm - 1] * host->imbe_standdev[k - 2]) : 0.0f;
                 ++m;
+            }
+            for (int j = 1; j <= ji && j <= 10; ++j) {
+                for (int k = 1; k <= ji && k <= 10; ++k) {
+                    d.imbe_blk_rows[l9][blk][j - 1][k - 1] = host->imbe_idct_cos[ji][j][k];
+                }
             }
             l += ji;
         }
@@ -531,15 +542,15 @@ int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, v
     if (rc < 0) {
         return rc;
     }
-    const unsigned egrid = (unsigned)((n + 7) / 8);   // 8 frames per 64-lane workgroup
+    const unsigned egrid = (unsigned)((n + 31) / 32);   // 8 frames per wave, 4 waves per workgroup (mbx_expand.hip)
     if (codec == MBX_CODEC_IMBE7200X4400) {
-        hipLaunchKernelGGL(mbx::expand_imbe_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
+        hipLaunchKernelGGL(mbx::expand_imbe_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n,
                            g_ctx.workspace, g_ctx.tabs);
     } else if (codec == MBX_CODEC_AMBE3600X2400) {
-        hipLaunchKernelGGL(mbx::expand_ambe2400_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
+        hipLaunchKernelGGL(mbx::expand_ambe2400_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n,
                            g_ctx.workspace, g_ctx.tabs);
     } else {
-        hipLaunchKernelGGL(mbx::expand_ambe_kernel, dim3(egrid), dim3(64), 0, (hipStream_t)stream, d_records, n,
+        hipLaunchKernelGGL(mbx::expand_ambe_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n,
                            g_ctx.workspace, g_ctx.tabs);
     }
     return check_launch("expand_kernel");

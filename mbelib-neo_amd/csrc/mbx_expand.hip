@@ -20,16 +20,20 @@
 
 namespace mbx {
 
-constexpr int kFramesPerBlock = 8;
+constexpr int kFramesPerWave = 8;
+constexpr int kWavesPerBlock = 4;    // 256-thread workgroups: a quarter of the workgroup launches of single-wave blocks
+constexpr int kFramesPerBlock = kFramesPerWave * kWavesPerBlock;
 constexpr int kRow = 65;   // 64 dwords + 1 pad
 
 __device__ __forceinline__ int rbit(const uint32_t w[3], int i) { return (int)((w[i >> 5] >> (31 - (i & 31))) & 1u); }
 
+// every wave writes the rows of its own eight frames (nothing crosses waves in these kernels)
 __device__ __forceinline__ void write_out(const float (*tile)[kRow], FrameParams* out, size_t first, size_t n) {
-    __syncthreads();
-    const int lane = threadIdx.x;
+    wave_lds_sync();
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
 #pragma unroll
-    for (int r = 0; r < kFramesPerBlock; ++r) {
+    for (int q = 0; q < kFramesPerWave; ++q) {
+        const int r = kFramesPerWave * wave + q;
         if (first + r < n) {
             reinterpret_cast<float*>(&out[first + r])[lane] = tile[r][lane];   // one coalesced 256-byte row
         }
@@ -38,7 +42,9 @@ __device__ __forceinline__ void write_out(const float (*tile)[kRow], FrameParams
 
 __device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
 
-__global__ void __launch_bounds__(64)
+// 8 waves per SIMD (<= 64 VGPRs): every wave of a 65,536-frame launch (8,192 of them) is then resident at once; at 7 per
+// SIMD the last eighth waits for a second round, which doubles the duration of a kernel this short.
+__global__ void __launch_bounds__(64 * kWavesPerBlock, 8)
 expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
     __shared__ float tile[kFramesPerBlock][kRow];
     __shared__ uint32_t words[kFramesPerBlock][64];   // parameter words b_0..b_57 of each frame
@@ -63,9 +69,10 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         b0 = (b0 << 1) | rbit(w, 85);
         b0 = (b0 << 1) | rbit(w, 86);
         if (b0 <= 207) {
-            w0 = T->imbe_w0[b0];
-            L = T->imbe_L[b0];
-            K = T->imbe_K[b0];
+            const uint2 q = tabs.d->imbe_b0[b0];
+            w0 = __uint_as_float(q.x);
+            L = (int)(q.y & 0xffu);
+            K = (int)(q.y >> 8);
             bad = (L == 0) ? 1 : 0;   // the reference has stored w0 but not L in this case
         }
     }
@@ -105,6 +112,12 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
         for (int k = 2; k <= 10; ++k) {
             qstep[k] = D->imbe_blk_step[L9][blk][k];
         }
+    }
+    const float* rows = &D->imbe_blk_rows[L9][blk][0][0];   // cosine rows of the block's outputs; the first one now
+    float cosr[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        cosr[k] = rows[k];
     }
     wave_lds_sync();
     // Bit layout (ref src/imbe/imbe7200x4400.c:156-168): payload bit i feeds bit e[1] of word e[0].  The
@@ -191,12 +204,7 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             // per-block inverse DCT (:251-270).  All ten terms are added unconditionally (x + 0*c == x for every x this
             // sum can take); the cosines of harmonic l are one contiguous row of a host-made table, fetched one
             // output ahead of the arithmetic.
-            const float* rows = &D->imbe_idct_rows[L9][l0][0];
-            float cosr[10], next[10];
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                cosr[k] = rows[k];
-            }
+            float next[10];
             for (int j = 1; j <= ji; ++j) {
                 const float* nr = rows + 10 * (j < ji ? j : j - 1);
 #pragma unroll
@@ -355,7 +363,7 @@ __device__ __forceinline__ void expand_ambe_body(const mbx_param_record* __restr
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();   // the block lanes and the summary lane of a frame are in the same wave
     if (i < n && sub == 0) {
         uint32_t vlo = 0, vhi = 0;
         float dg = 0.0f, sum42 = 0.0f;
@@ -399,12 +407,12 @@ __device__ __forceinline__ void expand_ambe_body(const mbx_param_record* __restr
     write_out(tile, out, first, n);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
 expand_ambe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
     expand_ambe_body<false>(recs, n, out, tabs);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
 expand_ambe2400_kernel(const mbx_param_record* __restrict__ recs, size_t n, FrameParams* __restrict__ out, DeviceTables tabs) {
     expand_ambe_body<true>(recs, n, out, tabs);
 }
