@@ -1,16 +1,18 @@
 // mbx_stream.hip -- stream stage: parameter records + per-stream model state -> PCM.
 //
-// Layout: ONE STREAM PER WAVEFRONT (one 64-lane wave per workgroup).  The three mbe_parms
-// structs of the stream live in registers for the whole launch: lane l holds element l of
-// every per-harmonic array (Vl, Ml, log2Ml, PHIl, PSIl; L <= 56 < 64), previousUw[256] is four
-// registers per lane, noiseOverlap[96] two.  A struct copy (cur <- prev, prev <- cur ...) is a
-// handful of register moves.  The T frames of the stream are processed in order inside the
-// kernel, state never leaves the register file between frames, and it is read from / written to
-// HBM once per launch with coalesced dword accesses (a struct is 651 consecutive dwords).
+// Layout: ONE STREAM PER WAVEFRONT (one 64-lane wave per workgroup).  Lane l holds element l of every per-harmonic
+// array (Vl, Ml, log2Ml, PHIl, PSIl; L <= 56 < 64), previousUw[256] is four registers per lane, noiseOverlap[96] two.
+// The T frames of the stream are processed in order inside the kernel.  `cur` stays in registers for the whole launch;
+// `prev` and `prev_enhanced` are live only where the reference reads them and are parked in their own HBM/L2 slots in
+// between (the loads and stores a T = 1 launch needs anyway); what the snapshot already holds is read back from it
+// instead of being carried across the synthesiser.  A struct is 651 consecutive dwords: coalesced dword accesses.
 //
 // Stages and the reference code they replace (ref = arancormonk/mbelib-neo v2.0.0):
-//   decode_imbe      src/imbe/imbe7200x4400.c:117-354, 589-630      (a8)
+//   expand_imbe_wave src/imbe/imbe7200x4400.c:117-270               (a8, stateless half; T > 1 launches)
+//   decode_imbe      src/imbe/imbe7200x4400.c:294-354               (a8, prediction)
+//   decode_ambe      src/ambe/ambe3600x2450.c:389-459, ambe3600x2400.c:427-497   (a9, prediction)
 //   imbe policy      src/imbe/imbe7200x4400.c:56-81, 780-888        (a10)
+//   ambe policies    src/ambe/ambe3600x2450.c:716-877, ambe3600x2400.c:629-763   (a11)
 //   enhance          src/core/mbelib.c:412-661                      (a13)
 //   smooth           src/core/mbe_adaptive.c:151-266                (a14)
 //   comfort noise    src/core/mbe_adaptive.c:50-60, 116-131         (a20)
@@ -18,11 +20,12 @@
 //   phases           src/core/mbelib.c:901-951                      (a16)
 //   voiced bank      src/core/mbelib.c:208-319, 953-1040            (a17)
 //   unvoiced         src/core/mbe_unvoiced_fft.c:210-275, 546-761   (a18)
+//   tones            src/core/mbelib.c:691-856                      (f2)
 //   clip / convert   src/core/mbelib.c:669-689, 1148-1177           (a19, a21)
 //
-// Numerics: integer decisions are reproduced exactly; float expressions keep the reference's
-// operand order with FMA contraction off, so differences come only from (1) libm vs ocml
-// transcendentals (<= 1-2 ulp), (2) the order of sums across harmonics, (3) the FFT.
+// Numerics: integer decisions are reproduced exactly.  Float expressions that feed decisions keep the reference's
+// operand order with FMA contraction off.  The synthesiser does not replay the reference's recurrences, it tracks them
+// (see the voiced bank); measured against the CPU oracle: PCM relative RMS <= 3e-6, int16 within 2 LSB.
 #include <type_traits>
 
 #include "mbx_device.h"
