@@ -12,10 +12,14 @@
 // Replaces (ref = arancormonk/mbelib-neo v2.0.0):
 //   IMBE  src/imbe/imbe7200x4400.c:117-270  (fundamental, bit layout, voicing, gains, Ri, HOC, IDCT)
 //   AMBE  src/ambe/ambe3600x2450.c:176-387, 461-553  (classification, V/UV, gain, PRBA, HOC, IDCT)
+//         src/ambe/ambe3600x2400.c:164-425            (the same for D-STAR: expand_ambe_body<true>)
+// The IMBE kernel serves launches with one frame per stream; with more the stream kernel expands the record itself
+// (expand_imbe_wave, mbx_stream.hip).  Workgroups are four independent waves.
 //
 // Output record (FrameParams, 64 dwords): v[1..56] T_l, v[57..58] voicing bits, v[59] w0, v[60] L,
 // v[61] K (IMBE) / mean residual Sum42 (AMBE), v[62] error-context word, v[63] frame class
-// (0 voice, 1 invalid IMBE fundamental, 2 AMBE erasure, 7 AMBE tone), v[0] AMBE gain increment.
+// (0 voice, 1 invalid IMBE fundamental, 2 AMBE+2 erasure, 7 AMBE+2 tone; D-STAR: 3 tone class without a usable index,
+// 5..122 tone index), v[0] AMBE gain increment.
 #include "mbx_device.h"
 
 namespace mbx {

@@ -7,6 +7,8 @@
 //   AMBE  src/ambe/ambe_common.c:22-46 (C0 Golay + overall parity), :75-100 (demodulation),
 //         :127-157 (Golay on C1, raw C2/C3); src/ambe/ambe3600x2450.c:649-682
 //   ECC   src/ecc/ecc.c:221-301 (Golay(23,12) by syndrome table), :366-408 (Hamming(15,11))
+// Further down: the IMBE 7100x4400 front end (its own C0 / seed / Hamming mapping / bit order) and the soft-decision
+// front end (one wavefront per frame, exhaustive maximum-likelihood decode of every block).
 // Integer work only: results are bit-exact.
 #include "mbx_device.h"
 
