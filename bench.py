@@ -55,6 +55,19 @@ def make_frames(name, codec, S, T, rank):
     return framegen.random_frames(codec, S * T, rng)
 
 
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 (non-MFMA) peak
+
+
+def nominal_flops_per_frame(workload):
+    """SURVEY.md §8(d)'s flop model (a count of the reference's arithmetic, not of this kernel's instructions):
+    voiced bank 9 flop x 160 samples x voiced components, unvoiced path 12 kflop, everything else 4 kflop.
+    imbe_voiced: prev and cur components voiced on all L harmonics, mean L over uniform b0 in [0, 207] = 32.35,
+    no unvoiced band; every other workload: the survey's measured random-bit mix (36 kflop of voiced bank)."""
+    if workload == "imbe_voiced":
+        return 9 * 160 * 2 * 32.35 + 4000, "9*160*(2*mean L = 64.7 voiced components) + 4k, no unvoiced band"
+    return 36000 + 12000 + 4000, "survey's random-bit mix: 36k voiced bank + 12k unvoiced FFT path + 4k"
+
+
 def algorithmic_bytes_per_launch(codec, S, T):
     """B_io = packed channel bits in + int16 PCM out per frame; B_state = load +
     store of the three-struct state per stream per launch."""
@@ -328,6 +341,15 @@ def main():
             "note": "algorithmic bytes = S*T*(wire frame + int16 PCM) + S*2*3*2604 state; the path is VALU/latency bound "
                     "(SURVEY.md §8(d)), the HBM fraction is reported because BASELINE.json asks for it",
         },
+    }
+    fpf, fpf_basis = nominal_flops_per_frame(args.workload)
+    line["valu"] = {   # "also report valu.achieved"; the resource that binds this path
+        "achieved": value / world * fpf / 1e12,
+        "peak": VALU_PEAK_TFLOPS,
+        "unit": "TFLOP/s per GPU",
+        "frac": value / world * fpf / 1e12 / VALU_PEAK_TFLOPS,
+        "flops_per_frame": fpf,
+        "basis": fpf_basis,
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # timed at N = 1 only, on rank 0

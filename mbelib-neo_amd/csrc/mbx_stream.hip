@@ -199,10 +199,12 @@ __device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
 
 struct WaveScratch {
     union {
-        struct {                       // voiced bank: complex amplitudes of harmonic l, (A, -B, -d B, -d A)
-            alignas(16) float4 coef_prev[64];
-            alignas(16) float4 coef_cur[64];
+        struct {                       // voiced bank, harmonic l: g (cos psi, sin psi) and d g (sin psi, cos psi),
+            alignas(16) float4 coef_amp[64];     //   each as (prev, cur) pairs = the operands of the packed FMAs
+            alignas(16) float4 coef_drift[64];
             alignas(16) float4 icoef[8];   // interpolated low harmonics: (phi_prev, w0 l + dw, 2 M_prev, 2 dM)
+            float bank_prev[112];          // windowed bank output, samples 0..104
+            float bank_cur[112];           //   and 56..159 (index n - 56), on their way to the lane = sample layout
         };
         struct {                       // in-wave parameter expansion (dead before synthesis starts)
             uint32_t words[64];        //   parameter words b_0..b_57
@@ -765,92 +767,97 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     }
 
     // (2) windowed oscillators.  The reference advances one oscillator per harmonic sample by sample
-    //     (src/core/mbelib.c:213-218).  Here the recurrence runs along the OTHER axis: lane = sample
-    //     (two samples per lane, packed fp32 math), loop over the harmonics l = 1..maxl, and the phasor
-    //     e^{i l w0 n} of a sample is advanced from harmonic to harmonic by its own step e^{i w0 n}:
-    //         sum_l Re[(A_l + i B_l) e^{i l w0 n}],  A_l + i B_l = 2 M_l e^{i phi_l}
-    //     The complex amplitudes are computed lane = harmonic and broadcast from LDS (two ds_read_b128
-    //     per harmonic); there is no transposition tile and no cross-lane sum.  The synthesis window
+    //     (src/core/mbelib.c:213-218).  Here the recurrence runs along the OTHER axis: loop over the harmonics
+    //     l = 1..maxl, and a sample's phasor e^{i l w0 m} is advanced from harmonic to harmonic by its own step
+    //     e^{i w0 m}.  The window leaves the prev model on n = 0..104 and the cur model on n = 56..159, so each
+    //     is taken about the CENTRE of its support (52 / 108): lane = distance k = 0..52, and one phasor
+    //     e^{i l w0 k} serves the two samples centre +- k,
+    //         g cos(psi + l w0 (+-k)) = g cos psi cos(l w0 k) -+ g sin psi sin(l w0 k),
+    //     an even sum and an odd sum.  The two models are the two halves of one packed register, so a harmonic
+    //     costs 8 packed instructions for all 209 samples.  psi_l = (phase at n = 0) + theta_l * centre, lane =
+    //     harmonic, broadcast from LDS (two ds_read_b128 per harmonic); no cross-lane sum.  The synthesis window
     //     depends on the sample only and is applied once, after the sum.
-    //       prev part: samples n = lane, lane + 64          weight Ws[n + 160] (zero from n = 105)
-    //       cur part:  samples n = lane + 32, lane + 96     weight Ws[n]       (zero below n = 56)
-    //     The reference's oscillator turns by theta_l = fl(w0 * l) per sample, not by l * w0; the
-    //     difference d_l (exact from one FMA, |d_l| < 1.2e-7) grows to 2e-5 rad over a frame, so it is
-    //     carried to first order: cos(x + d n) = cos x - d n sin x, a second sum weighted by n.
+    //     The reference's oscillator turns by theta_l = fl(w0 * l) per sample, not by l * w0; the difference
+    //     d_l (exact from one FMA, |d_l| < 1.2e-7) is exact in psi and carried to first order over the +-52
+    //     samples around it: cos(x + d m) = cos x - d m sin x, a second pair of sums weighted by k.
     {
         const bool wv_p = pv && !interp && !(tabs.ablate & 4), wv_c = cv && !interp && !(tabs.ablate & 4);
         const bool any = (__ballot(wv_p || wv_c) != 0ULL) && !(tabs.ablate & 8);
         if (any) {
             constexpr double kInv2Pi = 0.15915494309189533577;
-            {   // lane = harmonic: (A, -B, -d B, -d A) for the prev and the cur model
+            constexpr int kMidPrev = 52, kMidCur = 108;
+            {   // lane = harmonic: g (cos psi, sin psi, d sin psi, d cos psi) for the prev and the cur model
                 const float fl = (float)lane;
                 const float pw0l = pw0 * fl, cw0l = cw0 * fl;
-                float4 cp4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cc4 = cp4;
+                float4 ca = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cd = ca;
                 float c, d;
-                unit_phasor_hw((double)prev.PHIl * kInv2Pi, c, d);
+                unit_phasor_hw(fma((double)pw0l, (double)kMidPrev * kInv2Pi, (double)prev.PHIl * kInv2Pi), c, d);
                 if (wv_p) {
                     const float g = 2.0f * prev.Ml, dl = -fmaf(pw0, fl, -pw0l);
                     const float A = g * c, B = g * d;
-                    cp4 = make_float4(A, -B, -(dl * B), -(dl * A));
+                    ca.x = A;
+                    ca.z = B;
+                    cd.x = dl * B;
+                    cd.z = dl * A;
                 }
-                unit_phasor_hw((double)(cur.PHIl - (cw0l * (float)N)) * kInv2Pi, c, d);
+                unit_phasor_hw(fma((double)cw0l, (double)kMidCur * kInv2Pi, (double)(cur.PHIl - (cw0l * (float)N)) * kInv2Pi), c, d);
                 if (wv_c) {
                     const float g = 2.0f * cur.Ml, dl = -fmaf(cw0, fl, -cw0l);
                     const float A = g * c, B = g * d;
-                    cc4 = make_float4(A, -B, -(dl * B), -(dl * A));
+                    ca.y = A;
+                    ca.w = B;
+                    cd.y = dl * B;
+                    cd.w = dl * A;
                 }
-                S.coef_prev[lane] = cp4;
-                S.coef_cur[lane] = cc4;
+                S.coef_amp[lane] = ca;
+                S.coef_drift[lane] = cd;
             }
-            v2f Ecp, Esp, Ecc, Esc;   // per-sample steps e^{i w0 n}; their error is amplified by l
+            v2f Ec, Es;   // per-distance steps e^{i w0 k} (.x prev model, .y cur model); their error is amplified by l
             {
-                const double pr = (double)pw0 * kInv2Pi, cr = (double)cw0 * kInv2Pi;
                 float c, d;
-                unit_phasor(pr * (double)lane, c, d);
-                Ecp.x = c;
-                Esp.x = d;
-                unit_phasor(pr * (double)(lane + 64), c, d);
-                Ecp.y = c;
-                Esp.y = d;
-                unit_phasor(cr * (double)(lane + 32), c, d);   // the -N w0 l offset is in the amplitude's phase
-                Ecc.x = c;
-                Esc.x = d;
-                unit_phasor(cr * (double)(lane + 96), c, d);
-                Ecc.y = c;
-                Esc.y = d;
+                unit_phasor(((double)pw0 * kInv2Pi) * (double)lane, c, d);
+                Ec.x = c;
+                Es.x = d;
+                unit_phasor(((double)cw0 * kInv2Pi) * (double)lane, c, d);
+                Ec.y = c;
+                Es.y = d;
             }
+            const float* Ws = T->ws;
+            const int kk = lane <= kMidPrev ? lane : kMidPrev;   // lanes 53..63 idle along
+            const v2f w_plus = {Ws[N + kMidPrev + kk], Ws[kMidCur + (kk < 52 ? kk : 51)]};
+            const v2f w_minus = {Ws[N + kMidPrev - kk], Ws[kMidCur - kk]};
             wave_lds_sync();
-            v2f Pcp = Ecp, Psp = Esp, Pcc = Ecc, Psc = Esc;   // harmonic 1
-            v2f sum_p = {0.0f, 0.0f}, sum_c = {0.0f, 0.0f}, drift_p = {0.0f, 0.0f}, drift_c = {0.0f, 0.0f};
+            v2f Qc = Ec, Qs = Es;   // harmonic 1
+            v2f even = {0.0f, 0.0f}, odd = {0.0f, 0.0f}, even_d = {0.0f, 0.0f}, odd_d = {0.0f, 0.0f};
             const int last = uni(maxl);
 #pragma unroll 2
             for (int l = 1; l <= last; ++l) {
-                const float4 a = S.coef_prev[l], b = S.coef_cur[l];   // wave-uniform address: LDS broadcasts
-                sum_p = __builtin_elementwise_fma(Pcp, splat(a.x), sum_p);
-                sum_p = __builtin_elementwise_fma(Psp, splat(a.y), sum_p);
-                drift_p = __builtin_elementwise_fma(Pcp, splat(a.z), drift_p);
-                drift_p = __builtin_elementwise_fma(Psp, splat(a.w), drift_p);
-                sum_c = __builtin_elementwise_fma(Pcc, splat(b.x), sum_c);
-                sum_c = __builtin_elementwise_fma(Psc, splat(b.y), sum_c);
-                drift_c = __builtin_elementwise_fma(Pcc, splat(b.z), drift_c);
-                drift_c = __builtin_elementwise_fma(Psc, splat(b.w), drift_c);
-                const v2f np = __builtin_elementwise_fma(Pcp, Ecp, -(Psp * Esp));
-                Psp = __builtin_elementwise_fma(Psp, Ecp, Pcp * Esp);
-                Pcp = np;
-                const v2f nc = __builtin_elementwise_fma(Pcc, Ecc, -(Psc * Esc));
-                Psc = __builtin_elementwise_fma(Psc, Ecc, Pcc * Esc);
-                Pcc = nc;
+                const float4 a = S.coef_amp[l], b = S.coef_drift[l];   // wave-uniform address: LDS broadcasts
+                even = __builtin_elementwise_fma(Qc, v2f{a.x, a.y}, even);
+                odd = __builtin_elementwise_fma(Qs, v2f{a.z, a.w}, odd);
+                even_d = __builtin_elementwise_fma(Qc, v2f{b.x, b.y}, even_d);
+                odd_d = __builtin_elementwise_fma(Qs, v2f{b.z, b.w}, odd_d);
+                const v2f nq = __builtin_elementwise_fma(Qc, Ec, -(Qs * Es));
+                Qs = __builtin_elementwise_fma(Qs, Ec, Qc * Es);
+                Qc = nq;
             }
-            const float* Ws = T->ws;
-            const v2f wp = {Ws[lane + N], Ws[lane + 64 + N]};
-            const v2f wc = {Ws[lane + 32], Ws[lane + 96]};
-            const v2f n_p = {(float)lane, (float)(lane + 64)}, n_c = {(float)(lane + 32), (float)(lane + 96)};
-            const v2f vp = __builtin_elementwise_fma(drift_p, n_p, sum_p) * wp;
-            const v2f vc = __builtin_elementwise_fma(drift_c, n_c, sum_c) * wc;
-            const float c_lo = __shfl_xor(vc.x, 32, kWave), c_hi = __shfl_xor(vc.y, 32, kWave);
-            acc[0] += vp.x + ((lane >= 32) ? c_lo : 0.0f);
-            acc[1] += vp.y + ((lane < 32) ? c_lo : c_hi);
-            acc[2] += (lane < 32) ? c_hi : 0.0f;
+            // sample centre + k: even - odd - k (even_d + odd_d); centre - k: even + odd + k (even_d - odd_d)
+            const v2f kf = splat((float)lane);
+            const v2f v_plus = ((even - odd) - (kf * (even_d + odd_d))) * w_plus;
+            const v2f v_minus = ((even + odd) + (kf * (even_d - odd_d))) * w_minus;
+            wave_lds_sync();   // every lane is done with the coefficients (the sample rows alias nothing, but keep order)
+            if (lane <= kMidPrev) {
+                S.bank_prev[kMidPrev + lane] = v_plus.x;   // k = 0: both stores carry the same value (sin 0 = 0)
+                S.bank_prev[kMidPrev - lane] = v_minus.x;
+                S.bank_cur[kMidCur - 56 - lane] = v_minus.y;
+                if (lane < 52) {
+                    S.bank_cur[kMidCur - 56 + lane] = v_plus.y;
+                }
+            }
+            wave_lds_sync();
+            acc[0] += S.bank_prev[lane] + ((lane >= 56) ? S.bank_cur[lane - 56] : 0.0f);
+            acc[1] += ((lane <= 40) ? S.bank_prev[lane + 64] : 0.0f) + S.bank_cur[lane + 8];
+            acc[2] += (lane < 32) ? S.bank_cur[lane + 72] : 0.0f;
             wave_lds_sync();
         }
     }
