@@ -30,8 +30,11 @@
 
 #include "mbx_device.h"
 
+#ifndef MBX_PARK_N
+#define MBX_PARK_N 8   // how many per-lane values wait in LDS across the unvoiced transform pair (synth_core)
+#endif
 #ifndef MBX_STREAM_WAVES_PER_SIMD
-#define MBX_STREAM_WAVES_PER_SIMD 6   // occupancy target of the IMBE stream kernel (caps VGPRs at 512 / n = 80)
+#define MBX_STREAM_WAVES_PER_SIMD 7   // occupancy target of the IMBE stream kernel (caps VGPRs at 72; 7 x 4 waves x 5664 B of LDS = 155 KB)
 #endif
 
 namespace mbx {
@@ -203,9 +206,7 @@ struct WaveScratch {
             alignas(16) float4 coef_amp[64];     //   each as (prev, cur) pairs = the operands of the packed FMAs
             alignas(16) float4 coef_drift[64];
             alignas(16) float4 icoef[8];   // interpolated low harmonics: (phi_prev, w0 l + dw, 2 M_prev, 2 dM)
-            float bank_prev[112];          // windowed bank output, samples 0..104
-            float bank_cur[112];           //   and 56..159 (index n - 56), on their way to the lane = sample layout
-        };
+        };                                 // (the windowed bank output passes through coef_amp's bytes afterwards)
         struct {                       // in-wave parameter expansion (dead before synthesis starts)
             uint32_t words[64];        //   parameter words b_0..b_57
             float    gains[12];        //   IMBE G_1..G_6 / AMBE+2 R_1..R_8
@@ -214,10 +215,10 @@ struct WaveScratch {
         } x;
         struct {                       // unvoiced path (the coefficients are dead by then)
             float2 fft[256];           //   in-place radix-4 FFT
-            float  mag2[132];          //   |X(k)|^2, k = 0..128
-            float  scale[132];         //   per-bin scale, bins 0..128
+            float  bins[132];          //   |X(k)|^2, k = 0..128, then the per-bin scale in the same place
         };
     };
+    float park[MBX_PARK_N > 0 ? MBX_PARK_N : 1][64];                // per-lane values that only cross the unvoiced transform pair (see synth_core)
 };
 
 struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
@@ -845,19 +846,21 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const v2f kf = splat((float)lane);
             const v2f v_plus = ((even - odd) - (kf * (even_d + odd_d))) * w_plus;
             const v2f v_minus = ((even + odd) + (kf * (even_d - odd_d))) * w_minus;
-            wave_lds_sync();   // every lane is done with the coefficients (the sample rows alias nothing, but keep order)
+            wave_lds_sync();   // every lane is done with the coefficients: their bytes now carry the samples
+            float* const bank_prev = reinterpret_cast<float*>(S.coef_amp);   // samples 0..104
+            float* const bank_cur = bank_prev + 112;                          // samples 56..159 at index n - 56
             if (lane <= kMidPrev) {
-                S.bank_prev[kMidPrev + lane] = v_plus.x;   // k = 0: both stores carry the same value (sin 0 = 0)
-                S.bank_prev[kMidPrev - lane] = v_minus.x;
-                S.bank_cur[kMidCur - 56 - lane] = v_minus.y;
+                bank_prev[kMidPrev + lane] = v_plus.x;   // k = 0: both stores carry the same value (sin 0 = 0)
+                bank_prev[kMidPrev - lane] = v_minus.x;
+                bank_cur[kMidCur - 56 - lane] = v_minus.y;
                 if (lane < 52) {
-                    S.bank_cur[kMidCur - 56 + lane] = v_plus.y;
+                    bank_cur[kMidCur - 56 + lane] = v_plus.y;
                 }
             }
             wave_lds_sync();
-            acc[0] += S.bank_prev[lane] + ((lane >= 56) ? S.bank_cur[lane - 56] : 0.0f);
-            acc[1] += ((lane <= 40) ? S.bank_prev[lane + 64] : 0.0f) + S.bank_cur[lane + 8];
-            acc[2] += (lane < 32) ? S.bank_cur[lane + 72] : 0.0f;
+            acc[0] += bank_prev[lane] + ((lane >= 56) ? bank_cur[lane - 56] : 0.0f);
+            acc[1] += ((lane <= 40) ? bank_prev[lane + 64] : 0.0f) + bank_cur[lane + 8];
+            acc[2] += (lane < 32) ? bank_cur[lane + 72] : 0.0f;
             wave_lds_sync();
         }
     }
@@ -888,6 +891,43 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
     }
     if (!(tabs.ablate & 32) && any_unvoiced) {
+        // Register diet: the transform pair is the kernel's register peak, and everything that merely crosses it
+        // would cost a wave of occupancy for ALL frames.  Those values wait in the lane's own LDS column instead
+        // (same lane writes and reads: no synchronisation).
+#if MBX_PARK_N > 2
+        S.park[2][lane] = acc[0];
+#endif
+#if MBX_PARK_N > 3
+        S.park[3][lane] = acc[1];
+#endif
+#if MBX_PARK_N > 4
+        if (lane < 32) {
+            S.park[4][lane] = acc[2];
+            S.park[4][lane + 32] = cur.ov[1];
+        }
+#endif
+#if MBX_PARK_N > 5
+        S.park[5][lane] = cur.PHIl;
+#endif
+#if MBX_PARK_N > 6
+        S.park[6][lane] = cur.PSIl;
+#endif
+#if MBX_PARK_N > 7
+        S.park[7][lane] = cur.ov[0];
+#endif
+#if MBX_PARK_N > 8
+        S.park[8][lane] = prev.uw[2];
+#endif
+#if MBX_PARK_N > 9
+        S.park[9][lane] = prev.uw[3];
+#endif
+#if MBX_PARK_N > 0
+        S.park[0][lane] = cur.Ml;
+#endif
+#if MBX_PARK_N > 1
+        S.park[1][lane] = __int_as_float(cur.Vl);
+#endif
+        asm volatile("" ::: "memory");
         auto twiddle = [](int m) -> float2 {
             const float rev = (float)(m & 255) * (1.0f / 256.0f);
             return make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev));
@@ -898,11 +938,6 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             win[r] = T->uv_window[lane + 64 * r];
-        }
-        S.scale[lane] = 0.0f;
-        S.scale[lane + 64] = 0.0f;
-        if (lane < 4) {
-            S.scale[128 + lane] = 0.0f;
         }
         {   // forward stage 1 (span 64): real inputs straight from registers
             const float a0 = nz[0] * win[0], a1 = nz[1] * win[1], a2 = nz[2] * win[2], a3 = nz[3] * win[3];
@@ -945,12 +980,24 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const int k = rev4(pidx);
             if (k <= 128) {
                 const float2 X = S.fft[pidx];
-                S.mag2[k] = (k == 0) ? (X.x * X.x) : ((X.x * X.x) + (X.y * X.y));
+                S.bins[k] = (k == 0) ? (X.x * X.x) : ((X.x * X.x) + (X.y * X.y));
             }
         }
         wave_lds_sync();
         // per-band scale: lane = band; a band spans at most 14 bins (w0 <= 4 pi / 39.5)
-        if (lane >= 1 && lane <= cur.L && cur.Vl == 0) {
+#if MBX_PARK_N > 1
+        const bool band_unvoiced = __float_as_int(S.park[1][lane]) == 0;
+#else
+        const bool band_unvoiced = cur.Vl == 0;
+#endif
+#if MBX_PARK_N > 0
+        const float band_M = S.park[0][lane];
+#else
+        const float band_M = cur.Ml;
+#endif
+        float band_sc = 0.0f;
+        int band_a = 0, band_b = 0;
+        if (lane >= 1 && lane <= cur.L && band_unvoiced) {
             const float mult = (256.0f / (2.0f * 3.14159265358979323846f)) * cur.w0;
             int a = (int)ceilf(((float)lane - 0.5f) * mult);
             int b = (int)ceilf(((float)lane + 0.5f) * mult);
@@ -960,28 +1007,37 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
 #pragma unroll
             for (int c = 0; c < 14; ++c) {
                 const int k = a + c;
-                const float m2 = S.mag2[k < 128 ? k : 128];
+                const float m2 = S.bins[k < 128 ? k : 128];
                 if (k < b) {
                     num += m2;
                 }
             }
             for (int k = a + 14; k < b; ++k) {   // not reached for valid w0; keeps odd states exact
-                num += S.mag2[k];
+                num += S.bins[k];
             }
             const int count = b - a;
             if (count > 0 && num > 1e-10f) {
-                const float sc = 146.17696f * cur.Ml / sqrtf(num / (float)count);
-                for (int k = a; k < b; ++k) {
-                    S.scale[k] = sc;
-                }
+                band_sc = 146.17696f * band_M / sqrtf(num / (float)count);
+                band_a = a;
+                band_b = b;
             }
+        }
+        wave_lds_sync();   // every band has its energy: the bins turn into scales, zero outside the unvoiced bands
+        S.bins[lane] = 0.0f;
+        S.bins[lane + 64] = 0.0f;
+        if (lane < 4) {
+            S.bins[128 + lane] = 0.0f;
+        }
+        wave_lds_sync();
+        for (int k = band_a; k < band_b; ++k) {
+            S.bins[k] = band_sc;
         }
         wave_lds_sync();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int pidx = lane + 64 * r;
             const int k = rev4(pidx);
-            const float sc = S.scale[k > 128 ? 256 - k : k];
+            const float sc = S.bins[k > 128 ? 256 - k : k];
             const float2 X = S.fft[pidx];
             S.fft[pidx] = make_float2(X.x * sc, X.y * sc);
         }
@@ -1019,6 +1075,38 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             cur.uw[2] = (s02 - s13) * (1.0f / 256.0f);
             cur.uw[3] = (d02 + d13y) * (1.0f / 256.0f);   // Re(d02 - i*d13)
         }
+        asm volatile("" ::: "memory");
+#if MBX_PARK_N > 2
+        acc[0] = S.park[2][lane];
+#endif
+#if MBX_PARK_N > 3
+        acc[1] = S.park[3][lane];
+#endif
+#if MBX_PARK_N > 4
+        acc[2] = (lane < 32) ? S.park[4][lane] : 0.0f;
+        cur.ov[1] = (lane < 32) ? S.park[4][lane + 32] : 0.0f;
+#endif
+#if MBX_PARK_N > 5
+        cur.PHIl = S.park[5][lane];
+#endif
+#if MBX_PARK_N > 6
+        cur.PSIl = S.park[6][lane];
+#endif
+#if MBX_PARK_N > 7
+        cur.ov[0] = S.park[7][lane];
+#endif
+#if MBX_PARK_N > 8
+        prev.uw[2] = S.park[8][lane];
+#endif
+#if MBX_PARK_N > 9
+        prev.uw[3] = S.park[9][lane];
+#endif
+#if MBX_PARK_N > 0
+        cur.Ml = S.park[0][lane];
+#endif
+#if MBX_PARK_N > 1
+        cur.Vl = __float_as_int(S.park[1][lane]);
+#endif
     }
     if (!(tabs.ablate & 32)) {
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
@@ -1437,7 +1525,7 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
 }
 
 #ifndef MBX_AMBE_WAVES_PER_SIMD
-#define MBX_AMBE_WAVES_PER_SIMD 4   // the AMBE+2 kernel spills at 96 VGPRs; four spill-free waves are faster
+#define MBX_AMBE_WAVES_PER_SIMD 5   // the AMBE kernels need 93 VGPRs (tone paths); five spill-free waves
 #endif
 // D-STAR single tone (ref src/core/mbelib.c:813-856 + :708-736): 156.25 Hz (index 5), 187.5 Hz (6) or 31.25 Hz x index
 // (7..122) at the fixed amplitude 103
