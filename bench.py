@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-expand", action="store_true", help="run the parameter expansion as a separate launch")
+    ap.add_argument("--fuse-expand", action="store_true", help="development aid: IMBE at T = 1 through the fused (one-launch) path")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (mbx_debug_set_ablation); results invalid")
     args = ap.parse_args()
 
@@ -254,7 +255,7 @@ def main():
         # mbx_process_records is ONE launch for IMBE at T > 1 (expansion fused into the stream kernel); otherwise
         # it is the expand launch + the stream launch, issued separately here so that the events bracket the
         # stream kernel only.  --split-expand forces the separate launch for IMBE at T > 1 (development aid).
-        split = (codec in (1, 3)) or (T == 1) or args.split_expand
+        split = (codec in (1, 3)) or (T == 1 and not args.fuse_expand) or args.split_expand
         if split:
             _native.check(L.mbx_expand_records(stream_codec, out["records"].data_ptr(), n, stream), "expand")
             run = L.mbx_stream_expanded

@@ -184,6 +184,19 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     for (int L = 1; L < 64; ++L) {
         d.log2_int[L] = log2f((float)L);
     }
+    for (int p = 0; p < 57; ++p) {
+        for (int c = 1; c < 57; ++c) {
+            d.l_ratio[p][c] = (float)p / (float)c;
+        }
+    }
+    for (int L = 1; L < 57; ++L) {
+        const float rho = (L <= 15) ? 0.4f : ((L <= 24) ? ((0.03f * (float)L) - 0.05f) : 0.7f);
+        d.imbe_rho_over_l[L] = rho / (float)L;
+        d.ambe_pred_over_l[L] = (float)0.65 / (float)L;
+    }
+    for (int n = 0; n < 192; ++n) {
+        d.nfrac[n] = (float)n / (float)160;
+    }
     for (int l9 = 0; l9 < 48; ++l9) {   // who owns what in the IMBE parameter expansion (ref src/imbe/imbe7200x4400.c:233-270)
         const uint8_t* J = host->imbe_ji[l9];
         const int L = l9 + 9;

@@ -18,6 +18,13 @@ struct DerivedTables {
     uint32_t lcg_mul[161];    // 171^k mod 53125           (unvoiced-noise LCG jump-ahead)
     uint32_t lcg_add[161];    // additive term after k steps
     float    log2_int[64];    // log2f((float)L) from the host libm (AMBE gain term)
+    // Wave-uniform quotients of the parameter decode: one scalar load each instead of a 12-instruction IEEE
+    // division executed by all 64 lanes.  Made on the host with the same float expressions (correctly rounded
+    // division, no contraction), so the values are the ones the device would compute.
+    float    l_ratio[57][57];       // (float)prev_L / (float)cur_L
+    float    imbe_rho_over_l[57];   // rho(L) / (float)L, rho = 0.4 | 0.03 L - 0.05 | 0.7 (imbe7200x4400.c log-magnitude prediction)
+    float    ambe_pred_over_l[57];  // 0.65f / (float)L
+    float    nfrac[192];            // (float)n / 160.0f, the interpolated branch's amplitude ramp
     uint32_t pr_mul[116];     // 173^k mod 2^16             (demodulation sequence jump-ahead, k = 0..115)
     uint32_t pr_add[116];     // additive term after k steps
     uint32_t ham_basis[11];   // Hamming(15,11) code word of data bit i (soft-decision candidates)

@@ -240,6 +240,7 @@ struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
 // latency instead of a chain of dependent lookups.
 // ------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) mbx_tables* ConstTables;
+typedef const __attribute__((address_space(4))) DerivedTables* ConstDerived;
 __device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
 
 __device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, const mbx_tables* Tg, const DerivedTables* Dg, int lane) {
@@ -383,7 +384,7 @@ __device__ __forceinline__ int rec_bit(const uint32_t w[3], int i) { return (int
 // Frame parameters from the expand stage (mbx_expand.hip): v[1..56] prediction residuals T_l,
 // v[57..58] voicing bits, v[59] w0, v[60] L, v[61] K (IMBE) / mean residual (AMBE), v[62] error
 // context word, v[63] frame class, v[0] AMBE gain increment.
-__device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev, int lane) {
+__device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DerivedTables* Dg, int lane) {
     const int bad = uni(__float_as_int(fp[63]));
     if (bad != 0) {
         if (fp[59] != 0.0f) {
@@ -418,7 +419,8 @@ __device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev
             prev.log2Ml = l1;
         }
     }
-    const float pos = ((float)prev_L / (float)cur_L) * (float)lane;
+    const ConstDerived D = (ConstDerived)Dg;   // scalar loads
+    const float pos = D->l_ratio[uni(prev_L)][cur_L] * (float)lane;
     int lo = (int)pos;
     lo = lo < 0 ? 0 : (lo > 56 ? 56 : lo);
     const float frac = pos - (float)lo;
@@ -426,7 +428,7 @@ __device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev
     const float a = lane_get(prev.log2Ml, lo), b = lane_get(prev.log2Ml, hi);
     const bool in = lane >= 1 && lane <= cur_L;
     float Sum77 = wave_sum(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f);
-    Sum77 = ((rho / (float)cur_L) * Sum77);
+    Sum77 = (D->imbe_rho_over_l[cur_L] * Sum77);
     if (in) {
         const float c1 = (rho * ((float)1 - frac) * a);
         const float c2 = (rho * frac * b);
@@ -511,7 +513,8 @@ __device__ float enhance(Parms& cur, int lane) {
     float M = cur.Ml;
     M = (M < 0.0f) ? -M : M;
     const float sum = wave_sum(in ? (M * M) : 0.0f);
-    const float gamma = (sum == 0.0f) ? 1.0f : sqrtf(Rm0 / sum);
+    // v_rcp / v_sqrt (1 ulp each): the weights above are already that accurate
+    const float gamma = (sum == 0.0f) ? 1.0f : __builtin_amdgcn_sqrtf(Rm0 * __builtin_amdgcn_rcpf(sum));
     if (in) {
         cur.Ml = gamma * cur.Ml;
     }
@@ -742,10 +745,11 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const v2f cs = {__builtin_amdgcn_cosf(r.x), __builtin_amdgcn_cosf(r.y)};
             return __builtin_elementwise_fma(nfrac, damp, amp0) * cs;
         };
-        const v2f nf01 = {(float)lane, (float)(lane + 64)};
-        const v2f nsq01 = {(float)(lane * lane), (float)((lane + 64) * (lane + 64))};
-        const v2f nfrac01 = {(float)lane / (float)N, (float)(lane + 64) / (float)N};   // the reference's quotient
-        const float nf2 = (float)(lane + 128), nsq2 = (float)((lane + 128) * (lane + 128)), nfrac2 = (float)(lane + 128) / (float)N;
+        const float nf0 = (float)lane, nf2 = nf0 + 128.0f;
+        const v2f nf01 = {nf0, nf0 + 64.0f};
+        const v2f nsq01 = nf01 * nf01;                            // exact: n^2 < 2^24
+        const v2f nfrac01 = {D->nfrac[lane], D->nfrac[lane + 64]};   // (float)n / (float)N, the reference's quotient (host table)
+        const float nsq2 = nf2 * nf2, nfrac2 = D->nfrac[lane + 128];
         v2f acc01 = {0.0f, 0.0f}, acc2 = {0.0f, 0.0f};
         while (imask) {
             const int la = __ffsll((long long)imask) - 1;
@@ -884,13 +888,16 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         const float old0 = f[O_OVERLAP + lane];
         const float old1 = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
         nz[0] = old0;
-        nz[1] = (lane < 32) ? old1 : at(lane - 32);
-        nz[2] = at(lane + 32);
-        nz[3] = at(lane + 96);
+        nz[1] = old1;
         cur.ov[0] = at(lane + 64);
         cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
     }
     if (!(tabs.ablate & 32) && any_unvoiced) {
+        if (snap && !cold) {   // the fresh LCG samples of the transform's input (a voiced frame never needs them)
+            nz[1] = (lane < 32) ? nz[1] : at(lane - 32);
+            nz[2] = at(lane + 32);
+            nz[3] = at(lane + 96);
+        }
         // Register diet: the transform pair is the kernel's register peak, and everything that merely crosses it
         // would cost a wave of occupancy for ALL frames.  Those values wait in the lane's own LDS column instead
         // (same lane writes and reads: no synchronisation).
@@ -1251,7 +1258,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             cur.errorCountTotal = total;
             cur.errorRate = uni((0.95f * prev.errorRate) + (0.000365f * (float)total));
 
-            const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, lane);
+            const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, tabs.d, lane);
             const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
             const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
             const bool repeat =
@@ -1423,7 +1430,8 @@ __device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev
             prev.log2Ml = l1;
         }
     }
-    const float pos = ((float)prev_L / (float)cur_L) * (float)lane;
+    const ConstDerived D = (ConstDerived)tabs.d;   // scalar loads
+    const float pos = D->l_ratio[uni(prev_L)][cur_L] * (float)lane;
     int lo = (int)pos;
     lo = lo > 56 ? 56 : lo;
     const float frac = pos - (float)lo;
@@ -1433,9 +1441,9 @@ __device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev
     const float b = (lo + 1 > 56) ? phi0 : bnext;
     const bool in = lane >= 1 && lane <= cur_L;
     float Sum43 = wave_sum(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f);
-    Sum43 = (((float)0.65 / (float)cur_L) * Sum43);
+    Sum43 = (D->ambe_pred_over_l[cur_L] * Sum43);
     const float Sum42 = fp[61];   // mean residual, summed in the reference's order by the expand stage
-    const float BigGamma = cur.gamma - (0.5f * tabs.d->log2_int[cur_L]) - Sum42;
+    const float BigGamma = cur.gamma - (0.5f * D->log2_int[cur_L]) - Sum42;
     if (in) {
         const float c1 = ((float)0.65 * ((float)1 - frac) * a);
         const float c2 = ((float)0.65 * frac * b);
