@@ -935,12 +935,26 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         S.park[1][lane] = __int_as_float(cur.Vl);
 #endif
         asm volatile("" ::: "memory");
-        auto twiddle = [](int m) -> float2 {
+        // Complex values are (re, im) register pairs: a complex add is one v_pk_add_f32, a multiplication by -+i a
+        // swap + sign the packed instructions take as operand modifiers, a complex product two packed instructions.
+        v2f* const F = reinterpret_cast<v2f*>(S.fft);
+        auto twiddle = [](int m) -> v2f {
             const float rev = (float)(m & 255) * (1.0f / 256.0f);
-            return make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev));
+            return v2f{__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev)};
         };
-        auto cmul = [](float2 u, float2 w) -> float2 { return make_float2(u.x * w.x - u.y * w.y, u.x * w.y + u.y * w.x); };
-        auto cmulc = [](float2 u, float2 w) -> float2 { return make_float2(u.x * w.x + u.y * w.y, u.y * w.x - u.x * w.y); };
+        auto mul_mi = [](v2f a) -> v2f { return v2f{a.y, -a.x}; };   // -i a
+        auto cmul = [](v2f u, v2f w) -> v2f {                         // u w
+            return __builtin_elementwise_fma(v2f{u.y, u.y}, v2f{-w.y, w.x}, v2f{u.x, u.x} * w);
+        };
+        auto cmulc = [](v2f u, v2f w) -> v2f {                        // u conj(w)
+            return __builtin_elementwise_fma(v2f{u.y, u.y}, v2f{w.y, w.x}, v2f{u.x, u.x} * v2f{w.x, -w.y});
+        };
+        // w^1, w^2, w^3 of one stage: one hardware evaluation, two complex products (each 2-3 ulp, like the butterflies)
+        auto twiddles = [&](int m, v2f& w1, v2f& w2, v2f& w3) {
+            w1 = twiddle(m);
+            w2 = cmul(w1, w1);
+            w3 = cmul(w1, w2);
+        };
         float win[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -949,10 +963,12 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         {   // forward stage 1 (span 64): real inputs straight from registers
             const float a0 = nz[0] * win[0], a1 = nz[1] * win[1], a2 = nz[2] * win[2], a3 = nz[3] * win[3];
             const float s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
-            S.fft[lane] = make_float2(s02 + s13, 0.0f);
-            S.fft[lane + 64] = cmul(make_float2(d02, -d13), twiddle(lane));
-            S.fft[lane + 128] = cmul(make_float2(s02 - s13, 0.0f), twiddle(2 * lane));
-            S.fft[lane + 192] = cmul(make_float2(d02, d13), twiddle(3 * lane));
+            v2f w1, w2, w3;
+            twiddles(lane, w1, w2, w3);
+            F[lane] = v2f{s02 + s13, 0.0f};
+            F[lane + 64] = cmul(v2f{d02, -d13}, w1);
+            F[lane + 128] = splat(s02 - s13) * w2;
+            F[lane + 192] = cmul(v2f{d02, d13}, w3);
         }
         wave_lds_sync();
 #pragma unroll
@@ -960,33 +976,31 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const int g = lane / q, jj = lane % q;
             const int base = g * 4 * q + jj;
             const int tstep = 64 / q;   // 256 / (4q)
-            const float2 a0 = S.fft[base], a1 = S.fft[base + q], a2 = S.fft[base + 2 * q], a3 = S.fft[base + 3 * q];
-            const float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
-            const float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
-            const float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y);
-            const float2 u1 = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i*d13
-            const float2 u2 = make_float2(s02.x - s13.x, s02.y - s13.y);
-            const float2 u3 = make_float2(d02.x - d13.y, d02.y + d13.x);   // d02 + i*d13
+            const v2f a0 = F[base], a1 = F[base + q], a2 = F[base + 2 * q], a3 = F[base + 3 * q];
+            const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, md13 = mul_mi(a1 - a3);
             wave_lds_sync();
-            S.fft[base] = y0;
+            F[base] = s02 + s13;
             if (q == 1) {   // last forward stage: all twiddles are 1
-                S.fft[base + 1] = u1;
-                S.fft[base + 2] = u2;
-                S.fft[base + 3] = u3;
+                F[base + 1] = d02 + md13;   // d02 - i*d13
+                F[base + 2] = s02 - s13;
+                F[base + 3] = d02 - md13;   // d02 + i*d13
             } else {
-                S.fft[base + q] = cmul(u1, twiddle(jj * tstep));
-                S.fft[base + 2 * q] = cmul(u2, twiddle(2 * jj * tstep));
-                S.fft[base + 3 * q] = cmul(u3, twiddle(3 * jj * tstep));
+                v2f w1, w2, w3;
+                twiddles(jj * tstep, w1, w2, w3);
+                F[base + q] = cmul(d02 + md13, w1);
+                F[base + 2 * q] = cmul(s02 - s13, w2);
+                F[base + 3 * q] = cmul(d02 - md13, w3);
             }
             wave_lds_sync();
         }
-        // |X(k)|^2 for k = 0..128 in natural order (position p holds bin rev4(p))
+        // |X(k)|^2 for k = 0..128 in natural order (position p holds bin rev4(p); rev4(lane + 64 r) = rev4(lane) + r)
+        const int kbase = rev4(lane & 63);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int pidx = lane + 64 * r;
-            const int k = rev4(pidx);
+            const int k = kbase + r;
             if (k <= 128) {
-                const float2 X = S.fft[pidx];
+                const v2f X = F[pidx];
                 S.bins[k] = (k == 0) ? (X.x * X.x) : ((X.x * X.x) + (X.y * X.y));
             }
         }
@@ -1024,7 +1038,8 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             }
             const int count = b - a;
             if (count > 0 && num > 1e-10f) {
-                band_sc = 146.17696f * band_M / sqrtf(num / (float)count);
+                // v_rcp / v_rsq (1 ulp each): the bin energies come from a float FFT that differs from the reference's by more
+                band_sc = (146.17696f * band_M) * __builtin_amdgcn_rsqf(num * __builtin_amdgcn_rcpf((float)count));
                 band_a = a;
                 band_b = b;
             }
@@ -1043,10 +1058,9 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int pidx = lane + 64 * r;
-            const int k = rev4(pidx);
+            const int k = kbase + r;
             const float sc = S.bins[k > 128 ? 256 - k : k];
-            const float2 X = S.fft[pidx];
-            S.fft[pidx] = make_float2(X.x * sc, X.y * sc);
+            F[pidx] = F[pidx] * splat(sc);
         }
         wave_lds_sync();
         // inverse stages with spans 1, 4, 16 through LDS
@@ -1055,27 +1069,30 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const int g = lane / q, jj = lane % q;
             const int base = g * 4 * q + jj;
             const int tstep = 64 / q;
-            const float2 x0 = S.fft[base];
-            float2 z1 = S.fft[base + q], z2 = S.fft[base + 2 * q], z3 = S.fft[base + 3 * q];
+            const v2f x0 = F[base];
+            v2f z1 = F[base + q], z2 = F[base + 2 * q], z3 = F[base + 3 * q];
             if (q != 1) {   // multiply by the conjugate twiddles
-                z1 = cmulc(z1, twiddle(jj * tstep));
-                z2 = cmulc(z2, twiddle(2 * jj * tstep));
-                z3 = cmulc(z3, twiddle(3 * jj * tstep));
+                v2f w1, w2, w3;
+                twiddles(jj * tstep, w1, w2, w3);
+                z1 = cmulc(z1, w1);
+                z2 = cmulc(z2, w2);
+                z3 = cmulc(z3, w3);
             }
-            const float2 s02 = make_float2(x0.x + z2.x, x0.y + z2.y), d02 = make_float2(x0.x - z2.x, x0.y - z2.y);
-            const float2 s13 = make_float2(z1.x + z3.x, z1.y + z3.y), d13 = make_float2(z1.x - z3.x, z1.y - z3.y);
+            const v2f s02 = x0 + z2, d02 = x0 - z2, s13 = z1 + z3, md13 = mul_mi(z1 - z3);
             wave_lds_sync();
-            S.fft[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
-            S.fft[base + q] = make_float2(d02.x - d13.y, d02.y + d13.x);       // d02 + i*d13
-            S.fft[base + 2 * q] = make_float2(s02.x - s13.x, s02.y - s13.y);
-            S.fft[base + 3 * q] = make_float2(d02.x + d13.y, d02.y - d13.x);   // d02 - i*d13
+            F[base] = s02 + s13;
+            F[base + q] = d02 - md13;       // d02 + i*d13
+            F[base + 2 * q] = s02 - s13;
+            F[base + 3 * q] = d02 + md13;   // d02 - i*d13
             wave_lds_sync();
         }
         {   // last inverse stage (span 64): only the real parts are needed, results stay in registers
-            const float2 x0 = S.fft[lane];
-            const float2 z1 = cmulc(S.fft[lane + 64], twiddle(lane));
-            const float2 z2 = cmulc(S.fft[lane + 128], twiddle(2 * lane));
-            const float2 z3 = cmulc(S.fft[lane + 192], twiddle(3 * lane));
+            v2f w1, w2, w3;
+            twiddles(lane, w1, w2, w3);
+            const v2f x0 = F[lane];
+            const v2f z1 = cmulc(F[lane + 64], w1);
+            const v2f z2 = cmulc(F[lane + 128], w2);
+            const v2f z3 = cmulc(F[lane + 192], w3);
             const float s02 = x0.x + z2.x, d02 = x0.x - z2.x, s13 = z1.x + z3.x, d13y = z1.y - z3.y;
             cur.uw[0] = (s02 + s13) * (1.0f / 256.0f);
             cur.uw[1] = (d02 - d13y) * (1.0f / 256.0f);   // Re(d02 + i*d13)
