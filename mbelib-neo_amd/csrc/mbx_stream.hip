@@ -938,20 +938,16 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         // Complex values are (re, im) register pairs: a complex add is one v_pk_add_f32, a multiplication by -+i a
         // swap + sign the packed instructions take as operand modifiers, a complex product two packed instructions.
         v2f* const F = reinterpret_cast<v2f*>(S.fft);
-        auto twiddle = [](int m) -> v2f {
-            const float rev = (float)(m & 255) * (1.0f / 256.0f);
-            return v2f{__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev)};
-        };
         auto mul_mi = [](v2f a) -> v2f { return v2f{a.y, -a.x}; };   // -i a
         auto cmul = [](v2f u, v2f w) -> v2f {                         // u w
             return __builtin_elementwise_fma(v2f{u.y, u.y}, v2f{-w.y, w.x}, v2f{u.x, u.x} * w);
         };
-        auto cmulc = [](v2f u, v2f w) -> v2f {                        // u conj(w)
-            return __builtin_elementwise_fma(v2f{u.y, u.y}, v2f{w.y, w.x}, v2f{u.x, u.x} * v2f{w.x, -w.y});
-        };
-        // w^1, w^2, w^3 of one stage: one hardware evaluation, two complex products (each 2-3 ulp, like the butterflies)
-        auto twiddles = [&](int m, v2f& w1, v2f& w2, v2f& w3) {
-            w1 = twiddle(m);
+        // w^1, w^2, w^3 of one stage: one hardware evaluation, two complex products (each 2-3 ulp, like the butterflies);
+        // the inverse transform asks for the conjugates directly
+        auto twiddles = [&](int m, bool conj, v2f& w1, v2f& w2, v2f& w3) {
+            const float rev = (float)(m & 255) * (1.0f / 256.0f);
+            const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+            w1 = conj ? v2f{c, sn} : v2f{c, -sn};
             w2 = cmul(w1, w1);
             w3 = cmul(w1, w2);
         };
@@ -964,7 +960,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const float a0 = nz[0] * win[0], a1 = nz[1] * win[1], a2 = nz[2] * win[2], a3 = nz[3] * win[3];
             const float s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
             v2f w1, w2, w3;
-            twiddles(lane, w1, w2, w3);
+            twiddles(lane, false, w1, w2, w3);
             F[lane] = v2f{s02 + s13, 0.0f};
             F[lane + 64] = cmul(v2f{d02, -d13}, w1);
             F[lane + 128] = splat(s02 - s13) * w2;
@@ -986,7 +982,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 F[base + 3] = d02 - md13;   // d02 + i*d13
             } else {
                 v2f w1, w2, w3;
-                twiddles(jj * tstep, w1, w2, w3);
+                twiddles(jj * tstep, false, w1, w2, w3);
                 F[base + q] = cmul(d02 + md13, w1);
                 F[base + 2 * q] = cmul(s02 - s13, w2);
                 F[base + 3 * q] = cmul(d02 - md13, w3);
@@ -1073,10 +1069,10 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             v2f z1 = F[base + q], z2 = F[base + 2 * q], z3 = F[base + 3 * q];
             if (q != 1) {   // multiply by the conjugate twiddles
                 v2f w1, w2, w3;
-                twiddles(jj * tstep, w1, w2, w3);
-                z1 = cmulc(z1, w1);
-                z2 = cmulc(z2, w2);
-                z3 = cmulc(z3, w3);
+                twiddles(jj * tstep, true, w1, w2, w3);
+                z1 = cmul(z1, w1);
+                z2 = cmul(z2, w2);
+                z3 = cmul(z3, w3);
             }
             const v2f s02 = x0 + z2, d02 = x0 - z2, s13 = z1 + z3, md13 = mul_mi(z1 - z3);
             wave_lds_sync();
@@ -1088,11 +1084,11 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         {   // last inverse stage (span 64): only the real parts are needed, results stay in registers
             v2f w1, w2, w3;
-            twiddles(lane, w1, w2, w3);
+            twiddles(lane, true, w1, w2, w3);
             const v2f x0 = F[lane];
-            const v2f z1 = cmulc(F[lane + 64], w1);
-            const v2f z2 = cmulc(F[lane + 128], w2);
-            const v2f z3 = cmulc(F[lane + 192], w3);
+            const v2f z1 = cmul(F[lane + 64], w1);
+            const v2f z2 = cmul(F[lane + 128], w2);
+            const v2f z3 = cmul(F[lane + 192], w3);
             const float s02 = x0.x + z2.x, d02 = x0.x - z2.x, s13 = z1.x + z3.x, d13y = z1.y - z3.y;
             cur.uw[0] = (s02 + s13) * (1.0f / 256.0f);
             cur.uw[1] = (d02 - d13y) * (1.0f / 256.0f);   // Re(d02 + i*d13)
@@ -1550,7 +1546,10 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
 }
 
 #ifndef MBX_AMBE_WAVES_PER_SIMD
-#define MBX_AMBE_WAVES_PER_SIMD 5   // the AMBE kernels need 93 VGPRs (tone paths); five spill-free waves
+#define MBX_AMBE_WAVES_PER_SIMD 6       // AMBE+2 3600x2450: 79 VGPRs, spill-free
+#endif
+#ifndef MBX_AMBE2400_WAVES_PER_SIMD
+#define MBX_AMBE2400_WAVES_PER_SIMD 5   // AMBE 3600x2400 needs 81 (D-STAR tone path)
 #endif
 // D-STAR single tone (ref src/core/mbelib.c:813-856 + :708-736): 156.25 Hz (index 5), 187.5 Hz (6) or 31.25 Hz x index
 // (7..122) at the fixed amplitude 103
@@ -1617,6 +1616,10 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         const int total = c0 + prot;
         int bad;
         bool prev_max_repeat, valid_tone = false;
+        // The parts of prev_mp_enhanced that synthesis reads are requested together with prev_mp, so that one
+        // memory latency covers both (as in the IMBE kernel).
+        Parms enh;
+        load_enh_view(enh, slot_enh, lane);
         {
             Parms prev;
             load_prev_view(prev, slot_prev, lane);
@@ -1628,6 +1631,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 store_parms(prev, slot_prev, lane);
                 store_parms(prev, slot_enh, lane);
                 __threadfence_block();
+                load_enh_view(enh, slot_enh, lane);
             }
             cur.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
             cur.errorCountTotal = total;
@@ -1697,11 +1701,9 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
 
         float out[3];
-        Parms enh;
         float rm0 = 0.0f;
         if (action == kVoice) {
             store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
-            load_enh_view(enh, slot_enh, lane);
             cur.log2Ml = 0.0f;                   // read back from the snapshot after the synthesiser (see the IMBE kernel)
             cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
             rm0 = enhance(cur, lane);
@@ -1780,7 +1782,7 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
     ambe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
-__global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64, MBX_AMBE2400_WAVES_PER_SIMD)
 ambe2400_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
