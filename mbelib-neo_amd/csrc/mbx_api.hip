@@ -26,6 +26,8 @@ __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const Fram
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe_stream_kernel_w4(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                   int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe2400_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void synth_speech_kernel(int, mbe_parms*, mbe_parms*, mbx_stream_rng*, float*, int16_t*, DeviceTables);
@@ -52,6 +54,7 @@ struct Context {
     uint32_t           checksum = 0;
     mbx::FrameParams*  workspace = nullptr;   // expand-stage output, grow-only (mbx_reserve)
     size_t             workspace_frames = 0;
+    int                simds = 0;             // 4 per CU
 };
 Context     g_ctx;
 std::mutex  g_mu;
@@ -306,6 +309,9 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     g_ctx.tabs.t = static_cast<const mbx_tables*>(g_ctx.d_blob);
     g_ctx.tabs.d = static_cast<const mbx::DerivedTables*>(g_ctx.d_derived);
     g_ctx.device = device;
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    g_ctx.simds = 4 * cus;
     g_ctx.checksum = host->checksum;
     g_ctx.ready = true;
     return 0;
@@ -584,6 +590,25 @@ static int launch_stream(int codec, int S, int T, const mbx_param_record* d_reco
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
         return check_launch("ambe2400_stream_kernel");
     }
+    // Balanced rounds for long launches.  A stream kernel is one wave per stream and each wave runs all T frames; with
+    // room for w waves per SIMD a launch of n waves per SIMD runs in ceil(n / w) rounds.  When the last round is short
+    // (config 5's per-GPU shard: 8,192 streams x T = 128 on 6 x 1,024 slots, i.e. 6 waves per SIMD, then 2), its waves
+    // have the SIMD nearly to themselves and are bound by latency instead of VALU issue.  Capping the residency PER SIMD
+    // at ceil(n / rounds) keeps the number of rounds and evens them out: 4 + 4 here, 3.66 -> 3.51 ms.  The cap has to
+    // be per SIMD, i.e. by registers (a second instance of the kernel): an LDS cap is per CU and packs the SIMDs
+    // unevenly (measured slower).  One-frame launches are bound by memory latency, where every resident wave helps.
+    constexpr int kWaves = 6, kWavesCapped = 4;   // MBX_AMBE_WAVES_PER_SIMD / ambe_stream_kernel_w4
+    if (T >= 4 && g_ctx.simds > 0) {
+        const double n = (double)S / (double)g_ctx.simds;
+        if (n > (double)kWaves) {
+            const double rounds = ceil(n / (double)kWaves);
+            if (ceil(n / rounds) <= (double)kWavesCapped) {
+                hipLaunchKernelGGL(mbx::ambe_stream_kernel_w4, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T,
+                                   d_records, params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+                return check_launch("ambe_stream_kernel_w4");
+            }
+        }
+    }
     hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                        params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
     return check_launch("ambe_stream_kernel");
@@ -622,7 +647,7 @@ int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_recor
     }
     // IMBE: the stream kernel can expand the records itself.  With several frames per stream that saves the
     // workspace round trip and a launch (+4 % at T = 16).  With ONE frame per stream the whole-job rate is the same
-    // either way (measured 0.364 vs 0.363 ms per 65,536 frames): the table look-ups of the expansion are a latency
+    // either way (measured 0.296 vs 0.292 ms per 65,536 frames): the table look-ups of the expansion are a latency
     // chain a one-frame wave cannot hide, and the 8-lanes-per-frame expand kernel costs as much as it saves -- there
     // the expansion stays a separate launch, which keeps the dominant kernel to the stream stage proper.
     if (codec == MBX_CODEC_IMBE7200X4400 && T > 1) {

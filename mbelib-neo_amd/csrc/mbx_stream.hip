@@ -1782,6 +1782,15 @@ ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
     ambe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
+// The same kernel held to FOUR waves per SIMD (the register allocation is padded to enforce it), for launches whose
+// last round would otherwise be short -- see launch_stream() in mbx_api.hip.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+ambe_stream_kernel_w4(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                      mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                      float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
 __global__ void __launch_bounds__(64, MBX_AMBE2400_WAVES_PER_SIMD)
 ambe2400_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
