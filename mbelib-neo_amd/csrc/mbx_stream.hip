@@ -1159,20 +1159,16 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     return true;
 }
 
+// mbe_floattoshort (src/core/mbelib.c:1148-1321): trunc(clamp(7 x, +-31128.65)), NaN -> 0, +-Inf -> +-31128.  The two
+// special cases need no test of their own here: 7 * (+-Inf) is clamped like any large value, the comparisons are false
+// for NaN, and v_cvt_i32_f32 converts NaN to 0.
 __device__ __forceinline__ int16_t to_pcm16(float x) {
     const float top = 32767.0f * 0.95f;
-    const uint32_t bits = __float_as_uint(x);
-    const uint32_t mag = bits & 0x7FFFFFFFu;
-    float v;
-    if (mag > 0x7F800000u) {
-        v = 0.0f;
-    } else if (mag == 0x7F800000u) {
-        v = (bits & 0x80000000u) ? -top : top;
-    } else {
-        v = 7.0f * x;
-        v = (v > top) ? top : ((v < -top) ? -top : v);
-    }
-    return (int16_t)(int)v;
+    float v = 7.0f * x;
+    v = (v > top) ? top : ((v < -top) ? -top : v);
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return (int16_t)r;
 }
 
 __device__ __forceinline__ void store_pcm(const float out[3], size_t frame, int16_t* pcm16, float* pcmf, int lane) {

@@ -111,6 +111,25 @@ def test_golden_synth_scenario(mbx, oracle):
     parity.check_state(g["prev_out"].reshape(1), prev)
 
 
+def test_synth_int16_of_non_finite_samples(mbx, oracle):
+    """The stream / synthesis kernels convert to int16 with the reference's rules (NaN -> 0, clamp at +-31128)
+    without testing for NaN / Inf explicitly: amplitudes that make the float PCM non-finite or huge must still give
+    the int16 the reference's mbe_floattoshort gives for the same float samples."""
+    from mbelib_neo_amd import decoder
+    from mbelib_neo_amd.layout import rng_seeded
+
+    g = golden_io.golden_synth()
+    cur = np.repeat(g["cur_in"].reshape(1), 3)
+    prev = np.repeat(g["prev_in"].reshape(1), 3)
+    cur["Ml"][0, 3] = np.nan        # NaN amplitude: every sample of the frame becomes NaN
+    cur["Ml"][1, 2] = 3.0e38        # overflows to +-Inf in the sum
+    cur["Ml"][2, 2] = 1.0e6         # finite, far beyond the clip level
+    pcmf, _, _, _, pcm16 = decoder.synthesize_speech(cur, prev, rng_seeded([1, 2, 3]), want_pcm16=True)
+    assert np.array_equal(pcm16, oracle.floattoshort(pcmf)), "int16 differs from mbe_floattoshort of the same floats"
+    assert not np.isfinite(pcmf[0]).any() and (pcm16[0] == 0).all()
+    assert np.abs(pcm16[1:]).max() <= 31128
+
+
 # ---- full path vs the reference's golden streams ------------------------------------------------
 @pytest.mark.parametrize("codec", [0, 1])
 def test_stream_golden_fixtures(mbx, oracle, codec):
