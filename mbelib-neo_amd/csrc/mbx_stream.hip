@@ -1132,18 +1132,23 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
         // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
         // the division by w(n)^2 + w(n-160)^2 is a multiplication by its rounded reciprocal (<= 1 ulp of the unvoiced part)
-        const float winv[3] = {D->wola_inv[lane], D->wola_inv[lane + 64], (lane < 32) ? D->wola_inv[lane + 128] : 0.0f};
         const float wprev[2] = {T->wola_w_prev[lane], T->wola_w_prev[lane + 64]};   // w(n) is 0 from n = 106 on
-        const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
+        if (any_unvoiced) {
+            const float winv[3] = {D->wola_inv[lane], D->wola_inv[lane + 64], (lane < 32) ? D->wola_inv[lane + 128] : 0.0f};
+            const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float give = (lane < 32) ? cur.uw[j] : ((j == 0) ? 0.0f : cur.uw[j - 1]);
-            const float cs = __shfl_xor(give, 32, kWave);
-            const float ps = (j == 0) ? prev.uw[2] : ((j == 1) ? prev.uw[3] : 0.0f);
-            const float wp = (j < 2) ? wprev[j] : 0.0f;
-            if ((lane + 64 * j) < N) {
-                acc[j] += ((wp * ps) + (wcurr[j] * cs)) * winv[j];
+            for (int j = 0; j < 3; ++j) {
+                const float give = (lane < 32) ? cur.uw[j] : ((j == 0) ? 0.0f : cur.uw[j - 1]);
+                const float cs = __shfl_xor(give, 32, kWave);
+                const float ps = (j == 0) ? prev.uw[2] : ((j == 1) ? prev.uw[3] : 0.0f);
+                const float wp = (j < 2) ? wprev[j] : 0.0f;
+                if ((lane + 64 * j) < N) {
+                    acc[j] += ((wp * ps) + (wcurr[j] * cs)) * winv[j];
+                }
             }
+        } else {   // this frame's Uw is all zeros: only the previous frame's half of the overlap remains
+            acc[0] += (wprev[0] * prev.uw[2]) * D->wola_inv[lane];
+            acc[1] += (wprev[1] * prev.uw[3]) * D->wola_inv[lane + 64];
         }
         wave_lds_sync();
     }
