@@ -237,6 +237,34 @@ def test_full_size_properties(mbx, oracle):
     parity.check_state(ref["state"], a_state[pick])
 
 
+def test_ambe_capped_kernel_instance_is_identical(mbx, oracle):
+    """8,192 AMBE+2 streams x T = 4 take the four-waves-per-SIMD instance of the stream kernel (the launcher's balanced
+    rounds rule, mbx_api.hip); the same streams in two launches of 4,096 take the regular one.  Same code, different
+    register allocation: PCM and state must be bit-identical, and a strided sample must match the oracle."""
+    import torch
+    from mbelib_neo_amd import decoder, framegen
+
+    S, T = 8192, 4
+    frames = framegen.random_frames(1, S * T, framegen.rng_for(41)).reshape(S, T, 9)
+    seeds = np.arange(S) + 77
+
+    def run(lo, hi):
+        dec = decoder.BatchDecoder(1, hi - lo, seeds=seeds[lo:hi])
+        out = dec.decode(np.ascontiguousarray(frames[lo:hi]).reshape(-1, 9), T, want_float=True)
+        torch.cuda.synchronize()
+        return out["pcm16"].reshape(hi - lo, T, 160).cpu().numpy(), out["pcmf"].reshape(hi - lo, T, 160).cpu().numpy(), dec.state_numpy()
+
+    a16, af, astate = run(0, S)
+    halves = [run(0, S // 2), run(S // 2, S)]
+    assert np.array_equal(a16, np.concatenate([h[0] for h in halves]))
+    assert af.tobytes() == np.concatenate([h[1] for h in halves]).tobytes()
+    assert astate.tobytes() == np.concatenate([h[2] for h in halves]).tobytes()
+    pick = np.arange(0, S, 61)
+    ref = oracle.process_batch(1, len(pick), T, frames[pick].reshape(-1, 9), oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
+    parity.check_pcm(ref["pcmf"], af[pick].reshape(-1, 160), ref["pcm16"], a16[pick].reshape(-1, 160))
+    parity.check_state(ref["state"], astate[pick])
+
+
 def test_edge_cases(mbx, oracle):
     from mbelib_neo_amd import _native, decoder
     from mbelib_neo_amd.layout import init_state, rng_default
