@@ -48,7 +48,7 @@ namespace {
 struct Context {
     bool               ready = false;
     int                device = -1;
-    mbx::DeviceTables  tabs{nullptr, nullptr, 0};
+    mbx::DeviceTables  tabs{nullptr, nullptr, 0, 0};
     void*              d_blob = nullptr;
     void*              d_derived = nullptr;
     uint32_t           checksum = 0;
@@ -580,14 +580,24 @@ int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, v
 static int launch_stream(int codec, int S, int T, const mbx_param_record* d_records, const mbx::FrameParams* params,
                          mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
                          mbe_process_result* d_results, void* stream) {
+    // Successive launches walk the streams in opposite directions.  A decoder is called for the same streams every
+    // 20 ms; the state of 65,536 of them (512 MB) does not fit the 256 MB Infinity Cache, so in a fixed order every
+    // launch finds none of it there.  Starting where the previous launch ended finds its last quarter-gigabyte.
+    // The results do not depend on the order.
+    static bool toggle = false;
+    if (!getenv("MBX_NO_REVERSE")) {
+        toggle = !toggle;
+    }
+    mbx::DeviceTables tabs = g_ctx.tabs;
+    tabs.reverse = toggle ? 1 : 0;
     if (codec == MBX_CODEC_IMBE7200X4400) {
         hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
-                           params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+                           params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         return check_launch("imbe_stream_kernel");
     }
     if (codec == MBX_CODEC_AMBE3600X2400) {
         hipLaunchKernelGGL(mbx::ambe2400_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
-                           params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+                           params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         return check_launch("ambe2400_stream_kernel");
     }
     // Balanced rounds for long launches.  A stream kernel is one wave per stream and each wave runs all T frames; with
@@ -604,13 +614,13 @@ static int launch_stream(int codec, int S, int T, const mbx_param_record* d_reco
             const double rounds = ceil(n / (double)kWaves);
             if (ceil(n / rounds) <= (double)kWavesCapped) {
                 hipLaunchKernelGGL(mbx::ambe_stream_kernel_w4, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T,
-                                   d_records, params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+                                   d_records, params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
                 return check_launch("ambe_stream_kernel_w4");
             }
         }
     }
     hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
-                       params, d_state, d_rng, d_pcm16, d_pcmf, d_results, g_ctx.tabs);
+                       params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
     return check_launch("ambe_stream_kernel");
 }
 

@@ -52,6 +52,7 @@ struct DeviceTables {
     const mbx_tables*    t;
     const DerivedTables* d;
     int                  ablate;   // timing-only stage mask (mbx_debug_set_ablation); 0 in normal use
+    int                  reverse;  // stream kernels: workgroup b takes stream S - 1 - b (see launch_stream, mbx_api.hip)
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }

@@ -1216,10 +1216,10 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
                    mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                    mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
-    const int s = blockIdx.x;
-    if (s >= S) {
+    if ((int)blockIdx.x >= S) {
         return;
     }
+    const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const int lane_in = lane_id();
     // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
     // registers for the whole launch; `prev` is only needed from the start of a frame to the
@@ -1587,10 +1587,10 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
-    const int s = blockIdx.x;
-    if (s >= S) {
+    if ((int)blockIdx.x >= S) {
         return;
     }
+    const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const int lane_in = lane_id();
     // Same register discipline as the IMBE kernel: `cur` resident, `prev` / `enh` parked in their slots.
     mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
