@@ -733,11 +733,15 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         wave_lds_sync();
         const float dw0 = cw0 - pw0;
-        // 2 amp cos(theta) for two (harmonic, sample) combinations at once
-        auto term = [&](v2f phi, v2f a, v2f fl, v2f amp0, v2f damp, v2f nf, v2f nsq, v2f nfrac) -> v2f {
+        // 2 amp cos(theta) for two (harmonic, sample) combinations at once.  kFlat: the two frames have the same
+        // fundamental (dw0 == 0, e.g. a held pitch), so the quadratic phase term is an exact zero and is not formed.
+        auto term = [&](auto flat, v2f phi, v2f a, v2f fl, v2f amp0, v2f damp, v2f nf, v2f nsq, v2f nfrac) -> v2f {
             // (float)(l*n*n) is exact below 2^24, so l * n^2 in float is the same value; the division by
             // 2N = 320 becomes a multiplication by its rounded reciprocal (<= 1 ulp of a phase term < 16 rad)
-            const v2f theta = (phi + (a * nf)) + ((splat(dw0) * (fl * nsq)) * splat(1.0f / 320.0f));
+            v2f theta = phi + (a * nf);
+            if constexpr (!decltype(flat)::value) {
+                theta = theta + ((splat(dw0) * (fl * nsq)) * splat(1.0f / 320.0f));
+            }
             const v2f hi = theta * splat(0.15915494f);   // revolutions: theta / 2 pi as hi + lo
             const v2f lo = __builtin_elementwise_fma(theta, splat(6.4206382e-9f),
                                                      __builtin_elementwise_fma(theta, splat(0.15915494f), -hi));
@@ -751,18 +755,25 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         const v2f nfrac01 = {D->nfrac[lane], D->nfrac[lane + 64]};   // (float)n / (float)N, the reference's quotient (host table)
         const float nsq2 = nf2 * nf2, nfrac2 = D->nfrac[lane + 128];
         v2f acc01 = {0.0f, 0.0f}, acc2 = {0.0f, 0.0f};
-        while (imask) {
-            const int la = __ffsll((long long)imask) - 1;
-            imask &= imask - 1;
-            const int lb = imask ? (__ffsll((long long)imask) - 1) : 0;   // slot 0 holds zero amplitudes
-            imask &= imask - 1;
-            const float4 ka = S.icoef[la], kb = S.icoef[lb];
-            acc01 += term(splat(ka.x), splat(ka.y), splat((float)la), splat(ka.z), splat(ka.w), nf01, nsq01, nfrac01);
-            if (lb) {
-                acc01 += term(splat(kb.x), splat(kb.y), splat((float)lb), splat(kb.z), splat(kb.w), nf01, nsq01, nfrac01);
+        auto run = [&](auto flat) {
+            while (imask) {
+                const int la = __ffsll((long long)imask) - 1;
+                imask &= imask - 1;
+                const int lb = imask ? (__ffsll((long long)imask) - 1) : 0;   // slot 0 holds zero amplitudes
+                imask &= imask - 1;
+                const float4 ka = S.icoef[la], kb = S.icoef[lb];
+                acc01 += term(flat, splat(ka.x), splat(ka.y), splat((float)la), splat(ka.z), splat(ka.w), nf01, nsq01, nfrac01);
+                if (lb) {
+                    acc01 += term(flat, splat(kb.x), splat(kb.y), splat((float)lb), splat(kb.z), splat(kb.w), nf01, nsq01, nfrac01);
+                }
+                acc2 += term(flat, v2f{ka.x, kb.x}, v2f{ka.y, kb.y}, v2f{(float)la, (float)lb}, v2f{ka.z, kb.z}, v2f{ka.w, kb.w},
+                             splat(nf2), splat(nsq2), splat(nfrac2));
             }
-            acc2 += term(v2f{ka.x, kb.x}, v2f{ka.y, kb.y}, v2f{(float)la, (float)lb}, v2f{ka.z, kb.z}, v2f{ka.w, kb.w},
-                         splat(nf2), splat(nsq2), splat(nfrac2));
+        };
+        if (dw0 == 0.0f) {
+            run(std::true_type{});
+        } else {
+            run(std::false_type{});
         }
         acc[0] += acc01.x;
         acc[1] += acc01.y;
