@@ -369,17 +369,30 @@ ecc_words_kernel(int kind, const uint32_t* __restrict__ in, size_t n, uint32_t* 
 // ------------------------------------------------------------------------------------------
 struct SoftScratch {
     uint32_t cell[192];      // the frame's soft bits: bit | reliability << 8
+    uint32_t rel[192];       // the reliabilities alone (read wave-uniformly: LDS broadcasts, no v_readlane)
     uint32_t parity[2048];   // key contribution of a parity pattern: cost << shift (+ differing bits, Hamming)
     uint2    round[64];      // per-round constants: (table offset, key contribution) of the high bits j of u
 };
 
+// Minimum over the wave, returned wave-uniform in scalar registers (what follows it runs on the scalar unit):
+// four DPP steps inside each row of 16, the four row minima by v_readlane.
+template <int kCtrl>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kCtrl, 0xf, 0xf, true);
+}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, m, kWave);
-        v = o < v ? o : v;
-    }
-    return v;
+    uint32_t o = dpp_u32<kDppXor1>(v);
+    v = o < v ? o : v;
+    o = dpp_u32<kDppXor2>(v);
+    v = o < v ? o : v;
+    o = dpp_u32<kDppHalfMirror>(v);
+    v = o < v ? o : v;
+    o = dpp_u32<kDppMirror>(v);
+    v = o < v ? o : v;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
 }
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane_index) {   // wave-uniform lane index
@@ -403,11 +416,11 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int lane_index) {   // wave-u
 // reliability j.  Returns the chosen data bits over the HARD parity bits (ecc.c:354-356); `diffs` =
 // data-bit differences between the hard decisions and the chosen code word (the return value of
 // mbe_golay2312Soft).  Key: cost << 17 | !matches_hard << 16 | differing data bits << 12 | data.
-__device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int rel_lane, SoftScratch& S, int lane, int& diffs) {
+__device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int first, SoftScratch& S, int lane, int& diffs) {
     uint32_t hard_fixed;
     (void)golay2312(T, hard, hard_fixed);
     const uint32_t hd = hard >> 11, hp = hard & 0x7ffu;
-    const uint32_t rel = (uint32_t)rel_lane;
+    const uint32_t* rel = &S.rel[first];   // reliability of cell j of the block, read wave-uniformly
     // per-lane pieces: bit b of the lane index selects position ...
     uint32_t par_lo = 0, par_hi = 0, par_hd = 0;   // parity of data bits 0..5 / 6..11 (pattern = lane) / of hd
     uint32_t a_lo = 0, a_hi = 0;                    // data-part cost: cells 11..16 / 17..22
@@ -420,19 +433,23 @@ __device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int rel_
         par_hi ^= bit ? ghi : 0u;
         par_hd ^= ((hd >> b) & 1u) ? glo : 0u;
         par_hd ^= ((hd >> (b + 6)) & 1u) ? ghi : 0u;
-        a_lo += bit ? rl(rel, 11 + b) : 0u;
-        a_hi += bit ? rl(rel, 17 + b) : 0u;
-        b_lo += bit ? rl(rel, b) : 0u;
+        a_lo = __umul24(bit, rel[11 + b]) + a_lo;   // one v_mad_u32_u24 each
+        a_hi = __umul24(bit, rel[17 + b]) + a_hi;
+        b_lo = __umul24(bit, rel[b]) + b_lo;
         if (b < 5) {
-            b_hi += bit ? rl(rel, 6 + b) : 0u;
+            b_hi = __umul24(bit, rel[6 + b]) + b_hi;
         }
     }
     const uint32_t s = par_hd ^ hp;
     wave_lds_sync();
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(S.round);   // b_hi of pattern k, k < 32, read back wave-uniformly
+    stage[lane] = b_hi;
+    wave_lds_sync();
 #pragma unroll 8
     for (int k = 0; k < 32; ++k) {   // parity table: pattern lane + 64 k
-        S.parity[lane + 64 * k] = (b_lo + rl(b_hi, k)) << 17;
+        S.parity[lane + 64 * k] = (b_lo + stage[k]) << 17;
     }
+    wave_lds_sync();   // the staging words become the round constants below
     const uint32_t addr_lane = par_lo << 2;                                         // byte offsets into S.parity
     const uint32_t addr_round = (par_hi ^ s) << 2;                                  // for round j = lane
     const uint32_t key_lane = (a_lo << 17) + 0x10000u + ((uint32_t)__popc(lane) << 12) + ((uint32_t)lane ^ (hd & 63u));
@@ -464,7 +481,7 @@ __device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int rel_
 // Data bit i sits at cell kHamData[i], parity bit q at cell kHamParity[q] (ecc.c:128-131).
 // Key: cost << 16 | !matches_hard << 15 | differing bits << 11 | data.
 template <bool k7100>   // k7100: the IMBE 7100x4400 bit mapping (data at cells 4..14, parity at 0..3), ecc.c:130-131
-__device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, int rel_lane, SoftScratch& S, int lane, int& diffs) {
+__device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, int first, SoftScratch& S, int lane, int& diffs) {
     constexpr int kHamData[11] = {k7100 ? 4 : 2, k7100 ? 5 : 4, k7100 ? 6 : 5, k7100 ? 7 : 6, 8, 9, 10, 11, 12, 13, 14};
     constexpr int kHamParity[4] = {0, 1, k7100 ? 2 : 3, k7100 ? 3 : 7};
     const uint32_t* basis = k7100 ? tabs.d->ham7100_basis : tabs.d->ham_basis;
@@ -474,7 +491,7 @@ __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, i
     } else {
         (void)hamming1511(tabs.t, hard, hard_fixed);
     }
-    const uint32_t rel = (uint32_t)rel_lane;
+    const uint32_t* rel = &S.rel[first];   // reliability of cell j of the block, read wave-uniformly
     auto gather_data = [&](uint32_t cw) {
         uint32_t d = 0;
 #pragma unroll
@@ -499,15 +516,15 @@ __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, i
         const uint32_t plo = gather_parity(basis[b]);
         par_lo ^= bit ? plo : 0u;
         par_hd ^= ((hd >> b) & 1u) ? plo : 0u;
-        a_lo += bit ? rl(rel, kHamData[b]) : 0u;
+        a_lo = __umul24(bit, rel[kHamData[b]]) + a_lo;
         if (b < 5) {
             const uint32_t phi = gather_parity(basis[6 + b]);
             par_hi ^= bit ? phi : 0u;
             par_hd ^= ((hd >> (b + 6)) & 1u) ? phi : 0u;
-            a_hi += bit ? rl(rel, kHamData[6 + b]) : 0u;
+            a_hi = __umul24(bit, rel[kHamData[6 + b]]) + a_hi;
         }
         if (b < 4) {
-            p_cost += bit ? rl(rel, kHamParity[b]) : 0u;
+            p_cost = __umul24(bit, rel[kHamParity[b]]) + p_cost;
         }
     }
     const uint32_t s = par_hd ^ hp;
@@ -575,6 +592,7 @@ __device__ __forceinline__ void load_soft_cells(SoftScratch& S, const mbe_soft_b
         if (idx < count) {
             const uint32_t v = src[idx];
             S.cell[idx] = (v & 1u) | (v & 0xff00u);   // the reference masks the hard decision with & 1
+            S.rel[idx] = v >> 8;
         }
     }
     wave_lds_sync();
@@ -594,7 +612,7 @@ fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     uint32_t row[8];
     {
         const uint32_t hard = soft_block(S, tabs, 0, 23, 0, 0u, lane, rel);
-        row[0] = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+        row[0] = golay_soft_wave(tabs.t, hard, 0, S, lane, diffs);
     }
     const int c0 = diffs;
     const uint32_t x0 = (16u * (row[0] >> 11)) & 0xffffu;
@@ -602,14 +620,14 @@ fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
 #pragma unroll 1
     for (int r = 1; r < 4; ++r) {
         const uint32_t hard = soft_block(S, tabs, 23 * r, 23, k, x0, lane, rel);
-        row[r] = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+        row[r] = golay_soft_wave(tabs.t, hard, 23 * r, S, lane, diffs);
         prot += diffs;
         k += 23;
     }
 #pragma unroll 1
     for (int r = 4; r < 7; ++r) {
         const uint32_t hard = soft_block(S, tabs, 23 * r, 15, k, x0, lane, rel);
-        row[r] = hamming_soft_wave<false>(tabs, hard, rel, S, lane, diffs);
+        row[r] = hamming_soft_wave<false>(tabs, hard, 23 * r, S, lane, diffs);
         prot += diffs;
         if (r == 4) {
             c4 = diffs;
@@ -648,7 +666,7 @@ fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     int rel, diffs;
     // C0: cells 1..23 of row 0 are the Golay block, cell 0 the overall parity bit
     uint32_t hard = soft_block(S, tabs, 1, 23, 0, 0u, lane, rel);
-    const uint32_t cw = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    const uint32_t cw = golay_soft_wave(tabs.t, hard, 1, S, lane, diffs);
     int c0 = diffs;
     uint32_t row0 = (cw << 1) | (S.cell[0] & 1u);
     if (c0 == 0 && (__popc(row0) & 1)) {
@@ -657,7 +675,7 @@ fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     }
     const uint32_t x0 = (16u * ((row0 >> 12) & 0xfffu)) & 0xffffu;
     hard = soft_block(S, tabs, 24, 23, 1, x0, lane, rel);
-    const uint32_t row1 = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    const uint32_t row1 = golay_soft_wave(tabs.t, hard, 24, S, lane, diffs);
     const int prot = diffs;
     const uint32_t row2 = soft_block(S, tabs, 48, 11, 0, 0u, lane, rel);
     const uint32_t row3 = soft_block(S, tabs, 72, 14, 0, 0u, lane, rel);
@@ -690,11 +708,12 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     // the (unused) cells 19..23 of the row, so the block is simply cells 1..23
     if (lane >= 19 && lane < 24) {
         S.cell[lane] = 255u << 8;
+        S.rel[lane] = 255u;
     }
     wave_lds_sync();
     int rel, diffs;
     uint32_t hard = soft_block(S, tabs, 1, 23, 0, 0u, lane, rel);
-    uint32_t w = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    uint32_t w = golay_soft_wave(tabs.t, hard, 1, S, lane, diffs);
     const int c0 = diffs;
     const uint32_t row0 = ((w & 0x3ffffu) << 1) | (S.cell[0] & 1u);
     const uint32_t x0 = (16u * ((row0 >> 12) & 0x7fu)) & 0xffffu;
@@ -710,14 +729,14 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     };
     push(row0 >> 12, 7, 7);
     hard = soft_block(S, tabs, 24 + 1, 23, 1, x0, lane, rel);
-    w = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+    w = golay_soft_wave(tabs.t, hard, 24 + 1, S, lane, diffs);
     prot += diffs;
     push(w, 23, 12);
     int k = 25;
 #pragma unroll 1
     for (int r = 2; r < 4; ++r) {
         hard = soft_block(S, tabs, 24 * r, 23, k, x0, lane, rel);
-        w = golay_soft_wave(tabs.t, hard, rel, S, lane, diffs);
+        w = golay_soft_wave(tabs.t, hard, 24 * r, S, lane, diffs);
         prot += diffs;
         push(w, 23, 12);
         k += 23;
@@ -725,7 +744,7 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
 #pragma unroll 1
     for (int r = 4; r < 6; ++r) {
         hard = soft_block(S, tabs, 24 * r, 15, k, x0, lane, rel);
-        w = hamming_soft_wave<true>(tabs, hard, rel, S, lane, diffs);
+        w = hamming_soft_wave<true>(tabs, hard, 24 * r, S, lane, diffs);
         prot += diffs;
         if (r == 4) {
             c4 = diffs;
@@ -777,9 +796,9 @@ ecc_soft_words_kernel(int kind, const mbe_soft_bit* __restrict__ in, size_t n, u
     load_soft_cells(S, in + i * (size_t)width, width, lane);
     int rel, diffs;
     const uint32_t hard = soft_block(S, tabs, 0, width, 0, 0u, lane, rel);
-    const uint32_t w = (kind == 0)   ? golay_soft_wave(tabs.t, hard, rel, S, lane, diffs)
-                       : (kind == 1) ? hamming_soft_wave<false>(tabs, hard, rel, S, lane, diffs)
-                                     : hamming_soft_wave<true>(tabs, hard, rel, S, lane, diffs);
+    const uint32_t w = (kind == 0)   ? golay_soft_wave(tabs.t, hard, 0, S, lane, diffs)
+                       : (kind == 1) ? hamming_soft_wave<false>(tabs, hard, 0, S, lane, diffs)
+                                     : hamming_soft_wave<true>(tabs, hard, 0, S, lane, diffs);
     if (lane == 0) {
         out[i] = w;
         if (errs) {
