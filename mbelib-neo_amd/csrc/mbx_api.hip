@@ -187,6 +187,10 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     for (int L = 1; L < 64; ++L) {
         d.log2_int[L] = log2f((float)L);
     }
+    for (int i = 0; i < 12; ++i) {
+        const uint32_t g = host->golay_gen[i];
+        d.golay_rot[i] = ((g & 0x3fu) << 1) | ((g >> 6) & 1u) | (g & 0x780u);
+    }
     for (int p = 0; p < 57; ++p) {
         for (int c = 1; c < 57; ++c) {
             d.l_ratio[p][c] = (float)p / (float)c;

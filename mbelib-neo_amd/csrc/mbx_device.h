@@ -28,6 +28,7 @@ struct DerivedTables {
     uint32_t pr_mul[116];     // 173^k mod 2^16             (demodulation sequence jump-ahead, k = 0..115)
     uint32_t pr_add[116];     // additive term after k steps
     uint32_t ham_basis[11];   // Hamming(15,11) code word of data bit i (soft-decision candidates)
+    uint32_t golay_rot[12];   // golay_gen[i] with its low seven bits rotated left by one (soft Golay table index, mbx_fec.hip)
     uint32_t ham7100_basis[11];   // the same for the IMBE 7100x4400 bit mapping
     // IMBE parameter expansion, per L (index L - 9) and lane: which block / position a lane owns
     uint32_t imbe_lane_map[48][64];       // hoc block | hoc index k << 3 | harmonic's block << 7 | block length << 10 | index j << 14

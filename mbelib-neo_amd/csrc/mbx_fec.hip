@@ -368,10 +368,11 @@ ecc_words_kernel(int kind, const uint32_t* __restrict__ in, size_t n, uint32_t* 
 // the wave takes the minimum key.  Integer work: results are bit-exact.
 // ------------------------------------------------------------------------------------------
 struct SoftScratch {
-    uint32_t cell[192];      // the frame's soft bits: bit | reliability << 8
-    uint32_t rel[192];       // the reliabilities alone (read wave-uniformly: LDS broadcasts, no v_readlane)
-    uint32_t parity[2048];   // key contribution of a parity pattern: cost << shift (+ differing bits, Hamming)
+    // 4,992 B: eight waves per SIMD fit the CU's 160 KB (the allocation granule is 1,280 B; <= 5,120 B is what it takes)
+    uint16_t parity[2048];   // Golay: cost of parity pattern p at index rot(p) (golay_soft_wave); Hamming: 16 key dwords
     uint2    round[64];      // per-round constants: (table offset, key contribution) of the high bits j of u
+    uint8_t  bit[192];       // the frame's hard decisions
+    uint8_t  rel[192];       // and reliabilities (read wave-uniformly: LDS broadcasts, no v_readlane)
 };
 
 // Minimum over the wave, returned wave-uniform in scalar registers (what follows it runs on the scalar unit):
@@ -416,42 +417,56 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int lane_index) {   // wave-u
 // reliability j.  Returns the chosen data bits over the HARD parity bits (ecc.c:354-356); `diffs` =
 // data-bit differences between the hard decisions and the chosen code word (the return value of
 // mbe_golay2312Soft).  Key: cost << 17 | !matches_hard << 16 | differing data bits << 12 | data.
-__device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int first, SoftScratch& S, int lane, int& diffs) {
+// The parity-cost table holds 16-bit entries, pattern p at index rot(p) = p with its low seven bits rotated left by one:
+// the six parity bits that are an invertible function of the lane's six data bits then select the LDS bank (index bits
+// 1..6, 64 banks of four bytes), so the 64 lanes of a ds_read_u16 never collide.  rot is linear over XOR: the
+// generator rows come pre-rotated from the host (DerivedTables::golay_rot), the hard parity bits are rotated here.
+__device__ __forceinline__ uint32_t rot_parity(uint32_t p) { return ((p & 0x3fu) << 1) | ((p >> 6) & 1u) | (p & 0x780u); }
+
+__device__ uint32_t golay_soft_wave(const DeviceTables& tabs, uint32_t hard, int first, SoftScratch& S, int lane, int& diffs) {
     uint32_t hard_fixed;
-    (void)golay2312(T, hard, hard_fixed);
+    (void)golay2312(tabs.t, hard, hard_fixed);
     const uint32_t hd = hard >> 11, hp = hard & 0x7ffu;
-    const uint32_t* rel = &S.rel[first];   // reliability of cell j of the block, read wave-uniformly
+    const uint8_t* rel = &S.rel[first];   // reliability of cell j of the block, read wave-uniformly
+    const uint32_t* grot = tabs.d->golay_rot;
     // per-lane pieces: bit b of the lane index selects position ...
-    uint32_t par_lo = 0, par_hi = 0, par_hd = 0;   // parity of data bits 0..5 / 6..11 (pattern = lane) / of hd
+    uint32_t par_lo = 0, par_hi = 0, par_hd = 0;   // rotated parity of data bits 0..5 / 6..11 (pattern = lane) / of hd
     uint32_t a_lo = 0, a_hi = 0;                    // data-part cost: cells 11..16 / 17..22
     uint32_t b_lo = 0, b_hi = 0;                    // parity-part cost: cells 0..5 / 6..10 (pattern = lane, < 32)
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
         const uint32_t bit = (uint32_t)(lane >> b) & 1u;
-        const uint32_t glo = (uint32_t)T->golay_gen[11 - b], ghi = (uint32_t)T->golay_gen[5 - b];   // row i <-> data bit 11 - i
+        const uint32_t glo = grot[11 - b], ghi = grot[5 - b];   // row i <-> data bit 11 - i
         par_lo ^= bit ? glo : 0u;
         par_hi ^= bit ? ghi : 0u;
         par_hd ^= ((hd >> b) & 1u) ? glo : 0u;
         par_hd ^= ((hd >> (b + 6)) & 1u) ? ghi : 0u;
-        a_lo = __umul24(bit, rel[11 + b]) + a_lo;   // one v_mad_u32_u24 each
-        a_hi = __umul24(bit, rel[17 + b]) + a_hi;
-        b_lo = __umul24(bit, rel[b]) + b_lo;
+        a_lo = __umul24(bit, (uint32_t)rel[11 + b]) + a_lo;   // one v_mad_u32_u24 each
+        a_hi = __umul24(bit, (uint32_t)rel[17 + b]) + a_hi;
+        b_lo = __umul24(bit, (uint32_t)rel[b]) + b_lo;
         if (b < 5) {
-            b_hi = __umul24(bit, rel[6 + b]) + b_hi;
+            b_hi = __umul24(bit, (uint32_t)rel[6 + b]) + b_hi;
         }
     }
-    const uint32_t s = par_hd ^ hp;
+    const uint32_t s = par_hd ^ rot_parity(hp);
     wave_lds_sync();
-    uint32_t* const stage = reinterpret_cast<uint32_t*>(S.round);   // b_hi of pattern k, k < 32, read back wave-uniformly
-    stage[lane] = b_hi;
+    // parity table: pattern lane + 64 k sits at rot(...) = 2 lane + (k & 1) + 128 (k >> 1), i.e. the patterns k = 2 q
+    // and 2 q + 1 of a lane share dword lane + 64 q -- written as one packed sum (no carry: a cost is < 2^12)
+    uint16_t* const stage = reinterpret_cast<uint16_t*>(S.round);   // b_hi of pattern k, k < 32, read back in pairs
+    stage[lane] = (uint16_t)b_hi;
     wave_lds_sync();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {   // parity table: pattern lane + 64 k
-        S.parity[lane + 64 * k] = (b_lo + stage[k]) << 17;
+    {
+        const uint32_t* pairs = reinterpret_cast<const uint32_t*>(S.round);
+        uint32_t* table32 = reinterpret_cast<uint32_t*>(S.parity);
+        const uint32_t b_lo2 = b_lo | (b_lo << 16);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            table32[lane + 64 * q] = b_lo2 + pairs[q];
+        }
     }
     wave_lds_sync();   // the staging words become the round constants below
-    const uint32_t addr_lane = par_lo << 2;                                         // byte offsets into S.parity
-    const uint32_t addr_round = (par_hi ^ s) << 2;                                  // for round j = lane
+    const uint32_t addr_lane = par_lo << 1;                                         // byte offsets into S.parity
+    const uint32_t addr_round = (par_hi ^ s) << 1;                                  // for round j = lane
     const uint32_t key_lane = (a_lo << 17) + 0x10000u + ((uint32_t)__popc(lane) << 12) + ((uint32_t)lane ^ (hd & 63u));
     const uint32_t key_round = (a_hi << 17) + ((uint32_t)__popc(lane) << 12) + ((((uint32_t)lane ^ (hd >> 6)) & 63u) << 6);
     S.round[lane] = make_uint2(addr_round, key_round);   // read back wave-uniformly: LDS broadcasts, no VALU
@@ -461,16 +476,17 @@ __device__ uint32_t golay_soft_wave(const mbx_tables* T, uint32_t hard, int firs
 #pragma unroll 8
     for (int j = 0; j < 64; ++j) {
         const uint2 r = S.round[j];
-        const uint32_t val = *reinterpret_cast<const uint32_t*>(table + (addr_lane ^ r.x));
-        const uint32_t key = val + key_lane + r.y;
+        const uint32_t val = *reinterpret_cast<const uint16_t*>(table + (addr_lane ^ r.x));
+        const uint32_t key = (val << 17) + r.y;   // v_lshl_add_u32; the lane's own part is added after the loop
         best = key < best ? key : best;
     }
+    best += key_lane;
     best = wave_min_u32(best);
     {   // the candidate whose data equals the hard decoder's output
         const uint32_t ut = (hard_fixed >> 11) ^ hd;
         const int lt = (int)(ut & 63u), jt = (int)(ut >> 6);
-        const uint32_t val = *reinterpret_cast<const uint32_t*>(table + (rl(addr_lane, lt) ^ rl(addr_round, jt)));
-        const uint32_t key = val + rl(key_lane, lt) + rl(key_round, jt) - 0x10000u;
+        const uint32_t val = *reinterpret_cast<const uint16_t*>(table + (rl(addr_lane, lt) ^ rl(addr_round, jt)));
+        const uint32_t key = (val << 17) + rl(key_lane, lt) + rl(key_round, jt) - 0x10000u;
         best = key < best ? key : best;
     }
     diffs = (int)((best >> 12) & 0xfu);
@@ -491,7 +507,7 @@ __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, i
     } else {
         (void)hamming1511(tabs.t, hard, hard_fixed);
     }
-    const uint32_t* rel = &S.rel[first];   // reliability of cell j of the block, read wave-uniformly
+    const uint8_t* rel = &S.rel[first];   // reliability of cell j of the block, read wave-uniformly
     auto gather_data = [&](uint32_t cw) {
         uint32_t d = 0;
 #pragma unroll
@@ -516,21 +532,21 @@ __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, i
         const uint32_t plo = gather_parity(basis[b]);
         par_lo ^= bit ? plo : 0u;
         par_hd ^= ((hd >> b) & 1u) ? plo : 0u;
-        a_lo = __umul24(bit, rel[kHamData[b]]) + a_lo;
+        a_lo = __umul24(bit, (uint32_t)rel[kHamData[b]]) + a_lo;
         if (b < 5) {
             const uint32_t phi = gather_parity(basis[6 + b]);
             par_hi ^= bit ? phi : 0u;
             par_hd ^= ((hd >> (b + 6)) & 1u) ? phi : 0u;
-            a_hi = __umul24(bit, rel[kHamData[6 + b]]) + a_hi;
+            a_hi = __umul24(bit, (uint32_t)rel[kHamData[6 + b]]) + a_hi;
         }
         if (b < 4) {
-            p_cost = __umul24(bit, rel[kHamParity[b]]) + p_cost;
+            p_cost = __umul24(bit, (uint32_t)rel[kHamParity[b]]) + p_cost;
         }
     }
     const uint32_t s = par_hd ^ hp;
     wave_lds_sync();
     if (lane < 16) {   // parity pattern = lane: its cost and its differing-bit count, in key position
-        S.parity[lane] = (p_cost << 16) + ((uint32_t)__popc(lane) << 11);
+        reinterpret_cast<uint32_t*>(S.parity)[lane] = (p_cost << 16) + ((uint32_t)__popc(lane) << 11);
     }
     const uint32_t addr_lane = par_lo << 2, addr_round = (par_hi ^ s) << 2;
     const uint32_t key_lane = (a_lo << 16) + 0x8000u + ((uint32_t)__popc(lane) << 11) + ((uint32_t)lane ^ (hd & 63u));
@@ -572,9 +588,8 @@ __device__ __forceinline__ uint32_t soft_block(const SoftScratch& S, const Devic
     uint32_t bit = 0;
     rel_lane = 0;
     if (lane < width) {
-        const uint32_t c = S.cell[first + lane];
-        bit = c & 1u;
-        rel_lane = (int)(c >> 8);
+        bit = S.bit[first + lane];
+        rel_lane = (int)S.rel[first + lane];
         if (k_first > 0) {
             const int k = k_first + (width - 1 - lane);
             const uint32_t x = (tabs.d->pr_mul[k] * pr_x0 + tabs.d->pr_add[k]) & 0xffffu;
@@ -591,14 +606,14 @@ __device__ __forceinline__ void load_soft_cells(SoftScratch& S, const mbe_soft_b
         const int idx = lane + 64 * k;
         if (idx < count) {
             const uint32_t v = src[idx];
-            S.cell[idx] = (v & 1u) | (v & 0xff00u);   // the reference masks the hard decision with & 1
-            S.rel[idx] = v >> 8;
+            S.bit[idx] = (uint8_t)(v & 1u);   // the reference masks the hard decision with & 1
+            S.rel[idx] = (uint8_t)(v >> 8);
         }
     }
     wave_lds_sync();
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 8)
 fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, mbx_param_record* __restrict__ out,
                               DeviceTables tabs) {
     __shared__ SoftScratch S;
@@ -612,7 +627,7 @@ fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     uint32_t row[8];
     {
         const uint32_t hard = soft_block(S, tabs, 0, 23, 0, 0u, lane, rel);
-        row[0] = golay_soft_wave(tabs.t, hard, 0, S, lane, diffs);
+        row[0] = golay_soft_wave(tabs, hard, 0, S, lane, diffs);
     }
     const int c0 = diffs;
     const uint32_t x0 = (16u * (row[0] >> 11)) & 0xffffu;
@@ -620,7 +635,7 @@ fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
 #pragma unroll 1
     for (int r = 1; r < 4; ++r) {
         const uint32_t hard = soft_block(S, tabs, 23 * r, 23, k, x0, lane, rel);
-        row[r] = golay_soft_wave(tabs.t, hard, 23 * r, S, lane, diffs);
+        row[r] = golay_soft_wave(tabs, hard, 23 * r, S, lane, diffs);
         prot += diffs;
         k += 23;
     }
@@ -653,7 +668,7 @@ fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 8)
 fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, mbx_param_record* __restrict__ out,
                               DeviceTables tabs) {
     __shared__ SoftScratch S;
@@ -666,16 +681,16 @@ fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     int rel, diffs;
     // C0: cells 1..23 of row 0 are the Golay block, cell 0 the overall parity bit
     uint32_t hard = soft_block(S, tabs, 1, 23, 0, 0u, lane, rel);
-    const uint32_t cw = golay_soft_wave(tabs.t, hard, 1, S, lane, diffs);
+    const uint32_t cw = golay_soft_wave(tabs, hard, 1, S, lane, diffs);
     int c0 = diffs;
-    uint32_t row0 = (cw << 1) | (S.cell[0] & 1u);
+    uint32_t row0 = (cw << 1) | (uint32_t)S.bit[0];
     if (c0 == 0 && (__popc(row0) & 1)) {
         row0 ^= 1u;
         c0 = 1;
     }
     const uint32_t x0 = (16u * ((row0 >> 12) & 0xfffu)) & 0xffffu;
     hard = soft_block(S, tabs, 24, 23, 1, x0, lane, rel);
-    const uint32_t row1 = golay_soft_wave(tabs.t, hard, 24, S, lane, diffs);
+    const uint32_t row1 = golay_soft_wave(tabs, hard, 24, S, lane, diffs);
     const int prot = diffs;
     const uint32_t row2 = soft_block(S, tabs, 48, 11, 0, 0u, lane, rel);
     const uint32_t row3 = soft_block(S, tabs, 72, 14, 0, 0u, lane, rel);
@@ -694,7 +709,7 @@ fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
 // IMBE 7100x4400 soft frames, mbe_soft_bit[7][24] (ref src/imbe/imbe7100x4400.c:124-150, 214-274, 336-378, 481-525):
 // C0 = cells 1..18 of row 0 completed by five certain zeros, 7-bit demodulation seed, C1 = cells 1..23 of
 // row 1, the 7100 Hamming mapping on rows 4/5, then mbe_convertImbe7100to7200.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 8)
 fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, mbx_param_record* __restrict__ out,
                               DeviceTables tabs) {
     __shared__ SoftScratch S;
@@ -707,15 +722,15 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     // C0 is cells 1..18 of row 0 completed by five certain zeros, mbe_softBitFromHard(0, 255): they go into
     // the (unused) cells 19..23 of the row, so the block is simply cells 1..23
     if (lane >= 19 && lane < 24) {
-        S.cell[lane] = 255u << 8;
-        S.rel[lane] = 255u;
+        S.bit[lane] = 0;
+        S.rel[lane] = 255;
     }
     wave_lds_sync();
     int rel, diffs;
     uint32_t hard = soft_block(S, tabs, 1, 23, 0, 0u, lane, rel);
-    uint32_t w = golay_soft_wave(tabs.t, hard, 1, S, lane, diffs);
+    uint32_t w = golay_soft_wave(tabs, hard, 1, S, lane, diffs);
     const int c0 = diffs;
-    const uint32_t row0 = ((w & 0x3ffffu) << 1) | (S.cell[0] & 1u);
+    const uint32_t row0 = ((w & 0x3ffffu) << 1) | (uint32_t)S.bit[0];
     const uint32_t x0 = (16u * ((row0 >> 12) & 0x7fu)) & 0xffffu;
     // demodulation bit numbers: row 1 (24 cells) uses 1..24 with cell j <- 1 + (23 - j); its Golay block is
     // cells 1..23, i.e. a 23-wide block whose cell c uses number 1 + (22 - c)
@@ -729,14 +744,14 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     };
     push(row0 >> 12, 7, 7);
     hard = soft_block(S, tabs, 24 + 1, 23, 1, x0, lane, rel);
-    w = golay_soft_wave(tabs.t, hard, 24 + 1, S, lane, diffs);
+    w = golay_soft_wave(tabs, hard, 24 + 1, S, lane, diffs);
     prot += diffs;
     push(w, 23, 12);
     int k = 25;
 #pragma unroll 1
     for (int r = 2; r < 4; ++r) {
         hard = soft_block(S, tabs, 24 * r, 23, k, x0, lane, rel);
-        w = golay_soft_wave(tabs.t, hard, 24 * r, S, lane, diffs);
+        w = golay_soft_wave(tabs, hard, 24 * r, S, lane, diffs);
         prot += diffs;
         push(w, 23, 12);
         k += 23;
@@ -783,7 +798,7 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
 // Code-word level soft ECC, batched: kind 0 = Golay (23 soft bits per block), 1 = Hamming (15), 2 = Hamming
 // with the IMBE 7100x4400 bit mapping (mbe_7100x4400hamming1511Soft).
 // out = corrected word in the cell order of the hard helpers, errs = the reference's return value.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 8)
 ecc_soft_words_kernel(int kind, const mbe_soft_bit* __restrict__ in, size_t n, uint32_t* __restrict__ out, int32_t* __restrict__ errs,
                       DeviceTables tabs) {
     __shared__ SoftScratch S;
@@ -796,7 +811,7 @@ ecc_soft_words_kernel(int kind, const mbe_soft_bit* __restrict__ in, size_t n, u
     load_soft_cells(S, in + i * (size_t)width, width, lane);
     int rel, diffs;
     const uint32_t hard = soft_block(S, tabs, 0, width, 0, 0u, lane, rel);
-    const uint32_t w = (kind == 0)   ? golay_soft_wave(tabs.t, hard, 0, S, lane, diffs)
+    const uint32_t w = (kind == 0)   ? golay_soft_wave(tabs, hard, 0, S, lane, diffs)
                        : (kind == 1) ? hamming_soft_wave<false>(tabs, hard, 0, S, lane, diffs)
                                      : hamming_soft_wave<true>(tabs, hard, 0, S, lane, diffs);
     if (lane == 0) {
