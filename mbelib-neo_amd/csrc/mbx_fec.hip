@@ -423,24 +423,42 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, int lane_index) {   // wave-u
 // generator rows come pre-rotated from the host (DerivedTables::golay_rot), the hard parity bits are rotated here.
 __device__ __forceinline__ uint32_t rot_parity(uint32_t p) { return ((p & 0x3fu) << 1) | ((p >> 6) & 1u) | (p & 0x780u); }
 
-__device__ uint32_t golay_soft_wave(const DeviceTables& tabs, uint32_t hard, int first, SoftScratch& S, int lane, int& diffs) {
+// What depends on the lane alone (not on the block): the rotated parity patterns of the lane's six low / six high
+// candidate bits.  Computed once per frame.
+struct SoftLane {
+    uint32_t golay_lo, golay_hi;   // Golay(23,12)
+    uint32_t ham_lo, ham_hi;       // Hamming(15,11), 4-bit parity patterns
+};
+
+__device__ __forceinline__ void golay_lane_patterns(const DeviceTables& tabs, int lane, SoftLane& L) {
+    const uint32_t* grot = tabs.d->golay_rot;
+    L.golay_lo = 0;
+    L.golay_hi = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const uint32_t bit = (uint32_t)(lane >> b) & 1u;
+        L.golay_lo ^= bit ? grot[11 - b] : 0u;   // row i <-> data bit 11 - i
+        L.golay_hi ^= bit ? grot[5 - b] : 0u;
+    }
+}
+
+__device__ uint32_t golay_soft_wave(const DeviceTables& tabs, const SoftLane& L, uint32_t hard, int first, SoftScratch& S, int lane,
+                                    int& diffs) {
     uint32_t hard_fixed;
     (void)golay2312(tabs.t, hard, hard_fixed);
     const uint32_t hd = hard >> 11, hp = hard & 0x7ffu;
     const uint8_t* rel = &S.rel[first];   // reliability of cell j of the block, read wave-uniformly
     const uint32_t* grot = tabs.d->golay_rot;
     // per-lane pieces: bit b of the lane index selects position ...
-    uint32_t par_lo = 0, par_hi = 0, par_hd = 0;   // rotated parity of data bits 0..5 / 6..11 (pattern = lane) / of hd
+    const uint32_t par_lo = L.golay_lo, par_hi = L.golay_hi;   // rotated parity of data bits 0..5 / 6..11 (pattern = lane)
+    uint32_t par_hd = 0;                            // ... and of hd (wave-uniform: scalar unit)
     uint32_t a_lo = 0, a_hi = 0;                    // data-part cost: cells 11..16 / 17..22
     uint32_t b_lo = 0, b_hi = 0;                    // parity-part cost: cells 0..5 / 6..10 (pattern = lane, < 32)
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
         const uint32_t bit = (uint32_t)(lane >> b) & 1u;
-        const uint32_t glo = grot[11 - b], ghi = grot[5 - b];   // row i <-> data bit 11 - i
-        par_lo ^= bit ? glo : 0u;
-        par_hi ^= bit ? ghi : 0u;
-        par_hd ^= ((hd >> b) & 1u) ? glo : 0u;
-        par_hd ^= ((hd >> (b + 6)) & 1u) ? ghi : 0u;
+        par_hd ^= ((hd >> b) & 1u) ? grot[11 - b] : 0u;
+        par_hd ^= ((hd >> (b + 6)) & 1u) ? grot[5 - b] : 0u;
         a_lo = __umul24(bit, (uint32_t)rel[11 + b]) + a_lo;   // one v_mad_u32_u24 each
         a_hi = __umul24(bit, (uint32_t)rel[17 + b]) + a_hi;
         b_lo = __umul24(bit, (uint32_t)rel[b]) + b_lo;
@@ -496,8 +514,34 @@ __device__ uint32_t golay_soft_wave(const DeviceTables& tabs, uint32_t hard, int
 // Soft Hamming(15,11): returns the chosen code word, `diffs` = differing bits over all 15 positions.
 // Data bit i sits at cell kHamData[i], parity bit q at cell kHamParity[q] (ecc.c:128-131).
 // Key: cost << 16 | !matches_hard << 15 | differing bits << 11 | data.
-template <bool k7100>   // k7100: the IMBE 7100x4400 bit mapping (data at cells 4..14, parity at 0..3), ecc.c:130-131
-__device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, int first, SoftScratch& S, int lane, int& diffs) {
+// k7100: the IMBE 7100x4400 bit mapping (data at cells 4..14, parity at 0..3), ecc.c:130-131
+template <bool k7100>
+__device__ __forceinline__ void hamming_lane_patterns(const DeviceTables& tabs, int lane, SoftLane& L) {
+    constexpr int kHamParity[4] = {0, 1, k7100 ? 2 : 3, k7100 ? 3 : 7};
+    const uint32_t* basis = k7100 ? tabs.d->ham7100_basis : tabs.d->ham_basis;
+    auto gather_parity = [&](uint32_t cw) {
+        uint32_t q = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q |= ((cw >> kHamParity[i]) & 1u) << i;
+        }
+        return q;
+    };
+    L.ham_lo = 0;
+    L.ham_hi = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const uint32_t bit = (uint32_t)(lane >> b) & 1u;
+        L.ham_lo ^= bit ? gather_parity(basis[b]) : 0u;
+        if (b < 5) {
+            L.ham_hi ^= bit ? gather_parity(basis[6 + b]) : 0u;
+        }
+    }
+}
+
+template <bool k7100>
+__device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, const SoftLane& L, uint32_t hard, int first, SoftScratch& S, int lane,
+                                      int& diffs) {
     constexpr int kHamData[11] = {k7100 ? 4 : 2, k7100 ? 5 : 4, k7100 ? 6 : 5, k7100 ? 7 : 6, 8, 9, 10, 11, 12, 13, 14};
     constexpr int kHamParity[4] = {0, 1, k7100 ? 2 : 3, k7100 ? 3 : 7};
     const uint32_t* basis = k7100 ? tabs.d->ham7100_basis : tabs.d->ham_basis;
@@ -525,18 +569,15 @@ __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, uint32_t hard, i
         return q;
     };
     const uint32_t hd = gather_data(hard), hp = gather_parity(hard);
-    uint32_t par_lo = 0, par_hi = 0, par_hd = 0, a_lo = 0, a_hi = 0, p_cost = 0;
+    const uint32_t par_lo = L.ham_lo, par_hi = L.ham_hi;
+    uint32_t par_hd = 0, a_lo = 0, a_hi = 0, p_cost = 0;
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
         const uint32_t bit = (uint32_t)(lane >> b) & 1u;
-        const uint32_t plo = gather_parity(basis[b]);
-        par_lo ^= bit ? plo : 0u;
-        par_hd ^= ((hd >> b) & 1u) ? plo : 0u;
+        par_hd ^= ((hd >> b) & 1u) ? gather_parity(basis[b]) : 0u;
         a_lo = __umul24(bit, (uint32_t)rel[kHamData[b]]) + a_lo;
         if (b < 5) {
-            const uint32_t phi = gather_parity(basis[6 + b]);
-            par_hi ^= bit ? phi : 0u;
-            par_hd ^= ((hd >> (b + 6)) & 1u) ? phi : 0u;
+            par_hd ^= ((hd >> (b + 6)) & 1u) ? gather_parity(basis[6 + b]) : 0u;
             a_hi = __umul24(bit, (uint32_t)rel[kHamData[6 + b]]) + a_hi;
         }
         if (b < 4) {
@@ -623,11 +664,14 @@ fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     }
     const int lane = lane_id();
     load_soft_cells(S, soft + i * MBX_IMBE_SOFT_BITS, MBX_IMBE_SOFT_BITS, lane);
+    SoftLane L;
+    golay_lane_patterns(tabs, lane, L);
+    hamming_lane_patterns<false>(tabs, lane, L);
     int rel, diffs;
     uint32_t row[8];
     {
         const uint32_t hard = soft_block(S, tabs, 0, 23, 0, 0u, lane, rel);
-        row[0] = golay_soft_wave(tabs, hard, 0, S, lane, diffs);
+        row[0] = golay_soft_wave(tabs, L, hard, 0, S, lane, diffs);
     }
     const int c0 = diffs;
     const uint32_t x0 = (16u * (row[0] >> 11)) & 0xffffu;
@@ -635,14 +679,14 @@ fec_imbe7200x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
 #pragma unroll 1
     for (int r = 1; r < 4; ++r) {
         const uint32_t hard = soft_block(S, tabs, 23 * r, 23, k, x0, lane, rel);
-        row[r] = golay_soft_wave(tabs, hard, 23 * r, S, lane, diffs);
+        row[r] = golay_soft_wave(tabs, L, hard, 23 * r, S, lane, diffs);
         prot += diffs;
         k += 23;
     }
 #pragma unroll 1
     for (int r = 4; r < 7; ++r) {
         const uint32_t hard = soft_block(S, tabs, 23 * r, 15, k, x0, lane, rel);
-        row[r] = hamming_soft_wave<false>(tabs, hard, 23 * r, S, lane, diffs);
+        row[r] = hamming_soft_wave<false>(tabs, L, hard, 23 * r, S, lane, diffs);
         prot += diffs;
         if (r == 4) {
             c4 = diffs;
@@ -678,10 +722,13 @@ fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     }
     const int lane = lane_id();
     load_soft_cells(S, soft + i * MBX_AMBE_SOFT_BITS, MBX_AMBE_SOFT_BITS, lane);
+    SoftLane L;
+    golay_lane_patterns(tabs, lane, L);
+    L.ham_lo = L.ham_hi = 0;
     int rel, diffs;
     // C0: cells 1..23 of row 0 are the Golay block, cell 0 the overall parity bit
     uint32_t hard = soft_block(S, tabs, 1, 23, 0, 0u, lane, rel);
-    const uint32_t cw = golay_soft_wave(tabs, hard, 1, S, lane, diffs);
+    const uint32_t cw = golay_soft_wave(tabs, L, hard, 1, S, lane, diffs);
     int c0 = diffs;
     uint32_t row0 = (cw << 1) | (uint32_t)S.bit[0];
     if (c0 == 0 && (__popc(row0) & 1)) {
@@ -690,7 +737,7 @@ fec_ambe3600x2450_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     }
     const uint32_t x0 = (16u * ((row0 >> 12) & 0xfffu)) & 0xffffu;
     hard = soft_block(S, tabs, 24, 23, 1, x0, lane, rel);
-    const uint32_t row1 = golay_soft_wave(tabs, hard, 24, S, lane, diffs);
+    const uint32_t row1 = golay_soft_wave(tabs, L, hard, 24, S, lane, diffs);
     const int prot = diffs;
     const uint32_t row2 = soft_block(S, tabs, 48, 11, 0, 0u, lane, rel);
     const uint32_t row3 = soft_block(S, tabs, 72, 14, 0, 0u, lane, rel);
@@ -719,6 +766,9 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     }
     const int lane = lane_id();
     load_soft_cells(S, soft + i * MBX_IMBE7100_SOFT_BITS, MBX_IMBE7100_SOFT_BITS, lane);
+    SoftLane L;
+    golay_lane_patterns(tabs, lane, L);
+    hamming_lane_patterns<true>(tabs, lane, L);
     // C0 is cells 1..18 of row 0 completed by five certain zeros, mbe_softBitFromHard(0, 255): they go into
     // the (unused) cells 19..23 of the row, so the block is simply cells 1..23
     if (lane >= 19 && lane < 24) {
@@ -728,7 +778,7 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     wave_lds_sync();
     int rel, diffs;
     uint32_t hard = soft_block(S, tabs, 1, 23, 0, 0u, lane, rel);
-    uint32_t w = golay_soft_wave(tabs, hard, 1, S, lane, diffs);
+    uint32_t w = golay_soft_wave(tabs, L, hard, 1, S, lane, diffs);
     const int c0 = diffs;
     const uint32_t row0 = ((w & 0x3ffffu) << 1) | (uint32_t)S.bit[0];
     const uint32_t x0 = (16u * ((row0 >> 12) & 0x7fu)) & 0xffffu;
@@ -744,14 +794,14 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
     };
     push(row0 >> 12, 7, 7);
     hard = soft_block(S, tabs, 24 + 1, 23, 1, x0, lane, rel);
-    w = golay_soft_wave(tabs, hard, 24 + 1, S, lane, diffs);
+    w = golay_soft_wave(tabs, L, hard, 24 + 1, S, lane, diffs);
     prot += diffs;
     push(w, 23, 12);
     int k = 25;
 #pragma unroll 1
     for (int r = 2; r < 4; ++r) {
         hard = soft_block(S, tabs, 24 * r, 23, k, x0, lane, rel);
-        w = golay_soft_wave(tabs, hard, 24 * r, S, lane, diffs);
+        w = golay_soft_wave(tabs, L, hard, 24 * r, S, lane, diffs);
         prot += diffs;
         push(w, 23, 12);
         k += 23;
@@ -759,7 +809,7 @@ fec_imbe7100x4400_soft_kernel(const mbe_soft_bit* __restrict__ soft, size_t n, m
 #pragma unroll 1
     for (int r = 4; r < 6; ++r) {
         hard = soft_block(S, tabs, 24 * r, 15, k, x0, lane, rel);
-        w = hamming_soft_wave<true>(tabs, hard, 24 * r, S, lane, diffs);
+        w = hamming_soft_wave<true>(tabs, L, hard, 24 * r, S, lane, diffs);
         prot += diffs;
         if (r == 4) {
             c4 = diffs;
@@ -809,11 +859,18 @@ ecc_soft_words_kernel(int kind, const mbe_soft_bit* __restrict__ in, size_t n, u
     const int lane = lane_id();
     const int width = (kind == 0) ? 23 : 15;
     load_soft_cells(S, in + i * (size_t)width, width, lane);
+    SoftLane L;
+    golay_lane_patterns(tabs, lane, L);
+    if (kind == 2) {
+        hamming_lane_patterns<true>(tabs, lane, L);
+    } else {
+        hamming_lane_patterns<false>(tabs, lane, L);
+    }
     int rel, diffs;
     const uint32_t hard = soft_block(S, tabs, 0, width, 0, 0u, lane, rel);
-    const uint32_t w = (kind == 0)   ? golay_soft_wave(tabs, hard, 0, S, lane, diffs)
-                       : (kind == 1) ? hamming_soft_wave<false>(tabs, hard, 0, S, lane, diffs)
-                                     : hamming_soft_wave<true>(tabs, hard, 0, S, lane, diffs);
+    const uint32_t w = (kind == 0)   ? golay_soft_wave(tabs, L, hard, 0, S, lane, diffs)
+                       : (kind == 1) ? hamming_soft_wave<false>(tabs, L, hard, 0, S, lane, diffs)
+                                     : hamming_soft_wave<true>(tabs, L, hard, 0, S, lane, diffs);
     if (lane == 0) {
         out[i] = w;
         if (errs) {
