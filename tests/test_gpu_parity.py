@@ -265,6 +265,26 @@ def test_ambe_capped_kernel_instance_is_identical(mbx, oracle):
     parity.check_state(ref["state"], astate[pick])
 
 
+@pytest.mark.parametrize("codec", [0, 1])
+def test_both_stream_orders_small_batches(mbx, oracle, codec):
+    """Successive launches walk the streams in opposite directions (launch_stream, mbx_api.hip).  Odd and tiny
+    stream counts, two launches in a row on fresh state each: both directions must give the oracle's result."""
+    from mbelib_neo_amd import decoder, framegen
+    from mbelib_neo_amd.layout import init_state, rng_seeded
+
+    for S in (1, 3, 65):
+        T = 3
+        frames = framegen.random_frames(codec, S * T, framegen.rng_for(500 + S + codec))
+        seeds = [9 + 5 * s for s in range(S)]
+        ref = oracle.process_batch(codec, S, T, frames, oracle.init_state(S), oracle.rng_seeded(seeds))
+        for _ in range(2):   # one launch in each direction
+            got = decoder.process_batch_host(codec, S, T, frames, init_state(S), rng_seeded(seeds))
+            assert np.array_equal(got["records"]["w"], ref["records"]["w"])
+            parity.check_results(ref["results"], got["results"])
+            parity.check_pcm(ref["pcmf"], got["pcmf"], ref["pcm16"], got["pcm16"])
+            parity.check_state(ref["state"], got["state"])
+
+
 def test_edge_cases(mbx, oracle):
     from mbelib_neo_amd import _native, decoder
     from mbelib_neo_amd.layout import init_state, rng_default
