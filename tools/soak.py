@@ -23,8 +23,10 @@ def main():
     worst = {}
     for r in range(rounds):
         for codec in (0, 1, 2, 3):
-            for kind in ("random", "clean", "soft"):
+            for kind in ("random", "clean", "soft", "ticks"):
                 S, T = (2048, 8) if kind != "soft" else (256, 4)
+                if kind == "ticks":
+                    S, T = 1024, 12
                 rng = framegen.rng_for(90000 + 1000 * r + 10 * codec + len(kind))
                 seeds = [77 + 13 * s + r for s in range(S)]
                 t0 = time.perf_counter()
@@ -32,6 +34,24 @@ def main():
                     frames = framegen.soft_frames(codec, S * T, rng, snr_like=1.0 + r)
                     ref = o.process_batch(codec, S, T, frames, o.init_state(S), o.rng_seeded(seeds), soft=True)
                     got = decoder.process_batch_soft_host(codec, S, T, frames, init_state(S), rng_seeded(seeds))
+                elif kind == "ticks":   # T launches of one frame per stream (the per-tick operating point), state kept on the device
+                    import torch
+                    frames = framegen.random_frames(codec, S * T, rng)
+                    for _ in range(2):
+                        frames &= framegen.random_frames(codec, S * T, rng)
+                    ref = o.process_batch(codec, S, T, frames, o.init_state(S), o.rng_seeded(seeds))
+                    dec = decoder.BatchDecoder(codec, S, seeds=np.asarray(seeds))
+                    fr3 = frames.reshape(S, T, -1)
+                    parts = [dec.decode(np.ascontiguousarray(fr3[:, t]), 1, want_float=True) for t in range(T)]
+                    torch.cuda.synchronize()
+
+                    def cat(name, shape):
+                        return torch.stack([p[name].reshape(S, *shape) for p in parts], dim=1).cpu().numpy()
+
+                    got = {"pcmf": cat("pcmf", (160,)).reshape(-1, 160), "pcm16": cat("pcm16", (160,)).reshape(-1, 160),
+                           "records": decoder.records_numpy(torch.stack([p["records"].reshape(S, 4) for p in parts], dim=1).reshape(-1, 4)),
+                           "results": decoder.results_numpy(torch.stack([p["results"].reshape(S, 5) for p in parts], dim=1).reshape(-1, 5)),
+                           "state": dec.state_numpy(), "rng": dec.rng_numpy()}
                 else:
                     frames = framegen.random_frames(codec, S * T, rng)
                     if kind == "clean":
