@@ -13,6 +13,15 @@
  * asynchronous on `stream`, never synchronise, never allocate (after mbx_reserve()), and return 0 or a negative
  * MBE_STATUS_* / MBX_E* code.  There is no CPU fallback: without a HIP device every launcher
  * fails with MBX_ENODEVICE.
+ *
+ * Devices and threads.  mbx_init(device, ...) creates the context of ONE device; call it once per device the process
+ * uses.  Every launcher then works on the context of the calling thread's CURRENT device (hipSetDevice), like any HIP
+ * call, and its pointers / stream must belong to that device.  The library is re-entrant the way the reference is
+ * (ref include/mbelib-neo/mbelib.h:28-30: re-entrant per stream, mutable helper state thread-local): any number of host
+ * threads may call any launcher concurrently, on separate hipStream_t's or on a shared one; the only mutable launcher
+ * state -- the expand workspace below -- is owned per (device, hipStream_t) and guarded internally.  What the caller
+ * owns (state, rng, outputs of one stream set) must of course not be handed to two launches that can overlap.
+ * mbx_last_error() is per thread.
  */
 #ifndef MBX_H
 #define MBX_H
@@ -36,18 +45,33 @@ extern "C" {
 /* Upload the constant tables (include/mbx_tables.h) to `device` and build the derived
  * device tables (LCG jump-ahead, FFT twiddles).  Replaces the reference's lazily built
  * thread-local plan/caches: ref src/core/mbelib.c:164-171 (mbe_get_fft_plan),
- * src/imbe/imbe7200x4400.c:91-115, src/ambe/ambe3600x2450.c:54-78. */
+ * src/imbe/imbe7200x4400.c:91-115, src/ambe/ambe3600x2450.c:54-78.
+ * Makes `device` the calling thread's current device.  Idempotent: a second call for a device that already holds the
+ * same tables returns 0 without touching it (any thread may call it). */
 int mbx_init(int device, const void* table_blob, size_t table_bytes);
+/* frees the contexts of all devices (the caller must have no launches in flight) */
 void mbx_shutdown(void);
-/* FNV-1a-32 of the resident table blob (for the per-rank checksum after the broadcast). */
+/* 1 when mbx_init() has completed for `device` */
+int mbx_device_ready(int device);
+/* FNV-1a-32 of the table blob resident on the current device (for the per-rank checksum after the broadcast). */
 uint32_t mbx_table_checksum(void);
+/* message of the last failure on the calling thread */
 const char* mbx_last_error(void);
 
-/* Size the internal workspace of the stream stage (256 B per frame for the expanded parameters) for
- * launches of up to `max_frames` = S*T frames.  Launchers never allocate once this has been called
- * with a large enough value (required before graph capture); without it mbx_process_records() grows
- * the workspace on demand, which synchronises the device. */
+/* The expand workspace of the stream stage: 256 B per frame for the expanded parameters of the AMBE codecs and of
+ * one-frame-per-stream IMBE launches (IMBE launches with T > 1 expand inside the stream kernel and need none).
+ * Each (device, hipStream_t) owns one, grown on demand -- growth waits for that stream and allocates, so size it up
+ * front where that matters (required before stream capture):
+ *   mbx_reserve(n)            every stream already known to the current device now, and every stream first used later,
+ *                             holds >= n frames (n = the largest S*T of one launch)
+ *   mbx_reserve_stream(s, n)  the same for one stream, creating its slot
+ *   mbx_release_stream(s)     waits for `s` and frees its slot (call before hipStreamDestroy on long-lived processes)
+ * Alternatively the caller owns the workspace: the *_ws launchers take a device buffer of mbx_workspace_bytes(S*T)
+ * bytes and touch no internal buffer at all. */
 int mbx_reserve(size_t max_frames);
+int mbx_reserve_stream(void* stream, size_t max_frames);
+int mbx_release_stream(void* stream);
+size_t mbx_workspace_bytes(size_t max_frames);
 
 /* ---- host-side frame packing (no device work) ----------------------------------------- */
 
@@ -121,11 +145,17 @@ int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_recor
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream);
 
+/* The same with a caller-owned expand workspace (mbx_workspace_bytes(S*T) bytes; may be NULL for IMBE with T > 1). */
+int mbx_process_records_ws(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
+                           mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                           void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* The two halves of mbx_process_records(), exposed so that a caller (bench.py) can time them apart:
  * mbx_expand_records() runs the frame-parallel, stateless half of the parameter decode (one thread per
  * frame: fundamental, voicing, dequantisation, block inverse DCTs; ref src/imbe/imbe7200x4400.c:117-270,
- * src/ambe/ambe3600x2450.c:176-387) into the internal workspace; mbx_stream_expanded() runs the
- * stateful half (prediction, policy, synthesis) on that workspace, one wavefront per stream. */
+ * src/ambe/ambe3600x2450.c:176-387) into the workspace of `stream`; mbx_stream_expanded() runs the
+ * stateful half (prediction, policy, synthesis) on it, one wavefront per stream, and fails unless the last
+ * mbx_expand_records() on the same `stream` was for the same codec, frame count and record array. */
 int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream);
 int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
@@ -138,6 +168,9 @@ int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_recor
 int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,
                       int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
                       void* stream);
+int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,
+                         int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ref: mbe_synthesizeSpeechf  include/mbelib-neo/mbelib.h:652, src/core/mbelib.c:1112-1115.
  * One frame for each of S (cur, prev) pairs; both structs are updated like the reference does. */
@@ -184,11 +217,6 @@ int mbx_ecc_soft_words_host(int kind, const mbe_soft_bit* in, size_t n, uint32_t
 /* per-stream RNG helpers (host): ref mbe_setThreadRngSeed src/core/mbelib.c:173-181 */
 void mbx_rng_default(mbx_stream_rng* rng);
 void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed);
-
-/* Development aid for profiling: disables stages of the stream kernels (results become meaningless,
- * timing only; bit 0 decode, 1 enhance, 2 oscillator set-up, 3 oscillator loop, 4 interpolated low
- * harmonics, 5 unvoiced FFT path, 6 phase update, 7 whole synthesis).  0 = normal operation. */
-void mbx_debug_set_ablation(int mask);
 
 /* name of the dominant kernel and last launch geometry, for the bench */
 const char* mbx_stream_kernel_name(int codec);

@@ -12,7 +12,9 @@ class NativeLibraryError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    """The product library, or -- for tools/ only -- the development build named by MBX_HIP_LIBRARY
+    (libmbx_hip_ablate.so, which additionally exports mbx_debug_set_ablation)."""
+    return os.environ.get("MBX_HIP_LIBRARY") or os.path.join(_HERE, _LIB_NAME)
 
 
 _lib = None
@@ -23,6 +25,10 @@ _SIGNATURES = {
     "mbx_init": (C.c_int, [C.c_int, _vp, _sz]),
     "mbx_shutdown": (None, []),
     "mbx_reserve": (C.c_int, [_sz]),
+    "mbx_reserve_stream": (C.c_int, [_vp, _sz]),
+    "mbx_release_stream": (C.c_int, [_vp]),
+    "mbx_workspace_bytes": (_sz, [_sz]),
+    "mbx_device_ready": (C.c_int, [C.c_int]),
     "mbx_table_checksum": (C.c_uint32, []),
     "mbx_last_error": (C.c_char_p, []),
     "mbx_pack_imbe7200x4400": (C.c_int, [_vp, _sz, _vp]),
@@ -31,6 +37,8 @@ _SIGNATURES = {
     "mbx_fec_imbe7200x4400": (C.c_int, [_vp, _sz, _vp, _vp]),
     "mbx_fec_ambe3600x2450": (C.c_int, [_vp, _sz, _vp, _vp]),
     "mbx_process_records": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_process_records_ws": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mbx_process_batch_ws": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mbx_expand_records": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "mbx_stream_expanded": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -59,7 +67,6 @@ _SIGNATURES = {
     "mbx_ecc_soft_words_host": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
     "mbx_rng_default": (None, [_vp]),
     "mbx_rng_seed": (None, [_vp, C.c_uint32]),
-    "mbx_debug_set_ablation": (None, [C.c_int]),
     "mbx_stream_kernel_name": (C.c_char_p, [C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -92,6 +99,9 @@ def lib():
                 raise NativeLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
+        if hasattr(handle, "mbx_debug_set_ablation"):   # development build only
+            handle.mbx_debug_set_ablation.restype = None
+            handle.mbx_debug_set_ablation.argtypes = [C.c_int]
         _lib = handle
     return _lib
 

@@ -30,6 +30,7 @@ namespace {
 }
 
 std::once_flag g_once;
+int g_device = 0;   // MBX_DEVICE: the one device the per-frame API runs on
 
 void init_once() {
     std::string path;
@@ -52,7 +53,8 @@ void init_once() {
     const size_t n = fread(blob.data(), 1, blob.size(), f);
     fclose(f);
     const char* dev = getenv("MBX_DEVICE");
-    if (mbx_init(dev ? atoi(dev) : 0, blob.data(), n) != 0) {
+    g_device = dev ? atoi(dev) : 0;
+    if (mbx_init(g_device, blob.data(), n) != 0) {
         die("mbx_init");
     }
 }
@@ -80,6 +82,7 @@ struct Slot {
     mbe_soft_bit*     soft = nullptr;     // one soft frame (184 cells)
     Slot() {
         std::call_once(g_once, init_once);
+        HIP_OK(hipSetDevice(g_device));   // HIP's current device is per thread: every thread that decodes selects the library's
         HIP_OK(hipStreamCreate(&stream));
         HIP_OK(hipMalloc(&frame, 32));
         HIP_OK(hipMalloc(&rec, sizeof(mbx_param_record)));
@@ -98,6 +101,10 @@ struct Slot {
 
 Slot& slot() {
     thread_local Slot* s = new Slot();   // lives as long as the thread's HIP context; never freed
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != g_device) {   // the host application switched devices on this thread
+        HIP_OK(hipSetDevice(g_device));
+    }
     return *s;
 }
 

@@ -3,11 +3,13 @@
 // usable every entry point fails with MBX_ENODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
-#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "mbx.h"
@@ -45,29 +47,47 @@ __global__ void ecc_soft_words_kernel(int, const mbe_soft_bit*, size_t, uint32_t
 
 namespace {
 
+// ---- per-device contexts ---------------------------------------------------------------------------------------
+// One Context per HIP device, created by mbx_init(device, ...).  Every launcher works on the context of the calling
+// thread's CURRENT device (hipGetDevice), like any other HIP call, so one process can drive all eight GPUs of a node:
+// mbx_init() each device once, then hipSetDevice(d) before launching on d.  The reference keeps its mutable helper
+// state thread-local and is re-entrant per stream (ref include/mbelib-neo/mbelib.h:28-30); here the only mutable
+// launcher state is the per-(device, hipStream_t) StreamSlot below, guarded by the context's mutex, so any number of
+// host threads may launch concurrently on their own streams (or on a shared one: launches of one call stay together).
+constexpr int kMaxDevices = 32;
+
+struct StreamSlot {                      // what a hipStream_t owns inside a context
+    mbx::FrameParams* workspace = nullptr;   // expand-stage output of launches on this stream; grow-only
+    size_t            frames = 0;
+    unsigned          launches = 0;          // parity = direction in which the next stream-kernel launch walks the streams
+    int               exp_codec = -1;        // what mbx_expand_records() last left in the workspace
+    size_t            exp_n = 0;
+    const void*       exp_records = nullptr;
+};
+
 struct Context {
-    bool               ready = false;
+    std::mutex         mu;                   // guards slots / reserve_frames; held across the launches of one call
+    std::atomic<bool>  ready{false};
     int                device = -1;
     mbx::DeviceTables  tabs{nullptr, nullptr, 0, 0};
     void*              d_blob = nullptr;
     void*              d_derived = nullptr;
     uint32_t           checksum = 0;
-    mbx::FrameParams*  workspace = nullptr;   // expand-stage output, grow-only (mbx_reserve)
-    size_t             workspace_frames = 0;
-    int                simds = 0;             // 4 per CU
+    int                simds = 0;            // 4 per CU
+    size_t             reserve_frames = 0;   // mbx_reserve(): minimum workspace of every slot
+    std::unordered_map<void*, StreamSlot> slots;
 };
-Context     g_ctx;
-std::mutex  g_mu;
-std::string g_err;
+Context    g_ctx[kMaxDevices];
+std::mutex g_init_mu;                        // serialises mbx_init() / mbx_shutdown()
+
+thread_local char t_err[256] = "";           // mbx_last_error() is per thread, like errno
 
 int fail(int code, const char* what, hipError_t e = hipSuccess) {
-    char buf[256];
     if (e != hipSuccess) {
-        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        snprintf(t_err, sizeof(t_err), "%s: %s", what, hipGetErrorString(e));
     } else {
-        snprintf(buf, sizeof(buf), "%s", what);
+        snprintf(t_err, sizeof(t_err), "%s", what);
     }
-    g_err = buf;
     return code;
 }
 
@@ -78,6 +98,48 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
             return fail(MBX_ENODEVICE, #expr, e_);     \
         }                                              \
     } while (0)
+
+// context of the calling thread's current device, or nullptr with *rc set
+Context* current_ctx(int* rc) {
+    int dev = -1;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        *rc = fail(MBX_ENODEVICE, "hipGetDevice", e);
+        return nullptr;
+    }
+    Context& c = g_ctx[dev];
+    if (!c.ready.load(std::memory_order_acquire)) {
+        *rc = fail(MBX_ENOTINIT, "mbx_init() has not been called for the current device");
+        return nullptr;
+    }
+    return &c;
+}
+
+#define REQUIRE_CTX(c)                 \
+    int rc_ctx_ = 0;                   \
+    Context* c = current_ctx(&rc_ctx_); \
+    if (!c) {                          \
+        return rc_ctx_;                \
+    }
+
+void free_context(Context& c) {   // caller holds g_init_mu and c.mu
+    (void)hipFree(c.d_blob);
+    (void)hipFree(c.d_derived);
+    for (auto& kv : c.slots) {
+        (void)hipFree(kv.second.workspace);
+    }
+    c.slots.clear();
+    c.d_blob = c.d_derived = nullptr;
+    c.tabs = mbx::DeviceTables{nullptr, nullptr, 0, 0};
+    c.reserve_frames = 0;
+    c.checksum = 0;
+    c.device = -1;
+}
+
+bool reverse_enabled() {
+    static const bool on = getenv("MBX_NO_REVERSE") == nullptr;   // read once (thread-safe static initialisation)
+    return on;
+}
 
 uint32_t fnv1a(const uint8_t* p, size_t n) {
     uint32_t h = 2166136261u;
@@ -133,10 +195,9 @@ struct DevBuf {
 
 extern "C" {
 
-const char* mbx_last_error(void) { return g_err.c_str(); }
+const char* mbx_last_error(void) { return t_err; }
 
 int mbx_init(int device, const void* table_blob, size_t table_bytes) {
-    std::lock_guard<std::mutex> lock(g_mu);
     if (!table_blob || table_bytes != sizeof(mbx_tables)) {
         return fail(MBX_EBADTABLE, "table blob: wrong size");
     }
@@ -160,17 +221,23 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         return fail(MBX_ENODEVICE, "no HIP device");
     }
-    if (device < 0 || device >= count) {
+    if (device < 0 || device >= count || device >= kMaxDevices) {
         return fail(MBX_ENODEVICE, "device index out of range");
     }
-    HIP_TRY(hipSetDevice(device));
-    if (g_ctx.ready) {
-        (void)hipFree(g_ctx.d_blob);
-        (void)hipFree(g_ctx.d_derived);
-        (void)hipFree(g_ctx.workspace);
-        const int keep = g_ctx.tabs.ablate;
-        g_ctx = Context{};
-        g_ctx.tabs.ablate = keep;
+    std::lock_guard<std::mutex> init_lock(g_init_mu);
+    HIP_TRY(hipSetDevice(device));   // the calling thread's current device from here on, like hipSetDevice itself
+    Context& ctx = g_ctx[device];
+    if (ctx.ready.load(std::memory_order_acquire)) {
+        if (ctx.checksum == host->checksum) {
+            return 0;   // same tables already resident: nothing to do (any thread may call mbx_init again)
+        }
+        // different tables: the caller must have no launches in flight on this device
+        HIP_TRY(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> lock(ctx.mu);
+        ctx.ready.store(false, std::memory_order_release);
+        const int keep = ctx.tabs.ablate;
+        free_context(ctx);
+        ctx.tabs.ablate = keep;
     }
 
     // derived tables
@@ -306,32 +373,51 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
         }
     }
 
-    HIP_TRY(hipMalloc(&g_ctx.d_blob, sizeof(mbx_tables)));
-    HIP_TRY(hipMalloc(&g_ctx.d_derived, sizeof(mbx::DerivedTables)));
-    HIP_TRY(hipMemcpy(g_ctx.d_blob, table_blob, sizeof(mbx_tables), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(g_ctx.d_derived, &d, sizeof(d), hipMemcpyHostToDevice));
-    g_ctx.tabs.t = static_cast<const mbx_tables*>(g_ctx.d_blob);
-    g_ctx.tabs.d = static_cast<const mbx::DerivedTables*>(g_ctx.d_derived);
-    g_ctx.device = device;
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    HIP_TRY(hipMalloc(&ctx.d_blob, sizeof(mbx_tables)));
+    HIP_TRY(hipMalloc(&ctx.d_derived, sizeof(mbx::DerivedTables)));
+    HIP_TRY(hipMemcpy(ctx.d_blob, table_blob, sizeof(mbx_tables), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx.d_derived, &d, sizeof(d), hipMemcpyHostToDevice));
+    ctx.tabs.t = static_cast<const mbx_tables*>(ctx.d_blob);
+    ctx.tabs.d = static_cast<const mbx::DerivedTables*>(ctx.d_derived);
+    ctx.device = device;
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    g_ctx.simds = 4 * cus;
-    g_ctx.checksum = host->checksum;
-    g_ctx.ready = true;
+    ctx.simds = 4 * cus;
+    ctx.checksum = host->checksum;
+    ctx.ready.store(true, std::memory_order_release);
     return 0;
 }
 
 void mbx_shutdown(void) {
-    std::lock_guard<std::mutex> lock(g_mu);
-    if (g_ctx.ready) {
-        (void)hipFree(g_ctx.d_blob);
-        (void)hipFree(g_ctx.d_derived);
-        (void)hipFree(g_ctx.workspace);
+    std::lock_guard<std::mutex> init_lock(g_init_mu);
+    int before = -1;
+    (void)hipGetDevice(&before);
+    for (int dev = 0; dev < kMaxDevices; ++dev) {
+        Context& ctx = g_ctx[dev];
+        if (!ctx.ready.load(std::memory_order_acquire)) {
+            continue;
+        }
+        (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lock(ctx.mu);
+        ctx.ready.store(false, std::memory_order_release);
+        free_context(ctx);
     }
-    g_ctx = Context{};
+    if (before >= 0) {
+        (void)hipSetDevice(before);
+    }
 }
 
-uint32_t mbx_table_checksum(void) { return g_ctx.ready ? g_ctx.checksum : 0u; }
+int mbx_device_ready(int device) {
+    return device >= 0 && device < kMaxDevices && g_ctx[device].ready.load(std::memory_order_acquire) ? 1 : 0;
+}
+
+uint32_t mbx_table_checksum(void) {
+    int rc = 0;
+    Context* c = current_ctx(&rc);
+    return c ? c->checksum : 0u;
+}
 
 int mbx_pack_imbe7200x4400(const char* frames, size_t n, uint8_t* packed) {
     static const int width[8] = {23, 23, 23, 23, 15, 15, 15, 7};
@@ -411,31 +497,72 @@ void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed) {   // ref: src/core/mbeli
     rng->unvoiced_seed_override = 1;
 }
 
-#define REQUIRE_READY()                                           \
-    do {                                                          \
-        if (!g_ctx.ready) {                                       \
-            return fail(MBX_ENOTINIT, "mbx_init() not called");   \
-        }                                                         \
-    } while (0)
-
-int mbx_reserve(size_t max_frames) {
-    REQUIRE_READY();
-    if (max_frames <= g_ctx.workspace_frames) {
+// ---- workspace of the stream stage ------------------------------------------------------------------------------
+// caller holds c->mu
+static int ensure_workspace(Context* c, StreamSlot& slot, size_t frames, void* stream) {
+    if (frames <= slot.frames) {
         return 0;
     }
-    if (g_ctx.workspace) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(g_ctx.workspace));
-        g_ctx.workspace = nullptr;
-        g_ctx.workspace_frames = 0;
+    const size_t want = frames > c->reserve_frames ? frames : c->reserve_frames;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        return fail(MBE_STATUS_INVALID_ARGUMENT,
+                    "the expand workspace of this stream would have to grow during stream capture: call mbx_reserve_stream() first");
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_ctx.workspace), max_frames * sizeof(mbx::FrameParams)));
-    g_ctx.workspace_frames = max_frames;
+    (void)hipGetLastError();
+    if (slot.workspace) {   // earlier launches on this stream may still read it
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipFree(slot.workspace));
+        slot.workspace = nullptr;
+        slot.frames = 0;
+        slot.exp_codec = -1;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot.workspace), want * sizeof(mbx::FrameParams)));
+    slot.frames = want;
     return 0;
 }
 
+int mbx_reserve_stream(void* stream, size_t max_frames) {
+    REQUIRE_CTX(c);
+    std::lock_guard<std::mutex> lock(c->mu);
+    return ensure_workspace(c, c->slots[stream], max_frames, stream);
+}
+
+int mbx_reserve(size_t max_frames) {
+    REQUIRE_CTX(c);
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (max_frames > c->reserve_frames) {
+        c->reserve_frames = max_frames;   // every stream first used from now on starts with this much
+    }
+    (void)c->slots[nullptr];
+    for (auto& kv : c->slots) {
+        int rc = ensure_workspace(c, kv.second, max_frames, kv.first);
+        if (rc < 0) {
+            return rc;
+        }
+    }
+    return 0;
+}
+
+int mbx_release_stream(void* stream) {
+    REQUIRE_CTX(c);
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->slots.find(stream);
+    if (it == c->slots.end()) {
+        return 0;
+    }
+    if (it->second.workspace) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipFree(it->second.workspace));
+    }
+    c->slots.erase(it);
+    return 0;
+}
+
+size_t mbx_workspace_bytes(size_t max_frames) { return max_frames * sizeof(mbx::FrameParams); }
+
 int mbx_fec_imbe7200x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d_records, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_frames || !d_records) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -444,12 +571,12 @@ int mbx_fec_imbe7200x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d
     }
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(mbx::fec_imbe7200x4400_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, n,
-                       d_records, g_ctx.tabs);
+                       d_records, c->tabs);
     return check_launch("fec_imbe7200x4400_kernel");
 }
 
 int mbx_fec_ambe3600x2450(const uint8_t* d_frames, size_t n, mbx_param_record* d_records, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_frames || !d_records) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -458,12 +585,12 @@ int mbx_fec_ambe3600x2450(const uint8_t* d_frames, size_t n, mbx_param_record* d
     }
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(mbx::fec_ambe3600x2450_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, n,
-                       d_records, g_ctx.tabs);
+                       d_records, c->tabs);
     return check_launch("fec_ambe3600x2450_kernel");
 }
 
 int mbx_fec_imbe7100x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d_records, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_frames || !d_records) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -472,12 +599,12 @@ int mbx_fec_imbe7100x4400(const uint8_t* d_frames, size_t n, mbx_param_record* d
     }
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(mbx::fec_imbe7100x4400_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames, n,
-                       d_records, g_ctx.tabs);
+                       d_records, c->tabs);
     return check_launch("fec_imbe7100x4400_kernel");
 }
 
 int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft, size_t n, mbx_param_record* d_records, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_soft || !d_records || codec < MBX_CODEC_IMBE7200X4400 || codec > MBX_CODEC_AMBE3600X2400) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -489,19 +616,19 @@ int mbx_fec_soft(int codec, const mbe_soft_bit* d_soft, size_t n, mbx_param_reco
     }
     if (codec == MBX_CODEC_IMBE7200X4400) {   // one wavefront per frame
         hipLaunchKernelGGL(mbx::fec_imbe7200x4400_soft_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_soft, n,
-                           d_records, g_ctx.tabs);
+                           d_records, c->tabs);
     } else if (codec == MBX_CODEC_IMBE7100X4400) {
         hipLaunchKernelGGL(mbx::fec_imbe7100x4400_soft_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_soft, n,
-                           d_records, g_ctx.tabs);
+                           d_records, c->tabs);
     } else {
         hipLaunchKernelGGL(mbx::fec_ambe3600x2450_soft_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_soft, n,
-                           d_records, g_ctx.tabs);
+                           d_records, c->tabs);
     }
     return check_launch("fec_soft_kernel");
 }
 
 int mbx_ecc_soft_words(int kind, const mbe_soft_bit* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_in || !d_out || kind < 0 || kind > 2 || n > 0x7fffffffu) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -509,7 +636,7 @@ int mbx_ecc_soft_words(int kind, const mbe_soft_bit* d_in, size_t n, uint32_t* d
         return 0;
     }
     hipLaunchKernelGGL(mbx::ecc_soft_words_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, kind, d_in, n, d_out,
-                       d_errs, g_ctx.tabs);
+                       d_errs, c->tabs);
     return check_launch("ecc_soft_words_kernel");
 }
 
@@ -553,47 +680,36 @@ int mbx_soft_bits_from_llr(const int16_t* llr, mbe_soft_bit* soft, size_t count)
     return 0;
 }
 
-int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream) {
-    REQUIRE_READY();
-    if (!d_records || (codec != MBX_CODEC_IMBE7200X4400 && codec != MBX_CODEC_AMBE3600X2450 && codec != MBX_CODEC_AMBE3600X2400)) {
-        return MBE_STATUS_INVALID_ARGUMENT;
-    }
-    if (n == 0) {
-        return 0;
-    }
-    int rc = mbx_reserve(n);
-    if (rc < 0) {
-        return rc;
-    }
+static bool expand_codec_ok(int codec) {
+    return codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400;
+}
+
+// frame-parallel half of the parameter decode: records -> FrameParams rows at `out`
+static int launch_expand(Context* c, int codec, const mbx_param_record* d_records, size_t n, mbx::FrameParams* out, void* stream) {
     const unsigned egrid = (unsigned)((n + 31) / 32);   // 8 frames per wave, 4 waves per workgroup (mbx_expand.hip)
     if (codec == MBX_CODEC_IMBE7200X4400) {
-        hipLaunchKernelGGL(mbx::expand_imbe_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n,
-                           g_ctx.workspace, g_ctx.tabs);
+        hipLaunchKernelGGL(mbx::expand_imbe_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n, out, c->tabs);
     } else if (codec == MBX_CODEC_AMBE3600X2400) {
-        hipLaunchKernelGGL(mbx::expand_ambe2400_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n,
-                           g_ctx.workspace, g_ctx.tabs);
+        hipLaunchKernelGGL(mbx::expand_ambe2400_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n, out, c->tabs);
     } else {
-        hipLaunchKernelGGL(mbx::expand_ambe_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n,
-                           g_ctx.workspace, g_ctx.tabs);
+        hipLaunchKernelGGL(mbx::expand_ambe_kernel, dim3(egrid), dim3(256), 0, (hipStream_t)stream, d_records, n, out, c->tabs);
     }
     return check_launch("expand_kernel");
 }
 
-// Stream-stage launch.  `params` = FrameParams rows written by mbx_expand_records(), or nullptr: the
-// stream kernel then expands each record itself (one launch less, no workspace traffic).
-static int launch_stream(int codec, int S, int T, const mbx_param_record* d_records, const mbx::FrameParams* params,
-                         mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
-                         mbe_process_result* d_results, void* stream) {
-    // Successive launches walk the streams in opposite directions.  A decoder is called for the same streams every
-    // 20 ms; the state of 65,536 of them (512 MB) does not fit the 256 MB Infinity Cache, so in a fixed order every
-    // launch finds none of it there.  Starting where the previous launch ended finds its last quarter-gigabyte.
-    // The results do not depend on the order.
-    static bool toggle = false;
-    if (!getenv("MBX_NO_REVERSE")) {
-        toggle = !toggle;
-    }
-    mbx::DeviceTables tabs = g_ctx.tabs;
-    tabs.reverse = toggle ? 1 : 0;
+// Stream-stage launch.  `params` = FrameParams rows written by the expand stage, or nullptr: the IMBE stream kernel
+// then expands each record itself (one launch less, no workspace traffic).
+//
+// `reverse`: successive launches over the same streams walk them in opposite directions.  A decoder is called for the
+// same streams every 20 ms; the state of 65,536 of them (512 MB) does not fit the 256 MB Infinity Cache, so in a fixed
+// order every launch finds none of it there, while a launch that starts where the previous one ended finds its last
+// quarter-gigabyte.  The results do not depend on the order.  The alternation is kept per (device, hipStream_t) slot
+// and per session -- whoever re-walks the same state -- not process-wide.
+static int launch_stream(Context* c, bool reverse, int codec, int S, int T, const mbx_param_record* d_records,
+                         const mbx::FrameParams* params, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
+                         float* d_pcmf, mbe_process_result* d_results, void* stream) {
+    mbx::DeviceTables tabs = c->tabs;
+    tabs.reverse = (reverse && reverse_enabled()) ? 1 : 0;
     if (codec == MBX_CODEC_IMBE7200X4400) {
         hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
@@ -612,8 +728,8 @@ static int launch_stream(int codec, int S, int T, const mbx_param_record* d_reco
     // be per SIMD, i.e. by registers (a second instance of the kernel): an LDS cap is per CU and packs the SIMDs
     // unevenly (measured slower).  One-frame launches are bound by memory latency, where every resident wave helps.
     constexpr int kWaves = 6, kWavesCapped = 4;   // MBX_AMBE_WAVES_PER_SIMD / ambe_stream_kernel_w4
-    if (T >= 4 && g_ctx.simds > 0) {
-        const double n = (double)S / (double)g_ctx.simds;
+    if (T >= 4 && c->simds > 0) {
+        const double n = (double)S / (double)c->simds;
         if (n > (double)kWaves) {
             const double rounds = ceil(n / (double)kWaves);
             if (ceil(n / rounds) <= (double)kWavesCapped) {
@@ -629,80 +745,169 @@ static int launch_stream(int codec, int S, int T, const mbx_param_record* d_reco
 }
 
 static bool stream_args_ok(int codec, int S, int T, const void* d_records, const void* d_state, const void* d_rng) {
-    return d_records && d_state && d_rng && S >= 0 && T >= 0
-           && (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400);
+    return d_records && d_state && d_rng && S >= 0 && T >= 0 && expand_codec_ok(codec);
+}
+
+// IMBE with several frames per stream: the stream kernel expands the records itself, which saves the workspace round
+// trip and a launch (+4 % at T = 16).  With ONE frame per stream the whole-job rate is the same either way (measured
+// 0.296 vs 0.292 ms per 65,536 frames): the table look-ups of the expansion are a latency chain a one-frame wave cannot
+// hide, and the 8-lanes-per-frame expand kernel costs as much as it saves -- there the expansion stays a separate
+// launch, which keeps the dominant kernel to the stream stage proper.  The AMBE stream kernels always read rows.
+static bool needs_workspace(int codec, int T) { return !(codec == MBX_CODEC_IMBE7200X4400 && T > 1); }
+
+// expand (where needed) + stream kernel with the workspace at `ws` (nullptr when none is needed); `order` = the launch
+// counter that decides the walking direction
+static int run_stream_stage(Context* c, unsigned order, int codec, int S, int T, const mbx_param_record* d_records,
+                            mbx::FrameParams* ws, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                            mbe_process_result* d_results, void* stream) {
+    if (needs_workspace(codec, T)) {
+        int rc = launch_expand(c, codec, d_records, (size_t)S * (size_t)T, ws, stream);
+        if (rc < 0) {
+            return rc;
+        }
+    } else {
+        ws = nullptr;
+    }
+    return launch_stream(c, (order & 1u) != 0u, codec, S, T, d_records, ws, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+}
+
+int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream) {
+    REQUIRE_CTX(c);
+    if (!d_records || !expand_codec_ok(codec)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    StreamSlot& slot = c->slots[stream];
+    int rc = ensure_workspace(c, slot, n, stream);
+    if (rc < 0) {
+        return rc;
+    }
+    rc = launch_expand(c, codec, d_records, n, slot.workspace, stream);
+    slot.exp_codec = rc < 0 ? -1 : codec;
+    slot.exp_n = n;
+    slot.exp_records = d_records;
+    return rc;
 }
 
 int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!stream_args_ok(codec, S, T, d_records, d_state, d_rng)) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     if (S == 0 || T == 0) {
         return 0;
     }
-    if ((size_t)S * (size_t)T > g_ctx.workspace_frames) {
-        return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_stream_expanded: mbx_expand_records() has not been run for this batch");
+    std::lock_guard<std::mutex> lock(c->mu);
+    StreamSlot& slot = c->slots[stream];
+    if (slot.exp_codec != codec || slot.exp_n != (size_t)S * (size_t)T || slot.exp_records != d_records) {
+        return fail(MBE_STATUS_INVALID_ARGUMENT,
+                    "mbx_stream_expanded: the last mbx_expand_records() on this stream was not for this codec / batch / record array");
     }
-    return launch_stream(codec, S, T, d_records, g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+    return launch_stream(c, (slot.launches++ & 1u) != 0u, codec, S, T, d_records, slot.workspace, d_state, d_rng, d_pcm16, d_pcmf,
+                         d_results, stream);
 }
 
 int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!stream_args_ok(codec, S, T, d_records, d_state, d_rng)) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     if (S == 0 || T == 0) {
         return 0;
     }
-    // IMBE: the stream kernel can expand the records itself.  With several frames per stream that saves the
-    // workspace round trip and a launch (+4 % at T = 16).  With ONE frame per stream the whole-job rate is the same
-    // either way (measured 0.296 vs 0.292 ms per 65,536 frames): the table look-ups of the expansion are a latency
-    // chain a one-frame wave cannot hide, and the 8-lanes-per-frame expand kernel costs as much as it saves -- there
-    // the expansion stays a separate launch, which keeps the dominant kernel to the stream stage proper.
-    if (codec == MBX_CODEC_IMBE7200X4400 && T > 1) {
-        return launch_stream(codec, S, T, d_records, nullptr, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+    // The lock is held across the launches of this call: the workspace of `stream` cannot be grown (freed) by another
+    // thread between the expand launch and the stream launch, and two threads that share one hipStream_t cannot
+    // interleave their expand / stream pairs.
+    std::lock_guard<std::mutex> lock(c->mu);
+    StreamSlot& slot = c->slots[stream];
+    if (needs_workspace(codec, T)) {
+        int rc = ensure_workspace(c, slot, (size_t)S * (size_t)T, stream);
+        if (rc < 0) {
+            return rc;
+        }
+        slot.exp_codec = -1;   // the rows are about to be replaced
     }
-    int rc = mbx_expand_records(codec, d_records, (size_t)S * (size_t)T, stream);
-    if (rc < 0) {
-        return rc;
+    return run_stream_stage(c, slot.launches++, codec, S, T, d_records, slot.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results,
+                            stream);
+}
+
+int mbx_process_records_ws(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
+                           mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                           void* d_workspace, size_t workspace_bytes, void* stream) {
+    REQUIRE_CTX(c);
+    if (!stream_args_ok(codec, S, T, d_records, d_state, d_rng)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
     }
-    return launch_stream(codec, S, T, d_records, g_ctx.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+    if (S == 0 || T == 0) {
+        return 0;
+    }
+    if (needs_workspace(codec, T) && (!d_workspace || workspace_bytes < mbx_workspace_bytes((size_t)S * (size_t)T))) {
+        return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_process_records_ws: workspace missing or smaller than mbx_workspace_bytes(S*T)");
+    }
+    unsigned order;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        order = c->slots[stream].launches++;
+    }
+    return run_stream_stage(c, order, codec, S, T, d_records, static_cast<mbx::FrameParams*>(d_workspace), d_state, d_rng, d_pcm16,
+                            d_pcmf, d_results, stream);
+}
+
+// FEC stage of a hard-decision batch; *stream_codec = the codec of the stream stage that follows
+static int launch_fec(int codec, const uint8_t* d_frames, size_t n, mbx_param_record* d_records, void* stream, int* stream_codec) {
+    *stream_codec = codec;
+    if (codec == MBX_CODEC_IMBE7200X4400) {
+        return mbx_fec_imbe7200x4400(d_frames, n, d_records, stream);
+    }
+    if (codec == MBX_CODEC_IMBE7100X4400) {   // own front end; the records are in 7200x4400 order
+        *stream_codec = MBX_CODEC_IMBE7200X4400;
+        return mbx_fec_imbe7100x4400(d_frames, n, d_records, stream);
+    }
+    if (codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400) {   // shared AMBE FEC front end
+        return mbx_fec_ambe3600x2450(d_frames, n, d_records, stream);
+    }
+    return MBE_STATUS_INVALID_ARGUMENT;
 }
 
 int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,
                       int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
                       void* stream) {
-    REQUIRE_READY();
     if (!d_frames || !d_records || S < 0 || T < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    const size_t n = (size_t)S * (size_t)T;
-    int rc;
-    if (codec == MBX_CODEC_IMBE7200X4400) {
-        rc = mbx_fec_imbe7200x4400(d_frames, n, d_records, stream);
-    } else if (codec == MBX_CODEC_IMBE7100X4400) {   // own front end; the records are in 7200x4400 order
-        rc = mbx_fec_imbe7100x4400(d_frames, n, d_records, stream);
-        codec = MBX_CODEC_IMBE7200X4400;
-    } else if (codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400) {   // shared AMBE FEC front end
-        rc = mbx_fec_ambe3600x2450(d_frames, n, d_records, stream);
-    } else {
-        return MBE_STATUS_INVALID_ARGUMENT;
-    }
+    int stream_codec;
+    int rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
     if (rc < 0) {
         return rc;
     }
-    return mbx_process_records(codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+    return mbx_process_records(stream_codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+}
+
+int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,
+                         int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
+                         void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!d_frames || !d_records || S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int stream_codec;
+    int rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
+    if (rc < 0) {
+        return rc;
+    }
+    return mbx_process_records_ws(stream_codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, d_workspace,
+                                  workspace_bytes, stream);
 }
 
 int mbx_process_batch_soft(int codec, int S, int T, const mbe_soft_bit* d_soft, mbe_parms* d_state, mbx_stream_rng* d_rng,
                            int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
                            void* stream) {
-    REQUIRE_READY();
     if (!d_soft || !d_records || S < 0 || T < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -718,7 +923,7 @@ int mbx_process_batch_soft(int codec, int S, int T, const mbe_soft_bit* d_soft, 
 
 int mbx_synthesize_speech(int S, mbe_parms* d_cur, mbe_parms* d_prev, mbx_stream_rng* d_rng, float* d_pcmf,
                           int16_t* d_pcm16, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_cur || !d_prev || !d_rng || S < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -726,12 +931,12 @@ int mbx_synthesize_speech(int S, mbe_parms* d_cur, mbe_parms* d_prev, mbx_stream
         return 0;
     }
     hipLaunchKernelGGL(mbx::synth_speech_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_cur, d_prev,
-                       d_rng, d_pcmf, d_pcm16, g_ctx.tabs);
+                       d_rng, d_pcmf, d_pcm16, c->tabs);
     return check_launch("synth_speech_kernel");
 }
 
 int mbx_floattoshort(const float* d_in, int16_t* d_out, size_t nframes, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_in || !d_out) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -745,7 +950,7 @@ int mbx_floattoshort(const float* d_in, int16_t* d_out, size_t nframes, void* st
 }
 
 int mbx_spectral_amp_enhance(int S, mbe_parms* d_parms, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_parms || S < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -757,7 +962,7 @@ int mbx_spectral_amp_enhance(int S, mbe_parms* d_parms, void* stream) {
 }
 
 int mbx_adaptive_smoothing(int S, mbe_parms* d_cur, const mbe_parms* d_prev, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_cur || !d_prev || S < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -769,7 +974,7 @@ int mbx_adaptive_smoothing(int S, mbe_parms* d_cur, const mbe_parms* d_prev, voi
 }
 
 int mbx_comfort_noise(int S, mbx_stream_rng* d_rng, float* d_pcmf, int16_t* d_pcm16, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_rng || S < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -783,7 +988,7 @@ int mbx_comfort_noise(int S, mbx_stream_rng* d_rng, float* d_pcmf, int16_t* d_pc
 
 int mbx_synthesize_tone(int S, const mbx_param_record* d_records, const int32_t* d_dstar_ids, mbe_parms* d_cur, float* d_pcmf,
                         int16_t* d_pcm16, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_cur || S < 0 || (!d_records && !d_dstar_ids)) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -796,7 +1001,7 @@ int mbx_synthesize_tone(int S, const mbx_param_record* d_records, const int32_t*
 }
 
 int mbx_state_copy(int S, mbe_parms* d_state, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_state || S < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -808,7 +1013,7 @@ int mbx_state_copy(int S, mbe_parms* d_state, void* stream) {
 }
 
 int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int32_t* d_errs, void* stream) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!d_in || !d_out || kind < 0 || kind > 2) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -816,11 +1021,18 @@ int mbx_ecc_words(int kind, const uint32_t* d_in, size_t n, uint32_t* d_out, int
         return 0;
     }
     hipLaunchKernelGGL(mbx::ecc_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kind,
-                       d_in, n, d_out, d_errs, g_ctx.tabs);
+                       d_in, n, d_out, d_errs, c->tabs);
     return check_launch("ecc_words_kernel");
 }
 
-void mbx_debug_set_ablation(int mask) { g_ctx.tabs.ablate = mask; }
+#ifdef MBX_ABLATE
+// development build only (make ablate -> libmbx_hip_ablate.so): timing-only stage mask for every initialised device
+void mbx_debug_set_ablation(int mask) {
+    for (int dev = 0; dev < kMaxDevices; ++dev) {
+        g_ctx[dev].tabs.ablate = mask;
+    }
+}
+#endif
 
 const char* mbx_stream_kernel_name(int codec) {
     return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? "imbe_stream_kernel"
@@ -831,7 +1043,7 @@ const char* mbx_stream_kernel_name(int codec) {
 
 
 int mbx_fec_host(int codec, const uint8_t* frames, size_t n, mbx_param_record* records) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!frames || !records) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -901,7 +1113,7 @@ static int process_batch_host_impl(int codec, int S, int T, const void* frames, 
 
 int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,
                            int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!frames || !state || !rng || S < 0 || T < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -911,7 +1123,7 @@ int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_p
 
 int mbx_process_batch_soft_host(int codec, int S, int T, const mbe_soft_bit* soft, mbe_parms* state, mbx_stream_rng* rng,
                                 int16_t* pcm16, float* pcmf, mbe_process_result* results, mbx_param_record* records) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!soft || !state || !rng || S < 0 || T < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -925,7 +1137,7 @@ int mbx_process_batch_soft_host(int codec, int S, int T, const mbe_soft_bit* sof
 }
 
 int mbx_fec_soft_host(int codec, const mbe_soft_bit* soft, size_t n, mbx_param_record* records) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!soft || !records) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -947,7 +1159,7 @@ int mbx_fec_soft_host(int codec, const mbe_soft_bit* soft, size_t n, mbx_param_r
 }
 
 int mbx_ecc_soft_words_host(int kind, const mbe_soft_bit* in, size_t n, uint32_t* out, int32_t* errs) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!in || !out || kind < 0 || kind > 2) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -973,7 +1185,7 @@ int mbx_ecc_soft_words_host(int kind, const mbe_soft_bit* in, size_t n, uint32_t
 }
 
 int mbx_synthesize_speech_host(int S, mbe_parms* cur, mbe_parms* prev, mbx_stream_rng* rng, float* pcmf, int16_t* pcm16) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!cur || !prev || !rng || S < 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -1005,7 +1217,7 @@ int mbx_synthesize_speech_host(int S, mbe_parms* cur, mbe_parms* prev, mbx_strea
 }
 
 int mbx_floattoshort_host(const float* in, int16_t* out, size_t nframes) {
-    REQUIRE_READY();
+    REQUIRE_CTX(c);
     if (!in || !out) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }

@@ -52,9 +52,17 @@ struct FrameParams {
 struct DeviceTables {
     const mbx_tables*    t;
     const DerivedTables* d;
-    int                  ablate;   // timing-only stage mask (mbx_debug_set_ablation); 0 in normal use
+    int                  ablate;   // timing-only stage mask; read only by the -DMBX_ABLATE development build (tools/)
     int                  reverse;  // stream kernels: workgroup b takes stream S - 1 - b (see launch_stream, mbx_api.hip)
 };
+
+// Stage masks for timing experiments exist only in the development build (make ablate -> libmbx_hip_ablate.so, used by
+// tools/); in the product library the tests are compile-time zeros and no entry point can switch a stage off.
+#ifdef MBX_ABLATE
+#define MBX_ABL(tabs, mask) (((tabs).ablate & (mask)) != 0)
+#else
+#define MBX_ABL(tabs, mask) false
+#endif
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 

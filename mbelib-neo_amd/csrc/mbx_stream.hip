@@ -617,6 +617,11 @@ __device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
 template <bool kSnap>
 __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
                            WaveScratch& S, const DeviceTables& tabs, int lane, const mbe_parms* snap_ptr = nullptr) {
+    // The snapshot is read back through a pointer the compiler cannot trace to the stores that wrote it: otherwise it
+    // forwards the stored registers to the loads and carries them across the voiced bank -- the very thing the read-back avoids.
+    if (kSnap) {
+        asm volatile("" : "+s"(snap_ptr));
+    }
     const mbe_parms* const snap = kSnap ? snap_ptr : nullptr;
     const mbx_tables* T = tabs.t;
     const DerivedTables* D = tabs.d;
@@ -692,7 +697,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     const int numUv = popc64(__ballot(lane <= cur.L && cur.Vl == 0));
     const float cw0 = cur.w0, pw0 = prev.w0;
     const float TWO_PI = 2.0f * (float)M_PI;
-    if (lane >= 1 && lane <= 56 && !(tabs.ablate & 64)) {
+    if (lane >= 1 && lane <= 56 && !MBX_ABL(tabs, 64)) {
         float wrapped = fmodf(prev.PSIl, TWO_PI);
         if (wrapped < 0.0f) {
             wrapped += TWO_PI;
@@ -720,7 +725,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     //     one v2f, the short third block (128 + lane, lane < 32) packs two harmonics instead.  The phase
     //     is formed with the reference's own operation order (bit-identical float theta); its cosine uses
     //     a two-float reduction to revolutions and v_cos_f32.
-    unsigned long long imask = (tabs.ablate & 16) ? 0ULL : __ballot(interp);
+    unsigned long long imask = MBX_ABL(tabs, 16) ? 0ULL : __ballot(interp);
     if (imask) {
         if (lane < 8) {   // per-harmonic constants from the harmonic's own lane, broadcast through LDS
             float4 k = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -798,8 +803,8 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     //     d_l (exact from one FMA, |d_l| < 1.2e-7) is exact in psi and carried to first order over the +-52
     //     samples around it: cos(x + d m) = cos x - d m sin x, a second pair of sums weighted by k.
     {
-        const bool wv_p = pv && !interp && !(tabs.ablate & 4), wv_c = cv && !interp && !(tabs.ablate & 4);
-        const bool any = (__ballot(wv_p || wv_c) != 0ULL) && !(tabs.ablate & 8);
+        const bool wv_p = pv && !interp && !MBX_ABL(tabs, 4), wv_c = cv && !interp && !MBX_ABL(tabs, 4);
+        const bool any = (__ballot(wv_p || wv_c) != 0ULL) && !MBX_ABL(tabs, 8);
         if (any) {
             constexpr double kInv2Pi = 0.15915494309189533577;
             constexpr int kMidPrev = 52, kMidCur = 108;
@@ -904,7 +909,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         cur.ov[0] = at(lane + 64);
         cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
     }
-    if (!(tabs.ablate & 32) && any_unvoiced) {
+    if (!MBX_ABL(tabs, 32) && any_unvoiced) {
         if (snap && !cold) {   // the fresh LCG samples of the transform's input (a voiced frame never needs them)
             nz[1] = (lane < 32) ? nz[1] : at(lane - 32);
             nz[2] = at(lane + 32);
@@ -1140,7 +1145,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         cur.Vl = __float_as_int(S.park[1][lane]);
 #endif
     }
-    if (!(tabs.ablate & 32)) {
+    if (!MBX_ABL(tabs, 32)) {
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
         // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
         // the division by w(n)^2 + w(n-160)^2 is a multiplication by its rounded reciprocal (<= 1 ulp of the unvoiced part)
@@ -1284,7 +1289,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             cur.errorCountTotal = total;
             cur.errorRate = uni((0.95f * prev.errorRate) + (0.000365f * (float)total));
 
-            const int bad = (tabs.ablate & 1) ? 0 : decode_imbe(fp, cur, prev, tabs.d, lane);
+            const int bad = MBX_ABL(tabs, 1) ? 0 : decode_imbe(fp, cur, prev, tabs.d, lane);
             const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
             const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
             const bool repeat =
@@ -1306,7 +1311,9 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
             }
             muted = (cur.repeatCount >= MBE_MAX_FRAME_REPEATS) || (cur.errorRate > cur.mutingThreshold);
         }
-        if (!(tabs.ablate & 256)) store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp (snapshot before enhancement)
+        // prev_mp := cur_mp (snapshot before enhancement).  The scheduling barriers keep the 14 stores in one piece: mixed
+        // into the decode before them or the enhancement after them they stretch live ranges past the 72-register budget.
+        if (!MBX_ABL(tabs, 256)) store_parms(cur, slot_prev, lane);
         // Register diet for the synthesiser: what the snapshot holds and the synthesiser does not change (log2Ml) or
         // replaces only at its end (previousUw, the noise overlap) is dropped here and read back from the snapshot
         // afterwards -- seven VGPRs less across the voiced bank.
@@ -1315,14 +1322,15 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         float out[3] = {0.0f, 0.0f, 0.0f};
         bool fresh = false;
         {
-            const float rm0 = (tabs.ablate & 2) ? 1.0f : enhance(cur, lane);
-            if (!(tabs.ablate & 128)) {
+            const float rm0 = MBX_ABL(tabs, 2) ? 1.0f : enhance(cur, lane);
+            if (!MBX_ABL(tabs, 128)) {
                 fresh = synth_core<true>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
             }
         }
         {
             __threadfence_block();
             const float* f = reinterpret_cast<const float*>(slot_prev);
+            asm volatile("" : "+s"(f));   // a real load, not the stored registers carried across the synthesiser (see synth_core)
             if (lane < MBX_BAND_SLOTS) {
                 cur.log2Ml = f[O_LOG2ML + lane];
             }
@@ -1338,7 +1346,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         if (muted) {
             flags |= MBE_PROCESS_FLAG_MUTE;
         }
-        if (!(tabs.ablate & 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
+        if (!MBX_ABL(tabs, 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
         if (t + 1 < Tn) {
             __threadfence_block();           // the next frame of this wave reloads both slots
         }
@@ -1355,7 +1363,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         }
     }
 
-    if (!(tabs_in.ablate & 1024)) store_parms(cur, slot_cur, lane_in);
+    if (!MBX_ABL(tabs_in, 1024)) store_parms(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[s], lane_in);
 }
 
@@ -1736,6 +1744,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             {
                 __threadfence_block();
                 const float* f = reinterpret_cast<const float*>(snap);
+                asm volatile("" : "+s"(f));   // a real load (see the IMBE kernel)
                 if (lane < MBX_BAND_SLOTS) {
                     cur.log2Ml = f[O_LOG2ML + lane];
                 }

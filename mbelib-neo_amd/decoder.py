@@ -30,11 +30,13 @@ _initialised = {}
 
 
 def ensure_init(device_index, blob=None):
-    """mbx_init once per (process, device); returns the blob checksum."""
+    """mbx_init once per (process, device) -- the native library keeps one context per device and every
+    launcher uses the context of the calling thread's current device.  Returns the blob checksum."""
+    device_index = int(device_index)
     if device_index not in _initialised:
         blob = blob if blob is not None else load_tables_blob()
         L = _native.lib()
-        _native.check(L.mbx_init(int(device_index), blob, len(blob)), "mbx_init")
+        _native.check(L.mbx_init(device_index, blob, len(blob)), "mbx_init")   # also makes it the current device
         _initialised[device_index] = L.mbx_table_checksum()
     return _initialised[device_index]
 
@@ -89,7 +91,8 @@ class BatchDecoder:
         L = _native.lib()
         fn = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400,
               3: L.mbx_fec_ambe3600x2450}[self.codec]   # both AMBE codecs share the FEC front end
-        _native.check(fn(d_frames.data_ptr(), n, rec.data_ptr(), torch.cuda.current_stream().cuda_stream), "mbx_fec")
+        with torch.cuda.device(self.device):
+            _native.check(fn(d_frames.data_ptr(), n, rec.data_ptr(), torch.cuda.current_stream().cuda_stream), "mbx_fec")
         return rec
 
     def make_outputs(self, T, want_pcm16=True, want_float=False, want_results=True):
@@ -115,11 +118,12 @@ class BatchDecoder:
         def ptr(t):
             return t.data_ptr() if t is not None else None
 
-        rc = _native.lib().mbx_process_batch(
-            self.codec, self.streams, int(T), d_frames.data_ptr(), self.state.data_ptr(), self.rng.data_ptr(),
-            ptr(out["pcm16"]), ptr(out["pcmf"]), ptr(out["results"]), out["records"].data_ptr(),
-            torch.cuda.current_stream().cuda_stream,
-        )
+        with torch.cuda.device(self.device):   # the launcher works on the current device's context
+            rc = _native.lib().mbx_process_batch(
+                self.codec, self.streams, int(T), d_frames.data_ptr(), self.state.data_ptr(), self.rng.data_ptr(),
+                ptr(out["pcm16"]), ptr(out["pcmf"]), ptr(out["results"]), out["records"].data_ptr(),
+                torch.cuda.current_stream().cuda_stream,
+            )
         _native.check(rc, "mbx_process_batch")
         return out
 

@@ -61,24 +61,47 @@ def test_fec_golden_fixtures(mbx, oracle, codec):
     parity.check_results(fx["result"], oracle_lib.records_to_results(rec))
 
 
+def _ecc_words(kind, words):
+    import torch
+
+    from mbelib_neo_amd import _native
+
+    d_in = torch.from_numpy(np.ascontiguousarray(words, dtype=np.uint32).view(np.int32)).cuda()
+    d_out = torch.empty_like(d_in)
+    d_err = torch.empty_like(d_in)
+    rc = _native.lib().mbx_ecc_words(kind, d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_err.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "mbx_ecc_words")
+    return d_out.cpu().numpy().view(np.uint32), d_err.cpu().numpy()
+
+
 def test_ecc_exhaustive_hamming_and_golay_syndromes(mbx, oracle):
-    """Every Hamming(15,11) word and every Golay syndrome through the IMBE FEC kernel: rows 4-6
-    carry Hamming words, rows 1-3 Golay words (tests/test_ecc.c known answers generalised)."""
+    """Every known answer of the reference's exhaustive ECC fixture through the HIP code-word kernel: Golay(23,12) --
+    4 data words x all 2,048 parity patterns (every syndrome) + 4,096 random words + the 0xA55 / bit-5 case of
+    tests/test_ecc.c:356-375; Hamming(15,11) -- all 32,768 words (tests/test_ecc.c:163-259).  Bit-exact, including
+    the returned error counts.  Then the same decoders inside the frame kernel on noisy encoded frames vs the oracle."""
     from mbelib_neo_amd import decoder, framegen
 
     golay, ham = golden_io.ecc_kat()
+    assert len(golay) >= 4 * 2048 + 4096 and len(ham) == 32768
+    out, errs = _ecc_words(0, golay["inp"])
+    assert np.array_equal(out, golay["out"]) and np.array_equal(errs, golay["errs"])
+    assert (int(out[-1]) >> 11) == 0xA55 and int(errs[-1]) == 1
+    out, errs = _ecc_words(1, ham["inp"])
+    assert np.array_equal(out, ham["out"]) and np.array_equal(errs, ham["errs"])
+    kat7100 = golden_io.imbe7100_kat()["hamming"]   # the 7100x4400 bit mapping of the same code (src/ecc/ecc.c:422-464)
+    out, errs = _ecc_words(2, kat7100["inp"])
+    assert np.array_equal(out, kat7100["out"]) and np.array_equal(errs, kat7100["errs"])
+
     n = 32768
     rng = framegen.rng_for(7)
     param = rng.integers(0, 2, size=(n, 88), dtype=np.uint8)
     frames = framegen.encode_imbe7200x4400(param)
-    # overwrite row 4 (15 bits at stream offset 92) with every 15-bit word XOR its PR mask: simply
-    # compare against the oracle, which is itself pinned to the reference's exhaustive table
     frames ^= framegen.random_frames(0, n, rng) & framegen.random_frames(0, n, rng) & framegen.random_frames(0, n, rng)
     dec = decoder.BatchDecoder(0, 1)
     got = decoder.records_numpy(dec.fec(frames))
     ref = oracle.fec_batch(0, frames)
     assert np.array_equal(got["w"], ref["w"])
-    assert len(golay) > 8000 and len(ham) == 32768
 
 
 # ---- float -> int16: exact -------------------------------------------------------------------
@@ -109,6 +132,54 @@ def test_golden_synth_scenario(mbx, oracle):
     print("golden synth:", m)
     parity.check_state(g["cur_out"].reshape(1), cur)
     parity.check_state(g["prev_out"].reshape(1), prev)
+
+
+def test_synth_sequences_match_reference(mbx, oracle):
+    """The reference's bench recipes as 24-frame known answers (bench/bench_synth.c:40-67: L = 40, w0 alternating
+    0.09 / 0.11, Vl and Ml patterns; bench/bench_unvoiced.c:33-52,87: L = 36 all unvoiced), produced by the real
+    reference (tests/golden/synth_seq.bin), through the HIP mbe_synthesizeSpeechf frame by frame."""
+    from mbelib_neo_amd import decoder
+    from mbelib_neo_amd.layout import PARMS_DTYPE, rng_seeded
+
+    frames, fx = golden_io.synth_seq()
+    for recipe in range(2):
+        cur = np.zeros(1, dtype=PARMS_DTYPE)
+        cur[0] = oracle.init_state(1)[0, 0]
+        if recipe == 0:
+            rng = rng_seeded([0x123456])
+            cur["w0"] = np.float32(0.09378)
+            cur["L"] = 40
+            for k in range(1, 41):
+                cur["Vl"][0, k] = int((k % 3) != 0)
+                cur["Ml"][0, k] = np.float32(0.05) + np.float32(0.002) * np.float32(k)
+                cur["log2Ml"][0, k] = 0.0
+                cur["PHIl"][0, k] = np.float32(k) * np.float32(0.1)
+                cur["PSIl"][0, k] = np.float32(k) * np.float32(0.05)
+        else:
+            rng = rng_seeded([0xBEEF])
+            cur["w0"] = np.float32(0.11)
+            cur["L"] = 36
+            for k in range(1, 37):
+                cur["Vl"][0, k] = 0
+                cur["Ml"][0, k] = np.float32(0.03) + np.float32(0.002) * np.float32(k & 7)
+                cur["PHIl"][0, k] = 0.0
+                cur["PSIl"][0, k] = 0.0
+        prev = cur.copy()
+        got = []
+        for i in range(frames):
+            if recipe == 0:
+                cur["w0"] = np.float32(0.09) if (i & 1) else np.float32(0.11)
+                for k in range(1, 41):
+                    cur["Vl"][0, k] = 1 if ((i + k) % 5) else 0
+                    cur["Ml"][0, k] = np.float32(0.04) + np.float32(0.003) * np.float32((i + k) % 7)
+            else:
+                cur["w0"] = np.float32(0.10) if (i & 1) else np.float32(0.12)
+            pcmf, cur, prev, rng, _ = decoder.synthesize_speech(cur, prev, rng)
+            prev = cur.copy()
+            got.append(pcmf[0])
+        m = parity.check_pcm(fx[recipe]["pcmf"], np.array(got), what=f"recipe{recipe}")
+        print("synth_seq recipe", recipe, m)
+        parity.check_state(fx[recipe]["cur"].reshape(1), cur)
 
 
 def test_synth_int16_of_non_finite_samples(mbx, oracle):
@@ -214,27 +285,78 @@ def test_full_size_properties(mbx, oracle):
     frames = framegen.random_frames(0, S * T, framegen.rng_for(4)).reshape(S, T, 18)
     seeds = np.arange(S) + 1234
 
+    pick = np.arange(0, S, 257)
+    d_pick = torch.from_numpy(pick).cuda()
+
     def run(splits):
         dec = decoder.BatchDecoder(0, S, seeds=seeds)
-        pcs = []
+        pcs, pfs = [], []
         t0 = 0
         for t in splits:
             out = dec.decode(np.ascontiguousarray(frames[:, t0 : t0 + t]).reshape(-1, 18), t, want_float=True)
             pcs.append(out["pcm16"].reshape(S, t, 160))
+            pfs.append(out["pcmf"].reshape(S, t, 160)[d_pick])   # float PCM of the sampled streams only (host memory)
             t0 += t
         torch.cuda.synchronize()
-        return torch.cat(pcs, dim=1).cpu().numpy(), dec.state_numpy(), dec.rng_numpy()
+        return torch.cat(pcs, dim=1).cpu().numpy(), torch.cat(pfs, dim=1).cpu().numpy(), dec.state_numpy(), dec.rng_numpy()
 
-    a_pcm, a_state, a_rng = run([4])
-    b_pcm, b_state, b_rng = run([2, 2])
-    c_pcm, c_state, _ = run([4])
-    assert np.array_equal(a_pcm, c_pcm) and a_state.tobytes() == c_state.tobytes()
-    assert np.array_equal(a_pcm, b_pcm) and a_state.tobytes() == b_state.tobytes() and a_rng.tobytes() == b_rng.tobytes()
-    pick = np.arange(0, S, 257)
+    a_pcm, a_f, a_state, a_rng = run([4])
+    b_pcm, b_f, b_state, b_rng = run([2, 2])
+    c_pcm, c_f, c_state, _ = run([4])
+    assert np.array_equal(a_pcm, c_pcm) and a_f.tobytes() == c_f.tobytes() and a_state.tobytes() == c_state.tobytes()
+    assert np.array_equal(a_pcm, b_pcm) and a_f.tobytes() == b_f.tobytes()
+    assert a_state.tobytes() == b_state.tobytes() and a_rng.tobytes() == b_rng.tobytes()
     ref = oracle.process_batch(0, len(pick), T, frames[pick].reshape(-1, 18), oracle.init_state(len(pick)),
                                oracle.rng_seeded(seeds[pick]))
-    parity.check_pcm(ref["pcmf"], ref["pcmf"], ref["pcm16"], a_pcm[pick].reshape(-1, 160))
+    parity.check_pcm(ref["pcmf"], a_f.reshape(-1, 160), ref["pcm16"], a_pcm[pick].reshape(-1, 160))
     parity.check_state(ref["state"], a_state[pick])
+
+
+def test_ambe_long_streams_config5_shape(mbx, oracle):
+    """BASELINE configs[4], one GPU's shard: 8,192 AMBE+2 streams x T = 128 random-bit frames in ONE launch (the
+    capped-occupancy kernel instance; 128 frames of phase wrap, IIR memories, LCG hand-overs, erasures, tones, repeats
+    and max-repeat re-initialisations per stream), int16 output; a strided sample of streams against the oracle over
+    all 128 frames, the rest through determinism (a second run is bit-identical) and the T = 64 + 64 split."""
+    import torch
+    from mbelib_neo_amd import decoder, framegen
+
+    S, T = 8192, 128
+    frames = framegen.random_frames(1, S * T, framegen.rng_for(55)).reshape(S, T, 9)
+    seeds = np.arange(S) + 1234
+    pick = np.arange(3, S, 331)
+    d_pick = torch.from_numpy(pick).cuda()
+
+    def run(splits):
+        dec = decoder.BatchDecoder(1, S, seeds=seeds)
+        pcs, pfs, res = [], [], []
+        t0 = 0
+        for t in splits:
+            out = dec.decode(np.ascontiguousarray(frames[:, t0 : t0 + t]).reshape(-1, 9), t, want_float=True)
+            pcs.append(out["pcm16"].reshape(S, t, 160)[d_pick])
+            pfs.append(out["pcmf"].reshape(S, t, 160)[d_pick])
+            res.append(out["results"].reshape(S, t, 5)[d_pick])
+            digest = out["pcm16"].to(torch.int64).sum().item()   # every sample of every stream
+            t0 += t
+            del out
+        torch.cuda.synchronize()
+        return (torch.cat(pcs, dim=1).cpu().numpy(), torch.cat(pfs, dim=1).cpu().numpy(), torch.cat(res, dim=1).cpu().numpy(),
+                dec.state_numpy(), dec.rng_numpy(), digest)
+
+    a = run([128])
+    ref = oracle.process_batch(1, len(pick), T, frames[pick].reshape(-1, 9), oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
+    from mbelib_neo_amd.layout import RESULT_DTYPE
+
+    parity.check_results(ref["results"], np.ascontiguousarray(a[2]).view(RESULT_DTYPE).reshape(-1))
+    m = parity.check_pcm(ref["pcmf"], a[1].reshape(-1, 160), ref["pcm16"], a[0].reshape(-1, 160))
+    print("AMBE+2 8192 x 128:", m)
+    parity.check_state(ref["state"], a[3][pick])
+    flags = ref["results"]["flags"]
+    assert (flags & 0x20).any() and (flags & 0x40).any() and (flags & 0x80).any()   # erasures, repeats, mutes are in the sample
+    b = run([128])
+    assert a[5] == b[5] and a[3].tobytes() == b[3].tobytes() and a[0].tobytes() == b[0].tobytes()
+    c = run([64, 64])
+    assert a[3].tobytes() == c[3].tobytes() and a[4].tobytes() == c[4].tobytes()
+    assert a[0].tobytes() == c[0].tobytes() and a[1].tobytes() == c[1].tobytes()
 
 
 def test_ambe_capped_kernel_instance_is_identical(mbx, oracle):
@@ -498,3 +620,97 @@ def test_ambe2400_scripted_data_streams_match_reference(mbx):
     parity.check_state(data["final"], out["state"])
     flags = fr["result"]["flags"]
     assert np.any(flags & 0x10) and np.any(flags & 0x40)
+
+
+def test_batch_api_concurrent_threads_and_streams(mbx, oracle):
+    """The batch launcher from 4 host threads, each on its own HIP stream with its own decoder (AMBE+2 and IMBE at
+    T = 1 both go through the per-stream expand workspace): every thread gets what it gets alone."""
+    import threading
+
+    import torch
+
+    from mbelib_neo_amd import decoder, framegen
+
+    S, T, rounds = 256, 1, 6
+    jobs = []
+    for k in range(4):
+        codec = k % 2
+        frames = [framegen.random_frames(codec, S * T, framegen.rng_for(900 + 10 * k + r)) for r in range(rounds)]
+        jobs.append((codec, frames, np.arange(S) + 77 * k))
+
+    def run(job, stream):
+        codec, frames, seeds = job
+        with torch.cuda.stream(stream):
+            dec = decoder.BatchDecoder(codec, S, seeds=seeds)
+            outs = []
+            for fr in frames:
+                o = dec.decode(fr, T, want_float=True)
+                outs.append((o["pcmf"], o["pcm16"], o["results"]))
+            stream.synchronize()
+            return [tuple(t.cpu().numpy().tobytes() for t in o) for o in outs], dec.state_numpy().tobytes()
+
+    alone = [run(job, torch.cuda.Stream()) for job in jobs]
+    for attempt in range(3):
+        got, errors = [None] * 4, []
+
+        def work(k):
+            try:
+                got[k] = run(jobs[k], torch.cuda.Stream())
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        for k in range(4):
+            assert got[k] == alone[k], f"thread {k}: results differ from the run on its own"
+    # and the run on its own is the oracle's
+    codec, frames, seeds = jobs[1]
+    st, rg = oracle.init_state(S), oracle.rng_seeded(seeds)
+    for r, fr in enumerate(frames):
+        ref = oracle.process_batch(codec, S, T, fr, st, rg)
+        st, rg = ref["state"], ref["rng"]
+        assert np.frombuffer(alone[1][0][r][2], dtype=np.int32).reshape(-1, 5)[:, 4].tolist() == ref["results"]["flags"].tolist()
+
+
+def test_explicit_workspace_and_expand_token(mbx, oracle):
+    """mbx_process_batch_ws with a caller-owned workspace == mbx_process_batch; mbx_stream_expanded refuses a workspace
+    that the last mbx_expand_records() on the stream did not fill for this batch."""
+    import torch
+
+    from mbelib_neo_amd import _native, decoder, framegen
+
+    L = _native.lib()
+    S, T = 128, 2
+    for codec in (0, 1):
+        frames = framegen.random_frames(codec, S * T, framegen.rng_for(31 + codec))
+        seeds = np.arange(S) + 5
+        a = decoder.BatchDecoder(codec, S, seeds=seeds)
+        ref = a.decode(frames, T, want_float=True)
+        b = decoder.BatchDecoder(codec, S, seeds=seeds)
+        out = b.make_outputs(T, want_float=True)
+        ws = torch.empty(L.mbx_workspace_bytes(S * T), dtype=torch.uint8, device="cuda")
+        d_frames = b.to_device(frames)
+        strm = torch.cuda.current_stream().cuda_stream
+        rc = L.mbx_process_batch_ws(codec, S, T, d_frames.data_ptr(), b.state.data_ptr(), b.rng.data_ptr(), out["pcm16"].data_ptr(),
+                                    out["pcmf"].data_ptr(), out["results"].data_ptr(), out["records"].data_ptr(), ws.data_ptr(),
+                                    ws.numel(), strm)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(ref["pcmf"], out["pcmf"]) and torch.equal(ref["pcm16"], out["pcm16"])
+        assert a.state_numpy().tobytes() == b.state_numpy().tobytes()
+        if codec == 1:   # too small a workspace is refused, nothing launched
+            assert L.mbx_process_batch_ws(codec, S, T, d_frames.data_ptr(), b.state.data_ptr(), b.rng.data_ptr(), None, None, None,
+                                          out["records"].data_ptr(), ws.data_ptr(), 256, strm) == -1
+        # expand token
+        rec = out["records"]
+        assert L.mbx_expand_records(codec, rec.data_ptr(), S * T, strm) == 0
+        other = torch.empty_like(rec)
+        assert L.mbx_stream_expanded(codec, S, T, other.data_ptr(), b.state.data_ptr(), b.rng.data_ptr(), None, None, None, strm) == -1
+        assert L.mbx_stream_expanded(codec, S // 2, T, rec.data_ptr(), b.state.data_ptr(), b.rng.data_ptr(), None, None, None, strm) == -1
+        assert L.mbx_stream_expanded(codec, S, T, rec.data_ptr(), b.state.data_ptr(), b.rng.data_ptr(), out["pcm16"].data_ptr(), None,
+                                     None, strm) == 0
+        torch.cuda.synchronize()

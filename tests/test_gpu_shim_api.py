@@ -538,3 +538,60 @@ def test_tone_and_format_entry_points(mbe):
     assert buf.value == b"===ER"
     mbe.mbe_formatProcessResult(buf, 4, p(res))
     assert buf.value == b"==="
+
+
+# ---- re-entrancy: ref include/mbelib-neo/mbelib.h:28-30 (re-entrant per stream, helper state thread-local) --------
+def _decode_streams(mbe, codec, streams, fx, T):
+    """what one host thread does: its streams one after the other, frame by frame, thread-local RNG seeded per stream"""
+    fn, nd = ((mbe.mbe_processImbe7200x4400Framef, 88), (mbe.mbe_processAmbe3600x2450Framef, 49))[codec]
+    out = {}
+    for s in streams:
+        cur, prev, enh = new_state(mbe)
+        mbe.mbe_setThreadRngSeed(1234 + s)
+        pcm = np.zeros((T, 160), dtype=np.float32)
+        rets = []
+        for t in range(T):
+            fr = fx["frames"][s, t]
+            d = np.zeros(nd, dtype=np.int8)
+            r = result()
+            rets.append((fn(p(pcm[t]), p(r), p(fr["cells"].copy()), p(d), p(cur), p(prev), p(enh)), r.tobytes(), d.tobytes()))
+        out[s] = (pcm, rets, np.concatenate([cur, prev, enh]))
+    return out
+
+
+@pytest.mark.parametrize("codec", [0, 1])
+def test_four_host_threads_decode_concurrently(mbe, codec):
+    """4 host threads x 4 streams x 24 frames through libmbe_neo_amd.so at the same time (ctypes releases the GIL
+    around every call).  Each thread must get, bit for bit, what a single thread gets for the same streams -- the
+    threads share nothing but the device -- and stay within tolerance of the reference's golden streams."""
+    import threading
+
+    S, T, fx = golden_io.stream(codec)
+    T = min(T, 24)
+    groups = [list(range(4 * k, 4 * k + 4)) for k in range(4)]
+    serial = {}
+    for g in groups:
+        serial.update(_decode_streams(mbe, codec, g, fx, T))
+    for attempt in range(3):   # three concurrent rounds: a race needs the interleaving to happen
+        got, errors = {}, []
+
+        def work(g):
+            try:
+                got.update(_decode_streams(mbe, codec, g, fx, T))
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(g,)) for g in groups]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        for s in sorted(serial):
+            pcm, rets, st = got[s]
+            assert pcm.tobytes() == serial[s][0].tobytes(), f"stream {s}: PCM differs from the single-threaded run"
+            assert rets == serial[s][1] and st.tobytes() == serial[s][2].tobytes()
+    for s in sorted(serial):
+        pcm, rets, st = serial[s]
+        assert [r[0] for r in rets] == [int(x) for x in fx["frames"][s, :T]["ret"]]
+        parity.check_pcm(fx["frames"][s, :T]["pcmf"], pcm)

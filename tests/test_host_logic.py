@@ -38,11 +38,16 @@ def test_launchers_fail_loudly_without_init_or_device():
         L = _native.lib()
     except _native.NativeLibraryError as e:
         pytest.skip(str(e))
-    # no mbx_init(): every launcher refuses (no silent CPU path)
-    assert L.mbx_fec_imbe7200x4400(None, 1, None, None) == -101
-    assert L.mbx_process_records(0, 1, 1, None, None, None, None, None, None, None) == -101
-    blob = open(os.path.join(ROOT, "mbelib-neo_amd", "data", "mbx_tables.bin"), "rb").read()
+    # no device / no mbx_init() for the current device: every launcher refuses (no silent CPU path)
     import torch
+
+    refusal = -101 if torch.cuda.is_available() else -100   # MBX_ENOTINIT with a device, MBX_ENODEVICE without
+    assert L.mbx_fec_imbe7200x4400(None, 1, None, None) == refusal
+    assert L.mbx_process_records(0, 1, 1, None, None, None, None, None, None, None) == refusal
+    assert L.mbx_process_records_ws(0, 1, 1, None, None, None, None, None, None, None, 0, None) == refusal
+    assert L.mbx_reserve(16) == refusal and L.mbx_device_ready(0) == 0
+    assert L.mbx_last_error()   # a message is left for the calling thread
+    blob = open(os.path.join(ROOT, "mbelib-neo_amd", "data", "mbx_tables.bin"), "rb").read()
 
     if not torch.cuda.is_available():
         assert L.mbx_init(0, blob, len(blob)) == -100  # MBX_ENODEVICE
