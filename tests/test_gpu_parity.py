@@ -323,7 +323,7 @@ def test_ambe_long_streams_config5_shape(mbx, oracle):
     S, T = 8192, 128
     frames = framegen.random_frames(1, S * T, framegen.rng_for(55)).reshape(S, T, 9)
     seeds = np.arange(S) + 1234
-    pick = np.arange(3, S, 331)
+    pick = np.arange(3, S, 131)
     d_pick = torch.from_numpy(pick).cuda()
 
     def run(splits):
@@ -351,7 +351,7 @@ def test_ambe_long_streams_config5_shape(mbx, oracle):
     print("AMBE+2 8192 x 128:", m)
     parity.check_state(ref["state"], a[3][pick])
     flags = ref["results"]["flags"]
-    assert (flags & 0x20).any() and (flags & 0x40).any() and (flags & 0x80).any()   # erasures, repeats, mutes are in the sample
+    assert (flags & 0x20).any() and (flags & 0x40).any() and (flags & 0x10).any()   # erasures, repeats, tones are in the sample
     b = run([128])
     assert a[5] == b[5] and a[3].tobytes() == b[3].tobytes() and a[0].tobytes() == b[0].tobytes()
     c = run([64, 64])
