@@ -234,7 +234,9 @@ def main():
     d_frames = dec.to_device(frames)
     out = dec.make_outputs(T, want_pcm16=True, want_float=False, want_results=True)
     L = _native.lib()
-    L.mbx_debug_set_ablation(0)
+    if args.ablate and not hasattr(L, "mbx_debug_set_ablation"):
+        raise SystemExit("--ablate needs the development build: make -C mbelib-neo_amd/csrc ablate && "
+                         "MBX_HIP_LIBRARY=$PWD/mbelib-neo_amd/libmbx_hip_ablate.so python bench.py --ablate MASK")
     _native.check(L.mbx_reserve(S * T), "mbx_reserve")  # launches below never allocate
     stream = torch.cuda.current_stream().cuda_stream
     soft = args.workload.endswith("_soft")
@@ -271,7 +273,8 @@ def main():
 
     for _ in range(max(1, args.warmup)):  # the first pass also warms the model state
         step()
-    L.mbx_debug_set_ablation(args.ablate)  # development aid; 0 in every reported run
+    if args.ablate:
+        L.mbx_debug_set_ablation(args.ablate)  # development build only (tools/); never in a reported run
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:

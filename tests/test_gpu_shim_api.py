@@ -554,7 +554,8 @@ def _decode_streams(mbe, codec, streams, fx, T):
             fr = fx["frames"][s, t]
             d = np.zeros(nd, dtype=np.int8)
             r = result()
-            rets.append((fn(p(pcm[t]), p(r), p(fr["cells"].copy()), p(d), p(cur), p(prev), p(enh)), r.tobytes(), d.tobytes()))
+            cells = fr["cells"].copy()   # held in a local: a temporary would be freed (and reused by another thread) before the call reads it
+            rets.append((fn(p(pcm[t]), p(r), p(cells), p(d), p(cur), p(prev), p(enh)), r.tobytes(), d.tobytes()))
         out[s] = (pcm, rets, np.concatenate([cur, prev, enh]))
     return out
 
