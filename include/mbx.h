@@ -172,6 +172,15 @@ int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_p
                          int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
                          void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* The same for a SUBSET of a larger resident pool of streams: batch row s (its T frames, records, PCM and results at
+ * rows s*T .. s*T+T-1) belongs to the stream whose state / rng live in slot d_stream_index[s] of the pools.  The index
+ * must not name a slot twice.  This is what a host with many open channels needs each 20 ms tick: only the channels
+ * that received a frame are launched, the state of the others stays where it is (used by the queue mode of the
+ * per-frame API, include/mbe_neo_amd.h, and by mbx_session_submit_indexed). */
+int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_index, const uint8_t* d_frames,
+                              mbe_parms* d_state_pool, mbx_stream_rng* d_rng_pool, int16_t* d_pcm16, float* d_pcmf,
+                              mbe_process_result* d_results, mbx_param_record* d_records, void* stream);
+
 /* ref: mbe_synthesizeSpeechf  include/mbelib-neo/mbelib.h:652, src/core/mbelib.c:1112-1115.
  * One frame for each of S (cur, prev) pairs; both structs are updated like the reference does. */
 int mbx_synthesize_speech(int S, mbe_parms* d_cur, mbe_parms* d_prev, mbx_stream_rng* d_rng, float* d_pcmf,
@@ -201,6 +210,42 @@ int mbx_synthesize_tone(int S, const mbx_param_record* d_records, const int32_t*
 /* Loads and stores the state triplet of S streams without touching it: the HBM-traffic floor of the
  * stream stage (used by bench.py --calibrate to price the access pattern; not a reference function). */
 int mbx_state_copy(int S, mbe_parms* d_state, void* stream);
+
+/* ---- sessions: device-resident state, frames in from / PCM out to HOST memory (mbx_session.hip) -------------------
+ * The fan-in path for a C host that keeps the reference's per-frame bookkeeping but hands frames over in batches: the
+ * state triplets ({cur_mp, prev_mp, prev_mp_enhanced} of ref mbe_process*Frame, include/mbelib-neo/mbelib.h:429,505)
+ * and the per-stream RNG (the reference's thread-local helper state) of `streams` streams live on the device for the
+ * life of the session, so one 20 ms frame costs 18 B (9 B) of PCIe in and 320 B out (+ 20 B with results) instead of
+ * the 15.6 KB of state mbx_process_batch_host() moves.  Submissions are asynchronous and pipelined three deep (copy-in,
+ * kernels and copy-out of consecutive batches overlap on three HIP streams); outputs are valid after
+ * mbx_session_wait().  Pinned host buffers (mbx_host_alloc, hipHostMalloc, hipHostRegister) are used in place; pageable
+ * ones are staged through pinned memory owned by the session (frames are copied out before submit returns, outputs are
+ * copied in by the wait / by the submit that reuses the pipeline slot).  A session belongs to the device that was
+ * current when it was created and may be driven by one host thread at a time; any number of sessions may run
+ * concurrently.  Streams start from mbe_initMbeParms defaults and the default RNG. */
+typedef struct mbx_session mbx_session;
+#define MBX_SESSION_PCM16   1u   /* int16 PCM (mbe_floattoshort applied); the default when `outputs` is 0 */
+#define MBX_SESSION_PCMF    2u   /* float PCM */
+#define MBX_SESSION_RESULTS 4u   /* mbe_process_result per frame */
+int mbx_session_create(mbx_session** out, int codec, int streams, size_t max_frames_per_submit, unsigned outputs);
+int mbx_session_destroy(mbx_session* s);
+int mbx_session_streams(const mbx_session* s);
+/* frames: [streams][T] wire frames, stream-major; every stream advances by T frames.  Output pointers may be NULL. */
+int mbx_session_submit(mbx_session* s, int T, const uint8_t* frames, int16_t* pcm16, float* pcmf, mbe_process_result* results);
+/* the same for n of the session's streams: batch row i belongs to stream stream_index[i] (no stream twice); the
+ * others keep their state.  `records` (may be NULL) returns imbe_d / ambe_d + error context (mbx_unpack_records). */
+int mbx_session_submit_indexed(mbx_session* s, int n, int T, const int32_t* stream_index, const uint8_t* frames, int16_t* pcm16,
+                               float* pcmf, mbe_process_result* results, mbx_param_record* records);
+/* every batch submitted so far is complete and its outputs are in the caller's buffers */
+int mbx_session_wait(mbx_session* s);
+/* state of streams [first, first + count): ref mbe_initMbeParms / mbe_setThreadRngSeed / direct access.  These wait. */
+int mbx_session_reset(mbx_session* s, int first, int count);
+int mbx_session_seed(mbx_session* s, int first, int count, const uint32_t* seeds);
+int mbx_session_get_state(mbx_session* s, int first, int count, mbe_parms* state /* count*3, or NULL */, mbx_stream_rng* rng /* or NULL */);
+int mbx_session_set_state(mbx_session* s, int first, int count, const mbe_parms* state, const mbx_stream_rng* rng);
+/* pinned host memory for zero-copy DMA of frames / PCM */
+void* mbx_host_alloc(size_t bytes);
+void mbx_host_free(void* p);
 
 /* ---- convenience: same calls on HOST buffers (stages through device memory, synchronous) -- */
 int mbx_process_batch_host(int codec, int S, int T, const uint8_t* frames, mbe_parms* state, mbx_stream_rng* rng,

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "mbx_expand_records": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "mbx_stream_expanded": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_process_batch_indexed": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_synthesize_speech": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_floattoshort": (C.c_int, [_vp, _vp, _sz, _vp]),
     "mbx_spectral_amp_enhance": (C.c_int, [C.c_int, _vp, _vp]),
@@ -65,6 +66,18 @@ _SIGNATURES = {
     "mbx_fec_soft_host": (C.c_int, [C.c_int, _vp, _sz, _vp]),
     "mbx_process_batch_soft_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_ecc_soft_words_host": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
+    "mbx_session_create": (C.c_int, [_vp, C.c_int, C.c_int, _sz, C.c_uint]),
+    "mbx_session_destroy": (C.c_int, [_vp]),
+    "mbx_session_streams": (C.c_int, [_vp]),
+    "mbx_session_submit": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "mbx_session_submit_indexed": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_session_wait": (C.c_int, [_vp]),
+    "mbx_session_reset": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "mbx_session_seed": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "mbx_session_get_state": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "mbx_session_set_state": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "mbx_host_alloc": (_vp, [_sz]),
+    "mbx_host_free": (None, [_vp]),
     "mbx_rng_default": (None, [_vp]),
     "mbx_rng_seed": (None, [_vp, C.c_uint32]),
     "mbx_stream_kernel_name": (C.c_char_p, [C.c_int]),

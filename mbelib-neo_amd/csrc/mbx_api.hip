@@ -130,7 +130,7 @@ void free_context(Context& c) {   // caller holds g_init_mu and c.mu
     }
     c.slots.clear();
     c.d_blob = c.d_derived = nullptr;
-    c.tabs = mbx::DeviceTables{nullptr, nullptr, 0, 0};
+    c.tabs = mbx::DeviceTables{nullptr, nullptr, 0, 0, nullptr};
     c.reserve_frames = 0;
     c.checksum = 0;
     c.device = -1;
@@ -192,6 +192,8 @@ struct DevBuf {
     template <class U> U* as() { return static_cast<U*>(p); }
 };
 }  // namespace
+
+void mbx_set_error_text(const char* text) { snprintf(t_err, sizeof(t_err), "%s", text); }   // for mbx_session.hip
 
 extern "C" {
 
@@ -707,9 +709,10 @@ static int launch_expand(Context* c, int codec, const mbx_param_record* d_record
 // and per session -- whoever re-walks the same state -- not process-wide.
 static int launch_stream(Context* c, bool reverse, int codec, int S, int T, const mbx_param_record* d_records,
                          const mbx::FrameParams* params, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
-                         float* d_pcmf, mbe_process_result* d_results, void* stream) {
+                         float* d_pcmf, mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr) {
     mbx::DeviceTables tabs = c->tabs;
     tabs.reverse = (reverse && reverse_enabled()) ? 1 : 0;
+    tabs.stream_map = d_stream_index;
     if (codec == MBX_CODEC_IMBE7200X4400) {
         hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
@@ -759,7 +762,7 @@ static bool needs_workspace(int codec, int T) { return !(codec == MBX_CODEC_IMBE
 // counter that decides the walking direction
 static int run_stream_stage(Context* c, unsigned order, int codec, int S, int T, const mbx_param_record* d_records,
                             mbx::FrameParams* ws, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
-                            mbe_process_result* d_results, void* stream) {
+                            mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr) {
     if (needs_workspace(codec, T)) {
         int rc = launch_expand(c, codec, d_records, (size_t)S * (size_t)T, ws, stream);
         if (rc < 0) {
@@ -768,7 +771,8 @@ static int run_stream_stage(Context* c, unsigned order, int codec, int S, int T,
     } else {
         ws = nullptr;
     }
-    return launch_stream(c, (order & 1u) != 0u, codec, S, T, d_records, ws, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+    return launch_stream(c, (order & 1u) != 0u, codec, S, T, d_records, ws, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
+                         d_stream_index);
 }
 
 int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream) {
@@ -903,6 +907,34 @@ int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_p
     }
     return mbx_process_records_ws(stream_codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, d_workspace,
                                   workspace_bytes, stream);
+}
+
+int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_index, const uint8_t* d_frames,
+                              mbe_parms* d_state_pool, mbx_stream_rng* d_rng_pool, int16_t* d_pcm16, float* d_pcmf,
+                              mbe_process_result* d_results, mbx_param_record* d_records, void* stream) {
+    REQUIRE_CTX(c);
+    if (!d_frames || !d_records || !d_stream_index || !d_state_pool || !d_rng_pool || S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0 || T == 0) {
+        return 0;
+    }
+    int stream_codec;
+    int rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
+    if (rc < 0) {
+        return rc;
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    StreamSlot& slot = c->slots[stream];
+    if (needs_workspace(stream_codec, T)) {
+        rc = ensure_workspace(c, slot, (size_t)S * (size_t)T, stream);
+        if (rc < 0) {
+            return rc;
+        }
+        slot.exp_codec = -1;
+    }
+    return run_stream_stage(c, slot.launches++, stream_codec, S, T, d_records, slot.workspace, d_state_pool, d_rng_pool, d_pcm16,
+                            d_pcmf, d_results, stream, d_stream_index);
 }
 
 int mbx_process_batch_soft(int codec, int S, int T, const mbe_soft_bit* d_soft, mbe_parms* d_state, mbx_stream_rng* d_rng,

@@ -54,6 +54,7 @@ struct DeviceTables {
     const DerivedTables* d;
     int                  ablate;   // timing-only stage mask; read only by the -DMBX_ABLATE development build (tools/)
     int                  reverse;  // stream kernels: workgroup b takes stream S - 1 - b (see launch_stream, mbx_api.hip)
+    const int32_t*       stream_map;   // stream kernels: batch row s works on state / rng slot stream_map[s] (nullptr: slot s)
 };
 
 // Stage masks for timing experiments exist only in the development build (make ablate -> libmbx_hip_ablate.so, used by

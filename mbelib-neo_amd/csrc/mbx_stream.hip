@@ -1242,13 +1242,16 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
     // registers for the whole launch; `prev` is only needed from the start of a frame to the
     // snapshot and `enh` only from the snapshot to the end of synthesis, so both are parked in
     // their own HBM/L2 slots in between (exactly the loads and stores a T = 1 launch needs anyway).
-    mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
-    mbe_parms* const slot_prev = &state[3 * (size_t)s + 1];
-    mbe_parms* const slot_enh = &state[3 * (size_t)s + 2];
+    // batch row s (frames, records, PCM, results) belongs to state / rng slot `slot`: the same number unless the caller
+    // passed an index (mbx_process_batch_indexed: the streams that have frames this tick, out of a larger resident pool)
+    const size_t slot = tabs_in.stream_map ? (size_t)uni(tabs_in.stream_map[s]) : (size_t)s;
+    mbe_parms* const slot_cur = &state[3 * slot + 0];
+    mbe_parms* const slot_prev = &state[3 * slot + 1];
+    mbe_parms* const slot_enh = &state[3 * slot + 2];
     Parms cur;
     load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
-    load_rng(rng, &rngs[s]);
+    load_rng(rng, &rngs[slot]);
 
     for (int t = 0; t < Tn; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
@@ -1364,7 +1367,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
     }
 
     if (!MBX_ABL(tabs_in, 1024)) store_parms(cur, slot_cur, lane_in);
-    store_rng(rng, &rngs[s], lane_in);
+    store_rng(rng, &rngs[slot], lane_in);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1613,13 +1616,16 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const int lane_in = lane_id();
     // Same register discipline as the IMBE kernel: `cur` resident, `prev` / `enh` parked in their slots.
-    mbe_parms* const slot_cur = &state[3 * (size_t)s + 0];
-    mbe_parms* const slot_prev = &state[3 * (size_t)s + 1];
-    mbe_parms* const slot_enh = &state[3 * (size_t)s + 2];
+    // batch row s (frames, records, PCM, results) belongs to state / rng slot `slot`: the same number unless the caller
+    // passed an index (mbx_process_batch_indexed: the streams that have frames this tick, out of a larger resident pool)
+    const size_t slot = tabs_in.stream_map ? (size_t)uni(tabs_in.stream_map[s]) : (size_t)s;
+    mbe_parms* const slot_cur = &state[3 * slot + 0];
+    mbe_parms* const slot_prev = &state[3 * slot + 1];
+    mbe_parms* const slot_enh = &state[3 * slot + 2];
     Parms cur;
     load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
-    load_rng(rng, &rngs[s]);
+    load_rng(rng, &rngs[slot]);
 
     for (int t = 0; t < Tn; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
@@ -1792,7 +1798,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     }
 
     store_parms(cur, slot_cur, lane_in);
-    store_rng(rng, &rngs[s], lane_in);
+    store_rng(rng, &rngs[slot], lane_in);
 }
 
 // mbe_synthesizeSpeechf for S independent (cur, prev) pairs.

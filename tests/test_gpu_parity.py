@@ -714,3 +714,115 @@ def test_explicit_workspace_and_expand_token(mbx, oracle):
         assert L.mbx_stream_expanded(codec, S, T, rec.data_ptr(), b.state.data_ptr(), b.rng.data_ptr(), out["pcm16"].data_ptr(), None,
                                      None, strm) == 0
         torch.cuda.synchronize()
+
+
+# ---- sessions: device-resident state, host frames in / host PCM out (include/mbx.h "sessions") -------------------
+def _session(L, codec, S, max_frames, outputs):
+    import ctypes as C
+
+    h = C.c_void_p()
+    from mbelib_neo_amd import _native
+
+    _native.check(L.mbx_session_create(C.byref(h), codec, S, max_frames, outputs), "mbx_session_create")
+    return h
+
+
+@pytest.mark.parametrize("codec", [0, 1, 2, 3])
+def test_session_matches_batch_decoder_and_oracle(mbx, oracle, codec):
+    """A session fed from pageable host memory over several pipelined submits (T = 1, 1, 3, 1, 2) gives bit for bit what
+    the device-pointer batch API gives for the same frames, its state comes back identical, and the whole run is the
+    oracle's within the PCM tolerance."""
+    import ctypes as C
+
+    from mbelib_neo_amd import _native, decoder, framegen
+    from mbelib_neo_amd.layout import FRAME_BYTES, PARMS_DTYPE, RESULT_DTYPE, RNG_DTYPE
+
+    L = _native.lib()
+    S, Ts = 300, (1, 1, 3, 1, 2)
+    fb = FRAME_BYTES[codec]
+    seeds = (np.arange(S) + 4321).astype(np.uint32)
+    h = _session(L, codec, S, S * max(Ts), 1 | 2 | 4)
+    _native.check(L.mbx_session_seed(h, 0, S, seeds.ctypes.data), "seed")
+    dec = decoder.BatchDecoder(codec, S, seeds=seeds)
+    rng = framegen.rng_for(70 + codec)
+    keep, outs = [], []
+    st, rg = oracle.init_state(S), oracle.rng_seeded(seeds)
+    refs = []
+    for T in Ts:
+        frames = framegen.random_frames(codec, S * T, rng)
+        o16 = np.zeros((S * T, 160), dtype=np.int16)
+        of = np.zeros((S * T, 160), dtype=np.float32)
+        ores = np.zeros(S * T, dtype=RESULT_DTYPE)
+        keep.append(frames)   # pageable input is staged before submit returns, but keep it anyway
+        _native.check(L.mbx_session_submit(h, T, frames.ctypes.data, o16.ctypes.data, of.ctypes.data, ores.ctypes.data), "submit")
+        outs.append((o16, of, ores))
+        ref = oracle.process_batch(codec, S, T, frames, st, rg)
+        st, rg = ref["state"], ref["rng"]
+        refs.append(ref)
+    _native.check(L.mbx_session_wait(h), "wait")
+    for T, frames, (o16, of, ores), ref in zip(Ts, keep, outs, refs):
+        got = dec.decode(frames, T, want_float=True)
+        assert np.array_equal(got["pcm16"].cpu().numpy(), o16) and got["pcmf"].cpu().numpy().tobytes() == of.tobytes()
+        assert decoder.results_numpy(got["results"]).tobytes() == ores.tobytes()
+        parity.check_results(ref["results"], ores)
+        parity.check_pcm(ref["pcmf"], of, ref["pcm16"], o16)
+    state = np.zeros((S, 3), dtype=PARMS_DTYPE)
+    srng = np.zeros(S, dtype=RNG_DTYPE)
+    _native.check(L.mbx_session_get_state(h, 0, S, state.ctypes.data, srng.ctypes.data), "get_state")
+    assert state.tobytes() == dec.state_numpy().tobytes() and srng.tobytes() == dec.rng_numpy().tobytes()
+    parity.check_state(st, state)
+    assert L.mbx_session_submit(h, max(Ts) + 1, keep[0].ctypes.data, None, None, None) == -1   # more frames than the session was sized for
+    assert L.mbx_session_destroy(h) == 0
+
+
+def test_session_indexed_subset_pinned_buffers(mbx, oracle):
+    """Each tick only some of the session's streams have a frame (mbx_session_submit_indexed); buffers from mbx_host_alloc
+    are used in place.  Every stream's PCM sequence equals the one it produces when decoded alone."""
+    import ctypes as C
+
+    from mbelib_neo_amd import _native, framegen
+    from mbelib_neo_amd.layout import RECORD_DTYPE
+
+    L = _native.lib()
+    S, ticks = 96, 10
+    codec = 1
+    seeds = (np.arange(S) + 99).astype(np.uint32)
+    h = _session(L, codec, S, S, 1)
+    _native.check(L.mbx_session_seed(h, 0, S, seeds.ctypes.data), "seed")
+    gen = np.random.default_rng(5)
+    frames_of = {s: [] for s in range(S)}
+    pcm_of = {s: [] for s in range(S)}
+    pin_in = L.mbx_host_alloc(S * 9)
+    pin_out = [L.mbx_host_alloc(S * 320) for _ in range(ticks)]
+    assert pin_in and all(pin_out)
+    views = []
+    subsets = []
+    for k in range(ticks):
+        active = np.sort(gen.choice(S, size=int(gen.integers(1, S + 1)), replace=False)).astype(np.int32)
+        fr = framegen.random_frames(codec, len(active), framegen.rng_for(1000 + k))
+        _native.check(L.mbx_session_wait(h), "wait")   # the one pinned input buffer is reused every tick
+        C.memmove(pin_in, fr.ctypes.data, fr.size)
+        rec = np.zeros(len(active), dtype=RECORD_DTYPE)
+        _native.check(L.mbx_session_submit_indexed(h, len(active), 1, active.ctypes.data, pin_in, pin_out[k], None, None,
+                                                   rec.ctypes.data), "submit_indexed")
+        subsets.append((active, fr, rec))
+    _native.check(L.mbx_session_wait(h), "wait")
+    for k, (active, fr, rec) in enumerate(subsets):
+        out = np.ctypeslib.as_array(C.cast(pin_out[k], C.POINTER(C.c_int16)), shape=(S, 160))[: len(active)].copy()
+        assert np.array_equal(rec["w"], oracle.fec_batch(codec, fr)["w"])   # the records come back too
+        for i, s in enumerate(active):
+            frames_of[int(s)].append(fr.reshape(-1, 9)[i])
+            pcm_of[int(s)].append(out[i])
+    bad = np.array([0, S], dtype=np.int32)
+    assert L.mbx_session_submit_indexed(h, 2, 1, bad.ctypes.data, pin_in, None, None, None, None) == -1
+    for s in (0, 17, 95):
+        if not frames_of[s]:
+            continue
+        T = len(frames_of[s])
+        ref = oracle.process_batch(codec, 1, T, np.array(frames_of[s]).reshape(-1), oracle.init_state(1), oracle.rng_seeded([int(seeds[s])]))
+        d = np.abs(ref["pcm16"].astype(np.int32) - np.array(pcm_of[s]).astype(np.int32))
+        assert d.max() <= 3 and np.mean(d <= 1) >= 0.999
+    L.mbx_host_free(pin_in)
+    for q in pin_out:
+        L.mbx_host_free(q)
+    assert L.mbx_session_destroy(h) == 0
