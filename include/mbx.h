@@ -106,6 +106,20 @@ int mbx_fec_ambe3600x2450(const uint8_t* d_frames /* n*9 */, size_t n, mbx_param
 int mbx_fec_imbe7100x4400(const uint8_t* d_frames /* n*18 */, size_t n, mbx_param_record* d_records /* n */,
                           void* stream);
 
+/* The sub-stages of the frame decode one by one, as the reference exposes them for the classic
+ * ecc -> demodulate -> ecc call sequence (packed frames in, packed frames out; see mbx_fec.hip):
+ *   MBX_STAGE_C0          ref mbe_ecc{Imbe7200x4400,Imbe7100x4400,Ambe3600x2450,Ambe3600x2400}C0   mbelib.h:457,531,381,286
+ *   MBX_STAGE_DEMODULATE  ref mbe_demodulate*Data                                                  mbelib.h:463,535,387,307
+ *   MBX_STAGE_DATA        ref mbe_ecc*Data (parameter bits to d_out; 7100x4400 in its own bit order) mbelib.h:459,533,383,293
+ *   MBX_STAGE_CONVERT7100 ref mbe_convertImbe7100to7200 (d_in and d_out are parameter records)       mbelib.h:537
+ * d_out[i].w[3] = the reference's return value (corrected errors) in bits 0..7, the C4 count in bits 16..23. */
+#define MBX_STAGE_C0 1
+#define MBX_STAGE_DEMODULATE 2
+#define MBX_STAGE_DATA 4
+#define MBX_STAGE_CONVERT7100 8
+int mbx_fec_stage(int codec, int stage, const void* d_in, size_t n, uint8_t* d_frames_out /* C0, DEMODULATE */,
+                  mbx_param_record* d_out /* DATA, CONVERT7100 */, void* stream);
+
 /* ---- soft-decision FEC stage: soft frames -> parameter records ------
  * One wavefront per frame; exhaustive maximum-likelihood Golay/Hamming decode with the reference's
  * tie rules, bit-exact.  Frames keep the reference's own shapes: n x mbe_soft_bit[8][23] (IMBE) or
@@ -171,6 +185,12 @@ int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parm
 int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,
                          int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records,
                          void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ref: mbe_decodeImbe4400Parms / mbe_decodeAmbe2450Parms / mbe_decodeAmbe2400Parms  include/mbelib-neo/mbelib.h:461, 385, 301
+ * (src/imbe/imbe7200x4400.c:589-630, src/ambe/ambe3600x2450.c:555-634, src/ambe/ambe3600x2400.c:427-561): the parameter
+ * decode alone -- no frame policy, no synthesis -- for n (cur_mp, prev_mp) pairs.  d_rc[i] = the reference's return value. */
+int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe_parms* d_cur, mbe_parms* d_prev, int32_t* d_rc,
+                     void* stream);
 
 /* The same for a SUBSET of a larger resident pool of streams: batch row s (its T frames, records, PCM and results at
  * rows s*T .. s*T+T-1) belongs to the stream whose state / rng live in slot d_stream_index[s] of the pools.  The index

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "mbx_stream_expanded": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_batch_indexed": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_fec_stage": (C.c_int, [C.c_int, C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "mbx_decode_parms": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mbx_synthesize_speech": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_floattoshort": (C.c_int, [_vp, _vp, _sz, _vp]),
     "mbx_spectral_amp_enhance": (C.c_int, [C.c_int, _vp, _vp]),

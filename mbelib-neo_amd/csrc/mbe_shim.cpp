@@ -17,6 +17,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "mbe_neo_amd.h"
@@ -79,6 +80,7 @@ struct Slot {
     int16_t*          pcm16 = nullptr;    // 160
     mbe_process_result* res = nullptr;
     uint32_t*         words = nullptr;    // 4: in, out, errs
+    uint8_t*          frame_out = nullptr; // 18 bytes: a frame after one of the in-place sub-stages
     mbe_soft_bit*     soft = nullptr;     // one soft frame (184 cells)
     Slot() {
         std::call_once(g_once, init_once);
@@ -92,6 +94,7 @@ struct Slot {
         HIP_OK(hipMalloc(&pcm16, 160 * sizeof(int16_t)));
         HIP_OK(hipMalloc(&res, sizeof(mbe_process_result)));
         HIP_OK(hipMalloc(&words, 4 * sizeof(uint32_t)));
+        HIP_OK(hipMalloc(&frame_out, 32));
         HIP_OK(hipMalloc(&soft, MBX_IMBE_SOFT_BITS * sizeof(mbe_soft_bit)));   // the largest soft frame (184 cells)
     }
     void up(void* dst, const void* src, size_t n) { HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream)); }
@@ -217,6 +220,8 @@ int decode_frame(int codec, const char* cells, int ncell, int nbits, char* bits_
     return r.total_errors;
 }
 
+void sync_channel_for_direct_use(const mbe_parms* cur);   // queue mode, further down
+
 // mbe_process*Dataf: ref src/imbe/imbe7200x4400.c:858-909, src/ambe/ambe3600x2450.c:851-898
 int process_data(int codec, float* aout_f, short* aout_s, mbe_process_result* result, const char* bits, int nbits,
                  mbe_parms* cur, mbe_parms* prev, mbe_parms* enh) {
@@ -228,6 +233,7 @@ int process_data(int codec, float* aout_f, short* aout_s, mbe_process_result* re
     if ((!aout_f && !aout_s) || !cur || !prev || !enh) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
+    sync_channel_for_direct_use(cur);   // queue mode: a channel whose state lives on the device comes home first
     int total = 0;
     int rc = resolve_total_errors(result, &total);
     if (rc < 0) {
@@ -331,6 +337,419 @@ int decode_soft_frame(int codec, const mbe_soft_bit* cells, int ncell, int nbits
     }
     return r.total_errors;
 }
+
+
+struct FrameShapeLite {
+    int ncell, nbits;
+};
+FrameShapeLite frame_shape_lite(int codec) {
+    return codec == MBX_CODEC_IMBE7200X4400 ? FrameShapeLite{184, 88}
+           : codec == MBX_CODEC_IMBE7100X4400 ? FrameShapeLite{168, 88} : FrameShapeLite{96, 49};
+}
+
+// ==================================================================================================================
+// Queue mode (include/mbe_neo_amd.h): the hard-decision mbe_process*Frame[f] calls of a thread are recorded and run by
+// mbe_flush() as batched launches -- one mbx_process_batch_indexed() per (codec, frames-per-channel) group -- over a
+// pool of channel states that lives on the device.  Host work per queued frame: validation + packing (what the
+// synchronous call does on the host as well) and a 64-byte queue entry.
+// ==================================================================================================================
+struct QEntry {
+    void*               aout;
+    mbe_process_result* result;
+    char*               bits_out;
+    int                 channel;      // index into Batch::channels
+    uint8_t             codec;
+    uint8_t             want_short;
+    uint8_t             frame[MBX_IMBE_FRAME_BYTES];
+};
+
+struct QChannel {
+    mbe_parms *cur, *prev, *enh;
+    int  codec = -1;       // codec of the frames pending for this channel (one codec per channel and flush)
+    int  pending = 0;
+    int  first = -1;       // per-flush scratch: position of the channel inside its group
+    int  slot = -1;        // where its state lives in the device pool (resident mode: = channel index; write-back: per flush)
+    bool on_device = false;
+    mbx_stream_rng rng;    // the thread's RNG state at the channel's first queued frame; in write-back mode the channel's
+                           // own state between flushes (the reference keeps it per thread, here it is per channel)
+};
+
+template <class U>
+struct DevArr {   // grow-only device array
+    U*     p = nullptr;
+    size_t cap = 0;
+    void need(size_t n) {
+        if (n > cap) {
+            if (p) {
+                HIP_OK(hipFree(p));
+            }
+            cap = n + n / 2 + 64;
+            HIP_OK(hipMalloc(reinterpret_cast<void**>(&p), cap * sizeof(U)));
+        }
+    }
+};
+
+template <class U>
+struct PinArr {   // grow-only pinned host array
+    U*     p = nullptr;
+    size_t cap = 0;
+    void need(size_t n) {
+        if (n > cap) {
+            if (p) {
+                HIP_OK(hipHostFree(p));
+            }
+            cap = n + n / 2 + 64;
+            HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&p), cap * sizeof(U), hipHostMallocDefault));
+        }
+    }
+};
+
+struct Batch {
+    bool active = false;
+    int  mode = MBE_BATCH_STATE_WRITEBACK;
+    std::vector<QEntry>   q;
+    std::vector<QChannel> channels;                       // pool slot = index
+    std::unordered_map<const mbe_parms*, int> index;      // cur_mp -> channel
+    DevArr<mbe_parms>      d_state;                       // [channels][3]
+    DevArr<mbx_stream_rng> d_rng;
+    size_t                 resident = 0;                  // channels [0, resident) hold their state on the device
+    DevArr<uint8_t>            d_frames;
+    DevArr<mbx_param_record>   d_records;
+    DevArr<int16_t>            d_pcm16;
+    DevArr<float>              d_pcmf;
+    DevArr<mbe_process_result> d_results;
+    DevArr<int32_t>            d_index;
+    PinArr<uint8_t>            h_frames;
+    PinArr<mbx_param_record>   h_records;
+    PinArr<int16_t>            h_pcm16;
+    PinArr<float>              h_pcmf;
+    PinArr<mbe_process_result> h_results;
+    PinArr<int32_t>            h_index;
+    PinArr<mbe_parms>          h_state;
+    PinArr<mbx_stream_rng>     h_rng;
+};
+
+Batch& batch() {
+    thread_local Batch* b = new Batch();
+    return *b;
+}
+
+size_t frame_bytes_of(int codec) {
+    return (codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400) ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;
+}
+
+// grow the device pool to `n` channels, keeping what is resident
+void pool_reserve(Batch& b, Slot& s, size_t n) {
+    if (n <= b.d_state.cap / 3 && n <= b.d_rng.cap) {
+        return;
+    }
+    const size_t cap = n + n / 2 + 64;
+    mbe_parms* ns = nullptr;
+    mbx_stream_rng* nr = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&ns), cap * 3 * sizeof(mbe_parms)));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&nr), cap * sizeof(mbx_stream_rng)));
+    if (b.resident) {
+        HIP_OK(hipMemcpyAsync(ns, b.d_state.p, b.resident * 3 * sizeof(mbe_parms), hipMemcpyDeviceToDevice, s.stream));
+        HIP_OK(hipMemcpyAsync(nr, b.d_rng.p, b.resident * sizeof(mbx_stream_rng), hipMemcpyDeviceToDevice, s.stream));
+        s.sync();
+    }
+    if (b.d_state.p) {
+        HIP_OK(hipFree(b.d_state.p));
+        HIP_OK(hipFree(b.d_rng.p));
+    }
+    b.d_state.p = ns;
+    b.d_state.cap = cap * 3;
+    b.d_rng.p = nr;
+    b.d_rng.cap = cap;
+}
+
+// bring the state held in pool slots [first, first + count) back into the host structs of the channels that own them
+// (`owners[i]` = channel of slot first + i); with_rng: the per-channel RNG state as well
+void pool_download(Batch& b, Slot& s, size_t first, const std::vector<int>& owners, bool with_rng) {
+    const size_t count = owners.size();
+    if (count == 0) {
+        return;
+    }
+    b.h_state.need(count * 3);
+    s.down(b.h_state.p, b.d_state.p + 3 * first, count * 3 * sizeof(mbe_parms));
+    if (with_rng) {
+        b.h_rng.need(count);
+        s.down(b.h_rng.p, b.d_rng.p + first, count * sizeof(mbx_stream_rng));
+    }
+    s.sync();
+    for (size_t i = 0; i < count; ++i) {
+        QChannel& ch = b.channels[(size_t)owners[i]];
+        *ch.cur = b.h_state.p[3 * i + 0];
+        *ch.prev = b.h_state.p[3 * i + 1];
+        *ch.enh = b.h_state.p[3 * i + 2];
+        if (with_rng) {
+            ch.rng = b.h_rng.p[i];
+        }
+    }
+}
+
+int flush_batch(Batch& b) {
+    const size_t n = b.q.size();
+    if (n == 0) {
+        return 0;
+    }
+    Slot& s = slot();
+    // ---- state upload.  Resident mode: the channels first seen since the last flush, appended at slots [resident, total).
+    //      Write-back mode: every channel that has frames this time, at slots [0, k); nothing stays afterwards. ----
+    const size_t total = b.channels.size();
+    std::vector<int> upload;
+    size_t first_slot = 0;
+    if (b.mode == MBE_BATCH_STATE_RESIDENT) {
+        first_slot = b.resident;
+        for (size_t c = b.resident; c < total; ++c) {
+            b.channels[c].slot = (int)c;
+            upload.push_back((int)c);
+        }
+    } else {
+        for (size_t c = 0; c < total; ++c) {
+            if (b.channels[c].pending) {
+                b.channels[c].slot = (int)upload.size();
+                upload.push_back((int)c);
+            }
+        }
+    }
+    pool_reserve(b, s, first_slot + upload.size());
+    if (!upload.empty()) {
+        b.h_state.need(upload.size() * 3);
+        b.h_rng.need(upload.size());
+        for (size_t i = 0; i < upload.size(); ++i) {
+            QChannel& ch = b.channels[(size_t)upload[i]];
+            b.h_state.p[3 * i + 0] = *ch.cur;
+            b.h_state.p[3 * i + 1] = *ch.prev;
+            b.h_state.p[3 * i + 2] = *ch.enh;
+            b.h_rng.p[i] = ch.rng;
+            ch.on_device = true;
+        }
+        s.up(b.d_state.p + 3 * first_slot, b.h_state.p, upload.size() * 3 * sizeof(mbe_parms));
+        s.up(b.d_rng.p + first_slot, b.h_rng.p, upload.size() * sizeof(mbx_stream_rng));
+        b.resident = first_slot + upload.size();
+    }
+    // ---- groups of channels with the same codec and the same number of pending frames ----
+    struct Group {
+        int    codec, T;
+        size_t nch = 0, row0 = 0, byte0 = 0;    // channels, first batch row, byte offset of its frames
+        std::vector<int> members;
+    };
+    std::vector<Group> groups;
+    std::unordered_map<uint64_t, size_t> group_of;
+    for (size_t c = 0; c < total; ++c) {
+        QChannel& ch = b.channels[c];
+        if (ch.pending == 0) {
+            continue;
+        }
+        const uint64_t key = ((uint64_t)ch.codec << 32) | (uint32_t)ch.pending;
+        auto it = group_of.find(key);
+        if (it == group_of.end()) {
+            it = group_of.emplace(key, groups.size()).first;
+            groups.push_back(Group{ch.codec, ch.pending});
+        }
+        Group& g = groups[it->second];
+        ch.first = (int)g.nch++;
+        g.members.push_back((int)c);
+    }
+    size_t rows = 0, bytes = 0;
+    for (Group& g : groups) {
+        g.row0 = rows;
+        g.byte0 = bytes;
+        rows += g.nch * (size_t)g.T;
+        bytes += (g.nch * (size_t)g.T * frame_bytes_of(g.codec) + 15u) & ~(size_t)15u;   // frame arrays start 16-byte aligned
+    }
+    // row of every queue entry: group row0 + position of the channel * T + (how many of the channel's frames came before)
+    std::vector<size_t> row_of(n);
+    std::vector<int> seen(total, 0);
+    std::vector<size_t> group_idx(total);
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        for (int c : groups[gi].members) {
+            group_idx[(size_t)c] = gi;
+        }
+    }
+    b.h_frames.need(bytes);
+    b.h_index.need(total);
+    bool any_short = false, any_float = false;
+    for (size_t e = 0; e < n; ++e) {
+        const QEntry& qe = b.q[e];
+        const Group& g = groups[group_idx[(size_t)qe.channel]];
+        const size_t local = (size_t)b.channels[(size_t)qe.channel].first * (size_t)g.T + (size_t)seen[(size_t)qe.channel]++;
+        row_of[e] = g.row0 + local;
+        const size_t fb = frame_bytes_of(g.codec);
+        memcpy(b.h_frames.p + g.byte0 + local * fb, qe.frame, fb);
+        any_short |= qe.want_short != 0;
+        any_float |= qe.want_short == 0;
+    }
+    size_t idx0 = 0;
+    std::vector<size_t> index_off(groups.size());
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        index_off[gi] = idx0;
+        for (int c : groups[gi].members) {
+            b.h_index.p[idx0++] = b.channels[(size_t)c].slot;
+        }
+    }
+    b.d_frames.need(bytes);
+    b.d_index.need(total);
+    b.d_records.need(rows);
+    b.d_results.need(rows);
+    b.h_records.need(rows);
+    b.h_results.need(rows);
+    if (any_short) {
+        b.d_pcm16.need(rows * 160);
+        b.h_pcm16.need(rows * 160);
+    }
+    if (any_float) {
+        b.d_pcmf.need(rows * 160);
+        b.h_pcmf.need(rows * 160);
+    }
+    s.up(b.d_frames.p, b.h_frames.p, bytes);
+    s.up(b.d_index.p, b.h_index.p, idx0 * sizeof(int32_t));
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Group& g = groups[gi];
+        must(mbx_process_batch_indexed(g.codec, (int)g.nch, g.T, b.d_index.p + index_off[gi], b.d_frames.p + g.byte0, b.d_state.p,
+                                       b.d_rng.p, any_short ? b.d_pcm16.p + g.row0 * 160 : nullptr,
+                                       any_float ? b.d_pcmf.p + g.row0 * 160 : nullptr, b.d_results.p + g.row0,
+                                       b.d_records.p + g.row0, s.stream),
+             "mbx_process_batch_indexed");
+    }
+    if (any_short) {
+        s.down(b.h_pcm16.p, b.d_pcm16.p, rows * 160 * sizeof(int16_t));
+    }
+    if (any_float) {
+        s.down(b.h_pcmf.p, b.d_pcmf.p, rows * 160 * sizeof(float));
+    }
+    s.down(b.h_results.p, b.d_results.p, rows * sizeof(mbe_process_result));
+    s.down(b.h_records.p, b.d_records.p, rows * sizeof(mbx_param_record));
+    s.sync();
+    // ---- hand the outputs to the callers' buffers ----
+    for (size_t e = 0; e < n; ++e) {
+        const QEntry& qe = b.q[e];
+        const size_t r = row_of[e];
+        if (qe.want_short) {
+            memcpy(qe.aout, b.h_pcm16.p + r * 160, 160 * sizeof(int16_t));
+        } else {
+            memcpy(qe.aout, b.h_pcmf.p + r * 160, 160 * sizeof(float));
+        }
+        if (qe.result) {
+            *qe.result = b.h_results.p[r];
+        }
+        const int nbits = (qe.codec == MBX_CODEC_AMBE3600X2450 || qe.codec == MBX_CODEC_AMBE3600X2400) ? 49 : 88;
+        mbx_unpack_records(&b.h_records.p[r], 1, nbits, qe.bits_out, nullptr);
+    }
+    b.q.clear();
+    for (QChannel& ch : b.channels) {
+        ch.pending = 0;
+        ch.codec = -1;
+        ch.first = -1;
+    }
+    if (b.mode == MBE_BATCH_STATE_WRITEBACK) {   // the host structs are current again; nothing stays on the device
+        pool_download(b, s, 0, upload, true);
+        for (int c : upload) {
+            b.channels[(size_t)c].on_device = false;
+            b.channels[(size_t)c].slot = -1;
+        }
+        b.resident = 0;
+    }
+    return (int)n;
+}
+
+// forget one channel after bringing its state home (resident mode: the last channel takes its pool slot)
+void release_channel(Batch& b, int c) {
+    Slot& s = slot();
+    QChannel& ch = b.channels[(size_t)c];
+    const size_t last = b.channels.size() - 1;
+    if (ch.on_device) {   // resident mode: slot == channel index
+        pool_download(b, s, (size_t)c, std::vector<int>{c}, false);
+        if ((size_t)c != last) {
+            HIP_OK(hipMemcpyAsync(b.d_state.p + 3 * (size_t)c, b.d_state.p + 3 * last, 3 * sizeof(mbe_parms), hipMemcpyDeviceToDevice,
+                                  s.stream));
+            HIP_OK(hipMemcpyAsync(b.d_rng.p + c, b.d_rng.p + last, sizeof(mbx_stream_rng), hipMemcpyDeviceToDevice, s.stream));
+            s.sync();
+        }
+        b.resident = last;
+    }
+    b.index.erase(ch.cur);
+    if ((size_t)c != last) {
+        b.channels[(size_t)c] = b.channels[last];
+        if (b.channels[(size_t)c].on_device) {
+            b.channels[(size_t)c].slot = c;
+        }
+        b.index[b.channels[(size_t)c].cur] = c;
+    }
+    b.channels.pop_back();
+}
+
+// a synchronous call is about to use these structs: make sure the host copy is the current one
+void sync_channel_for_direct_use(const mbe_parms* cur) {
+    Batch& b = batch();
+    if (!b.active || b.index.empty()) {
+        return;
+    }
+    auto it = b.index.find(cur);
+    if (it != b.index.end()) {
+        (void)flush_batch(b);
+        release_channel(b, b.index.find(cur)->second);
+    }
+}
+
+// the queued form of mbe_process*Frame[f]
+int queue_frame(int codec, float* aout_f, short* aout_s, mbe_process_result* result, const char* cells, char* bits_out,
+                mbe_parms* cur, mbe_parms* prev, mbe_parms* enh) {
+    const FrameShapeLite sh = frame_shape_lite(codec);
+    if (!bits_out || (!aout_f && !aout_s) || !cur || !prev || !enh) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_bits(cells, (size_t)sh.ncell);
+    if (rc < 0) {
+        return rc;
+    }
+    Batch& b = batch();
+    auto it = b.index.find(cur);
+    int c;
+    if (it == b.index.end()) {
+        c = (int)b.channels.size();
+        QChannel ch;
+        ch.cur = cur;
+        ch.prev = prev;
+        ch.enh = enh;
+        ch.rng = t_rng.r;
+        b.channels.push_back(ch);
+        b.index.emplace(cur, c);
+    } else {
+        c = it->second;
+        QChannel& ch = b.channels[(size_t)c];
+        if (ch.prev != prev || ch.enh != enh) {
+            return MBE_STATUS_INVALID_ARGUMENT;   // a channel is its three structs; they cannot change while it is queued / resident
+        }
+        if (ch.pending && ch.codec != codec) {    // one codec per channel and flush: run what is queued first
+            (void)flush_batch(b);
+            return queue_frame(codec, aout_f, aout_s, result, cells, bits_out, cur, prev, enh);
+        }
+    }
+    QChannel& ch = b.channels[(size_t)c];
+    ch.codec = codec;
+    ch.pending++;
+    b.q.emplace_back();
+    QEntry& qe = b.q.back();
+    qe.aout = aout_s ? static_cast<void*>(aout_s) : static_cast<void*>(aout_f);
+    qe.want_short = aout_s ? 1 : 0;
+    qe.result = result;
+    qe.bits_out = bits_out;
+    qe.channel = c;
+    qe.codec = (uint8_t)codec;
+    rc = (codec == MBX_CODEC_IMBE7200X4400)   ? mbx_pack_imbe7200x4400(cells, 1, qe.frame)
+         : (codec == MBX_CODEC_IMBE7100X4400) ? mbx_pack_imbe7100x4400(cells, 1, qe.frame)
+                                              : mbx_pack_ambe3600x2450(cells, 1, qe.frame);
+    if (rc < 0) {
+        b.q.pop_back();
+        ch.pending--;
+        return rc;
+    }
+    return 0;
+}
+
+bool queueing() { return batch().active; }
 
 }  // namespace
 
@@ -471,6 +890,9 @@ int mbe_decodeImbe7100x4400Frame(const char imbe_fr[7][24], char imbe_d[88], mbe
 
 int mbe_processImbe7100x4400Framef(float* aout_buf, mbe_process_result* result, const char imbe_fr[7][24], char imbe_d[88],
                                    mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_IMBE7100X4400, aout_buf, nullptr, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    }
     mbe_process_result local;
     if (!result) {
         result = &local;
@@ -484,6 +906,9 @@ int mbe_processImbe7100x4400Framef(float* aout_buf, mbe_process_result* result, 
 
 int mbe_processImbe7100x4400Frame(short* aout_buf, mbe_process_result* result, const char imbe_fr[7][24], char imbe_d[88],
                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_IMBE7100X4400, nullptr, aout_buf, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    }
     if (!aout_buf) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -625,6 +1050,59 @@ int mbe_decodeAmbe3600x2450SoftFrame(const mbe_soft_bit ambe_fr[4][24], char amb
     return decode_soft_frame(MBX_CODEC_AMBE3600X2450, reinterpret_cast<const mbe_soft_bit*>(ambe_fr), 96, 49, ambe_d, result);
 }
 
+
+// ---- queue mode (include/mbe_neo_amd.h) -----------------------------------------------------------------------------
+int mbe_batchBegin(int state_mode) {
+    Batch& b = batch();
+    if (b.active || (state_mode != MBE_BATCH_STATE_WRITEBACK && state_mode != MBE_BATCH_STATE_RESIDENT)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    (void)slot();   // the thread's device scratch and stream exist from here on
+    b.active = true;
+    b.mode = state_mode;
+    return 0;
+}
+
+int mbe_flush(void) {
+    Batch& b = batch();
+    return b.active ? flush_batch(b) : 0;
+}
+
+int mbe_batchPending(void) { return (int)batch().q.size(); }
+
+int mbe_batchRelease(mbe_parms* cur_mp) {
+    Batch& b = batch();
+    if (!b.active || !cur_mp) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    (void)flush_batch(b);
+    auto it = b.index.find(cur_mp);
+    if (it != b.index.end()) {
+        release_channel(b, it->second);
+    }
+    return 0;
+}
+
+int mbe_batchEnd(void) {
+    Batch& b = batch();
+    if (!b.active) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    const int ran = flush_batch(b);
+    if (b.resident) {   // resident mode: slot == channel index
+        std::vector<int> owners(b.resident);
+        for (size_t c = 0; c < b.resident; ++c) {
+            owners[c] = (int)c;
+        }
+        pool_download(b, slot(), 0, owners, false);
+    }
+    b.channels.clear();
+    b.index.clear();
+    b.resident = 0;
+    b.active = false;
+    return ran;
+}
+
 // ---- frame decode ---------------------------------------------------------------------------
 int mbe_decodeImbe7200x4400Frame(const char imbe_fr[8][23], char imbe_d[88], mbe_process_result* result) {
     return decode_frame(MBX_CODEC_IMBE7200X4400, reinterpret_cast<const char*>(imbe_fr), 184, 88, imbe_d, result);
@@ -664,6 +1142,9 @@ int mbe_processAmbe2450Data(short* aout_buf, mbe_process_result* result, const c
 // ---- frames -> PCM: ref src/imbe/imbe7200x4400.c:935-1001, src/ambe/ambe3600x2450.c:924-990 ------
 int mbe_processImbe7200x4400Framef(float* aout_buf, mbe_process_result* result, const char imbe_fr[8][23], char imbe_d[88],
                                    mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_IMBE7200X4400, aout_buf, nullptr, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    }
     mbe_process_result local;
     if (!result) {
         result = &local;
@@ -677,6 +1158,9 @@ int mbe_processImbe7200x4400Framef(float* aout_buf, mbe_process_result* result, 
 
 int mbe_processImbe7200x4400Frame(short* aout_buf, mbe_process_result* result, const char imbe_fr[8][23], char imbe_d[88],
                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_IMBE7200X4400, nullptr, aout_buf, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    }
     if (!aout_buf) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -693,6 +1177,9 @@ int mbe_processImbe7200x4400Frame(short* aout_buf, mbe_process_result* result, c
 
 int mbe_processAmbe3600x2450Framef(float* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
                                    mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_AMBE3600X2450, aout_buf, nullptr, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    }
     mbe_process_result local;
     if (!result) {
         result = &local;
@@ -706,6 +1193,9 @@ int mbe_processAmbe3600x2450Framef(float* aout_buf, mbe_process_result* result, 
 
 int mbe_processAmbe3600x2450Frame(short* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_AMBE3600X2450, nullptr, aout_buf, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    }
     if (!aout_buf) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -875,6 +1365,9 @@ int mbe_processAmbe2400Data(short* aout_buf, mbe_process_result* result, const c
 
 int mbe_processAmbe3600x2400Framef(float* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
                                    mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_AMBE3600X2400, aout_buf, nullptr, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    }
     mbe_process_result local;
     if (!result) {
         result = &local;
@@ -888,6 +1381,9 @@ int mbe_processAmbe3600x2400Framef(float* aout_buf, mbe_process_result* result, 
 
 int mbe_processAmbe3600x2400Frame(short* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_AMBE3600X2400, nullptr, aout_buf, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    }
     if (!aout_buf) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
@@ -989,5 +1485,261 @@ int mbe_processAmbe3600x2450SoftFrame(short* aout_buf, mbe_process_result* resul
     }
     return mbe_processAmbe2450Data(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
+
+}  // extern "C"
+
+// ==================================================================================================================
+// The classic call sequence, stage by stage: ref include/mbelib-neo/mbelib.h:286-307, 381-387, 457-463, 531-537.
+// Each helper validates like the reference, runs its stage on the device (mbx_fec_stage: a slice of the frame kernel) and
+// writes back exactly the cells the reference writes.
+// ==================================================================================================================
+namespace {
+
+struct FrameShape {
+    int rows, stride, ncell, nbits, fbytes;
+    int width[8];
+    int first[8];   // first cell of each row that is on the wire (IMBE 7100x4400 C0 has cells 0..18, AMBE rows start at 0)
+};
+const FrameShape kShape[4] = {
+    {8, 23, 184, 88, MBX_IMBE_FRAME_BYTES, {23, 23, 23, 23, 15, 15, 15, 7}, {0, 0, 0, 0, 0, 0, 0, 0}},      // IMBE 7200x4400
+    {4, 24, 96, 49, MBX_AMBE_FRAME_BYTES, {24, 23, 11, 14, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}},           // AMBE 3600x2450
+    {7, 24, 168, 88, MBX_IMBE7100_FRAME_BYTES, {19, 24, 23, 23, 15, 15, 23, 0}, {0, 0, 0, 0, 0, 0, 0, 0}},   // IMBE 7100x4400
+    {4, 24, 96, 49, MBX_AMBE_FRAME_BYTES, {24, 23, 11, 14, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}},           // AMBE 3600x2400
+};
+
+int pack_cells(int codec, const char* cells, uint8_t* packed) {
+    return (codec == MBX_CODEC_IMBE7200X4400)   ? mbx_pack_imbe7200x4400(cells, 1, packed)
+           : (codec == MBX_CODEC_IMBE7100X4400) ? mbx_pack_imbe7100x4400(cells, 1, packed)
+                                                : mbx_pack_ambe3600x2450(cells, 1, packed);
+}
+
+// rows [r0, r1] of a packed frame back into the caller's cell array (the other cells are left alone, like the reference)
+void unpack_rows(int codec, const uint8_t* packed, char* cells, int r0, int r1) {
+    const FrameShape& sh = kShape[codec];
+    int pos = 0;
+    for (int r = 0; r < sh.rows; ++r) {
+        for (int j = sh.width[r] - 1; j >= 0; --j, ++pos) {
+            if (r >= r0 && r <= r1) {
+                cells[r * sh.stride + j] = (char)((packed[pos >> 3] >> (7 - (pos & 7))) & 1);
+            }
+        }
+    }
+}
+
+// stage 1 (C0 ECC) or 2 (demodulation), in place; returns the reference's return value
+int frame_stage(int codec, int stage, char* cells) {
+    const FrameShape& sh = kShape[codec];
+    int rc = validate_bits(cells, (size_t)sh.ncell);
+    if (rc < 0) {
+        return rc;
+    }
+    uint8_t packed[MBX_IMBE_FRAME_BYTES], back[MBX_IMBE_FRAME_BYTES];
+    rc = pack_cells(codec, cells, packed);
+    if (rc < 0) {
+        return rc;
+    }
+    Slot& s = slot();
+    s.up(s.frame, packed, (size_t)sh.fbytes);
+    must(mbx_fec_stage(codec, stage, s.frame, 1, s.frame_out, s.rec, s.stream), "mbx_fec_stage");
+    mbx_param_record rec;
+    s.down(back, s.frame_out, (size_t)sh.fbytes);
+    s.down(&rec, s.rec, sizeof(rec));
+    s.sync();
+    if (stage == MBX_STAGE_C0) {
+        if (codec == MBX_CODEC_IMBE7100X4400) {   // cells 1..18 of row 0 only (ref src/imbe/imbe7100x4400.c:100-122)
+            const char keep = cells[0];
+            unpack_rows(codec, back, cells, 0, 0);
+            cells[0] = keep;
+        } else {
+            unpack_rows(codec, back, cells, 0, 0);
+        }
+        return (int)(rec.w[3] & 0xffu);
+    }
+    const int last = (codec == MBX_CODEC_IMBE7200X4400) ? 6 : (codec == MBX_CODEC_IMBE7100X4400 ? 5 : 1);
+    unpack_rows(codec, back, cells, 1, last);
+    return 0;
+}
+
+int frame_data_ecc(int codec, char* cells, char* bits_out) {
+    const FrameShape& sh = kShape[codec];
+    if (!bits_out) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_bits(cells, (size_t)sh.ncell);
+    if (rc < 0) {
+        return rc;
+    }
+    uint8_t packed[MBX_IMBE_FRAME_BYTES];
+    rc = pack_cells(codec, cells, packed);
+    if (rc < 0) {
+        return rc;
+    }
+    Slot& s = slot();
+    s.up(s.frame, packed, (size_t)sh.fbytes);
+    must(mbx_fec_stage(codec, MBX_STAGE_DATA, s.frame, 1, nullptr, s.rec, s.stream), "mbx_fec_stage");
+    mbx_param_record rec;
+    s.down(&rec, s.rec, sizeof(rec));
+    s.sync();
+    mbx_unpack_records(&rec, 1, sh.nbits, bits_out, nullptr);
+    return (int)(rec.w[3] & 0xffu);
+}
+
+// mbe_decode*Parms: parameter decode alone (expand + prediction), both structs updated like the reference
+int decode_parms(int codec, const char* bits, int nbits, mbe_parms* cur, mbe_parms* prev) {
+    if (!cur || !prev) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int rc = validate_bits(bits, (size_t)nbits);
+    if (rc < 0) {
+        return rc;
+    }
+    mbe_process_result none;
+    memset(&none, 0, sizeof(none));
+    const mbx_param_record rec = make_record(bits, nbits, &none, 0);   // no error context: the tone gate stays open (total_errors < 0 in the reference)
+    Slot& s = slot();
+    s.up(s.rec, &rec, sizeof(rec));
+    s.up(&s.state[0], cur, sizeof(mbe_parms));
+    s.up(&s.state[1], prev, sizeof(mbe_parms));
+    must(mbx_decode_parms(codec, s.rec, 1, &s.state[0], &s.state[1], reinterpret_cast<int32_t*>(&s.words[0]), s.stream), "mbx_decode_parms");
+    int32_t ret = 0;
+    s.down(cur, &s.state[0], sizeof(mbe_parms));
+    s.down(prev, &s.state[1], sizeof(mbe_parms));
+    s.down(&ret, &s.words[0], sizeof(ret));
+    s.sync();
+    return (int)ret;
+}
+
+void dump_bits(const char* bits, int n, const int* gaps, int ngaps, bool trailing_space) {
+    if (!bits) {
+        return;
+    }
+    for (int i = 0; i < n; ++i) {
+        for (int g = 0; g < ngaps; ++g) {
+            if (gaps[g] == i) {
+                fprintf(stderr, " ");
+            }
+        }
+        fprintf(stderr, "%i", bits[i]);
+    }
+    if (trailing_space) {
+        fprintf(stderr, " ");
+    }
+}
+
+void dump_row(const char* row, int hi, int gap_at = -1) {
+    for (int j = hi; j >= 0; --j) {
+        if (j == gap_at) {
+            fprintf(stderr, " ");
+        }
+        fprintf(stderr, "%i", row[j]);
+    }
+}
+
+void dump_ambe_frame(const char fr[4][24]) {   // ref src/ambe/ambe3600x2450.c:113-142, src/ambe/ambe3600x2400.c:100-129
+    if (!fr) {
+        return;
+    }
+    static const int hi[4] = {23, 22, 10, 13};
+    for (int r = 0; r < 4; ++r) {
+        fprintf(stderr, "ambe_fr c%d: ", r);
+        dump_row(fr[r], hi[r]);
+        fprintf(stderr, " ");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mbe_eccImbe7200x4400C0(char imbe_fr[8][23]) { return frame_stage(MBX_CODEC_IMBE7200X4400, MBX_STAGE_C0, reinterpret_cast<char*>(imbe_fr)); }
+int mbe_demodulateImbe7200x4400Data(char imbe[8][23]) { return frame_stage(MBX_CODEC_IMBE7200X4400, MBX_STAGE_DEMODULATE, reinterpret_cast<char*>(imbe)); }
+int mbe_eccImbe7200x4400Data(char imbe_fr[8][23], char* imbe_d) { return frame_data_ecc(MBX_CODEC_IMBE7200X4400, reinterpret_cast<char*>(imbe_fr), imbe_d); }
+int mbe_decodeImbe4400Parms(const char* imbe_d, mbe_parms* cur_mp, mbe_parms* prev_mp) { return decode_parms(MBX_CODEC_IMBE7200X4400, imbe_d, 88, cur_mp, prev_mp); }
+
+int mbe_eccAmbe3600x2450C0(char ambe_fr[4][24]) { return frame_stage(MBX_CODEC_AMBE3600X2450, MBX_STAGE_C0, reinterpret_cast<char*>(ambe_fr)); }
+int mbe_demodulateAmbe3600x2450Data(char ambe_fr[4][24]) { return frame_stage(MBX_CODEC_AMBE3600X2450, MBX_STAGE_DEMODULATE, reinterpret_cast<char*>(ambe_fr)); }
+int mbe_eccAmbe3600x2450Data(char ambe_fr[4][24], char* ambe_d) { return frame_data_ecc(MBX_CODEC_AMBE3600X2450, reinterpret_cast<char*>(ambe_fr), ambe_d); }
+int mbe_decodeAmbe2450Parms(const char* ambe_d, mbe_parms* cur_mp, mbe_parms* prev_mp) { return decode_parms(MBX_CODEC_AMBE3600X2450, ambe_d, 49, cur_mp, prev_mp); }
+
+int mbe_eccAmbe3600x2400C0(char ambe_fr[4][24]) { return frame_stage(MBX_CODEC_AMBE3600X2400, MBX_STAGE_C0, reinterpret_cast<char*>(ambe_fr)); }
+int mbe_demodulateAmbe3600x2400Data(char ambe_fr[4][24]) { return frame_stage(MBX_CODEC_AMBE3600X2400, MBX_STAGE_DEMODULATE, reinterpret_cast<char*>(ambe_fr)); }
+int mbe_eccAmbe3600x2400Data(char ambe_fr[4][24], char* ambe_d) { return frame_data_ecc(MBX_CODEC_AMBE3600X2400, reinterpret_cast<char*>(ambe_fr), ambe_d); }
+int mbe_decodeAmbe2400Parms(const char* ambe_d, mbe_parms* cur_mp, mbe_parms* prev_mp) { return decode_parms(MBX_CODEC_AMBE3600X2400, ambe_d, 49, cur_mp, prev_mp); }
+
+int mbe_eccImbe7100x4400C0(char imbe_fr[7][24]) { return frame_stage(MBX_CODEC_IMBE7100X4400, MBX_STAGE_C0, reinterpret_cast<char*>(imbe_fr)); }
+int mbe_demodulateImbe7100x4400Data(char imbe[7][24]) { return frame_stage(MBX_CODEC_IMBE7100X4400, MBX_STAGE_DEMODULATE, reinterpret_cast<char*>(imbe)); }
+int mbe_eccImbe7100x4400Data(char imbe_fr[7][24], char* imbe_d) { return frame_data_ecc(MBX_CODEC_IMBE7100X4400, reinterpret_cast<char*>(imbe_fr), imbe_d); }
+
+int mbe_convertImbe7100to7200(char* imbe_d) {   // ref src/imbe/imbe7100x4400.c:381-438
+    int rc = validate_bits(imbe_d, 88u);
+    if (rc < 0) {
+        return rc;
+    }
+    mbe_process_result none;
+    memset(&none, 0, sizeof(none));
+    const mbx_param_record rec = make_record(imbe_d, 88, &none, 0);
+    Slot& s = slot();
+    s.up(s.rec, &rec, sizeof(rec));
+    mbx_param_record* d_out = reinterpret_cast<mbx_param_record*>(s.frame_out);   // 32 bytes: room for one record
+    must(mbx_fec_stage(MBX_CODEC_IMBE7100X4400, MBX_STAGE_CONVERT7100, s.rec, 1, nullptr, d_out, s.stream), "mbx_fec_stage");
+    mbx_param_record out;
+    s.down(&out, d_out, sizeof(out));
+    s.sync();
+    mbx_unpack_records(&out, 1, 88, imbe_d, nullptr);
+    return 0;
+}
+
+// ---- stderr dump helpers (host text only): formats of the reference, ref src/imbe/imbe7200x4400.c:356-418,
+//      src/imbe/imbe7100x4400.c:24-92, src/ambe/ambe3600x2450.c:91-142, src/ambe/ambe3600x2400.c:78-129 ----
+void mbe_dumpImbe4400Data(const char* imbe_d) { dump_bits(imbe_d, 88, nullptr, 0, false); }
+
+void mbe_dumpImbe7200x4400Data(const char* imbe_d) {
+    static const int gaps[7] = {12, 24, 36, 48, 59, 70, 81};
+    dump_bits(imbe_d, 88, gaps, 7, false);
+}
+
+void mbe_dumpImbe7200x4400Frame(const char imbe_fr[8][23]) {
+    if (!imbe_fr) {
+        return;
+    }
+    for (int i = 0; i < 4; ++i) {
+        dump_row(imbe_fr[i], 22);
+        fprintf(stderr, " ");
+    }
+    for (int i = 4; i < 7; ++i) {
+        dump_row(imbe_fr[i], 14);
+        fprintf(stderr, " ");
+    }
+    dump_row(imbe_fr[7], 6);
+}
+
+void mbe_dumpImbe7100x4400Data(const char* imbe_d) {
+    static const int gaps[6] = {7, 19, 31, 43, 54, 65};
+    dump_bits(imbe_d, 88, gaps, 6, false);
+}
+
+void mbe_dumpImbe7100x4400Frame(const char imbe_fr[7][24]) {
+    if (!imbe_fr) {
+        return;
+    }
+    dump_row(imbe_fr[0], 18, 11);
+    fprintf(stderr, " ");
+    dump_row(imbe_fr[1], 23, 11);
+    fprintf(stderr, " ");
+    for (int i = 2; i < 4; ++i) {
+        dump_row(imbe_fr[i], 22, 10);
+        fprintf(stderr, " ");
+    }
+    for (int i = 4; i < 6; ++i) {
+        dump_row(imbe_fr[i], 14, 3);
+        fprintf(stderr, " ");
+    }
+    dump_row(imbe_fr[6], 22);
+}
+
+void mbe_dumpAmbe2450Data(const char* ambe_d) { dump_bits(ambe_d, 49, nullptr, 0, true); }
+void mbe_dumpAmbe2400Data(const char* ambe_d) { dump_bits(ambe_d, 49, nullptr, 0, true); }
+void mbe_dumpAmbe3600x2450Frame(const char ambe_fr[4][24]) { dump_ambe_frame(ambe_fr); }
+void mbe_dumpAmbe3600x2400Frame(const char ambe_fr[4][24]) { dump_ambe_frame(ambe_fr); }
 
 }  // extern "C"

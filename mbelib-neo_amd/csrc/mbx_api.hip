@@ -39,6 +39,8 @@ __global__ void comfort_noise_kernel(int, mbx_stream_rng*, float*, int16_t*);
 __global__ void state_copy_kernel(int, mbe_parms*);
 __global__ void tone_kernel(int, const mbx_param_record*, const int32_t*, mbe_parms*, float*, int16_t*);
 __global__ void ecc_words_kernel(int, const uint32_t*, size_t, uint32_t*, int32_t*, DeviceTables);
+__global__ void fec_stage_kernel(int, int, const uint8_t*, size_t, uint8_t*, mbx_param_record*, DeviceTables);
+__global__ void decode_parms_kernel(int, int, const FrameParams*, mbe_parms*, mbe_parms*, int32_t*, DeviceTables);
 __global__ void fec_imbe7200x4400_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
 __global__ void fec_ambe3600x2450_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
 __global__ void fec_imbe7100x4400_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
@@ -1065,6 +1067,47 @@ void mbx_debug_set_ablation(int mask) {
     }
 }
 #endif
+
+int mbx_fec_stage(int codec, int stage, const void* d_in, size_t n, uint8_t* d_frames_out, mbx_param_record* d_out, void* stream) {
+    REQUIRE_CTX(c);
+    if (!d_in || codec < MBX_CODEC_IMBE7200X4400 || codec > MBX_CODEC_AMBE3600X2400
+        || !(stage == MBX_STAGE_C0 || stage == MBX_STAGE_DEMODULATE || stage == MBX_STAGE_DATA || stage == MBX_STAGE_CONVERT7100)
+        || ((stage == MBX_STAGE_DATA || stage == MBX_STAGE_CONVERT7100) && !d_out)
+        || ((stage == MBX_STAGE_C0 || stage == MBX_STAGE_DEMODULATE) && !d_frames_out)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::fec_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, codec, stage,
+                       static_cast<const uint8_t*>(d_in), n, d_frames_out, d_out, c->tabs);
+    return check_launch("fec_stage_kernel");
+}
+
+int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe_parms* d_cur, mbe_parms* d_prev, int32_t* d_rc,
+                     void* stream) {
+    REQUIRE_CTX(c);
+    if (!d_records || !d_cur || !d_prev || !d_rc || !expand_codec_ok(codec) || n > 0x7fffffffu) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    StreamSlot& slot = c->slots[stream];
+    int rc = ensure_workspace(c, slot, n, stream);
+    if (rc < 0) {
+        return rc;
+    }
+    slot.exp_codec = -1;
+    rc = launch_expand(c, codec, d_records, n, slot.workspace, stream);
+    if (rc < 0) {
+        return rc;
+    }
+    hipLaunchKernelGGL(mbx::decode_parms_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, codec, (int)n, slot.workspace,
+                       d_cur, d_prev, d_rc, c->tabs);
+    return check_launch("decode_parms_kernel");
+}
 
 const char* mbx_stream_kernel_name(int codec) {
     return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? "imbe_stream_kernel"

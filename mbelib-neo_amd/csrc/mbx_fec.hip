@@ -329,6 +329,181 @@ floattoshort_kernel(const float* __restrict__ in, int16_t* __restrict__ out, siz
 }
 
 
+// ------------------------------------------------------------------------------------------
+// The sub-stages of the frame decode as the reference exposes them one by one (in-place helpers of the classic
+// ecc -> demodulate -> ecc call sequence), batched: one thread per frame, packed frames in, packed frames out.
+//   stage 1  C0 ECC        mbe_eccImbe7200x4400C0 src/imbe/imbe7200x4400.c:424-443, mbe_eccAmbe3600C0_common
+//                          src/ambe/ambe_common.c:22-46, mbe_eccImbe7100x4400C0 src/imbe/imbe7100x4400.c:100-122
+//   stage 2  demodulation  mbe_demodulateImbe7200x4400Data :636-673, mbe_demodulateAmbe3600Data_common :75-100,
+//                          mbe_demodulateImbe7100x4400Data :292-334  (seed = the C0 data bits AS THEY ARE in the frame)
+//   stage 4  data ECC      mbe_eccImbe7200x4400Data :469-515,563-578, mbe_eccAmbe3600Data_common :127-157,
+//                          mbe_eccImbe7100x4400Data :153-212 (bits in 7100 order: no conversion here)
+//   stage 8  mbe_convertImbe7100to7200 src/imbe/imbe7100x4400.c:381-438 on a record (frames = records in, out = records)
+// out record: parameter bits of stage 4 / 8; w[3] = corrected-error count of the stage (bits 0..7), C4 errors (16..23).
+// These are slices of the frame kernels above, kept apart from them so that the hot kernels stay as they are.
+// ------------------------------------------------------------------------------------------
+struct BitWriter160 {
+    uint32_t w[5] = {0, 0, 0, 0, 0};
+    int      n = 0;
+    __device__ void push(uint32_t value, int width) {   // `width` bits, first = MSB of the field
+        for (int j = width - 1; j >= 0; --j, ++n) {
+            w[n >> 5] |= ((value >> j) & 1u) << (31 - (n & 31));
+        }
+    }
+    __device__ void store(uint8_t* p, int nbytes) const {
+        for (int b = 0; b < nbytes; ++b) {
+            p[b] = (uint8_t)(w[b >> 2] >> (24 - 8 * (b & 3)));
+        }
+    }
+};
+
+__device__ void convert_7100_to_7200(const mbx_tables* T, const Bits88& d, Bits88& t) {
+    const int b0 = (int)(((d.hi >> 56) & 0x7eull) << 1) | (d.get(86) << 1) | d.get(87);   // bits 1..6, 86, 87
+    const int K = (b0 < 208) ? (int)T->imbe_K[b0] : 12;
+    t.put(87, d.get(0));
+    t.put(48 + K, d.get(42));
+    t.put(49 + K, d.get(43));
+    for (int q = 0; q < K; ++q) {
+        t.put(48 + q, d.get(44 + q));
+    }
+    int j = 0, k = 1;
+    while (j < 87) {
+        t.put(j, d.get(k));
+        if (++j == 48) {
+            j += K + 2;
+        }
+        if (++k == 42) {
+            k += K + 2;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+fec_stage_kernel(int codec, int stage, const uint8_t* __restrict__ frames, size_t n, uint8_t* __restrict__ frames_out,
+                 mbx_param_record* __restrict__ out, DeviceTables tabs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const mbx_tables* T = tabs.t;
+    if (stage == 8) {   // records in, records out
+        const uint4 r = reinterpret_cast<const uint4*>(frames)[i];
+        Bits88 d, t;
+        d.hi = ((uint64_t)r.x << 32) | r.y;
+        d.lo = (uint64_t)r.z << 32;
+        convert_7100_to_7200(T, d, t);
+        reinterpret_cast<uint4*>(out)[i] = make_uint4((uint32_t)(t.hi >> 32), (uint32_t)t.hi, (uint32_t)(t.lo >> 32), 0u);
+        return;
+    }
+    const bool ambe = codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400;
+    const int fbytes = ambe ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;
+    const uint8_t* f = frames + i * (size_t)fbytes;
+    BitReader br;
+    for (int k = 0; k < 5; ++k) {
+        br.w[k] = 0;
+    }
+    for (int b = 0; b < fbytes; ++b) {
+        br.w[b >> 2] |= (uint32_t)f[b] << (24 - 8 * (b & 3));
+    }
+    int errs = 0, c4 = 0;
+    RecordWriter rw;
+    BitWriter160 bw;
+    uint32_t w;
+    if (codec == MBX_CODEC_IMBE7200X4400) {
+        const int width[8] = {23, 23, 23, 23, 15, 15, 15, 7};
+        uint32_t row[8];
+        for (int r = 0, pos = 0; r < 8; pos += width[r], ++r) {
+            row[r] = br.take(pos, width[r]);
+        }
+        if (stage == 1) {
+            errs = golay2312(T, row[0], row[0]);
+        } else if (stage == 2) {
+            PrSequence pr(row[0] >> 11);
+            for (int r = 1; r < 7; ++r) {
+                row[r] ^= pr.mask_for(width[r]);
+            }
+        } else {
+            rw.push(row[0], 23, 12);
+            for (int r = 1; r < 4; ++r) {
+                errs += golay2312(T, row[r], w);
+                rw.push(w, 23, 12);
+            }
+            for (int r = 4; r < 7; ++r) {
+                const int e = hamming1511(T, row[r], w);
+                errs += e;
+                c4 = (r == 4) ? e : c4;
+                rw.push(w, 15, 11);
+            }
+            rw.push(row[7], 7, 7);
+        }
+        for (int r = 0; r < 8; ++r) {
+            bw.push(row[r], width[r]);
+        }
+    } else if (codec == MBX_CODEC_IMBE7100X4400) {
+        const int width[7] = {19, 24, 23, 23, 15, 15, 23};
+        uint32_t row[7];
+        for (int r = 0, pos = 0; r < 7; pos += width[r], ++r) {
+            row[r] = br.take(pos, width[r]);
+        }
+        if (stage == 1) {   // cells 1..18 are the code word's low 18 positions, the five missing ones are zeros
+            errs = golay2312(T, (row[0] >> 1) & 0x3ffffu, w);
+            row[0] = ((w & 0x3ffffu) << 1) | (row[0] & 1u);
+        } else if (stage == 2) {
+            PrSequence pr((row[0] >> 12) & 0x7fu);
+            for (int r = 1; r < 6; ++r) {
+                row[r] ^= pr.mask_for(width[r]);
+            }
+        } else {
+            rw.push(row[0] >> 12, 7, 7);
+            errs += golay2312(T, row[1] >> 1, w);
+            rw.push(w, 23, 12);
+            errs += golay2312(T, row[2], w);
+            rw.push(w, 23, 12);
+            errs += golay2312(T, row[3], w);
+            rw.push(w, 23, 12);
+            c4 = hamming1511_7100(T, row[4], w);
+            errs += c4;
+            rw.push(w, 15, 11);
+            errs += hamming1511_7100(T, row[5], w);
+            rw.push(w, 15, 11);
+            rw.push(row[6], 23, 23);
+        }
+        for (int r = 0; r < 7; ++r) {
+            bw.push(row[r], width[r]);
+        }
+    } else {
+        uint32_t row0 = br.take(0, 24), row1 = br.take(24, 23), row2 = br.take(47, 11), row3 = br.take(58, 14);
+        if (stage == 1) {
+            errs = golay2312(T, row0 >> 1, w);
+            row0 = (w << 1) | (row0 & 1u);
+            if (errs == 0 && (__popc(row0) & 1)) {
+                row0 ^= 1u;
+                errs = 1;
+            }
+        } else if (stage == 2) {
+            PrSequence pr((row0 >> 12) & 0xfffu);
+            row1 ^= pr.mask_for(23);
+        } else {
+            rw.push(row0, 24, 12);
+            errs = golay2312(T, row1, w);
+            rw.push(w, 23, 12);
+            rw.push(row2, 11, 11);
+            rw.push(row3, 14, 14);
+        }
+        bw.push(row0, 24);
+        bw.push(row1, 23);
+        bw.push(row2, 11);
+        bw.push(row3, 14);
+    }
+    if (frames_out) {
+        bw.store(frames_out + i * (size_t)fbytes, fbytes);
+    }
+    if (out) {
+        reinterpret_cast<uint4*>(out)[i] = make_uint4((uint32_t)(rw.hi >> 32), (uint32_t)rw.hi, (uint32_t)(rw.lo >> 32),
+                                                      (uint32_t)errs | ((uint32_t)c4 << 16));
+    }
+}
+
 // Code-word level ECC (the public per-word helpers, batched): kind 0 = Golay(23,12), 1 = Hamming(15,11),
 // 2 = Hamming(15,11) with the IMBE 7100x4400 bit mapping (mbe_7100x4400hamming1511, src/ecc/ecc.c:422-464).
 //   ref mbe_golay2312 / mbe_checkGolayBlock src/ecc/ecc.c:221-301, mbe_hamming1511 src/ecc/ecc.c:366-408

@@ -1925,6 +1925,34 @@ comfort_noise_kernel(int S, mbx_stream_rng* __restrict__ rngs, float* __restrict
     store_rng(rng, &rngs[s], lane);
 }
 
+// mbe_decodeImbe4400Parms / mbe_decodeAmbe2450Parms / mbe_decodeAmbe2400Parms, batched: the stateful half of the parameter
+// decode (log-magnitude prediction from prev_mp) WITHOUT policy or synthesis, on FrameParams rows made by the expand
+// kernels.  One wavefront per (cur_mp, prev_mp) pair; both structs are updated the way the reference updates them (the
+// prediction memory of prev_mp is padded in place) and rc[i] is the reference's return value (0 voice, 1 invalid IMBE
+// fundamental, 2 erasure, 7 / tone index for tone frames).
+//   ref src/imbe/imbe7200x4400.c:589-630, src/ambe/ambe3600x2450.c:555-634, src/ambe/ambe3600x2400.c:427-561
+__global__ void __launch_bounds__(64)
+decode_parms_kernel(int codec, int n, const FrameParams* __restrict__ params, mbe_parms* __restrict__ curs,
+                    mbe_parms* __restrict__ prevs, int32_t* __restrict__ rc, DeviceTables tabs) {
+    __shared__ float fp[64];
+    const int i = blockIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const int lane = lane_id();
+    Parms cur, prev;
+    load_parms(cur, &curs[i], lane);
+    load_parms(prev, &prevs[i], lane);
+    fp[lane] = params[i].v[lane];
+    wave_lds_sync();
+    const int bad = (codec == MBX_CODEC_IMBE7200X4400) ? decode_imbe(fp, cur, prev, tabs.d, lane) : decode_ambe(fp, cur, prev, tabs, lane);
+    store_parms(cur, &curs[i], lane);
+    store_parms(prev, &prevs[i], lane);
+    if (lane == 0) {
+        rc[i] = bad;
+    }
+}
+
 // The state-I/O floor of the stream kernels: load the three structs and store them back.
 // Used by bench.py (--calibrate) to price the HBM traffic of the access pattern and to calibrate
 // the FETCH_SIZE / WRITE_SIZE counters on a known byte count.

@@ -94,6 +94,29 @@ def load():
     h.mbe_formatProcessResult.restype = None
     h.mbe_formatProcessResult.argtypes = [C.c_char_p, C.c_size_t, _vp]
     h.mbe_versionString.restype = C.c_char_p
+    for name in ("mbe_eccImbe7200x4400C0", "mbe_demodulateImbe7200x4400Data", "mbe_eccAmbe3600x2450C0", "mbe_demodulateAmbe3600x2450Data",
+                 "mbe_eccAmbe3600x2400C0", "mbe_demodulateAmbe3600x2400Data", "mbe_eccImbe7100x4400C0",
+                 "mbe_demodulateImbe7100x4400Data", "mbe_convertImbe7100to7200"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp]
+    for name in ("mbe_eccImbe7200x4400Data", "mbe_eccAmbe3600x2450Data", "mbe_eccAmbe3600x2400Data", "mbe_eccImbe7100x4400Data"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp, _vp]
+    for name in ("mbe_decodeImbe4400Parms", "mbe_decodeAmbe2450Parms", "mbe_decodeAmbe2400Parms"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = [_vp, _vp, _vp]
+    for name in ("mbe_dumpAmbe2400Data", "mbe_dumpAmbe3600x2400Frame", "mbe_dumpAmbe2450Data", "mbe_dumpAmbe3600x2450Frame",
+                 "mbe_dumpImbe4400Data", "mbe_dumpImbe7200x4400Data", "mbe_dumpImbe7200x4400Frame", "mbe_dumpImbe7100x4400Data",
+                 "mbe_dumpImbe7100x4400Frame"):
+        getattr(h, name).restype = None
+        getattr(h, name).argtypes = [_vp]
+    h.mbe_batchBegin.restype = C.c_int
+    h.mbe_batchBegin.argtypes = [C.c_int]
+    for name in ("mbe_flush", "mbe_batchPending", "mbe_batchEnd"):
+        getattr(h, name).restype = C.c_int
+        getattr(h, name).argtypes = []
+    h.mbe_batchRelease.restype = C.c_int
+    h.mbe_batchRelease.argtypes = [_vp]
     return h
 
 

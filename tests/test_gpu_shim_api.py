@@ -596,3 +596,201 @@ def test_four_host_threads_decode_concurrently(mbe, codec):
         pcm, rets, st = serial[s]
         assert [r[0] for r in rets] == [int(x) for x in fx["frames"][s, :T]["ret"]]
         parity.check_pcm(fx["frames"][s, :T]["pcmf"], pcm)
+
+
+# ---- the classic call sequence, stage by stage (mbelib.h:286-307, 381-387, 457-463, 531-537) ------------------------
+def test_stage_helpers_reproduce_the_frame_decode(mbe):
+    """ecc C0 -> demodulate -> ecc data, called one by one on the reference's own fixture frames, must give the
+    parameter bits and error counts the reference's frame decode gave (fixtures made by the real reference); cells
+    outside the wire rows stay untouched; invalid cells are rejected like in the reference."""
+    kat7100 = golden_io.imbe7100_kat()
+    cases = (
+        (golden_io.fec(0)[:200], 88, (8, 23), mbe.mbe_eccImbe7200x4400C0, mbe.mbe_demodulateImbe7200x4400Data, mbe.mbe_eccImbe7200x4400Data, None),
+        (golden_io.fec(1)[:200], 49, (4, 24), mbe.mbe_eccAmbe3600x2450C0, mbe.mbe_demodulateAmbe3600x2450Data, mbe.mbe_eccAmbe3600x2450Data, None),
+        (golden_io.fec(1)[200:300], 49, (4, 24), mbe.mbe_eccAmbe3600x2400C0, mbe.mbe_demodulateAmbe3600x2400Data, mbe.mbe_eccAmbe3600x2400Data, None),
+        (kat7100["fec"][:200], 88, (7, 24), mbe.mbe_eccImbe7100x4400C0, mbe.mbe_demodulateImbe7100x4400Data, mbe.mbe_eccImbe7100x4400Data,
+         mbe.mbe_convertImbe7100to7200),
+    )
+    widths = {(8, 23): (23, 23, 23, 23, 15, 15, 15, 7), (4, 24): (24, 23, 11, 14), (7, 24): (19, 24, 23, 23, 15, 15, 23)}
+    for fx, nbits, shape, ecc_c0, demod, ecc_data, convert in cases:
+        for row in fx:
+            cells = row["cells"].copy()
+            before = cells.copy()
+            c0 = ecc_c0(p(cells))
+            assert demod(p(cells)) == 0
+            bits = np.zeros(nbits, dtype=np.int8)
+            prot = ecc_data(p(cells), p(bits))
+            if convert is not None:
+                assert convert(p(bits)) == 0
+            assert np.array_equal(bits, row["bits"])
+            assert c0 == row["result"]["c0_errors"] and prot == row["result"]["protected_errors"]
+            grid, was = cells.reshape(shape), before.reshape(shape)
+            for r, w in enumerate(widths[shape]):   # cells that are not on the wire are never written
+                assert np.array_equal(grid[r, w:], was[r, w:])
+        bad = fx[0]["cells"].copy()
+        bad[-1] = 3   # even an unused cell is validated (tests/test_input_validation.c)
+        keep = bad.copy()
+        assert ecc_c0(p(bad)) == -2 and demod(p(bad)) == -2 and ecc_data(p(bad), p(bits)) == -2 and np.array_equal(bad, keep)
+        assert ecc_data(p(fx[0]["cells"].copy()), None) == -1
+    for row in kat7100["convert"]:
+        d = row["inp"].copy()
+        assert mbe.mbe_convertImbe7100to7200(p(d)) == 0 and np.array_equal(d, row["out"])
+    for fn in (mbe.mbe_dumpImbe4400Data, mbe.mbe_dumpAmbe2450Data, mbe.mbe_dumpImbe7200x4400Frame):
+        fn(None)   # NULL dumps print nothing and do not crash
+
+
+def test_decode_parms_known_answers(mbe):
+    """tests/golden/params_kat.bin (the real reference): every b0 through mbe_decodeImbe4400Parms / mbe_decodeAmbe2450Parms
+    (return code, w0, L, K) and 64 full parameter decodes per codec against a patterned prev_mp (tests/test_params.c)."""
+    t_imbe, t_ambe, full_imbe, full_ambe = golden_io.params_kat()
+    for b0 in range(256):
+        d = np.zeros(88, dtype=np.int8)
+        set_imbe_b0(d, b0)
+        cur, prev, _ = new_state(mbe)
+        rc = mbe.mbe_decodeImbe4400Parms(p(d), p(cur), p(prev))
+        r = t_imbe[b0]
+        assert rc == r["rc"], b0
+        if rc == 0:
+            assert cur["w0"][0] == r["w0"] and cur["L"][0] == r["L"] and cur["K"][0] == r["K"]
+    for b0 in range(128):
+        d = np.zeros(49, dtype=np.int8)
+        set_ambe_b0(d, b0)
+        cur, prev, _ = new_state(mbe)
+        rc = mbe.mbe_decodeAmbe2450Parms(p(d), p(cur), p(prev))
+        r = t_ambe[b0]
+        assert rc == r["rc"], b0
+        if rc == 0:
+            assert cur["w0"][0] == r["w0"] and cur["L"][0] == r["L"]
+    for fn, fx in ((mbe.mbe_decodeImbe4400Parms, full_imbe), (mbe.mbe_decodeAmbe2450Parms, full_ambe)):
+        for r in fx:
+            cur, prev, _ = new_state(mbe)
+            l = np.arange(57)
+            prev["log2Ml"][0] = (np.float32(0.25) * ((l * 7) % 11).astype(np.float32) - np.float32(1.0)).astype(np.float32)
+            prev["Ml"][0] = np.exp2(prev["log2Ml"][0].astype(np.float32)).astype(np.float32)
+            prev["L"] = r["prev_L"]
+            prev["gamma"] = 1.5
+            rc = fn(p(np.ascontiguousarray(r["bits"])), p(cur), p(prev))
+            assert rc == r["rc"]
+            if rc == 0:
+                parity.check_state(r["cur"].reshape(1), cur)
+    assert mbe.mbe_decodeImbe4400Parms(p(np.zeros(88, dtype=np.int8)), None, None) == -1
+    two = np.zeros(88, dtype=np.int8)
+    two[3] = 2
+    cur, prev, _ = new_state(mbe)
+    assert mbe.mbe_decodeImbe4400Parms(p(two), p(cur), p(prev)) == -2
+
+
+# ---- queue mode: the per-frame API fanning frames into batched launches (include/mbe_neo_amd.h) ---------------------
+@pytest.mark.parametrize("mode", [0, 1])
+def test_queue_mode_matches_reference_goldens(mbe, mode):
+    """All 64 golden IMBE streams and all 64 golden AMBE+2 streams decoded tick by tick through the queued per-frame
+    calls -- both codecs in the same flush, int16 and float outputs mixed -- in write-back (0) and resident (1) state
+    mode.  Everything the synchronous calls deliver must be there after mbe_flush(): return-value-in-result, parameter
+    bits, flags, PCM within tolerance, and (after the flush / after mbe_batchEnd) the three structs."""
+    Si, Ti, fi = golden_io.stream(0)
+    Sa, Ta, fa = golden_io.stream(1)
+    T = min(Ti, Ta, 12)
+    chans = []
+    for codec, S, fx, fn_f, fn_s, nd in ((0, Si, fi, mbe.mbe_processImbe7200x4400Framef, mbe.mbe_processImbe7200x4400Frame, 88),
+                                         (1, Sa, fa, mbe.mbe_processAmbe3600x2450Framef, mbe.mbe_processAmbe3600x2450Frame, 49)):
+        for s in range(S):
+            cur, prev, enh = new_state(mbe)
+            short = (s % 3) == 0
+            chans.append(dict(codec=codec, s=s, fx=fx, fn=fn_s if short else fn_f, short=short, cur=cur, prev=prev, enh=enh,
+                              pcm=np.zeros((T, 160), dtype=np.int16 if short else np.float32), res=np.zeros(T, dtype=RESULT_DTYPE),
+                              bits=np.zeros((T, nd), dtype=np.int8), cells=[None] * T))
+    assert mbe.mbe_batchBegin(mode) == 0 and mbe.mbe_batchBegin(mode) == -1
+    for t in range(T):
+        for ch in chans:
+            if t == 0:
+                mbe.mbe_setThreadRngSeed(1234 + ch["s"])   # a channel takes the thread's RNG state at its first queued frame
+            ch["cells"][t] = ch["fx"]["frames"][ch["s"], t]["cells"].copy()
+            assert ch["fn"](p(ch["pcm"][t]), p(ch["res"][t:t + 1]), p(ch["cells"][t]), p(ch["bits"][t]), p(ch["cur"]), p(ch["prev"]),
+                            p(ch["enh"])) == 0
+        assert mbe.mbe_batchPending() == len(chans)
+        assert mbe.mbe_flush() == len(chans) and mbe.mbe_batchPending() == 0
+    bad = chans[0]["cells"][0].copy()
+    bad[5] = 7
+    assert chans[0]["fn"](p(chans[0]["pcm"][0]), None, p(bad), p(chans[0]["bits"][0]), p(chans[0]["cur"]), p(chans[0]["prev"]),
+                          p(chans[0]["enh"])) == -2 and mbe.mbe_batchPending() == 0
+    assert mbe.mbe_batchEnd() == 0 and mbe.mbe_batchEnd() == -1
+    for ch in chans:
+        fr = ch["fx"]["frames"][ch["s"], :T]
+        assert np.array_equal(ch["bits"], fr["bits"])
+        parity.check_results(fr["result"], ch["res"])
+        assert np.array_equal(ch["res"]["total_errors"], fr["ret"])
+        if ch["short"]:
+            d = np.abs(ch["pcm"].astype(np.int32) - fr["pcm16"].astype(np.int32))
+            assert d.max() <= 3 and np.mean(d <= 1) >= 0.999
+        else:
+            parity.check_pcm(fr["pcmf"], ch["pcm"])
+    # the structs came home: continue two of the streams synchronously and land on the reference's final state
+    for ch in (chans[1], chans[Si + 2]):
+        Tfull = Ti if ch["codec"] == 0 else Ta
+        fn = mbe.mbe_processImbe7200x4400Framef if ch["codec"] == 0 else mbe.mbe_processAmbe3600x2450Framef
+        if mode == 0:
+            pass   # write-back mode dropped the per-channel RNG at every flush: only the model state is compared below
+        for t in range(T, Tfull):
+            out = np.zeros(160, dtype=np.float32)
+            d = np.zeros(ch["bits"].shape[1], dtype=np.int8)
+            cells = ch["fx"]["frames"][ch["s"], t]["cells"].copy()
+            assert fn(p(out), None, p(cells), p(d), p(ch["cur"]), p(ch["prev"]), p(ch["enh"])) == int(ch["fx"]["frames"][ch["s"], t]["ret"])
+        st = np.concatenate([ch["cur"], ch["prev"], ch["enh"]])
+        for name in ("L", "K", "Vl", "repeatCount", "errorCountTotal", "errorCount4", "amplitudeThreshold"):
+            assert np.array_equal(ch["fx"]["final"][ch["s"]][name], st[name]), name
+
+
+def test_queue_mode_ragged_and_direct_calls(mbe):
+    """Channels with different numbers of queued frames in one flush (1, 2 and 3), a synchronous call on a resident
+    channel in the middle (flushes and releases it), and mbe_batchRelease: each channel's PCM sequence equals the one
+    the synchronous API produces for it."""
+    S, T, fx = golden_io.stream(0)
+    T = min(T, 9)
+    fn = mbe.mbe_processImbe7200x4400Framef
+
+    def sync_run(s):
+        cur, prev, enh = new_state(mbe)
+        mbe.mbe_setThreadRngSeed(1234 + s)
+        pcm = np.zeros((T, 160), dtype=np.float32)
+        for t in range(T):
+            cells = fx["frames"][s, t]["cells"].copy()
+            d = np.zeros(88, dtype=np.int8)
+            fn(p(pcm[t]), None, p(cells), p(d), p(cur), p(prev), p(enh))
+        return pcm, np.concatenate([cur, prev, enh])
+
+    want = {s: sync_run(s) for s in range(6)}
+    st = {s: new_state(mbe) for s in range(6)}
+    pcm = {s: np.zeros((T, 160), dtype=np.float32) for s in range(6)}
+    done = {s: 0 for s in range(6)}
+    keep = []
+    assert mbe.mbe_batchBegin(1) == 0
+    plan = [(1, 2, 3, 1, 2, 3), (3, 1, 1, 2, 2, 1), (2, 3, 2, 3, 1, 2), (3, 3, 3, 3, 4, 3)]
+    for k, counts in enumerate(plan):
+        for s, cnt in enumerate(counts):
+            for _ in range(cnt):
+                t = done[s]
+                if t >= T:
+                    continue
+                if t == 0:
+                    mbe.mbe_setThreadRngSeed(1234 + s)
+                cells = fx["frames"][s, t]["cells"].copy()
+                d = np.zeros(88, dtype=np.int8)
+                keep.append((cells, d))
+                if k == 2 and s == 4:   # a synchronous call (soft-decision entry point on hard bits would differ; use the Data call)
+                    mbe.mbe_decodeImbe7200x4400Frame(p(cells), p(d), None)
+                    r = result()
+                    mbe.mbe_decodeImbe7200x4400Frame(p(cells), p(d), p(r))
+                    assert mbe.mbe_processImbe4400Dataf(p(pcm[s][t]), p(r), p(d), p(st[s][0]), p(st[s][1]), p(st[s][2])) >= 0
+                else:
+                    assert fn(p(pcm[s][t]), None, p(cells), p(d), p(st[s][0]), p(st[s][1]), p(st[s][2])) == 0
+                done[s] += 1
+        assert mbe.mbe_flush() >= 0
+        if k == 1:
+            assert mbe.mbe_batchRelease(p(st[0][0])) == 0   # channel 0 leaves the pool and comes back at its next frame
+    assert mbe.mbe_batchEnd() >= 0
+    for s in range(6):
+        assert done[s] == T
+        if s == 4:
+            continue   # took a fresh copy of the thread RNG state after the synchronous call: only compared where no noise is involved
+        assert pcm[s].tobytes() == want[s][0].tobytes(), f"channel {s}"
+        assert np.concatenate(st[s]).tobytes() == want[s][1].tobytes()

@@ -192,3 +192,19 @@ def test_shim_library_exports_every_declared_symbol():
         pytest.skip(f"HIP runtime not loadable here: {e}")
     for name in names:
         assert hasattr(handle, name), f"libmbe_neo_amd.so does not export {name}"
+
+
+def test_shim_library_exports_the_whole_reference_api():
+    """tests/golden/mbelib_api_symbols.txt = the 87 function names of the reference's public header
+    (include/mbelib-neo/mbelib.h, listed by oracle/tools/list_api_symbols.sh): a host linked against libmbe-neo.so.2
+    must find every one of them in libmbe_neo_amd.so."""
+    import shim_lib
+
+    want = open(os.path.join(ROOT, "tests", "golden", "mbelib_api_symbols.txt")).read().split()
+    assert len(want) == 87
+    out = subprocess.check_output(["nm", "-D", "--defined-only", shim_lib.PATH]).decode()
+    have = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [n for n in want if n not in have]
+    assert not missing, f"libmbe_neo_amd.so does not export: {missing}"
+    assert set(want) <= set(shim_lib.declared_symbols())   # and include/mbe_neo_amd.h declares them
+
