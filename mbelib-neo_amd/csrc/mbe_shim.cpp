@@ -69,9 +69,14 @@ void init_once() {
         }                                              \
     } while (0)
 
-// Per-thread device scratch for one frame.
+// Per-thread scratch for one frame, in PINNED HOST memory that the kernels read and write in place over PCIe (zero-copy):
+// a single 20 ms frame is a few KB, so what a synchronous call costs is launch + synchronise latency, and every
+// hipMemcpyAsync in front of or behind the kernels would add its own.  up() / down() on this block are plain host
+// memcpys (down() is deferred to sync()); on anything else they are DMA copies on the thread's stream (queue mode).
 struct Slot {
     hipStream_t       stream = nullptr;
+    uint8_t*          block = nullptr;    // one hipHostMalloc allocation holding everything below
+    size_t            block_bytes = 0;
     uint8_t*          frame = nullptr;    // 18 bytes
     mbx_param_record* rec = nullptr;
     mbe_parms*        state = nullptr;    // 3
@@ -82,24 +87,68 @@ struct Slot {
     uint32_t*         words = nullptr;    // 4: in, out, errs
     uint8_t*          frame_out = nullptr; // 18 bytes: a frame after one of the in-place sub-stages
     mbe_soft_bit*     soft = nullptr;     // one soft frame (184 cells)
+    struct Pending {
+        void*       dst;
+        const void* src;
+        size_t      n;
+    } pending[12];
+    int npending = 0;
     Slot() {
         std::call_once(g_once, init_once);
         HIP_OK(hipSetDevice(g_device));   // HIP's current device is per thread: every thread that decodes selects the library's
         HIP_OK(hipStreamCreate(&stream));
-        HIP_OK(hipMalloc(&frame, 32));
-        HIP_OK(hipMalloc(&rec, sizeof(mbx_param_record)));
-        HIP_OK(hipMalloc(&state, 3 * sizeof(mbe_parms)));
-        HIP_OK(hipMalloc(&rng, sizeof(mbx_stream_rng)));
-        HIP_OK(hipMalloc(&pcmf, 160 * sizeof(float)));
-        HIP_OK(hipMalloc(&pcm16, 160 * sizeof(int16_t)));
-        HIP_OK(hipMalloc(&res, sizeof(mbe_process_result)));
-        HIP_OK(hipMalloc(&words, 4 * sizeof(uint32_t)));
-        HIP_OK(hipMalloc(&frame_out, 32));
-        HIP_OK(hipMalloc(&soft, MBX_IMBE_SOFT_BITS * sizeof(mbe_soft_bit)));   // the largest soft frame (184 cells)
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            const size_t at = off;
+            off += (bytes + 63u) & ~(size_t)63u;
+            return at;
+        };
+        const size_t o_frame = take(32), o_rec = take(sizeof(mbx_param_record)), o_state = take(3 * sizeof(mbe_parms)),
+                     o_rng = take(sizeof(mbx_stream_rng)), o_pcmf = take(160 * sizeof(float)), o_pcm16 = take(160 * sizeof(int16_t)),
+                     o_res = take(sizeof(mbe_process_result)), o_words = take(4 * sizeof(uint32_t)), o_fout = take(32),
+                     o_soft = take(MBX_IMBE_SOFT_BITS * sizeof(mbe_soft_bit));   // the largest soft frame (184 cells)
+        block_bytes = off;
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&block), block_bytes, hipHostMallocDefault));   // coherent, device-visible
+        frame = block + o_frame;
+        rec = reinterpret_cast<mbx_param_record*>(block + o_rec);
+        state = reinterpret_cast<mbe_parms*>(block + o_state);
+        rng = reinterpret_cast<mbx_stream_rng*>(block + o_rng);
+        pcmf = reinterpret_cast<float*>(block + o_pcmf);
+        pcm16 = reinterpret_cast<int16_t*>(block + o_pcm16);
+        res = reinterpret_cast<mbe_process_result*>(block + o_res);
+        words = reinterpret_cast<uint32_t*>(block + o_words);
+        frame_out = block + o_fout;
+        soft = reinterpret_cast<mbe_soft_bit*>(block + o_soft);
     }
-    void up(void* dst, const void* src, size_t n) { HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream)); }
-    void down(void* dst, const void* src, size_t n) { HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream)); }
-    void sync() { HIP_OK(hipStreamSynchronize(stream)); }
+    bool mine(const void* p) const {
+        const uint8_t* q = static_cast<const uint8_t*>(p);
+        return q >= block && q < block + block_bytes;
+    }
+    void up(void* dst, const void* src, size_t n) {
+        if (mine(dst)) {
+            memcpy(dst, src, n);   // visible to every kernel launched after this point
+        } else {
+            HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream));
+        }
+    }
+    void down(void* dst, const void* src, size_t n) {
+        if (mine(src)) {
+            if (npending == (int)(sizeof(pending) / sizeof(pending[0]))) {
+                fprintf(stderr, "libmbe_neo_amd: too many deferred copies\n");
+                abort();
+            }
+            pending[npending++] = Pending{dst, src, n};   // the kernels have not run yet: copied by sync()
+        } else {
+            HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));
+        }
+    }
+    void sync() {
+        HIP_OK(hipStreamSynchronize(stream));
+        for (int i = 0; i < npending; ++i) {
+            memcpy(pending[i].dst, pending[i].src, pending[i].n);
+        }
+        npending = 0;
+    }
 };
 
 Slot& slot() {
@@ -751,6 +800,65 @@ int queue_frame(int codec, float* aout_f, short* aout_s, mbe_process_result* res
 
 bool queueing() { return batch().active; }
 
+// mbe_process*Frame[f], synchronous: frame decode + parameter processing in ONE device round trip (FEC, expand and stream
+// kernel back to back on the thread's stream, what mbx_process_batch does for S = T = 1).  The record the FEC kernel hands
+// to the stream stage is the one the reference's two calls hand over through imbe_d / result (c0, protected, c4, context
+// flags), so the outcome is that of mbe_decode*Frame followed by mbe_process*Dataf.  Argument errors that the reference
+// reports only AFTER the frame decode has written imbe_d / result take the two-call path below, which does the same.
+int process_frame(int codec, float* aout_f, short* aout_s, mbe_process_result* result, const char* cells, char* bits_out,
+                  mbe_parms* cur, mbe_parms* prev, mbe_parms* enh) {
+    const FrameShapeLite sh = frame_shape_lite(codec);
+    const int fec_codec = codec == MBX_CODEC_AMBE3600X2400 ? MBX_CODEC_AMBE3600X2450 : codec;   // shared AMBE front end
+    if (!bits_out || (!aout_f && !aout_s) || !cur || !prev || !enh) {
+        mbe_process_result local;
+        mbe_process_result* r = result ? result : &local;
+        const int rc = decode_frame(fec_codec, cells, sh.ncell, sh.nbits, bits_out, r);
+        if (rc < 0) {
+            return rc;
+        }
+        return process_data(codec, aout_f, aout_s, r, bits_out, sh.nbits, cur, prev, enh);
+    }
+    if (result) {
+        memset(result, 0, sizeof(*result));
+    }
+    int rc = validate_bits(cells, (size_t)sh.ncell);
+    if (rc < 0) {
+        return rc;
+    }
+    sync_channel_for_direct_use(cur);
+    Slot& s = slot();
+    rc = (codec == MBX_CODEC_IMBE7200X4400)   ? mbx_pack_imbe7200x4400(cells, 1, s.frame)
+         : (codec == MBX_CODEC_IMBE7100X4400) ? mbx_pack_imbe7100x4400(cells, 1, s.frame)
+                                              : mbx_pack_ambe3600x2450(cells, 1, s.frame);
+    if (rc < 0) {
+        return rc;
+    }
+    s.up(&s.state[0], cur, sizeof(mbe_parms));
+    s.up(&s.state[1], prev, sizeof(mbe_parms));
+    s.up(&s.state[2], enh, sizeof(mbe_parms));
+    s.up(s.rng, &t_rng.r, sizeof(mbx_stream_rng));
+    must(mbx_process_batch(codec, 1, 1, s.frame, s.state, s.rng, aout_s ? s.pcm16 : nullptr, aout_f ? s.pcmf : nullptr, s.res, s.rec,
+                           s.stream),
+         "mbx_process_batch");
+    s.sync();
+    if (aout_f) {
+        memcpy(aout_f, s.pcmf, 160 * sizeof(float));
+    }
+    if (aout_s) {
+        memcpy(aout_s, s.pcm16, 160 * sizeof(int16_t));
+    }
+    *cur = s.state[0];
+    *prev = s.state[1];
+    *enh = s.state[2];
+    t_rng.r = *s.rng;
+    mbx_unpack_records(s.rec, 1, sh.nbits, bits_out, nullptr);
+    const int total = s.res->total_errors;
+    if (result) {
+        *result = *s.res;
+    }
+    return total;
+}
+
 }  // namespace
 
 extern "C" {
@@ -893,34 +1001,18 @@ int mbe_processImbe7100x4400Framef(float* aout_buf, mbe_process_result* result, 
     if (queueing()) {
         return queue_frame(MBX_CODEC_IMBE7100X4400, aout_buf, nullptr, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
     }
-    mbe_process_result local;
-    if (!result) {
-        result = &local;
-    }
-    const int rc = mbe_decodeImbe7100x4400Frame(imbe_fr, imbe_d, result);
-    if (rc < 0) {
-        return rc;
-    }
-    return mbe_processImbe4400Dataf(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    return process_frame(MBX_CODEC_IMBE7100X4400, aout_buf, nullptr, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 int mbe_processImbe7100x4400Frame(short* aout_buf, mbe_process_result* result, const char imbe_fr[7][24], char imbe_d[88],
                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
-    if (queueing()) {
-        return queue_frame(MBX_CODEC_IMBE7100X4400, nullptr, aout_buf, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
-    }
     if (!aout_buf) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    mbe_process_result local;
-    if (!result) {
-        result = &local;
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_IMBE7100X4400, nullptr, aout_buf, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
     }
-    const int rc = mbe_decodeImbe7100x4400Frame(imbe_fr, imbe_d, result);
-    if (rc < 0) {
-        return rc;
-    }
-    return mbe_processImbe4400Data(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    return process_frame(MBX_CODEC_IMBE7100X4400, nullptr, aout_buf, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 // ---- tones and the status trace: ref src/core/mbelib.c:68-104 (format documented in mbelib.h:195-202), :745-856 ----
@@ -1145,34 +1237,18 @@ int mbe_processImbe7200x4400Framef(float* aout_buf, mbe_process_result* result, 
     if (queueing()) {
         return queue_frame(MBX_CODEC_IMBE7200X4400, aout_buf, nullptr, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
     }
-    mbe_process_result local;
-    if (!result) {
-        result = &local;
-    }
-    const int rc = mbe_decodeImbe7200x4400Frame(imbe_fr, imbe_d, result);
-    if (rc < 0) {
-        return rc;
-    }
-    return mbe_processImbe4400Dataf(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    return process_frame(MBX_CODEC_IMBE7200X4400, aout_buf, nullptr, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 int mbe_processImbe7200x4400Frame(short* aout_buf, mbe_process_result* result, const char imbe_fr[8][23], char imbe_d[88],
                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
-    if (queueing()) {
-        return queue_frame(MBX_CODEC_IMBE7200X4400, nullptr, aout_buf, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
-    }
     if (!aout_buf) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    mbe_process_result local;
-    if (!result) {
-        result = &local;
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_IMBE7200X4400, nullptr, aout_buf, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
     }
-    const int rc = mbe_decodeImbe7200x4400Frame(imbe_fr, imbe_d, result);
-    if (rc < 0) {
-        return rc;
-    }
-    return mbe_processImbe4400Data(aout_buf, result, imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    return process_frame(MBX_CODEC_IMBE7200X4400, nullptr, aout_buf, result, reinterpret_cast<const char*>(imbe_fr), imbe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 int mbe_processAmbe3600x2450Framef(float* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
@@ -1180,34 +1256,18 @@ int mbe_processAmbe3600x2450Framef(float* aout_buf, mbe_process_result* result, 
     if (queueing()) {
         return queue_frame(MBX_CODEC_AMBE3600X2450, aout_buf, nullptr, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
     }
-    mbe_process_result local;
-    if (!result) {
-        result = &local;
-    }
-    const int rc = mbe_decodeAmbe3600x2450Frame(ambe_fr, ambe_d, result);
-    if (rc < 0) {
-        return rc;
-    }
-    return mbe_processAmbe2450Dataf(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    return process_frame(MBX_CODEC_AMBE3600X2450, aout_buf, nullptr, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 int mbe_processAmbe3600x2450Frame(short* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
-    if (queueing()) {
-        return queue_frame(MBX_CODEC_AMBE3600X2450, nullptr, aout_buf, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
-    }
     if (!aout_buf) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    mbe_process_result local;
-    if (!result) {
-        result = &local;
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_AMBE3600X2450, nullptr, aout_buf, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
     }
-    const int rc = mbe_decodeAmbe3600x2450Frame(ambe_fr, ambe_d, result);
-    if (rc < 0) {
-        return rc;
-    }
-    return mbe_processAmbe2450Data(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    return process_frame(MBX_CODEC_AMBE3600X2450, nullptr, aout_buf, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 // ---- synthesis pieces --------------------------------------------------------------------------
@@ -1368,34 +1428,18 @@ int mbe_processAmbe3600x2400Framef(float* aout_buf, mbe_process_result* result, 
     if (queueing()) {
         return queue_frame(MBX_CODEC_AMBE3600X2400, aout_buf, nullptr, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
     }
-    mbe_process_result local;
-    if (!result) {
-        result = &local;
-    }
-    const int rc = mbe_decodeAmbe3600x2400Frame(ambe_fr, ambe_d, result);
-    if (rc < 0) {
-        return rc;
-    }
-    return mbe_processAmbe2400Dataf(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    return process_frame(MBX_CODEC_AMBE3600X2400, aout_buf, nullptr, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 int mbe_processAmbe3600x2400Frame(short* aout_buf, mbe_process_result* result, const char ambe_fr[4][24], char ambe_d[49],
                                   mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_enhanced) {
-    if (queueing()) {
-        return queue_frame(MBX_CODEC_AMBE3600X2400, nullptr, aout_buf, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
-    }
     if (!aout_buf) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    mbe_process_result local;
-    if (!result) {
-        result = &local;
+    if (queueing()) {
+        return queue_frame(MBX_CODEC_AMBE3600X2400, nullptr, aout_buf, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
     }
-    const int rc = mbe_decodeAmbe3600x2400Frame(ambe_fr, ambe_d, result);
-    if (rc < 0) {
-        return rc;
-    }
-    return mbe_processAmbe2400Data(aout_buf, result, ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
+    return process_frame(MBX_CODEC_AMBE3600X2400, nullptr, aout_buf, result, reinterpret_cast<const char*>(ambe_fr), ambe_d, cur_mp, prev_mp, prev_mp_enhanced);
 }
 
 int mbe_processAmbe3600x2400SoftFramef(float* aout_buf, mbe_process_result* result, const mbe_soft_bit ambe_fr[4][24],

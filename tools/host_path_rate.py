@@ -1,27 +1,33 @@
 #!/usr/bin/env python3
-"""Development aid (GPU box): PCIe-inclusive rate of the host-buffer convenience call
-mbx_process_batch_host (allocation + H2D + three launches + D2H, synchronous) -- never bench.py's value."""
+"""tools/host_path_rate.py [streams] -- end-to-end host-memory rates of the per-frame shim, its queue mode and the
+session API (mbelib-neo_amd/host_bench, a plain C program) on clean all-voiced IMBE frames; prints its JSON line."""
 import os
+import subprocess
 import sys
-import time
-
-import numpy as np
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from mbelib_neo_amd import decoder, framegen  # noqa: E402
-from mbelib_neo_amd.layout import init_state, rng_seeded  # noqa: E402
 
-S, T = 65536, 1
-frames = framegen.imbe_clean_voiced_frames(S * T, framegen.rng_for(7))
-state, rng = init_state(S), rng_seeded(np.arange(S) + 1234)
-out = decoder.process_batch_host(0, S, T, frames, state, rng)
-state, rng = out["state"], out["rng"]
-t0 = time.perf_counter()
-reps = 5
-for _ in range(reps):
-    out = decoder.process_batch_host(0, S, T, frames, state, rng)
-    state, rng = out["state"], out["rng"]
-dt = (time.perf_counter() - t0) / reps
-print(f"mbx_process_batch_host: {S*T/dt/1e6:.2f} M frames/s ({dt*1e3:.1f} ms per call; moves {S*3*2604*2/1e6:.0f} MB of state, "
-      f"{S*T*(18+320+640+20+16)/1e6:.0f} MB of frames/PCM/results over PCIe, plus allocation)")
+
+def run(streams=65536, device=0):
+    import mbelib_neo_amd as m
+    from mbelib_neo_amd import framegen
+
+    frames = framegen.imbe_clean_voiced_frames(streams, framegen.rng_for(0xBE0000))
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        f.write(frames.tobytes())
+        path = f.name
+    try:
+        exe = os.path.join(ROOT, "mbelib-neo_amd", "host_bench")
+        tables = os.path.join(ROOT, "mbelib-neo_amd", "data", "mbx_tables.bin")
+        out = subprocess.run([exe, tables, path, str(device)], capture_output=True, text=True, timeout=600)
+        if out.returncode != 0:
+            raise RuntimeError(f"host_bench failed ({out.returncode}): {out.stderr[-500:]}")
+        return out.stdout.strip().splitlines()[-1]
+    finally:
+        os.unlink(path)
+
+
+if __name__ == "__main__":
+    print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 65536))
