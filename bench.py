@@ -5,18 +5,30 @@ Metric (BASELINE.json): 20 ms frames/s, whole job, IMBE 7200x4400.
 Workload (default, BASELINE.json configs[1]): 65,536 streams per GPU x T=1 frame per step,
 clean-encoded all-voiced IMBE frames, state warmed by one identical frame so both the
 previous and the current model are voiced.  One "step" = one pass of the hot path
-(FEC kernel + stream kernel = mbx_process_batch) over the whole batch with every input
-already resident in HBM.  Streams are independent, so N GPUs = N independent shards
-(weak scaling, no data-path collective); the only collective is the RCCL broadcast of the
-constant-table blob at start-up (plus timing reductions).
+(mbx_process_batch: FEC kernel, parameter-expansion kernel, stream kernel) over the whole batch
+with every input already resident in HBM.  Streams are independent, so N GPUs = N independent
+shards (weak scaling, no data-path collective); the only collective is the RCCL broadcast of the
+constant-table blob at start-up (plus the timing reduction and the checksum all-gather).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload imbe_voiced|imbe_mixed|ambe_fec|ambe_stream]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-Prints ONE JSON line on rank 0.
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) bench.py starts the N ranks itself
+(child processes, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before anything touches a GPU) and
+relays rank 0's line; under torch.distributed.run it is one of the ranks.  `--workload ambe_stream
+--gpus 8` is BASELINE configs[4] (8 x 8,192 AMBE+2 streams x T = 128).
+
+Prints ONE JSON line on rank 0.  At N = 1 with the default workload the line also carries
+`other_configs` (the other three GPU configs of BASELINE.json, 10 steps each), `cpu_baseline` (+ the
+list `cpu_baselines`: the reference's scalar and SIMD builds, full path and its own bench_synth /
+bench_unvoiced recipes, one core and all cores), `host_path` (what a C host sees from host memory to
+host memory) and `no_reverse` (the headline with the alternating stream order switched off).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 (non-MFMA) peak
 
 WORKLOADS = {
     # name: (codec, streams per GPU, T, description)
@@ -40,6 +53,7 @@ WORKLOADS = {
     "imbe_soft": (0, 65536, 1, "65,536 IMBE 7200x4400 streams x T=1, soft-decision frames (noisy observations of random bits)"),
     "ambe_soft": (1, 65536, 1, "65,536 AMBE+2 3600x2450 streams x T=1, soft-decision frames (noisy observations of random bits)"),
 }
+CODEC_NAME = {0: "IMBE 7200x4400", 1: "AMBE+2 3600x2450", 2: "IMBE 7100x4400", 3: "AMBE 3600x2400"}
 
 
 def make_frames(name, codec, S, T, rank):
@@ -53,9 +67,6 @@ def make_frames(name, codec, S, T, rank):
     if name.endswith("_soft"):
         return framegen.soft_frames(codec, S * T, rng)
     return framegen.random_frames(codec, S * T, rng)
-
-
-VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 (non-MFMA) peak
 
 
 def nominal_flops_per_frame(workload):
@@ -75,22 +86,38 @@ def algorithmic_bytes_per_launch(codec, S, T):
     return S * T * b_io + S * 2 * 3 * 2604
 
 
+def soft_fec_bytes_per_launch(codec, n):
+    """soft-decision FEC kernel: the mbe_soft_bit frame in (2 B per cell) + the 16-byte parameter record out"""
+    return n * ({0: 184, 1: 96, 2: 168, 3: 96}[codec] * 2 + 16)
+
+
+def library_sha():
+    from mbelib_neo_amd import _native
+
+    return hashlib.sha256(open(_native.library_path(), "rb").read()).hexdigest()[:16]
+
+
 def measured_traffic(workload, S, T):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary of this
-    workload and size (profiles/rNN/<workload>_pmc.json, written by tools/profile_round.sh: FETCH_SIZE
-    and WRITE_SIZE in separate rocprofv3 passes, each calibrated on state_copy_kernel's known byte
-    count).  PMC counters cannot be read from inside this process; None when no summary matches."""
+    """HBM bytes per launch of the dominant kernel from a committed PMC summary of this workload and size
+    (profiles/rNN/<workload>_pmc.json, written by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate
+    rocprofv3 passes, each calibrated on state_copy_kernel's known byte count).  PMC counters cannot be read from
+    inside this process, so the summary must come from the SAME build: it records the sha256 of libmbx_hip.so it was
+    taken with, and a summary of another build gives (None, reason)."""
     import glob
 
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc.json"))):
+    sha = library_sha()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
         if d.get("streams_per_gpu") == S and d.get("frames_per_stream_per_step") == T and "dominant_kernel" in d:
-            best = (d["dominant_kernel"]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
-    return best
+            rel = os.path.relpath(path, ROOT)
+            if d.get("libmbx_hip_sha256_16") == sha:
+                return d["dominant_kernel"]["traffic_bytes_per_launch"], rel
+            stale = stale or f"{rel} was taken with another build of libmbx_hip.so ({d.get('libmbx_hip_sha256_16', 'unrecorded')} != {sha})"
+    return None, stale or "no PMC summary for this workload and size"
 
 
 def unpack_cells(codec, frames):
@@ -107,30 +134,41 @@ def unpack_cells(codec, frames):
     return cells.reshape(frames.shape[0], rows * cols)
 
 
-def reference_baseline(name, codec, T, budget_s=12.0):
-    """The REAL reference (oracle/_ref/libmbe_ref.so, IEEE scalar build made by oracle/Makefile from the reference's
-    own sources) through oracle/tools/ref_bench.c, ONE host core, bounded sample.  None when the library is absent."""
+# ---- CPU baselines ------------------------------------------------------------------------------------------------
+def _ref_lib(simd):
     import ctypes as C
 
-    path = os.path.join(ROOT, "oracle", "_ref", "libref_bench.so")
-    if not os.path.exists(path) or name.endswith("_soft"):
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_bench_simd.so" if simd else "libref_bench.so")
+    if not os.path.exists(path):
         return None
     try:
         lib = C.CDLL(path)
     except OSError:
         return None
+    lib.ref_process_batch_mt.restype = C.c_int
+    lib.ref_process_batch_mt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+    lib.ref_bench_recipe.restype = C.c_double
+    lib.ref_bench_recipe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    return lib
+
+
+def reference_full_path(name, codec, T, simd, threads, budget_s):
+    """The REAL reference (oracle/_ref: its own sources built -O2 IEEE by oracle/Makefile, scalar or with its SSE2 / PFFFT-SIMD
+    paths) through oracle/tools/ref_bench.c on a bounded sample of the same workload.  None when the library is absent."""
     from mbelib_neo_amd.layout import FRAME_CELLS, init_state
 
-    lib.ref_process_batch.restype = C.c_int
-    lib.ref_process_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
-    S = 4096 if T == 1 else max(64, 4096 // T)
+    lib = _ref_lib(simd)
+    if lib is None or name.endswith("_soft"):
+        return None
+    per = (4096 if threads == 1 else 1024) if T == 1 else max(64, 4096 // T)
+    S = per * threads
     cells = np.ascontiguousarray(unpack_cells(codec, make_frames(name, codec, S, T, rank=0)))
     ncell = FRAME_CELLS[codec][0] * FRAME_CELLS[codec][1]
     state = np.ascontiguousarray(init_state(S))
     pcm = np.zeros((S * T, 160), dtype=np.int16)
 
     def once():
-        rc = lib.ref_process_batch(codec, S, T, cells.ctypes.data, ncell, state.ctypes.data, 1234, pcm.ctypes.data)
+        rc = lib.ref_process_batch_mt(codec, S, T, cells.ctypes.data, ncell, state.ctypes.data, 1234, pcm.ctypes.data, threads)
         assert rc == 0, rc
 
     once()   # warm-up pass (also warms the state, like the GPU run)
@@ -141,22 +179,45 @@ def reference_baseline(name, codec, T, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s:
             break
+    build = "SSE2 + PFFFT SIMD (MBELIB_ENABLE_SIMD=1)" if simd else "scalar (SIMD off)"
     return {
         "value": done / dt,
         "unit": "frames/s",
-        "cores": 1,
+        "cores": threads,
         "kind": "reference",
-        "sample": f"{done} frames ({S} streams x T={T}, same generator as the GPU workload) in {dt:.1f} s, single thread, "
-                  "the reference's own sources built -O2 IEEE scalar (oracle/_ref/libmbe_ref.so), int16 output",
+        "build": "simd" if simd else "scalar",
+        "recipe": "full path (mbe_process*Frame, int16 out) on the bench workload",
+        "sample": f"{done} frames ({S} streams x T={T}, same generator as the GPU workload) in {dt:.1f} s on {threads} thread(s), "
+                  f"the reference's own sources built -O2 IEEE, {build}",
     }
 
 
-def cpu_baseline(name, codec, T, budget_s=12.0):
-    """CPU baseline on ONE host core, on a bounded sample of the same workload: the real reference when its
-    library travelled with the snapshot, else the CPU oracle (a port of the reference path, oracle/mbx_oracle.c)."""
-    ref = reference_baseline(name, codec, T, budget_s)
-    if ref is not None:
-        return ref
+def reference_recipe(recipe, simd):
+    """bench/bench_synth.c:40-67 (recipe 0) / bench/bench_unvoiced.c:33-52,87-100 (recipe 1) of the reference, as
+    functions of oracle/tools/ref_bench.c: 2,000 frames of mbe_synthesizeSpeechf per run, best of 5, one core."""
+    import ctypes as C
+
+    lib = _ref_lib(simd)
+    if lib is None:
+        return None
+    frames, runs = 2000, 5
+    sink = C.c_float()
+    lib.ref_bench_recipe(recipe, 200, 1, C.byref(sink))
+    best = lib.ref_bench_recipe(recipe, frames, runs, C.byref(sink))
+    return {
+        "value": frames / best,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "reference",
+        "build": "simd" if simd else "scalar",
+        "recipe": "bench_synth (L=40, mixed voicing, w0 alternating)" if recipe == 0 else "bench_unvoiced (L=36, all unvoiced)",
+        "us_per_frame": best / frames * 1e6,
+        "sample": f"{frames} frames of mbe_synthesizeSpeechf, best of {runs} runs ({best * 1e3:.1f} ms), single thread",
+    }
+
+
+def oracle_port_baseline(name, codec, T, budget_s):
+    """the CPU oracle (oracle/mbx_oracle.c, a port of the reference path) when the reference build has not travelled"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
@@ -177,13 +238,201 @@ def cpu_baseline(name, codec, T, budget_s=12.0):
         if dt >= budget_s:
             break
     return {
-        "value": done / dt,
-        "unit": "frames/s",
-        "cores": 1,
-        "kind": "port",
+        "value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port", "build": "scalar",
+        "recipe": "full path on the bench workload",
         "sample": f"{done} frames ({S} streams x T={T}, same generator as the GPU workload) in {dt:.1f} s, single thread, "
                   "oracle/mbx_oracle.c -O2 IEEE",
     }
+
+
+def host_cpu_share():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each
+    GPU a share of the host's cores; threads beyond it only time-slice)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baselines(name, codec, T, full=True):
+    """All CPU numbers of the line.  The first entry of the returned list is `cpu_baseline`: what north_star names -- the
+    reference's SIMD build on the host cores of this box (all of them, count stated) -- or, without the reference
+    build, the oracle port on one core.  Total budget about 25 s."""
+    ncpu = host_cpu_share()
+    out = []
+    main = reference_full_path(name, codec, T, simd=True, threads=ncpu, budget_s=4.0)
+    if main is None:
+        main = reference_full_path(name, codec, T, simd=False, threads=ncpu, budget_s=4.0)
+    if main is None:
+        return [oracle_port_baseline(name, codec, T, 10.0)], ncpu
+    out.append(main)
+    if full:
+        for simd, threads in ((True, 1), (False, 1), (False, ncpu)):
+            r = reference_full_path(name, codec, T, simd=simd, threads=threads, budget_s=3.0)
+            if r is not None:
+                out.append(r)
+        for recipe in (0, 1):
+            for simd in (True, False):
+                r = reference_recipe(recipe, simd)
+                if r is not None:
+                    out.append(r)
+    return out, ncpu
+
+
+# ---- multi-GPU self-launch ------------------------------------------------------------------------------------------
+def self_launch(argv, n, script=None):
+    """Start the n ranks as child processes of this (GPU-free) process and relay rank 0's output.  Nothing here imports
+    torch or touches HIP; a process that has initialised the GPU is never replaced."""
+    script = script or os.path.abspath(__file__)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(rcs) if min(rcs) >= 0 else 1
+
+
+# ---- one workload on this rank's GPU ----------------------------------------------------------------------------------
+def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args):
+    """Returns the measurements of one workload: wall time of `steps` steps (max over ranks), HIP-event time of the
+    dominant kernel, frame mix.  The launches of a step are what mbx_process_batch issues; they are issued one by one
+    here only so that the dominant kernel can be bracketed by events on the launch stream."""
+    import torch
+
+    from mbelib_neo_amd import _native, decoder
+
+    codec = WORKLOADS[name][0]
+    frames = make_frames(name, codec, S, T, rank)
+    dec = decoder.BatchDecoder(codec, S, device=local_rank, seeds=np.arange(first_stream, first_stream + S) + 1234, tables_blob=blob)
+    d_frames = dec.to_device(frames)
+    out = dec.make_outputs(T, want_pcm16=True, want_float=False, want_results=True)
+    L = _native.lib()
+    if args.ablate and not hasattr(L, "mbx_debug_set_ablation"):
+        raise SystemExit("--ablate needs the development build: make -C mbelib-neo_amd/csrc ablate && "
+                         "MBX_HIP_LIBRARY=$PWD/mbelib-neo_amd/libmbx_hip_ablate.so python bench.py --ablate MASK")
+    stream = torch.cuda.current_stream().cuda_stream
+    _native.check(L.mbx_reserve_stream(stream, S * T), "mbx_reserve_stream")  # launches below never allocate
+    soft = name.endswith("_soft")
+    if soft:
+        def fec(frames_ptr, count, records_ptr, strm):
+            return L.mbx_fec_soft(codec, frames_ptr, count, records_ptr, strm)
+    else:
+        fec = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400, 3: L.mbx_fec_ambe3600x2450}[codec]
+    n = S * T
+    stream_codec = 0 if codec == 2 else codec   # 7100x4400 records are in 7200x4400 order after its FEC stage
+    # mbx_process_records is ONE launch for IMBE at T > 1 (expansion fused into the stream kernel); otherwise it is the
+    # expand launch + the stream launch.  --split-expand forces the separate launch for IMBE at T > 1 (development aid).
+    split = (codec in (1, 3)) or (T == 1 and not args.fuse_expand) or args.split_expand
+
+    def step(ev=None):
+        if ev is not None and soft:
+            ev[0].record()
+        _native.check(fec(d_frames.data_ptr(), n, out["records"].data_ptr(), stream), "fec")
+        if ev is not None and soft:
+            ev[1].record()
+        run = L.mbx_process_records
+        if split:
+            _native.check(L.mbx_expand_records(stream_codec, out["records"].data_ptr(), n, stream), "expand")
+            run = L.mbx_stream_expanded
+        if ev is not None and not soft:
+            ev[0].record()
+        _native.check(
+            run(stream_codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
+                out["pcm16"].data_ptr(), None, out["results"].data_ptr(), stream),
+            "stream",
+        )
+        if ev is not None and not soft:
+            ev[1].record()
+
+    for _ in range(max(1, warmup)):  # the first pass also warms the model state
+        step()
+    if args.ablate:
+        L.mbx_debug_set_ablation(args.ablate)  # development build only (tools/); never in a reported run
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    if world > 1:
+        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, kernel_ms = float(t[0]), float(t[1])
+    flags = decoder.results_numpy(out["results"])["flags"]
+    pcm_digest = int(out["pcm16"].to(torch.int64).sum().item())
+    if soft:
+        kernel = {0: "fec_imbe7200x4400_soft_kernel", 1: "fec_ambe3600x2450_soft_kernel", 2: "fec_imbe7100x4400_soft_kernel",
+                  3: "fec_ambe3600x2450_soft_kernel"}[codec]
+        alg_bytes = soft_fec_bytes_per_launch(codec, n)
+    else:
+        kernel = L.mbx_stream_kernel_name(codec).decode()
+        if codec == 1 and T >= 4 and S == 8192:
+            kernel = "ambe_stream_kernel_w4"
+        alg_bytes = algorithmic_bytes_per_launch(codec, S, T)
+    del dec, d_frames, out
+    torch.cuda.empty_cache()
+    return {
+        "dt": dt, "kernel_ms": kernel_ms, "kernel": kernel, "alg_bytes": alg_bytes, "frames_per_step": world * n,
+        "value": world * n * steps / dt, "ms_per_step": dt / steps * 1e3, "pcm_digest": pcm_digest,
+        "frame_mix": {
+            "repeat": float(np.mean((flags & 0x40) != 0)),
+            "mute": float(np.mean((flags & 0x80) != 0)),
+            "erasure": float(np.mean((flags & 0x20) != 0)),
+            "tone": float(np.mean((flags & 0x10) != 0)),
+        },
+    }
+
+
+def roofline_of(name, S, T, m):
+    traffic, source = measured_traffic(name, S, T)
+    achieved = m["alg_bytes"] / (m["kernel_ms"] * 1e-3) / 1e9
+    r = {
+        "bound": "hbm",
+        "kernel": m["kernel"],
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": source,
+        "algorithmic_bytes_per_launch": m["alg_bytes"],
+        "kernel_ms": m["kernel_ms"],
+        "frac_on_counter_bytes": (traffic / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "binding_resource": "VALU issue and memory latency (DESIGN.md section 3); the HBM fraction is what BASELINE.json asks to be reported",
+    }
+    if name.endswith("_soft"):
+        r["note"] = "dominant kernel of this workload is the soft-decision FEC kernel: algorithmic bytes = n * (2 B per soft cell + 16 B record)"
+    else:
+        r["note"] = "algorithmic bytes = S*T*(wire frame + int16 PCM) + S*2*3*2604 state (SURVEY.md §8(d))"
+    return r
 
 
 def main():
@@ -194,10 +443,15 @@ def main():
     ap.add_argument("--workload", default="imbe_voiced", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline (and cpu_baseline) only: no other_configs, host_path, no_reverse")
     ap.add_argument("--split-expand", action="store_true", help="run the parameter expansion as a separate launch")
     ap.add_argument("--fuse-expand", action="store_true", help="development aid: IMBE at T = 1 through the fused (one-launch) path")
-    ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (mbx_debug_set_ablation); results invalid")
+    ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (development build of the library only); results invalid")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become one, before anything touches a GPU
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -206,112 +460,43 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import mbelib_neo_amd as mbx
-    from mbelib_neo_amd import _native, decoder
+    from mbelib_neo_amd import decoder
     from mbelib_neo_amd.parallel import broadcast_tables, shard_range
 
-    # rank 0 reads the blob, RCCL broadcasts it, every rank uploads it and checks the checksum
+    # rank 0 reads the blob, RCCL broadcasts it, every rank uploads it and the checksums are compared
     blob = broadcast_tables(mbx.load_tables_blob() if rank == 0 else None, device)
     checksum = decoder.ensure_init(local_rank, blob)
+    if world > 1:
+        cs = torch.tensor([checksum], dtype=torch.int64, device=device)
+        gathered = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(gathered, cs)
+        assert all(int(g) == checksum for g in gathered), "table checksum differs between ranks"
 
     codec, S, T, desc = WORKLOADS[args.workload]
     if args.streams:
         S = args.streams
     first, count = shard_range(S * world, world, rank)  # weak scaling: S streams on every rank
     assert count == S
-    frames = make_frames(args.workload, codec, S, T, rank)
-    dec = decoder.BatchDecoder(codec, S, device=local_rank, seeds=np.arange(first, first + S) + 1234, tables_blob=blob)
-    d_frames = dec.to_device(frames)
-    out = dec.make_outputs(T, want_pcm16=True, want_float=False, want_results=True)
-    L = _native.lib()
-    if args.ablate and not hasattr(L, "mbx_debug_set_ablation"):
-        raise SystemExit("--ablate needs the development build: make -C mbelib-neo_amd/csrc ablate && "
-                         "MBX_HIP_LIBRARY=$PWD/mbelib-neo_amd/libmbx_hip_ablate.so python bench.py --ablate MASK")
-    _native.check(L.mbx_reserve(S * T), "mbx_reserve")  # launches below never allocate
-    stream = torch.cuda.current_stream().cuda_stream
-    soft = args.workload.endswith("_soft")
-    if soft:
-        def fec(frames_ptr, count, records_ptr, strm):
-            return L.mbx_fec_soft(codec, frames_ptr, count, records_ptr, strm)
-    else:
-        fec = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400, 3: L.mbx_fec_ambe3600x2450}[codec]
-    n = S * T
+    m = run_workload(args.workload, S, T, args.steps, args.warmup, rank, first, local_rank, blob, world, dist, args)
 
-    def step(ev=None):
-        # mbx_process_batch() = these launches (FEC stage, then mbx_process_records: the stream kernel,
-        # which expands the parameter records itself); they are issued separately only so that the
-        # dominant (stream) kernel can be bracketed by events
-        _native.check(fec(d_frames.data_ptr(), n, out["records"].data_ptr(), stream), "fec")
-        run = L.mbx_process_records
-        stream_codec = 0 if codec == 2 else codec   # 7100x4400 records are in 7200x4400 order after its FEC stage
-        # mbx_process_records is ONE launch for IMBE at T > 1 (expansion fused into the stream kernel); otherwise
-        # it is the expand launch + the stream launch, issued separately here so that the events bracket the
-        # stream kernel only.  --split-expand forces the separate launch for IMBE at T > 1 (development aid).
-        split = (codec in (1, 3)) or (T == 1 and not args.fuse_expand) or args.split_expand
-        if split:
-            _native.check(L.mbx_expand_records(stream_codec, out["records"].data_ptr(), n, stream), "expand")
-            run = L.mbx_stream_expanded
-        if ev is not None:
-            ev[0].record()
-        _native.check(
-            run(stream_codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
-                out["pcm16"].data_ptr(), None, out["results"].data_ptr(), stream),
-            "stream",
-        )
-        if ev is not None:
-            ev[1].record()
-
-    for _ in range(max(1, args.warmup)):  # the first pass also warms the model state
-        step()
-    if args.ablate:
-        L.mbx_debug_set_ablation(args.ablate)  # development build only (tools/); never in a reported run
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    if world > 1:
-        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kernel_ms = float(t[0]), float(t[1])
-        cs = torch.tensor([checksum], dtype=torch.int64, device=device)
-        gathered = [torch.zeros_like(cs) for _ in range(world)]
-        dist.all_gather(gathered, cs)
-        assert all(int(g) == checksum for g in gathered), "table checksum differs between ranks"
-
-    flags = decoder.results_numpy(out["results"])["flags"]
-    total_frames = world * n * args.steps
-    value = total_frames / dt
-    alg_bytes = algorithmic_bytes_per_launch(codec, S, T)
-    traffic = measured_traffic(args.workload, S, T)
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     line = {
-        "metric": "20ms frames/sec (whole node), " + {0: "IMBE 7200x4400", 1: "AMBE+2 3600x2450", 2: "IMBE 7100x4400", 3: "AMBE 3600x2400"}[codec],
-        "value": value,
+        "metric": "20ms frames/sec (whole node), " + CODEC_NAME[codec],
+        "value": m["value"],
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": m["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -321,43 +506,81 @@ def main():
             "workload": desc,
             "streams_per_gpu": S,
             "frames_per_stream_per_step": T,
-            "frames_per_step": world * n,
+            "frames_per_step": m["frames_per_step"],
             "output": "int16 PCM + mbe_process_result per frame",
-            "parallelism": f"{world} independent stream shard(s), table blob broadcast over RCCL",
-            "frame_mix": {
-                "repeat": float(np.mean((flags & 0x40) != 0)),
-                "mute": float(np.mean((flags & 0x80) != 0)),
-                "erasure": float(np.mean((flags & 0x20) != 0)),
-                "tone": float(np.mean((flags & 0x10) != 0)),
-            },
+            "parallelism": f"{world} independent stream shard(s), table blob broadcast over RCCL, per-rank checksums equal",
+            "frame_mix": m["frame_mix"],
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": L.mbx_stream_kernel_name(codec).decode(),
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic[0] if traffic else None,
-            "traffic_source": traffic[1] if traffic else None,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms": kernel_ms,
-            "note": "algorithmic bytes = S*T*(wire frame + int16 PCM) + S*2*3*2604 state; the path is VALU/latency bound "
-                    "(SURVEY.md §8(d)), the HBM fraction is reported because BASELINE.json asks for it",
-        },
+        "roofline": roofline_of(args.workload, S, T, m),
     }
     fpf, fpf_basis = nominal_flops_per_frame(args.workload)
     line["valu"] = {   # "also report valu.achieved"; the resource that binds this path
-        "achieved": value / world * fpf / 1e12,
+        "achieved": m["value"] / world * fpf / 1e12,
         "peak": VALU_PEAK_TFLOPS,
         "unit": "TFLOP/s per GPU",
-        "frac": value / world * fpf / 1e12 / VALU_PEAK_TFLOPS,
+        "frac": m["value"] / world * fpf / 1e12 / VALU_PEAK_TFLOPS,
         "flops_per_frame": fpf,
         "basis": fpf_basis,
     }
+    extras = world == 1 and not args.no_extras and not args.ablate and not args.streams
+    if extras and args.workload == "imbe_voiced":
+        # the other three GPU configs of BASELINE.json, driver-timed in the same line (10 steps each)
+        line["other_configs"] = {}
+        for other in ("ambe_fec", "imbe_mixed", "ambe_stream"):
+            oc, oS, oT, odesc = WORKLOADS[other]
+            om = run_workload(other, oS, oT, 10, 2, rank, 0, local_rank, blob, 1, dist, args)
+            orf = roofline_of(other, oS, oT, om)
+            line["other_configs"][other] = {
+                "workload": odesc, "value": om["value"], "unit": "frames/s", "steps": 10, "ms_per_step": om["ms_per_step"],
+                "kernel": om["kernel"], "kernel_ms": om["kernel_ms"], "algorithmic_bytes_per_launch": om["alg_bytes"],
+                "frac": orf["frac"], "traffic": orf["traffic"], "frac_on_counter_bytes": orf["frac_on_counter_bytes"],
+                "frame_mix": om["frame_mix"],
+            }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # timed at N = 1 only, on rank 0
-            line["cpu_baseline"] = cpu_baseline(args.workload, codec, T)
+            lst, ncpu = cpu_baselines(args.workload, codec, T, full=extras)
+            line["cpu_baseline"] = lst[0]
+            line["cpu_baselines"] = lst
+            line["host_cores"] = ncpu
+        if extras and args.workload == "imbe_voiced":
+            # what a C host sees from host memory to host memory (a child process: plain C against the two libraries)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import host_path_rate
+
+                hp = json.loads(host_path_rate.run(65536, local_rank))
+                one_core = [b for b in line.get("cpu_baselines", []) if b["cores"] == 1 and b["recipe"].startswith("full path")]
+                line["host_path"] = {
+                    "frames_per_s": hp["session_pinned_frames_per_s"],
+                    "bytes_over_pcie_per_frame": 18 + 320,
+                    "what": "mbx_session_submit, 65,536 IMBE streams x T=1 per submit, 40 submits, pinned host buffers in and out "
+                            "(int16 PCM), state resident on the device; end to end from host memory to host memory",
+                    "with_results_frames_per_s": hp["session_pinned_with_results_frames_per_s"],
+                    "pageable_buffers_frames_per_s": hp["session_pageable_frames_per_s"],
+                    "per_frame_api": {
+                        "sync_call_us": hp["sync_call_us"],
+                        "reference_call_us": (1e6 / one_core[0]["value"]) if one_core else None,
+                        "queue_mode_resident_frames_per_s": hp["queue_resident_frames_per_s"],
+                        "queue_mode_writeback_frames_per_s": hp["queue_writeback_frames_per_s"],
+                        "queue_mode_host_ns_per_call": hp["queue_resident_call_ns"],
+                        "queue_channels": hp["queue_channels"],
+                        "what": "mbe_processImbe7200x4400Frame through libmbe_neo_amd.so from one host thread: synchronous "
+                                "(S=T=1 round trip per call) and in queue mode (mbe_batchBegin / mbe_flush, one frame per channel and flush)",
+                    },
+                }
+            except Exception as e:   # noqa: BLE001 -- the headline must not depend on the extras
+                line["host_path"] = {"error": str(e)[:300]}
+            # the headline with the alternating stream order switched off (separate process: the switch is read once)
+            try:
+                env = dict(os.environ, MBX_NO_REVERSE="1")
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "30", "--no-cpu-baseline", "--no-extras"],
+                                   env=env, capture_output=True, text=True, timeout=600)
+                nr = json.loads(r.stdout.strip().splitlines()[-1])
+                line["no_reverse"] = {"value": nr["value"], "kernel_ms": nr["roofline"]["kernel_ms"], "frac": nr["roofline"]["frac"],
+                                      "what": "MBX_NO_REVERSE=1: every launch walks the streams in the same direction (no Infinity Cache reuse "
+                                              "between back-to-back launches over the same state)"}
+            except Exception as e:   # noqa: BLE001
+                line["no_reverse"] = {"error": str(e)[:300]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

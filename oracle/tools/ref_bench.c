@@ -43,3 +43,125 @@ ref_process_batch(int codec, int S, int T, const char* cells, int ncell, mbe_par
     }
     return 0;
 }
+
+/* ---- all host cores: the streams split over `nthreads` POSIX threads (the reference is re-entrant per stream with
+ *      thread-local helper state, include/mbelib-neo/mbelib.h:28-30) ---------------------------------------------- */
+#include <pthread.h>
+#include <time.h>
+
+struct mt_job {
+    int codec, S, T, ncell, rc;
+    const char* cells;
+    mbe_parms* state;
+    uint32_t seed0;
+    int16_t* pcm16;
+};
+
+static void*
+mt_worker(void* arg) {
+    struct mt_job* j = (struct mt_job*)arg;
+    j->rc = ref_process_batch(j->codec, j->S, j->T, j->cells, j->ncell, j->state, j->seed0, j->pcm16);
+    return NULL;
+}
+
+int
+ref_process_batch_mt(int codec, int S, int T, const char* cells, int ncell, mbe_parms* state, uint32_t seed0, int16_t* pcm16,
+                     int nthreads) {
+    if (nthreads < 1) {
+        nthreads = 1;
+    }
+    if (nthreads > 256) {
+        nthreads = 256;
+    }
+    pthread_t th[256];
+    struct mt_job job[256];
+    int first = 0;
+    for (int k = 0; k < nthreads; ++k) {
+        const int count = S / nthreads + (k < S % nthreads ? 1 : 0);
+        job[k] = (struct mt_job){codec, count, T, ncell, 0, cells + (size_t)first * (size_t)T * (size_t)ncell, state + 3 * (size_t)first,
+                                 seed0 + (uint32_t)first, pcm16 + (size_t)first * (size_t)T * 160};
+        first += count;
+        if (pthread_create(&th[k], NULL, mt_worker, &job[k]) != 0) {
+            return -1;
+        }
+    }
+    int rc = 0;
+    for (int k = 0; k < nthreads; ++k) {
+        pthread_join(th[k], NULL);
+        if (job[k].rc < 0) {
+            rc = job[k].rc;
+        }
+    }
+    return rc;
+}
+
+/* ---- the reference's own micro-benchmark recipes, as functions (drivers of the reference API written here; the
+ *      workloads are those of bench/bench_synth.c:40-67 and bench/bench_unvoiced.c:33-52,87-100) --------------------- */
+extern void mbe_initMbeParms(mbe_parms*, mbe_parms*, mbe_parms*);
+extern void mbe_moveMbeParms(const mbe_parms*, mbe_parms*);
+extern void mbe_synthesizeSpeechf(float*, mbe_parms*, mbe_parms*);
+
+static double
+wall(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* recipe 0 = bench_synth (L = 40, w0 alternating 0.09 / 0.11, mixed voicing), 1 = bench_unvoiced (L = 36, all unvoiced);
+ * returns seconds for `frames` calls of mbe_synthesizeSpeechf (best of `runs`), checksum of the output in *sink */
+double
+ref_bench_recipe(int recipe, int frames, int runs, float* sink) {
+    float out[160];
+    mbe_parms cur, prev, enh;
+    double best = 1e30;
+    float acc = 0.0f;
+    for (int r = 0; r < runs; ++r) {
+        mbe_setThreadRngSeed(recipe == 0 ? 0x123456u : 0xBEEFu);
+        mbe_initMbeParms(&cur, &prev, &enh);
+        if (recipe == 0) {
+            cur.w0 = 0.09378f;
+            cur.L = 40;
+            for (int l = 1; l <= cur.L; ++l) {
+                cur.Vl[l] = (l % 3) != 0;
+                cur.Ml[l] = 0.05f + 0.002f * l;
+                cur.log2Ml[l] = 0.0f;
+                cur.PHIl[l] = (float)l * 0.1f;
+                cur.PSIl[l] = (float)l * 0.05f;
+            }
+        } else {
+            cur.w0 = 0.11f;
+            cur.L = 36;
+            for (int l = 1; l <= cur.L; ++l) {
+                cur.Vl[l] = 0;
+                cur.Ml[l] = 0.03f + 0.002f * (float)(l & 7);
+                cur.PHIl[l] = 0.0f;
+                cur.PSIl[l] = 0.0f;
+            }
+        }
+        prev = cur;
+        const double t0 = wall();
+        for (int i = 0; i < frames; ++i) {
+            if (recipe == 0) {
+                cur.w0 = (i & 1) ? 0.09f : 0.11f;
+                for (int l = 1; l <= cur.L; ++l) {
+                    cur.Vl[l] = ((i + l) % 5) ? 1 : 0;
+                    cur.Ml[l] = 0.04f + 0.003f * (float)((i + l) % 7);
+                }
+            } else {
+                cur.w0 = (i & 1) ? 0.10f : 0.12f;
+            }
+            mbe_synthesizeSpeechf(out, &cur, &prev);
+            mbe_moveMbeParms(&cur, &prev);
+            acc += out[i % 160];
+        }
+        const double dt = wall() - t0;
+        if (dt < best) {
+            best = dt;
+        }
+    }
+    if (sink) {
+        *sink = acc;
+    }
+    return best;
+}

@@ -208,3 +208,24 @@ def test_shim_library_exports_the_whole_reference_api():
     assert not missing, f"libmbe_neo_amd.so does not export: {missing}"
     assert set(want) <= set(shim_lib.declared_symbols())   # and include/mbe_neo_amd.h declares them
 
+
+def test_bench_self_launch_starts_ranks_and_relays_rank0(tmp_path):
+    """bench.py --gpus N without a launcher environment starts the N ranks itself (before any GPU call): every child gets
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, rank 0's output is relayed, the worst exit code is returned."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys\n"
+        "r = int(os.environ['RANK'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert int(os.environ['MASTER_PORT']) > 0 and 'torch' not in sys.modules\n"
+        "print('{\"rank\": %d, \"args\": \"%s\"}' % (r, ' '.join(sys.argv[1:])))\n"
+        "sys.exit(3 if (r == 2 and '--fail' in sys.argv) else 0)\n")
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.self_launch(sys.argv[1:], 3, script=%r))" % (ROOT, str(script)))
+    ok = subprocess.run([sys.executable, "-c", code, "--gpus", "3", "--steps", "7"], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and ok.stdout.strip() == '{"rank": 0, "args": "--gpus 3 --steps 7"}', ok.stdout + ok.stderr
+    bad = subprocess.run([sys.executable, "-c", code, "--fail"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 3
