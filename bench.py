@@ -393,9 +393,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
                   3: "fec_ambe3600x2450_soft_kernel"}[codec]
         alg_bytes = soft_fec_bytes_per_launch(codec, n)
     else:
-        kernel = L.mbx_stream_kernel_name(codec).decode()
-        if codec == 1 and T >= 4 and S == 8192:
-            kernel = "ambe_stream_kernel_w4"
+        kernel = L.mbx_stream_kernel_name(codec, T).decode()
         alg_bytes = algorithmic_bytes_per_launch(codec, S, T)
     del dec, d_frames, out
     torch.cuda.empty_cache()

@@ -283,8 +283,9 @@ int mbx_ecc_soft_words_host(int kind, const mbe_soft_bit* in, size_t n, uint32_t
 void mbx_rng_default(mbx_stream_rng* rng);
 void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed);
 
-/* name of the dominant kernel and last launch geometry, for the bench */
-const char* mbx_stream_kernel_name(int codec);
+/* name of the stream kernel a launch with T frames per stream takes (for the bench / profile summaries): with T >= 4 the
+ * instance that keeps prev_mp / prev_mp_enhanced in LDS for the whole launch (*_lds), otherwise the HBM-slot one */
+const char* mbx_stream_kernel_name(int codec, int T);
 
 #ifdef __cplusplus
 }

@@ -26,9 +26,13 @@ __global__ void expand_ambe_kernel(const mbx_param_record*, size_t, FrameParams*
 __global__ void expand_ambe2400_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void imbe_stream_kernel_lds(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                       int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe_stream_kernel_lds(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                       int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe2400_stream_kernel_lds(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                           int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
-                                   int16_t*, float*, mbe_process_result*, DeviceTables);
-__global__ void ambe_stream_kernel_w4(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe2400_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
@@ -136,6 +140,12 @@ void free_context(Context& c) {   // caller holds g_init_mu and c.mu
     c.reserve_frames = 0;
     c.checksum = 0;
     c.device = -1;
+}
+
+constexpr int kLdsResidentMinFrames = 4;
+bool lds_resident_enabled() {
+    static const bool on = getenv("MBX_NO_LDS_RESIDENT") == nullptr;   // development switch for A/B timing; read once
+    return on;
 }
 
 bool reverse_enabled() {
@@ -715,34 +725,36 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
     mbx::DeviceTables tabs = c->tabs;
     tabs.reverse = (reverse && reverse_enabled()) ? 1 : 0;
     tabs.stream_map = d_stream_index;
+    // With several frames per stream prev_mp / prev_mp_enhanced stay in LDS for the whole launch (the *_lds instances,
+    // four waves per SIMD) instead of being parked in their HBM slots every frame: mbx_stream.hip, ParkedState.
+    const bool lds_resident = T >= kLdsResidentMinFrames && lds_resident_enabled();
     if (codec == MBX_CODEC_IMBE7200X4400) {
+        if (lds_resident) {
+            hipLaunchKernelGGL(mbx::imbe_stream_kernel_lds, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                               params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+            return check_launch("imbe_stream_kernel_lds");
+        }
         hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         return check_launch("imbe_stream_kernel");
     }
     if (codec == MBX_CODEC_AMBE3600X2400) {
+        if (lds_resident) {
+            hipLaunchKernelGGL(mbx::ambe2400_stream_kernel_lds, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                               params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+            return check_launch("ambe2400_stream_kernel_lds");
+        }
         hipLaunchKernelGGL(mbx::ambe2400_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         return check_launch("ambe2400_stream_kernel");
     }
-    // Balanced rounds for long launches.  A stream kernel is one wave per stream and each wave runs all T frames; with
-    // room for w waves per SIMD a launch of n waves per SIMD runs in ceil(n / w) rounds.  When the last round is short
-    // (config 5's per-GPU shard: 8,192 streams x T = 128 on 6 x 1,024 slots, i.e. 6 waves per SIMD, then 2), its waves
-    // have the SIMD nearly to themselves and are bound by latency instead of VALU issue.  Capping the residency PER SIMD
-    // at ceil(n / rounds) keeps the number of rounds and evens them out: 4 + 4 here, 3.66 -> 3.51 ms.  The cap has to
-    // be per SIMD, i.e. by registers (a second instance of the kernel): an LDS cap is per CU and packs the SIMDs
-    // unevenly (measured slower).  One-frame launches are bound by memory latency, where every resident wave helps.
-    constexpr int kWaves = 6, kWavesCapped = 4;   // MBX_AMBE_WAVES_PER_SIMD / ambe_stream_kernel_w4
-    if (T >= 4 && c->simds > 0) {
-        const double n = (double)S / (double)c->simds;
-        if (n > (double)kWaves) {
-            const double rounds = ceil(n / (double)kWaves);
-            if (ceil(n / rounds) <= (double)kWavesCapped) {
-                hipLaunchKernelGGL(mbx::ambe_stream_kernel_w4, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T,
-                                   d_records, params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
-                return check_launch("ambe_stream_kernel_w4");
-            }
-        }
+    // (Long AMBE+2 launches used to need a second, register-padded instance to even out their rounds of waves -- config 5's
+    // shard is 8 waves per SIMD on 6 slots: 6 + 2.  The LDS-resident instance runs 16 waves per CU: 2 x 16, and
+    // 8,192 streams x T = 128 went from 3.51 ms to 3.18 ms.)
+    if (lds_resident) {
+        hipLaunchKernelGGL(mbx::ambe_stream_kernel_lds, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                           params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+        return check_launch("ambe_stream_kernel_lds");
     }
     hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                        params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
@@ -1109,9 +1121,15 @@ int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe
     return check_launch("decode_parms_kernel");
 }
 
-const char* mbx_stream_kernel_name(int codec) {
-    return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? "imbe_stream_kernel"
-           : (codec == MBX_CODEC_AMBE3600X2400 ? "ambe2400_stream_kernel" : "ambe_stream_kernel");
+const char* mbx_stream_kernel_name(int codec, int T) {
+    const bool lds = T >= kLdsResidentMinFrames && lds_resident_enabled();
+    if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {
+        return lds ? "imbe_stream_kernel_lds" : "imbe_stream_kernel";
+    }
+    if (codec == MBX_CODEC_AMBE3600X2400) {
+        return lds ? "ambe2400_stream_kernel_lds" : "ambe2400_stream_kernel";
+    }
+    return lds ? "ambe_stream_kernel_lds" : "ambe_stream_kernel";
 }
 
 // ---- host-buffer conveniences ------------------------------------------------------------

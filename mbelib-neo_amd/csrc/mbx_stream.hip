@@ -614,12 +614,14 @@ __device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
 // samples are recomputed from the seed.  Returns true when the frame was synthesised (cur.uw / cur.ov / cur.PHIl /
 // cur.PSIl are new), false when it left early (silence, comfort noise): the per-lane state is then still what
 // the snapshot holds.
-template <bool kSnap>
+// kPark: the snapshot lives in LDS (the launch-resident copies of the T >= 4 kernel instances) instead of the stream's HBM slot.
+template <bool kSnap, bool kPark = false>
 __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
                            WaveScratch& S, const DeviceTables& tabs, int lane, const mbe_parms* snap_ptr = nullptr) {
-    // The snapshot is read back through a pointer the compiler cannot trace to the stores that wrote it: otherwise it
+    // The HBM snapshot is read back through a pointer the compiler cannot trace to the stores that wrote it: otherwise it
     // forwards the stored registers to the loads and carries them across the voiced bank -- the very thing the read-back avoids.
-    if (kSnap) {
+    // (The LDS-resident instances run at four waves per SIMD with registers to spare: there the forwarding is welcome.)
+    if (kSnap && !kPark) {
         asm volatile("" : "+s"(snap_ptr));
     }
     const mbe_parms* const snap = kSnap ? snap_ptr : nullptr;
@@ -900,7 +902,11 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
     }
     if (snap && !cold) {
-        __threadfence_block();   // the snapshot was stored by this wave; its stores have long been issued
+        if (kPark) {
+            wave_lds_sync();
+        } else {
+            __threadfence_block();   // the snapshot was stored by this wave; its stores have long been issued
+        }
         const float* f = reinterpret_cast<const float*>(snap);
         const float old0 = f[O_OVERLAP + lane];
         const float old1 = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
@@ -1225,14 +1231,47 @@ __device__ __forceinline__ void store_rng(const StreamRng& r, mbx_stream_rng* p,
 }
 
 // ------------------------------------------------------------------------------------------
+// Where prev_mp and prev_mp_enhanced live between the frames of a launch.
+//   kPark = false (launches with few frames per stream): in their HBM slots -- the loads and stores a one-frame launch
+//           needs anyway; seven / six waves per SIMD.
+//   kPark = true  (T >= 4): in LDS for the whole launch, copied in once and written back once, so a launch moves each
+//           struct over HBM exactly twice whatever T is (at T = 16 the HBM-slot scheme wrote 5.2 KB per FRAME: 5.8x the
+//           algorithmic bytes).  2 x 2,604 B on top of the 4,624 B of scratch = 16 waves per CU = four per SIMD, which
+//           costs nothing there: with many frames per stream the kernel is bound by VALU issue, not by latency.
+// ------------------------------------------------------------------------------------------
+template <bool kPark>
+struct ParkedState {};
+template <>
+struct ParkedState<true> {
+    mbe_parms prev, enh;   // the ABI layout, so every load / store helper works on either home
+};
+
+template <bool kPark>
+__device__ __forceinline__ void slot_fence() {   // the wave is about to re-read what it stored to its slots
+    if (kPark) {
+        wave_lds_sync();          // LDS: program order is enough, and outstanding PCM stores are not waited for
+    } else {
+        __threadfence_block();
+    }
+}
+
+__device__ __forceinline__ void copy_parms(mbe_parms* dst, const mbe_parms* src, int lane) {
+    Parms t;
+    load_parms(t, src, lane);
+    store_parms(t, dst, lane);
+}
+
+// ------------------------------------------------------------------------------------------
 // IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
-imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
-                   mbe_parms* __restrict__ state,
-                   mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                   mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+template <bool kPark>
+__device__ __forceinline__ void
+imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                 mbe_parms* __restrict__ state,
+                 mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                 mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
+    __shared__ ParkedState<kPark> park;
     if ((int)blockIdx.x >= S) {
         return;
     }
@@ -1246,8 +1285,19 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
     // passed an index (mbx_process_batch_indexed: the streams that have frames this tick, out of a larger resident pool)
     const size_t slot = tabs_in.stream_map ? (size_t)uni(tabs_in.stream_map[s]) : (size_t)s;
     mbe_parms* const slot_cur = &state[3 * slot + 0];
-    mbe_parms* const slot_prev = &state[3 * slot + 1];
-    mbe_parms* const slot_enh = &state[3 * slot + 2];
+    mbe_parms* const home_prev = &state[3 * slot + 1];
+    mbe_parms* const home_enh = &state[3 * slot + 2];
+    mbe_parms *slot_prev, *slot_enh;
+    if constexpr (kPark) {
+        slot_prev = &park.prev;
+        slot_enh = &park.enh;
+        copy_parms(slot_prev, home_prev, lane_in);
+        copy_parms(slot_enh, home_enh, lane_in);
+        wave_lds_sync();
+    } else {
+        slot_prev = home_prev;
+        slot_enh = home_enh;
+    }
     Parms cur;
     load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
@@ -1327,13 +1377,15 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         {
             const float rm0 = MBX_ABL(tabs, 2) ? 1.0f : enhance(cur, lane);
             if (!MBX_ABL(tabs, 128)) {
-                fresh = synth_core<true>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
+                fresh = synth_core<true, kPark>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
             }
         }
         {
-            __threadfence_block();
+            slot_fence<kPark>();
             const float* f = reinterpret_cast<const float*>(slot_prev);
-            asm volatile("" : "+s"(f));   // a real load, not the stored registers carried across the synthesiser (see synth_core)
+            if constexpr (!kPark) {
+                asm volatile("" : "+s"(f));   // a real load, not the stored registers carried across the synthesiser (see synth_core)
+            }
             if (lane < MBX_BAND_SLOTS) {
                 cur.log2Ml = f[O_LOG2ML + lane];
             }
@@ -1351,7 +1403,7 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
         }
         if (!MBX_ABL(tabs, 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
         if (t + 1 < Tn) {
-            __threadfence_block();           // the next frame of this wave reloads both slots
+            slot_fence<kPark>();             // the next frame of this wave reloads both slots
         }
 
         store_pcm(out, f, pcm16, pcmf, lane);
@@ -1368,6 +1420,32 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
 
     if (!MBX_ABL(tabs_in, 1024)) store_parms(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
+    if constexpr (kPark) {   // the two structs go home
+        wave_lds_sync();
+        copy_parms(home_prev, slot_prev, lane_in);
+        copy_parms(home_enh, slot_enh, lane_in);
+    }
+}
+
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                   mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                   float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// T >= 4: prev_mp / prev_mp_enhanced resident in LDS, four waves per SIMD (see ParkedState)
+// Occupancy is set by LDS here (9,840 B per wave = 16 waves per CU); the register budget stays that of the HBM-slot
+// instance.  Measured on configs[3] (65,536 x T=16): register allocation padded to exactly four waves per SIMD
+// (amdgpu_waves_per_eu(4, 4)) 3.47 ms, launch bounds as below 3.37 ms, HBM-slot instance 3.31-3.36 ms.
+// (The compiler notes that the occupancy asked for is not reached -- LDS allows four waves per SIMD -- and relaxes the
+// register budget accordingly; -Wno-pass-failed in the Makefile silences exactly that remark.)
+#define MBX_LDS_KERNEL_ATTR(waves) __launch_bounds__(64, waves)
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_STREAM_WAVES_PER_SIMD)
+imbe_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                       mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                       float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1603,13 +1681,14 @@ __device__ void tone_dstar_frame(float out[3], int id1, Parms& cur, int lane) {
 
 // k2400: AMBE 3600x2400 (D-STAR) frame policy, ref src/ambe/ambe3600x2400.c:629-763 -- no erasure class, D-STAR
 // tones, repeats decided by the total error count alone.  The prediction (decode_ambe) is common.
-template <bool k2400>
+template <bool k2400, bool kPark>
 __device__ __forceinline__ void
 ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratch scratch;
+    __shared__ ParkedState<kPark> park;   // T >= 4: prev_mp / prev_mp_enhanced resident in LDS (see the IMBE kernel)
     if ((int)blockIdx.x >= S) {
         return;
     }
@@ -1620,8 +1699,19 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     // passed an index (mbx_process_batch_indexed: the streams that have frames this tick, out of a larger resident pool)
     const size_t slot = tabs_in.stream_map ? (size_t)uni(tabs_in.stream_map[s]) : (size_t)s;
     mbe_parms* const slot_cur = &state[3 * slot + 0];
-    mbe_parms* const slot_prev = &state[3 * slot + 1];
-    mbe_parms* const slot_enh = &state[3 * slot + 2];
+    mbe_parms* const home_prev = &state[3 * slot + 1];
+    mbe_parms* const home_enh = &state[3 * slot + 2];
+    mbe_parms *slot_prev, *slot_enh;
+    if constexpr (kPark) {
+        slot_prev = &park.prev;
+        slot_enh = &park.enh;
+        copy_parms(slot_prev, home_prev, lane_in);
+        copy_parms(slot_enh, home_enh, lane_in);
+        wave_lds_sync();
+    } else {
+        slot_prev = home_prev;
+        slot_enh = home_enh;
+    }
     Parms cur;
     load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
@@ -1657,7 +1747,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 cur = prev;
                 store_parms(prev, slot_prev, lane);
                 store_parms(prev, slot_enh, lane);
-                __threadfence_block();
+                slot_fence<kPark>();
                 load_enh_view(enh, slot_enh, lane);
             }
             cur.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
@@ -1738,7 +1828,8 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             // invalid tone id: run the synthesiser on a copy of the enhanced model.  `cur` is parked in
             // its slot meanwhile so that still only two structs are live.
             store_parms(cur, slot_cur, lane);
-            __threadfence_block();
+            __threadfence_block();               // (slot_cur is always the HBM slot)
+            slot_fence<kPark>();
             load_parms(cur, slot_enh, lane);     // the copy that is synthesised ...
             load_enh_view(enh, slot_enh, lane);  // ... against the enhanced model itself (only the fields synthesis reads)
             cur.log2Ml = 0.0f;   // slot_enh itself is the snapshot of this copy
@@ -1746,11 +1837,13 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         if (action == kVoice || action == kToneFallback) {
             const mbe_parms* snap = (action == kVoice) ? slot_prev : slot_enh;
-            const bool fresh = synth_core<true>(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane, snap);
+            const bool fresh = synth_core<true, kPark>(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane, snap);
             {
-                __threadfence_block();
+                slot_fence<kPark>();
                 const float* f = reinterpret_cast<const float*>(snap);
-                asm volatile("" : "+s"(f));   // a real load (see the IMBE kernel)
+                if constexpr (!kPark) {
+                    asm volatile("" : "+s"(f));   // a real load (see the IMBE kernel)
+                }
                 if (lane < MBX_BAND_SLOTS) {
                     cur.log2Ml = f[O_LOG2ML + lane];
                 }
@@ -1782,7 +1875,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             store_parms(cur, slot_enh, lane);
         }
         if (t + 1 < Tn) {
-            __threadfence_block();   // the next frame of this wave reloads the parked structs
+            slot_fence<kPark>();   // the next frame of this wave reloads the parked structs
         }
 
         store_pcm(out, f, pcm16, pcmf, lane);
@@ -1799,6 +1892,11 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 
     store_parms(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
+    if constexpr (kPark) {   // the two structs go home
+        wave_lds_sync();
+        copy_parms(home_prev, slot_prev, lane_in);
+        copy_parms(home_enh, slot_enh, lane_in);
+    }
 }
 
 // mbe_synthesizeSpeechf for S independent (cur, prev) pairs.
@@ -1807,23 +1905,29 @@ __global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)
 ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                    mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                    float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
-    ambe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
-}
-
-// The same kernel held to FOUR waves per SIMD (the register allocation is padded to enforce it), for launches whose
-// last round would otherwise be short -- see launch_stream() in mbx_api.hip.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-ambe_stream_kernel_w4(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
-                      mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
-                      float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
-    ambe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+    ambe_stream_body<false, false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 __global__ void __launch_bounds__(64, MBX_AMBE2400_WAVES_PER_SIMD)
 ambe2400_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
-    ambe_stream_body<true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+    ambe_stream_body<true, false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// T >= 4: prev_mp / prev_mp_enhanced resident in LDS (see the IMBE kernel)
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_WAVES_PER_SIMD)
+ambe_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                       mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                       float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE2400_WAVES_PER_SIMD)
+ambe2400_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                           mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                           float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<true, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 __global__ void __launch_bounds__(64)

@@ -359,32 +359,41 @@ def test_ambe_long_streams_config5_shape(mbx, oracle):
     assert a[0].tobytes() == c[0].tobytes() and a[1].tobytes() == c[1].tobytes()
 
 
-def test_ambe_capped_kernel_instance_is_identical(mbx, oracle):
-    """8,192 AMBE+2 streams x T = 4 take the four-waves-per-SIMD instance of the stream kernel (the launcher's balanced
-    rounds rule, mbx_api.hip); the same streams in two launches of 4,096 take the regular one.  Same code, different
-    register allocation: PCM and state must be bit-identical, and a strided sample must match the oracle."""
+@pytest.mark.parametrize("codec", [0, 1, 2, 3])
+def test_lds_resident_and_hbm_slot_kernel_instances_are_identical(mbx, oracle, codec):
+    """Launches with T >= 4 frames per stream take the stream-kernel instance that keeps prev_mp / prev_mp_enhanced in LDS
+    for the whole launch; shorter ones park them in their HBM slots (mbx_api.hip launch_stream, mbx_stream.hip
+    ParkedState).  Same arithmetic, different home for two structs: 4,096 streams x 12 frames as one launch (LDS), as
+    3 x 4 (LDS, state through HBM between launches) and as 4 x 3 (HBM slots) must be bit-identical in PCM and state, and
+    a strided sample must match the oracle."""
     import torch
     from mbelib_neo_amd import decoder, framegen
+    from mbelib_neo_amd.layout import FRAME_BYTES
 
-    S, T = 8192, 4
-    frames = framegen.random_frames(1, S * T, framegen.rng_for(41)).reshape(S, T, 9)
+    S, T = 4096, 12
+    fb = FRAME_BYTES[codec]
+    frames = framegen.random_frames(codec, S * T, framegen.rng_for(41 + codec)).reshape(S, T, fb)
     seeds = np.arange(S) + 77
 
-    def run(lo, hi):
-        dec = decoder.BatchDecoder(1, hi - lo, seeds=seeds[lo:hi])
-        out = dec.decode(np.ascontiguousarray(frames[lo:hi]).reshape(-1, 9), T, want_float=True)
+    def run(split):
+        dec = decoder.BatchDecoder(codec, S, seeds=seeds)
+        p16, pf = [], []
+        for t0 in range(0, T, split):
+            out = dec.decode(np.ascontiguousarray(frames[:, t0:t0 + split]).reshape(-1, fb), split, want_float=True)
+            p16.append(out["pcm16"].reshape(S, split, 160))
+            pf.append(out["pcmf"].reshape(S, split, 160))
         torch.cuda.synchronize()
-        return out["pcm16"].reshape(hi - lo, T, 160).cpu().numpy(), out["pcmf"].reshape(hi - lo, T, 160).cpu().numpy(), dec.state_numpy()
+        return torch.cat(p16, dim=1).cpu().numpy(), torch.cat(pf, dim=1).cpu().numpy(), dec.state_numpy(), dec.rng_numpy()
 
-    a16, af, astate = run(0, S)
-    halves = [run(0, S // 2), run(S // 2, S)]
-    assert np.array_equal(a16, np.concatenate([h[0] for h in halves]))
-    assert af.tobytes() == np.concatenate([h[1] for h in halves]).tobytes()
-    assert astate.tobytes() == np.concatenate([h[2] for h in halves]).tobytes()
+    a = run(12)
+    for split in (4, 3):
+        b = run(split)
+        assert np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes(), f"PCM differs between T=12 and T={split} launches"
+        assert a[2].tobytes() == b[2].tobytes() and a[3].tobytes() == b[3].tobytes()
     pick = np.arange(0, S, 61)
-    ref = oracle.process_batch(1, len(pick), T, frames[pick].reshape(-1, 9), oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
-    parity.check_pcm(ref["pcmf"], af[pick].reshape(-1, 160), ref["pcm16"], a16[pick].reshape(-1, 160))
-    parity.check_state(ref["state"], astate[pick])
+    ref = oracle.process_batch(codec, len(pick), T, frames[pick].reshape(-1, fb), oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
+    parity.check_pcm(ref["pcmf"], a[1][pick].reshape(-1, 160), ref["pcm16"], a[0][pick].reshape(-1, 160))
+    parity.check_state(ref["state"], a[2][pick])
 
 
 @pytest.mark.parametrize("codec", [0, 1])
