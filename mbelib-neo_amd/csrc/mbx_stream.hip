@@ -523,13 +523,104 @@ __device__ float enhance(Parms& cur, int lane) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Adaptive smoothing.
+// Exact replay of the reference's float arithmetic around ONE threshold decision.
+//
+// The adaptive smoothing forces a band voiced when its ENHANCED amplitude exceeds a threshold VM derived from the
+// pre-enhancement energy Rm0 (src/core/mbe_adaptive.c:217-233).  enhance() / smooth() reach both numbers by wave-parallel
+// sums and 1-ulp hardware sqrt / rcp, i.e. within a few ulp of the reference's values but not bit for bit, so an
+// amplitude that lands within ~1e-6 of VM could fall on the other side (3 such frames in 49.8 M).
+// Frames that have an amplitude within 2e-5 of VM -- about one in a thousand of the frames whose smoothing is active --
+// are therefore decided again here with the reference's own sequence of float operations:
+//   cos(l w0) by L rotations of (1, 0) by (cosf w0, sinf w0)                 src/core/mbelib.c:412-424
+//   Rm0, Rm1 and the sum of squares as sequential sums over l = 1..L          :426-483 (scalar path), :532-590
+//   weights with IEEE sqrtf and division, the [0.5, 1.2] clamp, gamma         :485-512, :641-661
+//   localEnergy and VM from that Rm0                                          src/core/mbe_adaptive.c:164-195
+// and the frame continues with those amplitudes.  (sinf / cosf of w0: double-precision series, rounded to float; the
+// reference's libm is within 0.56 ulp of the same value.  expf: the device's, as in the fast path.)
 // ------------------------------------------------------------------------------------------
-__device__ void smooth(Parms& cur, const Parms& prev, float RM0, int lane) {
-    const int L = cur.L;
-    const float er = cur.errorRate;
-    const int et = cur.errorCountTotal, e4 = cur.errorCount4;
-    float pe = prev.localEnergy;
+__device__ __forceinline__ float seq_sum(float v, int L, float* tmp, int lane) {   // tmp[1..L] summed in index order
+    tmp[lane] = v;
+    wave_lds_sync();
+    float acc = 0.0f;
+    for (int l = 1; l <= L; ++l) {
+        acc = acc + tmp[l];   // wave-uniform address: an LDS broadcast; every lane forms the same sum
+    }
+    wave_lds_sync();
+    return acc;
+}
+
+// sinf / cosf for 0 <= x < 1 (every fundamental of the codec tables is below 0.51): series in double, rounded once
+__device__ __forceinline__ void small_sincosf(float xf, float& sn, float& cs) {
+    const double x = (double)xf, x2 = x * x;
+    double ps = -1.0 / 121645100408832000.0, pc = 1.0 / 2432902008176640000.0;   // -1/19!, 1/20!
+    const double ks[9] = {1.0 / 355687428096000.0, -1.0 / 1307674368000.0, 1.0 / 6227020800.0, -1.0 / 39916800.0, 1.0 / 362880.0,
+                          -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0, 1.0};
+    const double kc[10] = {-1.0 / 6402373705728000.0, 1.0 / 20922789888000.0, -1.0 / 87178291200.0, 1.0 / 479001600.0, -1.0 / 3628800.0,
+                           1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0, -0.5, 1.0};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        ps = fma(ps, x2, ks[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        pc = fma(pc, x2, kc[i]);
+    }
+    sn = (float)(ps * x);
+    cs = (float)pc;
+}
+
+// pre: lane l holds Ml[l] BEFORE enhancement.  Returns lane l's enhanced Ml[l] exactly as the reference computes it and
+// the reference's Rm0 (wave-uniform).
+__device__ __forceinline__ float enhance_exact(float pre, float w0, int L, float* tmp, int lane, float& Rm0_out) {
+    float s_step, c_step;
+    small_sincosf(w0, s_step, c_step);
+    float c = 1.0f, sn = 0.0f, cosl = 0.0f;
+    for (int l = 1; l <= L; ++l) {
+        const float cn = (c * c_step) - (sn * s_step);
+        const float sq = (sn * c_step) + (c * s_step);
+        c = cn;
+        sn = sq;
+        cosl = (l == lane) ? c : cosl;
+    }
+    const float Ml2 = pre * pre;
+    const float Rm0 = seq_sum(Ml2, L, tmp, lane);
+    const float Rm1 = seq_sum(Ml2 * cosl, L, tmp, lane);
+    const float R2m0 = Rm0 * Rm0, R2m1 = Rm1 * Rm1;
+    const bool in = lane >= 1 && lane <= L;
+    float M = pre;
+    if (in && M != 0.0f) {
+        const float Wl = sqrtf(M)
+                         * sqrtf(sqrtf(((float)0.96 * (float)M_PI * ((R2m0 + R2m1) - ((float)2 * Rm0 * Rm1 * cosl)))
+                                       / (w0 * Rm0 * (R2m0 - R2m1))));
+        if ((8 * lane) <= L) {
+        } else if (Wl > 1.2f) {
+            M = 1.2f * M;
+        } else if (Wl < 0.5f) {
+            M = 0.5f * M;
+        } else {
+            M = Wl * M;
+        }
+    }
+    const float A = (M < 0.0f) ? -M : M;
+    const float sum = seq_sum(A * A, L, tmp, lane);
+    const float gamma = (sum == 0.0f) ? 1.0f : sqrtf(Rm0 / sum);
+    Rm0_out = Rm0;
+    return in ? (gamma * M) : M;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adaptive smoothing.  `pre_ml`: where the amplitudes from before this frame's enhancement can be read back (Ml[0..56] of
+// the snapshot), or nullptr when `cur` was not enhanced in this frame -- only touched by the rare exact replay; `tmp`: 64
+// floats of LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float smoothing_threshold(float le, float er, int e4) {   // VM for er / et beyond the low thresholds
+    const float x8 = sqrtf(sqrtf(sqrtf(le)));
+    const float energy = x8 * x8 * x8;
+    return (er <= 0.0125f && e4 == 0) ? ((45.255f * energy) / expf(277.26f * er)) : (1.414f * energy);
+}
+
+__device__ __forceinline__ float local_energy(float prev_le, float RM0) {
+    float pe = prev_le;
     if (pe < 10000.0f) {
         pe = 75000.0f;
     }
@@ -537,23 +628,40 @@ __device__ void smooth(Parms& cur, const Parms& prev, float RM0, int lane) {
     if (le < 10000.0f) {
         le = 10000.0f;
     }
-    cur.localEnergy = uni(le);
+    return le;
+}
+
+__device__ __forceinline__ void smooth(Parms& cur, const Parms& prev, float RM0, int lane, const float* pre_ml, float* tmp) {
+    const int L = cur.L;
+    const float er = cur.errorRate;
+    const int et = cur.errorCountTotal, e4 = cur.errorCount4;
+    float le = local_energy(prev.localEnergy, RM0);
     const bool in = lane >= 1 && lane <= L;
+    bool force = false;
     if (!(er <= 0.005f && et <= 4)) {   // otherwise VM = FLT_MAX and nothing can exceed it
-        const float x8 = sqrtf(sqrtf(sqrtf(le)));
-        const float energy = x8 * x8 * x8;
-        float VM;
-        if (er <= 0.0125f && e4 == 0) {
-            VM = (45.255f * energy) / expf(277.26f * er);
-        } else {
-            VM = 1.414f * energy;
+        float VM = smoothing_threshold(le, er, e4);
+        force = in && cur.Ml > VM;
+        const bool near = in && fabsf(cur.Ml - VM) <= 2e-5f * VM;
+        if (__ballot(near) != 0ULL && cur.w0 >= 0.0f && cur.w0 < 1.0f) {   // rare: decide again with the reference's own arithmetic
+            float rm0e;
+            if (pre_ml) {
+                __threadfence_block();   // the snapshot was stored by this wave
+                const float pre = (lane < MBX_BAND_SLOTS) ? pre_ml[lane] : 0.0f;
+                cur.Ml = enhance_exact(pre, cur.w0, L, tmp, lane, rm0e);
+            } else {
+                rm0e = seq_sum(cur.Ml * cur.Ml, L, tmp, lane);
+            }
+            le = local_energy(prev.localEnergy, rm0e);
+            VM = smoothing_threshold(le, er, e4);
+            force = in && cur.Ml > VM;
         }
-        if (in && cur.Ml > VM) {
-            cur.Vl = 1;
-        }
-    } else if (in && cur.Ml > __FLT_MAX__) {
-        cur.Vl = 1;   // +inf amplitude still compares greater than FLT_MAX
+    } else {
+        force = in && cur.Ml > __FLT_MAX__;   // +inf amplitude still compares greater than FLT_MAX
     }
+    if (force) {
+        cur.Vl = 1;
+    }
+    cur.localEnergy = uni(le);
     const float Am = wave_sum(in ? cur.Ml : 0.0f);
     int pt = prev.amplitudeThreshold;
     if (pt <= 0) {
@@ -636,7 +744,9 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         const bool in = lane >= 1 && lane <= cur.L;
         rm0 = wave_sum(in ? (cur.Ml * cur.Ml) : 0.0f);
     }
-    smooth(cur, prev, rm0, lane);
+    // the amplitudes before this frame's enhancement are in the snapshot (read only by the rare exact replay, see smooth)
+    smooth(cur, prev, rm0, lane, (kSnap && have_rm0) ? reinterpret_cast<const float*>(snap) + O_ML : nullptr,
+           reinterpret_cast<float*>(S.fft));
 
     const bool rate_mutes = fabsf(cur.mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f;
     if (cur.repeatCount >= MBE_MAX_FRAME_REPEATS || (rate_mutes && cur.errorRate > cur.mutingThreshold)) {
@@ -2009,7 +2119,8 @@ smoothing_kernel(int S, mbe_parms* __restrict__ curs, const mbe_parms* __restric
     if (cur.L >= 1 && cur.L <= 56 && prev.L >= 1 && prev.L <= 56) {
         const bool in = lane >= 1 && lane <= cur.L;
         const float rm0 = wave_sum(in ? (cur.Ml * cur.Ml) : 0.0f);
-        smooth(cur, prev, rm0, lane);
+        __shared__ float tmp[64];
+        smooth(cur, prev, rm0, lane, nullptr, tmp);
         store_parms(cur, &curs[s], lane);
     }
 }

@@ -835,3 +835,44 @@ def test_session_indexed_subset_pinned_buffers(mbx, oracle):
     for q in pin_out:
         L.mbx_host_free(q)
     assert L.mbx_session_destroy(h) == 0
+
+
+def test_near_threshold_smoothing_decisions_are_the_references(mbx, oracle):
+    """tests/golden/threshold_cases.npz: streams (found by tools/find_flips.py over the seeded soak of tools/soak.py) in
+    which an enhanced amplitude lands within a few ulp of the adaptive-smoothing threshold VM
+    (src/core/mbe_adaptive.c:217-233), so that wave-parallel sums used to put a band on the other side of `Ml > VM`
+    than the reference's sequential ones.  Such frames are replayed with the reference's own operation order
+    (mbx_stream.hip, enhance_exact): the voicing decisions (integer state) must be the oracle's in every frame, as one
+    launch over the whole stream and frame by frame."""
+    import os
+
+    import torch
+
+    from mbelib_neo_amd import decoder
+    from mbelib_neo_amd.layout import FRAME_BYTES
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "threshold_cases.npz"))
+    for codec, seed, frames in zip(z["codec"], z["seed"], z["frames"]):
+        codec, seed = int(codec), int(seed)
+        T = frames.shape[0]
+        fb = FRAME_BYTES[codec]
+        flat = np.ascontiguousarray(frames).reshape(-1)[: T * fb].reshape(T, fb)
+        st, rg = oracle.init_state(1), oracle.rng_seeded([seed])
+        refs = []
+        for t in range(T):   # frame by frame: the state after every frame is compared, not just the last
+            r = oracle.process_batch(codec, 1, 1, flat[t], st, rg)
+            st, rg = r["state"], r["rng"]
+            refs.append(r)
+        for split in (T, 1):
+            dec = decoder.BatchDecoder(codec, 1, seeds=[seed])
+            k = 0
+            for t0 in range(0, T, split):
+                out = dec.decode(np.ascontiguousarray(flat[t0:t0 + split]).reshape(-1), split, want_float=True)
+                torch.cuda.synchronize()
+                k = t0 + split - 1
+                got = dec.state_numpy()
+                assert np.array_equal(refs[k]["state"]["Vl"], got["Vl"]), f"codec {codec} seed {seed}: voicing differs after frame {k}"
+                parity.check_state(refs[k]["state"], got)
+                pf = out["pcmf"].cpu().numpy().reshape(split, 160)
+                want = np.concatenate([refs[t]["pcmf"].reshape(1, 160) for t in range(t0, t0 + split)])
+                parity.check_pcm(want, pf, what=f"codec {codec} seed {seed} frames {t0}..{k}")

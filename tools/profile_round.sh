@@ -13,14 +13,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 50 --warmup 5 --workload $WL > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write /tmp/c_fetch /tmp/c_write
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --workload $WL > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $WL > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $WL > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --workload $WL > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --workload $WL > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --workload $WL > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/c_fetch -- python3 $R/tools/calibrate_fetch.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/c_write -- python3 $R/tools/calibrate_fetch.py > /dev/null 2>&1
 cp /tmp/p_stats/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 python3 - "$OUT/${TAG}_pmc.json" "$OUT/${TAG}_bench.json" "$WL" <<'PY'
-import csv, glob, collections, json, sys
+import csv, glob, collections, hashlib, json, os, sys
 
 def mean_kb(d):
     acc = collections.defaultdict(list)
@@ -37,8 +37,11 @@ f_fac = known / (cf[k_copy][0] * 1024.0)
 w_fac = known / (cw[k_copy][0] * 1024.0)
 bench = json.load(open(sys.argv[2]))
 kern = bench["roofline"]["kernel"]
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 out = {
     "workload": sys.argv[3],
+    # bench.py reports this file's traffic only next to timings of the SAME build of the library
+    "libmbx_hip_sha256_16": hashlib.sha256(open(os.path.join(root, "mbelib-neo_amd", "libmbx_hip.so"), "rb").read()).hexdigest()[:16],
     "streams_per_gpu": bench["config"]["streams_per_gpu"],
     "frames_per_stream_per_step": bench["config"]["frames_per_stream_per_step"],
     "unit": "KB per dispatch (rocprofv3 Counter_Value), mean over dispatches",
@@ -51,7 +54,7 @@ out = {
         "note": "factor = known bytes / counter bytes for dword-per-lane coalesced accesses (the stream kernels' pattern)",
     },
 }
-fk = [k for k in fetch if k.endswith(kern) or kern in k]
+fk = [k for k in fetch if k.split("::")[-1] == kern] or [k for k in fetch if kern in k]
 if fk:
     k = fk[0]
     rd, wr = fetch[k][0] * 1024.0 * f_fac, write[k][0] * 1024.0 * w_fac
