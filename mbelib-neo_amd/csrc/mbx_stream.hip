@@ -222,6 +222,30 @@ struct WaveScratch {
     float park[MBX_PARK_N > 0 ? MBX_PARK_N : 1][64];                // per-lane values that only cross the unvoiced transform pair (see synth_core)
 };
 
+// Sum of the per-lane terms v_1 .. v_L in INDEX ORDER with a float rounding after every addition -- the reference's
+// `for (l = 1; l <= L; l++) sum += v[l]`, bit for bit, returned wave-uniform.  Used where a sum feeds state that later
+// frames build on (the log-magnitude prediction memory, the local-energy filter): a wave-parallel tree sum is a few ulp
+// away from the sequential one, the difference is carried from frame to frame, and float-threshold decisions downstream
+// could then fall on the other side than the reference's.  The terms go through 64 floats of LDS and
+// come back as broadcast 16-byte reads, so the cost is L dependent v_add_f32 and L / 4 LDS reads.
+// v must be 0.0f in lanes outside 1..L; tmp is 16-byte aligned.
+__device__ __forceinline__ float seq_sum4(float v, int L, float* tmp, int lane) {
+    tmp[(lane - 1) & 63] = v;   // term l at index l - 1 (lane 0 holds a zero and lands on index 63)
+    wave_lds_sync();
+    float acc = 0.0f;
+    const int n4 = (L + 3) >> 2;
+    const float4* q = reinterpret_cast<const float4*>(tmp);
+    for (int k = 0; k < n4; ++k) {
+        const float4 t = q[k];   // wave-uniform address: one LDS broadcast per four terms
+        acc = acc + t.x;
+        acc = acc + t.y;         // terms past L are +0.0f: x + 0 == x
+        acc = acc + t.z;
+        acc = acc + t.w;
+    }
+    wave_lds_sync();
+    return acc;
+}
+
 struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
     unsigned long long cn_seed48;
     uint32_t           cn_seeded, unv_state, unv_override;
@@ -385,7 +409,7 @@ __device__ __forceinline__ int rec_bit(const uint32_t w[3], int i) { return (int
 // Frame parameters from the expand stage (mbx_expand.hip): v[1..56] prediction residuals T_l,
 // v[57..58] voicing bits, v[59] w0, v[60] L, v[61] K (IMBE) / mean residual (AMBE), v[62] error
 // context word, v[63] frame class, v[0] AMBE gain increment.
-__device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DerivedTables* Dg, int lane) {
+__device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DerivedTables* Dg, int lane, float* tmp) {
     const int bad = uni(__float_as_int(fp[63]));
     if (bad != 0) {
         if (fp[59] != 0.0f) {
@@ -428,7 +452,7 @@ __device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev
     const int hi = (lo + 1 > 56) ? 56 : lo + 1;
     const float a = lane_get(prev.log2Ml, lo), b = lane_get(prev.log2Ml, hi);
     const bool in = lane >= 1 && lane <= cur_L;
-    float Sum77 = wave_sum(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f);
+    float Sum77 = seq_sum4(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f, cur_L, tmp, lane);   // feeds the prediction memory
     Sum77 = (D->imbe_rho_over_l[cur_L] * Sum77);
     if (in) {
         const float c1 = (rho * ((float)1 - frac) * a);
@@ -480,7 +504,7 @@ __device__ __forceinline__ void unit_phasor(double rev, float& c, float& s) {
 // ------------------------------------------------------------------------------------------
 // Spectral amplitude enhancement; returns the pre-enhancement Rm0.
 // ------------------------------------------------------------------------------------------
-__device__ float enhance(Parms& cur, int lane) {
+__device__ float enhance(Parms& cur, int lane, float* tmp) {
     const int L = cur.L;
     if (L < 1 || L > 56) {
         return 0.0f;
@@ -491,7 +515,7 @@ __device__ float enhance(Parms& cur, int lane) {
     unit_phasor_hw(((double)cur.w0 * 0.15915494309189533577) * (double)lane, cw, sw_unused);
     const bool in = lane >= 1 && lane <= L;
     const float Ml2 = cur.Ml * cur.Ml;
-    const float Rm0 = wave_sum(in ? Ml2 : 0.0f);
+    const float Rm0 = seq_sum4(in ? Ml2 : 0.0f, L, tmp, lane);   // returned to the caller: feeds the local-energy filter (state)
     const float Rm1 = wave_sum(in ? (Ml2 * cw) : 0.0f);
     const float R2m0 = Rm0 * Rm0;
     const float R2m1 = Rm1 * Rm1;
@@ -538,17 +562,6 @@ __device__ float enhance(Parms& cur, int lane) {
 // and the frame continues with those amplitudes.  (sinf / cosf of w0: double-precision series, rounded to float; the
 // reference's libm is within 0.56 ulp of the same value.  expf: the device's, as in the fast path.)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float seq_sum(float v, int L, float* tmp, int lane) {   // tmp[1..L] summed in index order
-    tmp[lane] = v;
-    wave_lds_sync();
-    float acc = 0.0f;
-    for (int l = 1; l <= L; ++l) {
-        acc = acc + tmp[l];   // wave-uniform address: an LDS broadcast; every lane forms the same sum
-    }
-    wave_lds_sync();
-    return acc;
-}
-
 // sinf / cosf for 0 <= x < 1 (every fundamental of the codec tables is below 0.51): series in double, rounded once
 __device__ __forceinline__ void small_sincosf(float xf, float& sn, float& cs) {
     const double x = (double)xf, x2 = x * x;
@@ -583,10 +596,10 @@ __device__ __forceinline__ float enhance_exact(float pre, float w0, int L, float
         cosl = (l == lane) ? c : cosl;
     }
     const float Ml2 = pre * pre;
-    const float Rm0 = seq_sum(Ml2, L, tmp, lane);
-    const float Rm1 = seq_sum(Ml2 * cosl, L, tmp, lane);
-    const float R2m0 = Rm0 * Rm0, R2m1 = Rm1 * Rm1;
     const bool in = lane >= 1 && lane <= L;
+    const float Rm0 = seq_sum4(in ? Ml2 : 0.0f, L, tmp, lane);
+    const float Rm1 = seq_sum4(in ? (Ml2 * cosl) : 0.0f, L, tmp, lane);
+    const float R2m0 = Rm0 * Rm0, R2m1 = Rm1 * Rm1;
     float M = pre;
     if (in && M != 0.0f) {
         const float Wl = sqrtf(M)
@@ -602,7 +615,7 @@ __device__ __forceinline__ float enhance_exact(float pre, float w0, int L, float
         }
     }
     const float A = (M < 0.0f) ? -M : M;
-    const float sum = seq_sum(A * A, L, tmp, lane);
+    const float sum = seq_sum4(in ? (A * A) : 0.0f, L, tmp, lane);
     const float gamma = (sum == 0.0f) ? 1.0f : sqrtf(Rm0 / sum);
     Rm0_out = Rm0;
     return in ? (gamma * M) : M;
@@ -649,7 +662,7 @@ __device__ __forceinline__ void smooth(Parms& cur, const Parms& prev, float RM0,
                 const float pre = (lane < MBX_BAND_SLOTS) ? pre_ml[lane] : 0.0f;
                 cur.Ml = enhance_exact(pre, cur.w0, L, tmp, lane, rm0e);
             } else {
-                rm0e = seq_sum(cur.Ml * cur.Ml, L, tmp, lane);
+                rm0e = RM0;   // the caller's sequential sum already
             }
             le = local_energy(prev.localEnergy, rm0e);
             VM = smoothing_threshold(le, er, e4);
@@ -742,7 +755,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     }
     if (!have_rm0) {
         const bool in = lane >= 1 && lane <= cur.L;
-        rm0 = wave_sum(in ? (cur.Ml * cur.Ml) : 0.0f);
+        rm0 = seq_sum4(in ? (cur.Ml * cur.Ml) : 0.0f, cur.L, reinterpret_cast<float*>(S.fft), lane);
     }
     // the amplitudes before this frame's enhancement are in the snapshot (read only by the rare exact replay, see smooth)
     smooth(cur, prev, rm0, lane, (kSnap && have_rm0) ? reinterpret_cast<const float*>(snap) + O_ML : nullptr,
@@ -1452,7 +1465,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             cur.errorCountTotal = total;
             cur.errorRate = uni((0.95f * prev.errorRate) + (0.000365f * (float)total));
 
-            const int bad = MBX_ABL(tabs, 1) ? 0 : decode_imbe(fp, cur, prev, tabs.d, lane);
+            const int bad = MBX_ABL(tabs, 1) ? 0 : decode_imbe(fp, cur, prev, tabs.d, lane, scratch.x.C);
             const float repeat_threshold = 10.0f + (40.0f * cur.errorRate);
             const bool c0_valid = (flags & MBE_PROCESS_FLAG_C0_VALID) != 0u;
             const bool repeat =
@@ -1485,7 +1498,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         float out[3] = {0.0f, 0.0f, 0.0f};
         bool fresh = false;
         {
-            const float rm0 = MBX_ABL(tabs, 2) ? 1.0f : enhance(cur, lane);
+            const float rm0 = MBX_ABL(tabs, 2) ? 1.0f : enhance(cur, lane, scratch.x.C);
             if (!MBX_ABL(tabs, 128)) {
                 fresh = synth_core<true, kPark>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
             }
@@ -1624,7 +1637,7 @@ __device__ __forceinline__ int pick_bits(const uint32_t w[3], int i0, int i1, in
 }
 
 // Returns 0 voice, 2 erasure, 7 tone (classified by the expand stage).
-__device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DeviceTables& tabs, int lane) {
+__device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DeviceTables& tabs, int lane, float* tmp) {
     const int bad = uni(__float_as_int(fp[63]));
     if (bad != 0) {
         return bad;
@@ -1665,7 +1678,7 @@ __device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev
     const float bnext = lane_get(prev.log2Ml, (lo + 1) & 63);
     const float b = (lo + 1 > 56) ? phi0 : bnext;
     const bool in = lane >= 1 && lane <= cur_L;
-    float Sum43 = wave_sum(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f);
+    float Sum43 = seq_sum4(in ? ((((float)1 - frac) * a) + (frac * b)) : 0.0f, cur_L, tmp, lane);   // feeds the prediction memory
     Sum43 = (D->ambe_pred_over_l[cur_L] * Sum43);
     const float Sum42 = fp[61];   // mean residual, summed in the reference's order by the expand stage
     const float BigGamma = cur.gamma - (0.5f * D->log2_int[cur_L]) - Sum42;
@@ -1865,7 +1878,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             cur.errorCount4 = 0;
             cur.errorRate = uni((0.95f * prev.errorRate) + (0.001064f * (float)total));
 
-            bad = decode_ambe(fp, cur, prev, tabs, lane);
+            bad = decode_ambe(fp, cur, prev, tabs, lane, scratch.x.C);
             prev_max_repeat = prev.repeatCount >= MBE_MAX_FRAME_REPEATS;
             if (k2400) {   // ambe2400_update_decode_state (:661-686)
                 const int c0v = ((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? c0 : 0;
@@ -1933,7 +1946,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
             cur.log2Ml = 0.0f;                   // read back from the snapshot after the synthesiser (see the IMBE kernel)
             cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
-            rm0 = enhance(cur, lane);
+            rm0 = enhance(cur, lane, scratch.x.C);
         } else if (action == kToneFallback) {
             // invalid tone id: run the synthesiser on a copy of the enhanced model.  `cur` is parked in
             // its slot meanwhile so that still only two structs are live.
@@ -2100,9 +2113,10 @@ enhance_kernel(int S, mbe_parms* __restrict__ parms) {
         return;
     }
     const int lane = lane_id();
+    __shared__ alignas(16) float tmp[64];
     Parms cur;
     load_parms(cur, &parms[s], lane);
-    (void)enhance(cur, lane);
+    (void)enhance(cur, lane, tmp);
     store_parms(cur, &parms[s], lane);
 }
 
@@ -2118,8 +2132,8 @@ smoothing_kernel(int S, mbe_parms* __restrict__ curs, const mbe_parms* __restric
     load_parms(prev, &prevs[s], lane);
     if (cur.L >= 1 && cur.L <= 56 && prev.L >= 1 && prev.L <= 56) {
         const bool in = lane >= 1 && lane <= cur.L;
-        const float rm0 = wave_sum(in ? (cur.Ml * cur.Ml) : 0.0f);
-        __shared__ float tmp[64];
+        __shared__ alignas(16) float tmp[64];
+        const float rm0 = seq_sum4(in ? (cur.Ml * cur.Ml) : 0.0f, cur.L, tmp, lane);
         smooth(cur, prev, rm0, lane, nullptr, tmp);
         store_parms(cur, &curs[s], lane);
     }
@@ -2150,6 +2164,7 @@ __global__ void __launch_bounds__(64)
 decode_parms_kernel(int codec, int n, const FrameParams* __restrict__ params, mbe_parms* __restrict__ curs,
                     mbe_parms* __restrict__ prevs, int32_t* __restrict__ rc, DeviceTables tabs) {
     __shared__ float fp[64];
+    __shared__ alignas(16) float tmp[64];
     const int i = blockIdx.x;
     if (i >= n) {
         return;
@@ -2160,7 +2175,7 @@ decode_parms_kernel(int codec, int n, const FrameParams* __restrict__ params, mb
     load_parms(prev, &prevs[i], lane);
     fp[lane] = params[i].v[lane];
     wave_lds_sync();
-    const int bad = (codec == MBX_CODEC_IMBE7200X4400) ? decode_imbe(fp, cur, prev, tabs.d, lane) : decode_ambe(fp, cur, prev, tabs, lane);
+    const int bad = (codec == MBX_CODEC_IMBE7200X4400) ? decode_imbe(fp, cur, prev, tabs.d, lane, tmp) : decode_ambe(fp, cur, prev, tabs, lane, tmp);
     store_parms(cur, &curs[i], lane);
     store_parms(prev, &prevs[i], lane);
     if (lane == 0) {
