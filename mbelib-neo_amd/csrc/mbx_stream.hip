@@ -266,10 +266,20 @@ struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
 // ------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) mbx_tables* ConstTables;
 typedef const __attribute__((address_space(4))) DerivedTables* ConstDerived;
+// The table pointers pass through an asm barrier once per frame (see the kernels), after which the compiler no longer
+// knows that they point to global memory and would emit FLAT loads -- which count against the LDS counter as well and
+// make every LDS wait also a wait for outstanding table reads.  Vector table reads therefore go through pointers that
+// say "global" explicitly.
+#define MBX_GLOBAL __attribute__((address_space(1)))
+typedef const MBX_GLOBAL mbx_tables* GlobalTables;
+typedef const MBX_GLOBAL DerivedTables* GlobalDerived;
+typedef const MBX_GLOBAL float* GlobalFloats;
 __device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
 
-__device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, const mbx_tables* Tg, const DerivedTables* Dg, int lane) {
-    ConstTables T = (ConstTables)Tg;
+__device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane) {
+    ConstTables T = (ConstTables)Tgen;
+    GlobalTables Tg = (GlobalTables)Tgen;
+    GlobalDerived Dg = (GlobalDerived)Dgen;
     const __attribute__((address_space(4))) uint32_t* rq = (const __attribute__((address_space(4))) uint32_t*)rp;
     const uint4 rec = make_uint4(rq[0], rq[1], rq[2], rq[3]);
     int b0 = (int)(rec.x >> 26);
@@ -291,7 +301,7 @@ __device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, con
     if (!bad) {
         const int L9 = L - 9;
         // ---- every per-lane table value is requested here ----
-        const uint16_t* bo = reinterpret_cast<const uint16_t*>(&Tg->imbe_bo[L9][0][0]);
+        const MBX_GLOBAL uint16_t* bo = (const MBX_GLOBAL uint16_t*)(&Tg->imbe_bo[L9][0][0]);
         const uint32_t e0 = bo[lane], e1 = bo[lane < 15 ? lane + 64 : 78];
         const int g = (lane >= 2 && lane <= 6) ? lane - 2 : 0;
         const float nb = Tg->imbe_ba[L9][g][0], step = Tg->imbe_ba[L9][g][1];
@@ -306,12 +316,12 @@ __device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, con
         const bool harm = lane >= 1 && lane <= L;
         float cosr[11], ric[7];   // fetched now: loads cannot move up across the LDS fences below
         {
-            const float* row = &Dg->imbe_idct_rows[L9][lane][0];
+            GlobalFloats row = &Dg->imbe_idct_rows[L9][lane][0];
 #pragma unroll
             for (int k = 1; k <= 10; ++k) {
                 cosr[k] = row[k - 1];
             }
-            const float* col = &Tg->imbe_ri_cos[0][(lane >= 1 && lane <= 6) ? lane : 0];
+            GlobalFloats col = &Tg->imbe_ri_cos[0][(lane >= 1 && lane <= 6) ? lane : 0];
 #pragma unroll
             for (int m = 1; m <= 6; ++m) {
                 ric[m] = col[7 * m];
@@ -746,8 +756,15 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         asm volatile("" : "+s"(snap_ptr));
     }
     const mbe_parms* const snap = kSnap ? snap_ptr : nullptr;
-    const mbx_tables* T = tabs.t;
-    const DerivedTables* D = tabs.d;
+    auto snap_f = [&](int dword) -> float {   // one float of the snapshot
+        if constexpr (kPark) {
+            return reinterpret_cast<const float*>(snap)[dword];   // LDS
+        } else {
+            return ((GlobalFloats)snap)[dword];
+        }
+    };
+    GlobalTables T = (GlobalTables)tabs.t;
+    GlobalDerived D = (GlobalDerived)tabs.d;
     constexpr int N = 160;
     out[0] = out[1] = out[2] = 0.0f;
     if (cur.L < 1 || cur.L > 56 || prev.L < 1 || prev.L > 56) {
@@ -969,7 +986,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 Ec.y = c;
                 Es.y = d;
             }
-            const float* Ws = T->ws;
+            GlobalFloats Ws = T->ws;
             const int kk = lane <= kMidPrev ? lane : kMidPrev;   // lanes 53..63 idle along
             const v2f w_plus = {Ws[N + kMidPrev + kk], Ws[kMidCur + (kk < 52 ? kk : 51)]};
             const v2f w_minus = {Ws[N + kMidPrev - kk], Ws[kMidCur - kk]};
@@ -1030,9 +1047,8 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         } else {
             __threadfence_block();   // the snapshot was stored by this wave; its stores have long been issued
         }
-        const float* f = reinterpret_cast<const float*>(snap);
-        const float old0 = f[O_OVERLAP + lane];
-        const float old1 = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
+        const float old0 = snap_f(O_OVERLAP + lane);
+        const float old1 = (lane < 32) ? snap_f(O_OVERLAP + 64 + lane) : 0.0f;
         nz[0] = old0;
         nz[1] = old1;
         cur.ov[0] = at(lane + 64);
@@ -1378,6 +1394,15 @@ __device__ __forceinline__ void slot_fence() {   // the wave is about to re-read
     }
 }
 
+template <bool kPark>
+__device__ __forceinline__ float slot_read(const float* f, int dword) {   // one float of a parked struct (after an asm barrier on f)
+    if constexpr (kPark) {
+        return f[dword];                    // LDS: the compiler still knows
+    } else {
+        return ((GlobalFloats)f)[dword];    // HBM slot: a global load, not a flat one
+    }
+}
+
 __device__ __forceinline__ void copy_parms(mbe_parms* dst, const mbe_parms* src, int lane) {
     Parms t;
     load_parms(t, src, lane);
@@ -1510,15 +1535,15 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 asm volatile("" : "+s"(f));   // a real load, not the stored registers carried across the synthesiser (see synth_core)
             }
             if (lane < MBX_BAND_SLOTS) {
-                cur.log2Ml = f[O_LOG2ML + lane];
+                cur.log2Ml = slot_read<kPark>(f, O_LOG2ML + lane);
             }
             if (!fresh) {   // silence / comfort noise: previousUw and the noise overlap are unchanged
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    cur.uw[j] = f[O_UW + lane + 64 * j];
+                    cur.uw[j] = slot_read<kPark>(f, O_UW + lane + 64 * j);
                 }
-                cur.ov[0] = f[O_OVERLAP + lane];
-                cur.ov[1] = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
+                cur.ov[0] = slot_read<kPark>(f, O_OVERLAP + lane);
+                cur.ov[1] = (lane < 32) ? slot_read<kPark>(f, O_OVERLAP + 64 + lane) : 0.0f;
             }
         }
         if (muted) {
@@ -1968,15 +1993,15 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     asm volatile("" : "+s"(f));   // a real load (see the IMBE kernel)
                 }
                 if (lane < MBX_BAND_SLOTS) {
-                    cur.log2Ml = f[O_LOG2ML + lane];
+                    cur.log2Ml = slot_read<kPark>(f, O_LOG2ML + lane);
                 }
                 if (!fresh) {   // silence / comfort noise: previousUw and the noise overlap are unchanged
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        cur.uw[j] = f[O_UW + lane + 64 * j];
+                        cur.uw[j] = slot_read<kPark>(f, O_UW + lane + 64 * j);
                     }
-                    cur.ov[0] = f[O_OVERLAP + lane];
-                    cur.ov[1] = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
+                    cur.ov[0] = slot_read<kPark>(f, O_OVERLAP + lane);
+                    cur.ov[1] = (lane < 32) ? slot_read<kPark>(f, O_OVERLAP + 64 + lane) : 0.0f;
                 }
             }
             store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := synthesised model
