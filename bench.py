@@ -52,6 +52,9 @@ WORKLOADS = {
     # SURVEY.md §8(f) row 1 (not a BASELINE config): the soft-decision front end in front of the same path
     "imbe_soft": (0, 65536, 1, "65,536 IMBE 7200x4400 streams x T=1, soft-decision frames (noisy observations of random bits)"),
     "ambe_soft": (1, 65536, 1, "65,536 AMBE+2 3600x2450 streams x T=1, soft-decision frames (noisy observations of random bits)"),
+    # the same front end on what a receiver sees: encoded voice frames through noise (about 2.3 % wrong hard decisions)
+    "imbe_soft_coded": (0, 65536, 1, "65,536 IMBE 7200x4400 streams x T=1, soft-decision frames (noisy observations of ENCODED voice frames)"),
+    "ambe_soft_coded": (1, 65536, 1, "65,536 AMBE+2 3600x2450 streams x T=1, soft-decision frames (noisy observations of ENCODED voice frames)"),
 }
 CODEC_NAME = {0: "IMBE 7200x4400", 1: "AMBE+2 3600x2450", 2: "IMBE 7100x4400", 3: "AMBE 3600x2400"}
 
@@ -64,6 +67,8 @@ def make_frames(name, codec, S, T, rank):
         return framegen.imbe_clean_voiced_frames(S * T, rng)
     if name == "ambe_fec":
         return framegen.ambe_noisy_voice_frames(S * T, rng, ber=0.01)
+    if name.endswith("_soft_coded"):
+        return framegen.soft_frames_coded(codec, S * T, rng)
     if name.endswith("_soft"):
         return framegen.soft_frames(codec, S * T, rng)
     return framegen.random_frames(codec, S * T, rng)
@@ -158,7 +163,7 @@ def reference_full_path(name, codec, T, simd, threads, budget_s):
     from mbelib_neo_amd.layout import FRAME_CELLS, init_state
 
     lib = _ref_lib(simd)
-    if lib is None or name.endswith("_soft"):
+    if lib is None or "_soft" in name:
         return None
     per = (4096 if threads == 1 else 1024) if T == 1 else max(64, 4096 // T)
     S = per * threads
@@ -222,7 +227,7 @@ def oracle_port_baseline(name, codec, T, budget_s):
     import oracle_lib
 
     o = oracle_lib.load()
-    soft = name.endswith("_soft")
+    soft = "_soft" in name
     S = (512 if soft else 4096) if T == 1 else max(64, 4096 // T)
     frames = make_frames(name, codec, S, T, rank=0)
     seeds = np.arange(S) + 1234
@@ -332,7 +337,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
                          "MBX_HIP_LIBRARY=$PWD/mbelib-neo_amd/libmbx_hip_ablate.so python bench.py --ablate MASK")
     stream = torch.cuda.current_stream().cuda_stream
     _native.check(L.mbx_reserve_stream(stream, S * T), "mbx_reserve_stream")  # launches below never allocate
-    soft = name.endswith("_soft")
+    soft = "_soft" in name
     if soft:
         def fec(frames_ptr, count, records_ptr, strm):
             return L.mbx_fec_soft(codec, frames_ptr, count, records_ptr, strm)
@@ -426,7 +431,7 @@ def roofline_of(name, S, T, m):
         "frac_on_counter_bytes": (traffic / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
         "binding_resource": "VALU issue and memory latency (DESIGN.md section 3); the HBM fraction is what BASELINE.json asks to be reported",
     }
-    if name.endswith("_soft"):
+    if "_soft" in name:
         r["note"] = "dominant kernel of this workload is the soft-decision FEC kernel: algorithmic bytes = n * (2 B per soft cell + 16 B record)"
     else:
         r["note"] = "algorithmic bytes = S*T*(wire frame + int16 PCM) + S*2*3*2604 state (SURVEY.md §8(d))"

@@ -665,23 +665,47 @@ __device__ uint32_t golay_soft_wave(const DeviceTables& tabs, const SoftLane& L,
     S.round[lane] = make_uint2(addr_round, key_round);   // read back wave-uniformly: LDS broadcasts, no VALU
     wave_lds_sync();
     const char* table = reinterpret_cast<const char*>(S.parity);
-    uint32_t best = 0xffffffffu;
-#pragma unroll 8
-    for (int j = 0; j < 64; ++j) {
+    auto score_round = [&](int j, uint32_t& best) {   // the lane's candidate of round j (u_hi = j); j is wave-uniform
         const uint2 r = S.round[j];
         const uint32_t val = *reinterpret_cast<const uint16_t*>(table + (addr_lane ^ r.x));
         const uint32_t key = (val << 17) + r.y;   // v_lshl_add_u32; the lane's own part is added after the loop
         best = key < best ? key : best;
-    }
-    best += key_lane;
-    best = wave_min_u32(best);
+    };
+    // Exact pruning.  The cost of a candidate is at least the cost of the high data bits it flips, a_hi(j), which is the
+    // same for the 64 candidates of round j.  Two candidates give an upper bound on the winning cost before the search:
+    // the hard decoder's own code word (scored anyway, for its cleared tie bit) and the best candidate of round 0
+    // (no high data bit flipped).  A round with a_hi(j) above that bound cannot hold the minimum -- keys order by cost
+    // first, and rounds that merely TIE the bound are kept, so the reference's tie rules see every candidate they could
+    // pick.  On noisy random words 10 to 30 of the 64 rounds survive, on clean code words a handful.
+    uint32_t key_hard;
     {   // the candidate whose data equals the hard decoder's output
         const uint32_t ut = (hard_fixed >> 11) ^ hd;
         const int lt = (int)(ut & 63u), jt = (int)(ut >> 6);
         const uint32_t val = *reinterpret_cast<const uint16_t*>(table + (rl(addr_lane, lt) ^ rl(addr_round, jt)));
-        const uint32_t key = (val << 17) + rl(key_lane, lt) + rl(key_round, jt) - 0x10000u;
-        best = key < best ? key : best;
+        key_hard = (val << 17) + rl(key_lane, lt) + rl(key_round, jt) - 0x10000u;
     }
+    uint32_t best = 0xffffffffu;
+    score_round(0, best);
+    const uint32_t round0 = wave_min_u32(best + key_lane);
+    const uint32_t limit = (round0 < key_hard ? round0 : key_hard) >> 17;   // a cost no winner can exceed
+    unsigned long long live = __ballot(a_hi <= limit) & ~1ULL;           // lane j speaks for round j
+    while (live) {   // four rounds per trip (the two LDS reads of a round are a dependent pair: give the scheduler several)
+        const int j0 = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        const int j1 = live ? (__ffsll((long long)live) - 1) : j0;   // a repeated round changes nothing: min is idempotent
+        live &= live - 1;
+        const int j2 = live ? (__ffsll((long long)live) - 1) : j0;
+        live &= live - 1;
+        const int j3 = live ? (__ffsll((long long)live) - 1) : j0;
+        live &= live - 1;
+        score_round(j0, best);
+        score_round(j1, best);
+        score_round(j2, best);
+        score_round(j3, best);
+    }
+    best += key_lane;
+    best = wave_min_u32(best);
+    best = key_hard < best ? key_hard : best;
     diffs = (int)((best >> 12) & 0xfu);
     return ((best & 0xfffu) << 11) | hp;
 }
@@ -770,22 +794,36 @@ __device__ uint32_t hamming_soft_wave(const DeviceTables& tabs, const SoftLane& 
     S.round[lane] = make_uint2(addr_round, key_round);
     wave_lds_sync();
     const char* table = reinterpret_cast<const char*>(S.parity);
-    uint32_t best = 0xffffffffu;
-#pragma unroll 8
-    for (int j = 0; j < 32; ++j) {
+    auto score_round = [&](int j, uint32_t& best) {
         const uint2 r = S.round[j];
         const uint32_t val = *reinterpret_cast<const uint32_t*>(table + (addr_lane ^ r.x));
-        const uint32_t key = val + key_lane + r.y;
+        const uint32_t key = val + r.y;   // the lane's own part is added after the loop
         best = key < best ? key : best;
-    }
-    best = wave_min_u32(best);
+    };
+    // exact pruning of whole rounds by the cost of their high data bits, as in golay_soft_wave
+    uint32_t key_hard;
     {   // the candidate that equals the hard decoder's output
         const uint32_t ut = gather_data(hard_fixed) ^ hd;
         const int lt = (int)(ut & 63u), jt = (int)(ut >> 6);
         const uint32_t val = *reinterpret_cast<const uint32_t*>(table + (rl(addr_lane, lt) ^ rl(addr_round, jt)));
-        const uint32_t key = val + rl(key_lane, lt) + rl(key_round, jt) - 0x8000u;
-        best = key < best ? key : best;
+        key_hard = val + rl(key_lane, lt) + rl(key_round, jt) - 0x8000u;
     }
+    uint32_t best = 0xffffffffu;
+    score_round(0, best);
+    const uint32_t round0 = wave_min_u32(best + key_lane);
+    const uint32_t limit = (round0 < key_hard ? round0 : key_hard) >> 16;
+    unsigned long long live = __ballot(lane < 32 && a_hi <= limit) & ~1ULL;   // lane j < 32 speaks for round j
+    while (live) {
+        const int j0 = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        const int j1 = live ? (__ffsll((long long)live) - 1) : j0;
+        live &= live - 1;
+        score_round(j0, best);
+        score_round(j1, best);
+    }
+    best += key_lane;
+    best = wave_min_u32(best);
+    best = key_hard < best ? key_hard : best;
     diffs = (int)((best >> 11) & 0xfu);
     const uint32_t data = best & 0x7ffu;
     uint32_t cw = 0;

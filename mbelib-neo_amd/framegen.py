@@ -190,3 +190,36 @@ def soft_frames(codec, n, rng, snr_like=2.0):
     coarse = rng.integers(0, 4, size=(n, 1)) == 0          # a quarter of the frames: 3-level confidences
     rel = np.where(coarse, (rel // 96) * 96, rel).astype(np.uint8)
     return np.stack([hard, rel], axis=-1)
+
+
+def soft_frames_coded(codec, n, rng, snr_like=2.0):
+    """Soft-decision frames as a receiver sees them: clean ENCODED voice frames (IMBE 7200x4400 all-voiced / AMBE+2 voice)
+    observed through additive noise, reliability = clamped |observation| (snr_like 2.0: about 2.3 % wrong hard decisions,
+    low confidence on most of them).  uint8 [n, 184|96, 2] = (bit, reliability), unused cells 0 / 0."""
+    from .layout import FRAME_CELLS, ROW_WIDTHS
+
+    codec = int(codec)
+    if codec == CODEC_IMBE7200X4400:
+        packed = imbe_clean_voiced_frames(n, rng)
+    elif codec == CODEC_AMBE3600X2450:
+        packed = encode_ambe3600x2450(ambe_voice_param_bits(n, rng))
+    else:
+        raise ValueError("coded soft frames: IMBE 7200x4400 and AMBE+2 3600x2450 only")
+    rows, cols = FRAME_CELLS[codec]
+    wire = np.unpackbits(np.ascontiguousarray(packed, dtype=np.uint8), axis=1)
+    bits = np.zeros((n, rows, cols), dtype=np.int64)
+    used = np.zeros((rows, cols), dtype=bool)
+    off = 0
+    for r, w in enumerate(ROW_WIDTHS[codec]):
+        bits[:, r, :w] = wire[:, off:off + w][:, ::-1]   # the first wire bit of a row is its highest cell
+        used[r, :w] = True
+        off += w
+    bits = bits.reshape(n, rows * cols)
+    obs = (2.0 * bits - 1.0) * snr_like + rng.normal(0.0, 1.0, size=bits.shape)
+    hard = (obs > 0).astype(np.uint8)
+    rel = np.clip(np.abs(obs) * 40.0, 0, 255).astype(np.uint8)
+    mask = used.reshape(-1)
+    hard[:, ~mask] = 0
+    rel[:, ~mask] = 0
+    return np.stack([hard, rel], axis=-1)
+

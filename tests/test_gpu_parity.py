@@ -524,6 +524,31 @@ def test_soft_pipeline_vs_oracle(mbx, oracle, codec, S, T):
     parity.check_state(ref["state"], got["state"])
 
 
+@pytest.mark.parametrize("codec", [0, 1])
+def test_soft_fec_pruned_search_bit_exact_on_coded_and_degenerate_frames(mbx, oracle, codec):
+    """The soft-decision search skips whole rounds of candidates that cannot hold the minimum (mbx_fec.hip, "exact
+    pruning").  Bit-exact against the oracle's exhaustive search on the inputs where the bound is tightest and ties are
+    most frequent: encoded frames through noise at three noise levels, all-equal reliabilities (every cost ties),
+    all-zero reliabilities, and saturated ones."""
+    from mbelib_neo_amd import decoder, framegen
+
+    n = 3000
+    batches = [framegen.soft_frames_coded(codec, n, framegen.rng_for(8100 + codec + 10 * k), snr_like=snr)
+               for k, snr in enumerate((0.8, 2.0, 4.0))]
+    rnd = framegen.soft_frames(codec, n, framegen.rng_for(8200 + codec))
+    for value in (0, 1, 7, 255):
+        f = rnd.copy()
+        f[..., 1] = value
+        batches.append(f)
+    two = rnd.copy()
+    two[..., 1] = (two[..., 1] & 1) * 200   # two confidence levels only
+    batches.append(two)
+    for soft in batches:
+        got = decoder.fec_soft_host(codec, soft)
+        ref = oracle.fec_soft_batch(codec, soft)
+        assert np.array_equal(got["w"], ref["w"])
+
+
 # ---- IMBE 7100x4400 front end (SURVEY.md §8(f) row 4) ---------------------------------------------
 def test_imbe7100_fec_bit_exact(mbx, oracle):
     from mbelib_neo_amd import decoder, framegen
