@@ -87,6 +87,15 @@ int mbx_pack_ambe3600x2450(const char* frames /* n*4*24 */, size_t n, uint8_t* p
 void mbx_unpack_records(const mbx_param_record* rec, size_t n, int nbits /* 88|49 */, char* bits /* n*nbits, or NULL */,
                         mbe_process_result* results /* n, or NULL */);
 
+/* The same packing on the DEVICE, for hosts that keep whole batches of bursts as the reference's
+ * cell arrays: d_cells = n x (8*23 | 4*24 | 7*24) chars as uploaded, d_packed = n wire frames, d_status[i] (may be NULL)
+ * = 0 or MBE_STATUS_INVALID_BITS when any cell of frame i -- unused cells included, like mbe_validate_bits -- is outside
+ * {0, 1}; such a frame must not be decoded (mask it out of the batch or drop the stream's tick).  184 B instead of 18 B
+ * of PCIe per IMBE frame, but no per-frame host loop.
+ * Wire order = row after row (C0 first), inside a row from the highest cell down to cell 0: the order in which a
+ * deinterleaver that fills imbe_fr[r][j] / ambe_fr[r][j] per the air-interface tables would emit the bits of row r. */
+int mbx_pack_cells(int codec, const char* d_cells, size_t n, uint8_t* d_packed, int32_t* d_status, void* stream);
+
 /* ---- FEC stage: frames -> parameter records (stateless, one thread per frame) ---------- */
 
 /* ref: mbe_decodeImbe7200x4400Frame  include/mbelib-neo/mbelib.h:471, src/imbe/imbe7200x4400.c:709-744

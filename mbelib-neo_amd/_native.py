@@ -33,6 +33,7 @@ _SIGNATURES = {
     "mbx_last_error": (C.c_char_p, []),
     "mbx_pack_imbe7200x4400": (C.c_int, [_vp, _sz, _vp]),
     "mbx_pack_ambe3600x2450": (C.c_int, [_vp, _sz, _vp]),
+    "mbx_pack_cells": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp]),
     "mbx_unpack_records": (None, [_vp, _sz, C.c_int, _vp, _vp]),
     "mbx_fec_imbe7200x4400": (C.c_int, [_vp, _sz, _vp, _vp]),
     "mbx_fec_ambe3600x2450": (C.c_int, [_vp, _sz, _vp, _vp]),

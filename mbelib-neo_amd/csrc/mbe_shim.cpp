@@ -928,9 +928,11 @@ int mbe_checkGolayBlock(long int* block) {
     if (!block) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
+    const uint32_t block_u = (uint32_t)(*block);
     uint32_t fixed;
-    (void)ecc_word(0, (uint32_t)(*block) & 0x7fffffu, &fixed);
-    *block = (long)(fixed >> 11);
+    (void)ecc_word(0, block_u & 0x7fffffu, &fixed);
+    // the reference corrects (block >> 11) as a whole (ref src/ecc/ecc.c:246-249): bits above the 23-bit code word pass through
+    *block = (long)(int)((fixed >> 11) | ((block_u >> 23) << 12));
     return 0;
 }
 

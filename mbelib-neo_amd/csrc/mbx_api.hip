@@ -43,6 +43,7 @@ __global__ void comfort_noise_kernel(int, mbx_stream_rng*, float*, int16_t*);
 __global__ void state_copy_kernel(int, mbe_parms*);
 __global__ void tone_kernel(int, const mbx_param_record*, const int32_t*, mbe_parms*, float*, int16_t*);
 __global__ void ecc_words_kernel(int, const uint32_t*, size_t, uint32_t*, int32_t*, DeviceTables);
+__global__ void pack_cells_kernel(int, const char*, size_t, uint8_t*, int32_t*);
 __global__ void fec_stage_kernel(int, int, const uint8_t*, size_t, uint8_t*, mbx_param_record*, DeviceTables);
 __global__ void decode_parms_kernel(int, int, const FrameParams*, mbe_parms*, mbe_parms*, int32_t*, DeviceTables);
 __global__ void fec_imbe7200x4400_soft_kernel(const mbe_soft_bit*, size_t, mbx_param_record*, DeviceTables);
@@ -1079,6 +1080,20 @@ void mbx_debug_set_ablation(int mask) {
     }
 }
 #endif
+
+int mbx_pack_cells(int codec, const char* d_cells, size_t n, uint8_t* d_packed, int32_t* d_status, void* stream) {
+    REQUIRE_CTX(c);
+    (void)c;
+    if (!d_cells || !d_packed || codec < MBX_CODEC_IMBE7200X4400 || codec > MBX_CODEC_AMBE3600X2400) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::pack_cells_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, codec, d_cells, n,
+                       d_packed, d_status);
+    return check_launch("pack_cells_kernel");
+}
 
 int mbx_fec_stage(int codec, int stage, const void* d_in, size_t n, uint8_t* d_frames_out, mbx_param_record* d_out, void* stream) {
     REQUIRE_CTX(c);

@@ -504,6 +504,65 @@ fec_stage_kernel(int codec, int stage, const uint8_t* __restrict__ frames, size_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Cell arrays -> wire frames on the device: hosts that hold their bursts as the reference's
+// char arrays (imbe_fr[8][23] / ambe_fr[4][24] / imbe_fr[7][24], one char per bit) can upload them as they are; this
+// kernel validates every cell like the reference does (mbe_validate_bits, src/internal/mbe_result.h:18-29: the WHOLE
+// array, unused cells included) and packs the rows in wire order (row r, cells width[r]-1 .. 0).
+// One workgroup of 256 threads takes 32 frames: the cells are staged through LDS with coalesced 4-byte loads, then one
+// thread per output byte gathers its eight cells.  status[i] = 0 or MBE_STATUS_INVALID_BITS (the frame is then packed
+// from the low bit of each cell and must be ignored by the caller, like the reference's "nothing is written").
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pack_cells_kernel(int codec, const char* __restrict__ cells, size_t n, uint8_t* __restrict__ packed, int32_t* __restrict__ status) {
+    constexpr int kFrames = 32;
+    __shared__ uint32_t stage[kFrames * 184 / 4];
+    __shared__ int bad[kFrames];
+    const bool ambe = codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400;
+    const int ncell = codec == MBX_CODEC_IMBE7200X4400 ? 184 : (ambe ? 96 : 168);
+    const int stride = codec == MBX_CODEC_IMBE7200X4400 ? 23 : 24;
+    const int fbytes = ambe ? MBX_AMBE_FRAME_BYTES : MBX_IMBE_FRAME_BYTES;
+    const int rows = codec == MBX_CODEC_IMBE7200X4400 ? 8 : (ambe ? 4 : 7);
+    const int w0[8] = {23, 23, 23, 23, 15, 15, 15, 7}, w1[8] = {24, 23, 11, 14, 0, 0, 0, 0}, w2[8] = {19, 24, 23, 23, 15, 15, 23, 0};
+    const size_t first = (size_t)blockIdx.x * kFrames;
+    const int here = (int)((n - first) < (size_t)kFrames ? (n - first) : (size_t)kFrames);
+    if (threadIdx.x < kFrames) {
+        bad[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const int words = here * ncell / 4;   // ncell is a multiple of 4 for all three shapes
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(cells + first * (size_t)ncell);
+    for (int i = (int)threadIdx.x; i < words; i += 256) {
+        const uint32_t v = src[i];
+        stage[i] = v;
+        if (v & 0xfefefefeu) {   // a cell outside {0, 1}
+            bad[(i * 4) / ncell] = 1;   // the four cells of a word may straddle two frames: mark both
+            bad[(i * 4 + 3) / ncell] = 1;
+        }
+    }
+    __syncthreads();
+    const char* c = reinterpret_cast<const char*>(stage);
+    for (int o = (int)threadIdx.x; o < here * fbytes; o += 256) {
+        const int f = o / fbytes, b = o % fbytes;
+        uint32_t byte = 0;
+        for (int k = 0; k < 8; ++k) {
+            int pos = 8 * b + k, r = 0;   // wire position -> (row, cell)
+            for (; r < rows; ++r) {
+                const int w = codec == MBX_CODEC_IMBE7200X4400 ? w0[r] : (ambe ? w1[r] : w2[r]);
+                if (pos < w) {
+                    byte |= (uint32_t)(c[f * ncell + r * stride + (w - 1 - pos)] & 1) << (7 - k);
+                    break;
+                }
+                pos -= w;
+            }
+        }
+        packed[(first + (size_t)f) * (size_t)fbytes + (size_t)b] = (uint8_t)byte;
+    }
+    if ((int)threadIdx.x < here && status) {
+        status[first + threadIdx.x] = bad[threadIdx.x] ? MBE_STATUS_INVALID_BITS : 0;
+    }
+}
+
 // Code-word level ECC (the public per-word helpers, batched): kind 0 = Golay(23,12), 1 = Hamming(15,11),
 // 2 = Hamming(15,11) with the IMBE 7100x4400 bit mapping (mbe_7100x4400hamming1511, src/ecc/ecc.c:422-464).
 //   ref mbe_golay2312 / mbe_checkGolayBlock src/ecc/ecc.c:221-301, mbe_hamming1511 src/ecc/ecc.c:366-408

@@ -901,3 +901,39 @@ def test_near_threshold_smoothing_decisions_are_the_references(mbx, oracle):
                 pf = out["pcmf"].cpu().numpy().reshape(split, 160)
                 want = np.concatenate([refs[t]["pcmf"].reshape(1, 160) for t in range(t0, t0 + split)])
                 parity.check_pcm(want, pf, what=f"codec {codec} seed {seed} frames {t0}..{k}")
+
+
+@pytest.mark.parametrize("codec", [0, 1, 2, 3])
+def test_device_cell_packing_matches_host_packer(mbx, oracle, codec):
+    """mbx_pack_cells (cell arrays -> wire frames on the device, whole-array validation) against the host packer, on a
+    ragged count (not a multiple of the 32 frames a workgroup takes), with invalid cells -- also in unused positions --
+    flagged per frame."""
+    import torch
+
+    from mbelib_neo_amd import _native
+    from mbelib_neo_amd.layout import FRAME_BYTES, FRAME_CELLS
+
+    L = _native.lib()
+    rows, cols = FRAME_CELLS[codec]
+    ncell, n = rows * cols, 1000 + codec
+    rng = np.random.default_rng(17 + codec)
+    cells = rng.integers(0, 2, size=(n, ncell), dtype=np.int8)
+    host_pack = {0: L.mbx_pack_imbe7200x4400, 1: L.mbx_pack_ambe3600x2450, 2: L.mbx_pack_imbe7100x4400, 3: L.mbx_pack_ambe3600x2450}[codec]
+    want = np.zeros((n, FRAME_BYTES[codec]), dtype=np.uint8)
+    assert host_pack(cells.ctypes.data, n, want.ctypes.data) == 0
+    bad_frames = [0, 31, 32, 500, n - 1]
+    dirty = cells.copy()
+    for k, f in enumerate(bad_frames):
+        dirty[f, (ncell - 1) if k % 2 else 3] = (2, -1, 77, 3, -128)[k]
+    d_cells = torch.from_numpy(dirty).cuda()
+    d_packed = torch.zeros((n, FRAME_BYTES[codec]), dtype=torch.uint8, device="cuda")
+    d_status = torch.full((n,), 5, dtype=torch.int32, device="cuda")
+    _native.check(L.mbx_pack_cells(codec, d_cells.data_ptr(), n, d_packed.data_ptr(), d_status.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), "mbx_pack_cells")
+    status = d_status.cpu().numpy()
+    got = d_packed.cpu().numpy()
+    expect = np.zeros(n, dtype=np.int32)
+    expect[bad_frames] = -2
+    assert np.array_equal(status, expect)
+    ok = status == 0
+    assert np.array_equal(got[ok], want[ok])

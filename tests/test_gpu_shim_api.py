@@ -142,6 +142,9 @@ def test_ecc_known_answers(mbe):
 
     blk = C.c_long(cw ^ (1 << (11 + 5)))
     assert mbe.mbe_checkGolayBlock(C.byref(blk)) == 0 and blk.value == 0xA55
+    # bits above the 23-bit code word pass through the correction like in the reference (src/ecc/ecc.c:246-249)
+    hi = C.c_long((0x5A << 23) | (cw ^ (1 << 16)))
+    assert mbe.mbe_checkGolayBlock(C.byref(hi)) == 0 and hi.value == ((0x5A << 12) | 0xA55)
     code = np.array([(cw >> j) & 1 for j in range(23)], dtype=np.int8)
     out = np.zeros(23, dtype=np.int8)
     for flips in ((11,), (12, 20), (13, 17, 22)):
