@@ -176,16 +176,21 @@ void must(int rc, const char* what) {
 constexpr unsigned kContext = MBE_PROCESS_FLAG_SOFT_INPUT | MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID;
 constexpr unsigned kStatus = MBE_PROCESS_FLAG_TONE | MBE_PROCESS_FLAG_ERASURE | MBE_PROCESS_FLAG_REPEAT | MBE_PROCESS_FLAG_MUTE;
 
-int validate_bits(const char* bits, size_t count) {
+int validate_bits(const char* bits, size_t count) {   // ref src/internal/mbe_result.h:18-29; eight cells at a time
     if (!bits) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    for (size_t i = 0; i < count; ++i) {
-        if (bits[i] != 0 && bits[i] != 1) {
-            return MBE_STATUS_INVALID_BITS;
-        }
+    uint64_t acc = 0;
+    size_t i = 0;
+    for (; i + 8 <= count; i += 8) {
+        uint64_t v;
+        memcpy(&v, bits + i, 8);
+        acc |= v;
     }
-    return 0;
+    for (; i < count; ++i) {
+        acc |= (uint8_t)bits[i];
+    }
+    return (acc & 0xfefefefefefefefeULL) ? MBE_STATUS_INVALID_BITS : 0;
 }
 
 bool count_ok(int c) { return c >= 0 && c <= 184; }

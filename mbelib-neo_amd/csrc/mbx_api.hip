@@ -171,23 +171,52 @@ int validate_bits(const char* bits, size_t count) {   // ref: src/internal/mbe_r
     if (!bits) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
-    for (size_t i = 0; i < count; ++i) {
-        if (bits[i] != 0 && bits[i] != 1) {
-            return MBE_STATUS_INVALID_BITS;
-        }
+    // eight cells at a time: a cell is valid iff no bit but bit 0 is set
+    uint64_t acc = 0;
+    size_t i = 0;
+    for (; i + 8 <= count; i += 8) {
+        uint64_t v;
+        memcpy(&v, bits + i, 8);
+        acc |= v;
     }
-    return 0;
+    for (; i < count; ++i) {
+        acc |= (uint8_t)bits[i];
+    }
+    return (acc & 0xfefefefefefefefeULL) ? MBE_STATUS_INVALID_BITS : 0;
 }
 
+// rows of 0/1 cells -> wire bits: row r contributes cells width[r]-1 .. 0.  Eight cells become eight bits with one
+// multiplication (byte i of x lands on bit 56 + i of x * 0x0102040810204080), three of those cover a row of up to 24 cells.
 void pack_rows(const char* cells, int rows, int stride, const int* width, uint8_t* out, int nbytes) {
-    memset(out, 0, (size_t)nbytes);
-    int pos = 0;
+    char pad[200];   // the last row is read eight cells at a time: give it room (frames are at most 184 cells)
+    const int ncell = rows * stride;
+    memcpy(pad, cells, (size_t)ncell);
+    memset(pad + ncell, 0, sizeof(pad) - (size_t)ncell);
+    uint64_t acc = 0;   // bit accumulator, filled from the top
+    int have = 0, o = 0;
     for (int r = 0; r < rows; ++r) {
-        for (int j = width[r] - 1; j >= 0; --j, ++pos) {
-            if (cells[r * stride + j]) {
-                out[pos >> 3] |= (uint8_t)(0x80u >> (pos & 7));
-            }
+        const char* row = pad + r * stride;
+        uint32_t v = 0;   // bit j = cell j
+        for (int k = 0; k < 3; ++k) {
+            uint64_t x;
+            memcpy(&x, row + 8 * k, 8);
+            v |= (uint32_t)(((x & 0x0101010101010101ULL) * 0x0102040810204080ULL) >> 56) << (8 * k);
         }
+        const int w = width[r];
+        v &= (w >= 32) ? 0xffffffffu : ((1u << w) - 1u);
+        acc |= (uint64_t)v << (64 - have - w);   // cell w-1 first
+        have += w;
+        while (have >= 8) {
+            out[o++] = (uint8_t)(acc >> 56);
+            acc <<= 8;
+            have -= 8;
+        }
+    }
+    if (have > 0 && o < nbytes) {
+        out[o++] = (uint8_t)(acc >> 56);
+    }
+    while (o < nbytes) {
+        out[o++] = 0;
     }
 }
 
