@@ -318,7 +318,7 @@ def self_launch(argv, n, script=None):
 
 
 # ---- one workload on this rank's GPU ----------------------------------------------------------------------------------
-def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args):
+def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args, use_dist=False):
     """Returns the measurements of one workload: wall time of `steps` steps (max over ranks), HIP-event time of the
     dominant kernel, frame mix.  The launches of a step are what mbx_process_batch issues; they are issued one by one
     here only so that the dominant kernel can be bracketed by events on the launch stream."""
@@ -375,19 +375,19 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
         L.mbx_debug_set_ablation(args.ablate)  # development build only (tools/); never in a reported run
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
         step(events[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
@@ -449,6 +449,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline (and cpu_baseline) only: no other_configs, host_path, no_reverse")
     ap.add_argument("--split-expand", action="store_true", help="run the parameter expansion as a separate launch")
     ap.add_argument("--fuse-expand", action="store_true", help="development aid: IMBE at T = 1 through the fused (one-launch) path")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the collectives even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (development build of the library only); results invalid")
     args = ap.parse_args()
 
@@ -468,8 +470,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import mbelib_neo_amd as mbx
@@ -477,9 +481,9 @@ def main():
     from mbelib_neo_amd.parallel import broadcast_tables, shard_range
 
     # rank 0 reads the blob, RCCL broadcasts it, every rank uploads it and the checksums are compared
-    blob = broadcast_tables(mbx.load_tables_blob() if rank == 0 else None, device)
+    blob = broadcast_tables(mbx.load_tables_blob() if rank == 0 else None, device, force=args.force_dist)
     checksum = decoder.ensure_init(local_rank, blob)
-    if world > 1:
+    if use_dist:
         cs = torch.tensor([checksum], dtype=torch.int64, device=device)
         gathered = [torch.zeros_like(cs) for _ in range(world)]
         dist.all_gather(gathered, cs)
@@ -490,7 +494,7 @@ def main():
         S = args.streams
     first, count = shard_range(S * world, world, rank)  # weak scaling: S streams on every rank
     assert count == S
-    m = run_workload(args.workload, S, T, args.steps, args.warmup, rank, first, local_rank, blob, world, dist, args)
+    m = run_workload(args.workload, S, T, args.steps, args.warmup, rank, first, local_rank, blob, world, dist, args, use_dist)
 
     line = {
         "metric": "20ms frames/sec (whole node), " + CODEC_NAME[codec],
@@ -511,7 +515,8 @@ def main():
             "frames_per_stream_per_step": T,
             "frames_per_step": m["frames_per_step"],
             "output": "int16 PCM + mbe_process_result per frame",
-            "parallelism": f"{world} independent stream shard(s), table blob broadcast over RCCL, per-rank checksums equal",
+            "parallelism": f"{world} independent stream shard(s), table blob broadcast over RCCL, per-rank checksums equal"
+                           + (" (process group initialised)" if use_dist else ""),
             "frame_mix": m["frame_mix"],
         },
         "roofline": roofline_of(args.workload, S, T, m),
@@ -585,7 +590,7 @@ def main():
             except Exception as e:   # noqa: BLE001
                 line["no_reverse"] = {"error": str(e)[:300]}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,13 +15,14 @@ def shard_range(total_streams, world_size, rank):
     return first, count
 
 
-def broadcast_tables(blob, device=None):
+def broadcast_tables(blob, device=None, force=False):
     """Rank 0 passes the blob bytes, the others None; returns the bytes on every rank.  Uses the
-    default process group if one is initialised, otherwise returns the input unchanged."""
+    default process group if one is initialised, otherwise returns the input unchanged (a group of one
+    rank runs the collectives only when `force` is set: bench.py --force-dist on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         if blob is None:
             raise ValueError("rank 0 must provide the table blob")
         return bytes(blob)

@@ -937,3 +937,23 @@ def test_device_cell_packing_matches_host_packer(mbx, oracle, codec):
     assert np.array_equal(status, expect)
     ok = status == 0
     assert np.array_equal(got[ok], want[ok])
+
+
+def test_bench_rccl_code_path_runs_with_one_rank():
+    """bench.py under torch.distributed.run with one rank and --force-dist: the process group is initialised on RCCL, the
+    table blob goes through a device-tensor broadcast, timings through all_reduce, checksums through all_gather -- the
+    code path of --gpus N, on the one GPU this box has.  (The N-rank launch itself is covered on CPU:
+    tests/test_host_logic.py::test_bench_self_launch_starts_ranks_and_relays_rank0 and the gloo broadcast test.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                        "--streams", "4096", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "process group initialised" in line["config"]["parallelism"]
