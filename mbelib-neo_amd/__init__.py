@@ -31,6 +31,5 @@ from .layout import (  # noqa: F401
 from ._native import NativeLibraryError, lib, library_path  # noqa: F401
 from . import framegen  # noqa: F401
 from .decoder import BatchDecoder  # noqa: F401
-from . import compat  # noqa: F401
 
-__all__ = ["BatchDecoder", "framegen", "compat", "lib", "NativeLibraryError"]
+__all__ = ["BatchDecoder", "framegen", "lib", "NativeLibraryError"]

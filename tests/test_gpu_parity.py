@@ -439,27 +439,6 @@ def test_edge_cases(mbx, oracle):
     assert (packed == 0xAA).all()
 
 
-def test_compat_per_frame_api(mbx, oracle):
-    """The per-frame mbe_* mirror drives the same kernels (S = T = 1) and keeps the reference's
-    call conventions: state updated in place, negative status leaves everything untouched."""
-    from mbelib_neo_amd import compat
-
-    S, T, fx = golden_io.stream(0)
-    cur, prev, enh = compat.mbe_initMbeParms()
-    compat.mbe_setThreadRngSeed(1234)
-    for t in range(6):
-        fr = fx["frames"][0, t]
-        ret, pcm, res, bits = compat.mbe_processImbe7200x4400Framef(fr["cells"].reshape(8, 23), cur, prev, enh)
-        assert ret == int(fr["ret"])
-        assert np.array_equal(bits, fr["bits"])
-        parity.check_pcm(fr["pcmf"], pcm)
-    bad = fx["frames"][0, 0]["cells"].copy()
-    bad[10] = 3
-    before = cur.tobytes()
-    ret, pcm, res, bits = compat.mbe_processImbe7200x4400Framef(bad.reshape(8, 23), cur, prev, enh)
-    assert ret == -2 and pcm is None and cur.tobytes() == before
-
-
 # ---- soft-decision front end (SURVEY.md §8(f) row 1): bit-exact against the reference's own outputs ----
 def test_soft_ecc_words_match_reference_fixture(mbx):
     from mbelib_neo_amd import decoder
