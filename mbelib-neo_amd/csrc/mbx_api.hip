@@ -800,14 +800,22 @@ static bool stream_args_ok(int codec, int S, int T, const void* d_records, const
 // 0.296 vs 0.292 ms per 65,536 frames): the table look-ups of the expansion are a latency chain a one-frame wave cannot
 // hide, and the 8-lanes-per-frame expand kernel costs as much as it saves -- there the expansion stays a separate
 // launch, which keeps the dominant kernel to the stream stage proper.  The AMBE stream kernels always read rows.
-static bool needs_workspace(int codec, int T) { return !(codec == MBX_CODEC_IMBE7200X4400 && T > 1); }
+// ... except for small batches (the synchronous per-frame API is S = T = 1): there a launch less is worth more than the
+// last few per cent of kernel efficiency, and the IMBE stream kernel expands the record itself.
+constexpr int kSmallBatchFrames = 256;
+static bool needs_workspace(int codec, int S, int T) {
+    if (codec == MBX_CODEC_IMBE7200X4400) {
+        return T == 1 && S > kSmallBatchFrames;
+    }
+    return true;   // the AMBE stream kernels always read rows
+}
 
 // expand (where needed) + stream kernel with the workspace at `ws` (nullptr when none is needed); `order` = the launch
 // counter that decides the walking direction
 static int run_stream_stage(Context* c, unsigned order, int codec, int S, int T, const mbx_param_record* d_records,
                             mbx::FrameParams* ws, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
                             mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr) {
-    if (needs_workspace(codec, T)) {
+    if (needs_workspace(codec, S, T)) {
         int rc = launch_expand(c, codec, d_records, (size_t)S * (size_t)T, ws, stream);
         if (rc < 0) {
             return rc;
@@ -875,7 +883,7 @@ int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_recor
     // interleave their expand / stream pairs.
     std::lock_guard<std::mutex> lock(c->mu);
     StreamSlot& slot = c->slots[stream];
-    if (needs_workspace(codec, T)) {
+    if (needs_workspace(codec, S, T)) {
         int rc = ensure_workspace(c, slot, (size_t)S * (size_t)T, stream);
         if (rc < 0) {
             return rc;
@@ -896,7 +904,7 @@ int mbx_process_records_ws(int codec, int S, int T, const mbx_param_record* d_re
     if (S == 0 || T == 0) {
         return 0;
     }
-    if (needs_workspace(codec, T) && (!d_workspace || workspace_bytes < mbx_workspace_bytes((size_t)S * (size_t)T))) {
+    if (needs_workspace(codec, S, T) && (!d_workspace || workspace_bytes < mbx_workspace_bytes((size_t)S * (size_t)T))) {
         return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_process_records_ws: workspace missing or smaller than mbx_workspace_bytes(S*T)");
     }
     unsigned order;
@@ -970,7 +978,7 @@ int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_i
     }
     std::lock_guard<std::mutex> lock(c->mu);
     StreamSlot& slot = c->slots[stream];
-    if (needs_workspace(stream_codec, T)) {
+    if (needs_workspace(stream_codec, S, T)) {
         rc = ensure_workspace(c, slot, (size_t)S * (size_t)T, stream);
         if (rc < 0) {
             return rc;
