@@ -59,7 +59,8 @@ uint32_t mbx_table_checksum(void);
 const char* mbx_last_error(void);
 
 /* The expand workspace of the stream stage: 256 B per frame for the expanded parameters of the AMBE codecs and of
- * one-frame-per-stream IMBE launches (IMBE launches with T > 1 expand inside the stream kernel and need none).
+ * one-frame-per-stream IMBE launches of more than 256 streams (other IMBE launches expand inside the stream kernel and
+ * need none).
  * Each (device, hipStream_t) owns one, grown on demand -- growth waits for that stream and allocates, so size it up
  * front where that matters (required before stream capture):
  *   mbx_reserve(n)            every stream already known to the current device now, and every stream first used later,
