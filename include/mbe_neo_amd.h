@@ -15,8 +15,8 @@
  * message on stderr if that fails.  Like the reference (mbelib.h:28-30) the processing functions are re-entrant per
  * stream: each host thread has its own HIP stream, device scratch and RNG state.
  *
- * Throughput.  A synchronous call is one 20 ms frame = a few tiny transfers and launches (tens of
- * microseconds, against 18 us of CPU time in the reference), so a host that decodes many channels has two better
+ * Throughput.  A synchronous call is one 20 ms frame = one device round trip (about 33 us measured,
+ * against 18 us of CPU time in the reference), so a host that decodes many channels has two better
  * options, both measured in bench.py's `host_path`:
  *   * queue mode (below): keep calling the per-frame functions, mbe_flush() runs everything queued as batched launches;
  *   * sessions (include/mbx.h): hand whole batches of wire frames over, state stays on the device.
