@@ -229,3 +229,57 @@ def test_bench_self_launch_starts_ranks_and_relays_rank0(tmp_path):
     assert ok.returncode == 0 and ok.stdout.strip() == '{"rank": 0, "args": "--gpus 3 --steps 7"}', ok.stdout + ok.stderr
     bad = subprocess.run([sys.executable, "-c", code, "--fail"], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 3
+
+
+def test_program_written_against_the_reference_header_links(tmp_path):
+    """Drop-in at link level: a C program that includes the REFERENCE's own public header (where the reference tree is
+    present, i.e. in the authoring container; skipped elsewhere) and calls one function of every family links against
+    libmbe_neo_amd.so with no undefined symbol and no prototype conflict."""
+    import shim_lib
+
+    ref_inc = "/root/reference/include"
+    gen_inc = os.path.join(ROOT, "oracle", "_ref", "include")   # the generated one-line version.h (oracle/Makefile)
+    if not os.path.exists(os.path.join(ref_inc, "mbelib-neo", "mbelib.h")) or not os.path.exists(os.path.join(gen_inc, "mbelib-neo", "version.h")):
+        pytest.skip("reference tree not present here")
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <mbelib-neo/mbelib.h>
+int main(void) {
+    static mbe_parms cur, prev, enh;
+    static char imbe_fr[8][23], imbe7100_fr[7][24], ambe_fr[4][24], imbe_d[88], ambe_d[49];
+    static mbe_soft_bit soft_i[8][23], soft_a[4][24];
+    static short pcm[160];
+    static float pcmf[160];
+    mbe_process_result res;
+    long block = 0;
+    mbe_initMbeParms(&cur, &prev, &enh);
+    mbe_initProcessResult(&res);
+    mbe_setThreadRngSeed(1u);
+    int n = 0;
+    n += mbe_eccImbe7200x4400C0(imbe_fr) + mbe_demodulateImbe7200x4400Data(imbe_fr) + mbe_eccImbe7200x4400Data(imbe_fr, imbe_d);
+    n += mbe_decodeImbe4400Parms(imbe_d, &cur, &prev);
+    n += mbe_processImbe7200x4400Frame(pcm, &res, (const char(*)[23])imbe_fr, imbe_d, &cur, &prev, &enh);
+    n += mbe_processImbe7200x4400SoftFramef(pcmf, &res, (const mbe_soft_bit(*)[23])soft_i, imbe_d, &cur, &prev, &enh);
+    n += mbe_processImbe7100x4400Framef(pcmf, &res, (const char(*)[24])imbe7100_fr, imbe_d, &cur, &prev, &enh);
+    n += mbe_convertImbe7100to7200(imbe_d);
+    n += mbe_processAmbe3600x2450Frame(pcm, &res, (const char(*)[24])ambe_fr, ambe_d, &cur, &prev, &enh);
+    n += mbe_processAmbe3600x2450SoftFrame(pcm, &res, (const mbe_soft_bit(*)[24])soft_a, ambe_d, &cur, &prev, &enh);
+    n += mbe_processAmbe3600x2400Framef(pcmf, &res, (const char(*)[24])ambe_fr, ambe_d, &cur, &prev, &enh);
+    n += mbe_decodeAmbe2450Parms(ambe_d, &cur, &prev) + mbe_decodeAmbe2400Parms(ambe_d, &cur, &prev);
+    n += mbe_eccAmbe3600x2450C0(ambe_fr) + mbe_demodulateAmbe3600x2400Data(ambe_fr);
+    n += mbe_checkGolayBlock(&block) + mbe_golay2312(imbe_fr[0], imbe_fr[1]) + mbe_hamming1511(imbe_fr[4], imbe_fr[5]);
+    mbe_synthesizeSpeechf(pcmf, &cur, &prev);
+    mbe_spectralAmpEnhance(&cur);
+    mbe_applyAdaptiveSmoothing(&cur, &prev);
+    mbe_floattoshort(pcmf, pcm);
+    mbe_synthesizeComfortNoise(pcm);
+    mbe_synthesizeTonef(pcmf, ambe_d, &cur);
+    mbe_dumpImbe7200x4400Frame((const char(*)[23])imbe_fr);
+    return n + (mbe_versionString() != 0);
+}
+''')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(shim_lib.PATH)
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", ref_inc, "-I", gen_inc, str(src), "-o", str(exe), "-L", libdir, "-lmbe_neo_amd",
+                        "-Wl,--no-undefined", "-Wl,--allow-shlib-undefined", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
