@@ -318,7 +318,7 @@ def self_launch(argv, n, script=None):
 
 
 # ---- one workload on this rank's GPU ----------------------------------------------------------------------------------
-def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args, use_dist=False):
+def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args, use_dist=False, coll_device=None):
     """Returns the measurements of one workload: wall time of `steps` steps (max over ranks), HIP-event time of the
     dominant kernel, frame mix.  The launches of a step are what mbx_process_batch issues; they are issued one by one
     here only so that the dominant kernel can be bracketed by events on the launch stream."""
@@ -388,7 +388,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     dt = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     if use_dist:
-        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=coll_device if coll_device is not None else torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
     flags = decoder.results_numpy(out["results"])["flags"]
@@ -451,6 +451,9 @@ def main():
     ap.add_argument("--fuse-expand", action="store_true", help="development aid: IMBE at T = 1 through the fused (one-launch) path")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the collectives even with one rank (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collectives backend; gloo (CPU tensors) only to rehearse N > 1 on a box with fewer GPUs than ranks, "
+                         "together with MBX_BENCH_SHARE_GPU=1 (every rank on device 0)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (development build of the library only); results invalid")
     args = ap.parse_args()
 
@@ -464,6 +467,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MBX_BENCH_SHARE_GPU"):   # rehearsal only: all ranks on one card (RCCL refuses that: use --dist-backend gloo)
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -474,17 +479,21 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_device = device if args.dist_backend == "nccl" else torch.device("cpu")   # where the tensors of the collectives live
 
     import mbelib_neo_amd as mbx
     from mbelib_neo_amd import decoder
     from mbelib_neo_amd.parallel import broadcast_tables, shard_range
 
     # rank 0 reads the blob, RCCL broadcasts it, every rank uploads it and the checksums are compared
-    blob = broadcast_tables(mbx.load_tables_blob() if rank == 0 else None, device, force=args.force_dist)
+    blob = broadcast_tables(mbx.load_tables_blob() if rank == 0 else None, coll_device, force=args.force_dist)
     checksum = decoder.ensure_init(local_rank, blob)
     if use_dist:
-        cs = torch.tensor([checksum], dtype=torch.int64, device=device)
+        cs = torch.tensor([checksum], dtype=torch.int64, device=coll_device)
         gathered = [torch.zeros_like(cs) for _ in range(world)]
         dist.all_gather(gathered, cs)
         assert all(int(g) == checksum for g in gathered), "table checksum differs between ranks"
@@ -494,7 +503,7 @@ def main():
         S = args.streams
     first, count = shard_range(S * world, world, rank)  # weak scaling: S streams on every rank
     assert count == S
-    m = run_workload(args.workload, S, T, args.steps, args.warmup, rank, first, local_rank, blob, world, dist, args, use_dist)
+    m = run_workload(args.workload, S, T, args.steps, args.warmup, rank, first, local_rank, blob, world, dist, args, use_dist, coll_device)
 
     line = {
         "metric": "20ms frames/sec (whole node), " + CODEC_NAME[codec],

@@ -936,3 +936,24 @@ def test_bench_rccl_code_path_runs_with_one_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "process group initialised" in line["config"]["parallelism"]
+
+
+def test_bench_two_ranks_self_launched_on_one_card():
+    """`python bench.py --gpus 2` from a plain shell: bench.py starts the two ranks itself (no launcher), they shard the
+    streams, run, meet at the barriers and rank 0 prints the line.  This box has one GPU, so both ranks use device 0
+    (MBX_BENCH_SHARE_GPU=1) and the collectives go over gloo -- RCCL refuses two ranks on one device; its code path is
+    covered with one rank in test_bench_rccl_code_path_runs_with_one_rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MBX_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--streams", "8192", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["frames_per_step"] == 2 * 8192 and line["value"] > 0
