@@ -1459,6 +1459,12 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         DeviceTables ft = tabs_in;
         int lane = lane_in;
         asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
+        if constexpr (kPark) {
+            // Tell the compiler again that the lane index is 0..63: struct fields are then addressed as SGPR base + 32-bit
+            // lane offset instead of 64-bit per-lane addresses (two VALU and a register pair each).  Only where registers are
+            // plentiful: under the 72 / 80-register caps of the HBM-slot instances the extra freedom ends in spills.
+            lane &= 63;
+        }
         const DeviceTables& tabs = ft;
         // Frame parameters: expanded here from the FEC record (the normal path), or taken from the
         // workspace row a separate mbx_expand_records() launch has written.  Either way decode reads LDS.
@@ -1873,6 +1879,12 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         DeviceTables ft = tabs_in;
         int lane = lane_in;
         asm volatile("" : "+s"(ft.t), "+s"(ft.d), "+v"(lane));
+        if constexpr (kPark) {
+            // Tell the compiler again that the lane index is 0..63: struct fields are then addressed as SGPR base + 32-bit
+            // lane offset instead of 64-bit per-lane addresses (two VALU and a register pair each).  Only where registers are
+            // plentiful: under the 72 / 80-register caps of the HBM-slot instances the extra freedom ends in spills.
+            lane &= 63;
+        }
         const DeviceTables& tabs = ft;
         const float* fp = params[f].v;
         const uint32_t errw = uni(__float_as_uint(fp[62]));
