@@ -3,9 +3,10 @@
 // Layout: ONE STREAM PER WAVEFRONT (one 64-lane wave per workgroup).  Lane l holds element l of every per-harmonic
 // array (Vl, Ml, log2Ml, PHIl, PSIl; L <= 56 < 64), previousUw[256] is four registers per lane, noiseOverlap[96] two.
 // The T frames of the stream are processed in order inside the kernel.  `cur` stays in registers for the whole launch;
-// `prev` and `prev_enhanced` are live only where the reference reads them and are parked in their own HBM/L2 slots in
-// between (the loads and stores a T = 1 launch needs anyway); what the snapshot already holds is read back from it
-// instead of being carried across the synthesiser.  A struct is 651 consecutive dwords: coalesced dword accesses.
+// `prev` and `prev_enhanced` are live only where the reference reads them and are parked in between: in their own HBM/L2
+// slots (the loads and stores a T = 1 launch needs anyway; launches with one to three frames per stream), or in LDS for
+// the whole launch (the *_lds kernel instances, T >= 4: see ParkedState); what the snapshot already holds is read back
+// from it instead of being carried across the synthesiser.  A struct is 651 consecutive dwords: coalesced dword accesses.
 //
 // Stages and the reference code they replace (ref = arancormonk/mbelib-neo v2.0.0):
 //   expand_imbe_wave src/imbe/imbe7200x4400.c:117-270               (a8, stateless half; T > 1 launches)
@@ -26,7 +27,9 @@
 // Numerics: integer decisions are reproduced exactly.  Float expressions that feed decisions keep the reference's
 // operand order with FMA contraction off.  The synthesiser does not replay the reference's recurrences, it tracks them
 // (see the voiced bank); measured against the CPU oracle: PCM relative RMS <= 3e-6, int16 within 1 LSB on 99.9998 % of
-// samples (DESIGN.md section 4 for the tail).
+// samples (DESIGN.md section 4 for the tail).  Sums that feed state later frames build on are formed in the reference's
+// index order (seq_sum4), so the decision state (log2Ml, localEnergy) is bit-identical to the reference's; a frame whose
+// smoothing decision is within 2e-5 of its threshold is decided again with the reference's own arithmetic (enhance_exact).
 #include <type_traits>
 
 #include "mbx_device.h"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the development build of the library: make -C mbelib-neo_amd/csrc ablate; the masks do not exist in the product
+export MBX_HIP_LIBRARY=${MBX_HIP_LIBRARY:-$(cd "$(dirname "$0")/.." && pwd)/mbelib-neo_amd/libmbx_hip_ablate.so}
 # development aid: VALU/SALU/LDS instruction counts of the stream kernel per ablation mask
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
