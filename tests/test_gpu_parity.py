@@ -957,3 +957,45 @@ def test_bench_two_ranks_self_launched_on_one_card():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["frames_per_step"] == 2 * 8192 and line["value"] > 0
+
+
+def test_launchers_are_graph_capturable(mbx, oracle):
+    """include/mbx.h: the launchers never synchronise and never allocate once the stream's expand workspace has been sized,
+    so a tick can be captured into a HIP graph and replayed.  One AMBE+2 tick (FEC + expand + stream kernel, i.e. the path
+    that uses the workspace) is captured on a side stream after mbx_reserve_stream(); three replays equal three eager
+    ticks on a second decoder.  Without the reservation the capture is refused instead of synchronising mid-capture."""
+    import torch
+
+    from mbelib_neo_amd import _native, decoder, framegen
+
+    L = _native.lib()
+    codec, S = 1, 2048
+    frames = framegen.random_frames(codec, S, framegen.rng_for(77))
+    seeds = np.arange(S) + 9
+    eager = decoder.BatchDecoder(codec, S, seeds=seeds)
+    want = []
+    for _ in range(3):
+        o = eager.decode(frames, 1, want_float=True)
+        want.append((o["pcm16"].clone(), o["pcmf"].clone()))
+    torch.cuda.synchronize()
+
+    dec = decoder.BatchDecoder(codec, S, seeds=seeds)
+    d_frames = dec.to_device(frames)
+    out = dec.make_outputs(1, want_float=True)
+    side = torch.cuda.Stream()
+    args = (codec, S, 1, d_frames.data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(), out["pcm16"].data_ptr(), out["pcmf"].data_ptr(),
+            out["results"].data_ptr(), out["records"].data_ptr())
+    g = torch.cuda.CUDAGraph()
+    refused = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(refused, stream=side):   # nothing reserved for this stream yet: growth during capture is refused
+        rc = L.mbx_process_batch(*args, side.cuda_stream)
+    assert rc == -1 and b"capture" in L.mbx_last_error()
+    _native.check(L.mbx_reserve_stream(side.cuda_stream, S), "mbx_reserve_stream")
+    with torch.cuda.graph(g, stream=side):
+        rc = L.mbx_process_batch(*args, side.cuda_stream)
+    assert rc == 0
+    for k in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out["pcm16"], want[k][0]) and torch.equal(out["pcmf"], want[k][1]), f"replay {k}"
+    assert dec.state_numpy().tobytes() == eager.state_numpy().tobytes()
