@@ -797,3 +797,62 @@ def test_queue_mode_ragged_and_direct_calls(mbe):
             continue   # took a fresh copy of the thread RNG state after the synchronous call: only compared where no noise is involved
         assert pcm[s].tobytes() == want[s][0].tobytes(), f"channel {s}"
         assert np.concatenate(st[s]).tobytes() == want[s][1].tobytes()
+
+
+def test_queue_mode_other_codecs_equal_synchronous_calls(mbe):
+    """IMBE 7100x4400 and AMBE 3600x2400 channels through the queue (both in one flush, three frames per channel and
+    flush): PCM, results, parameter bits and the final structs are bit for bit those of the synchronous calls on the same
+    frames (reference fixtures imbe7100_kat.bin / ambe2400_kat.bin)."""
+    k7100 = golden_io.imbe7100_kat()["stream"]
+    k2400 = golden_io.ambe2400_kat()[0]
+    plans = []
+    for s in range(4):
+        plans.append((mbe.mbe_processImbe7100x4400Framef, 88, k7100[s]["frames"]["cells"], 1234 + s))
+        plans.append((mbe.mbe_processAmbe3600x2400Framef, 49, k2400[s]["frames"]["cells"], 1234 + s))
+
+    def run(queued):
+        outs = []
+        chans = []
+        for fn, nd, cells, seed in plans:
+            T = len(cells)
+            cur, prev, enh = new_state(mbe)
+            chans.append(dict(fn=fn, nd=nd, cells=[c.copy() for c in cells], seed=seed, cur=cur, prev=prev, enh=enh, T=T,
+                              pcm=np.zeros((T, 160), dtype=np.float32), res=np.zeros(T, dtype=RESULT_DTYPE),
+                              bits=np.zeros((T, nd), dtype=np.int8), rets=[]))
+        if queued:
+            assert mbe.mbe_batchBegin(1) == 0
+        tmax = max(c["T"] for c in chans)
+        for t0 in range(0, tmax, 3):
+            for ch in chans:
+                for t in range(t0, min(t0 + 3, ch["T"])):
+                    if t == 0:
+                        mbe.mbe_setThreadRngSeed(ch["seed"])
+                    elif not queued:
+                        pass
+                    ch["rets"].append(ch["fn"](p(ch["pcm"][t]), p(ch["res"][t:t + 1]), p(ch["cells"][t]), p(ch["bits"][t]), p(ch["cur"]),
+                                               p(ch["prev"]), p(ch["enh"])))
+            if queued:
+                assert mbe.mbe_flush() >= 0
+        if queued:
+            assert mbe.mbe_batchEnd() >= 0
+        return chans
+
+    # synchronous: one channel after the other would share the thread RNG across channels; run each channel alone
+    sync = []
+    for plan in plans:
+        fn, nd, cells, seed = plan
+        T = len(cells)
+        cur, prev, enh = new_state(mbe)
+        mbe.mbe_setThreadRngSeed(seed)
+        pcm = np.zeros((T, 160), dtype=np.float32)
+        res = np.zeros(T, dtype=RESULT_DTYPE)
+        bits = np.zeros((T, nd), dtype=np.int8)
+        for t in range(T):
+            c = cells[t].copy()
+            assert fn(p(pcm[t]), p(res[t:t + 1]), p(c), p(bits[t]), p(cur), p(prev), p(enh)) == res[t]["total_errors"]
+        sync.append((pcm, res, bits, np.concatenate([cur, prev, enh])))
+    got = run(True)
+    for ch, (pcm, res, bits, st) in zip(got, sync):
+        assert all(r == 0 for r in ch["rets"])
+        assert ch["pcm"].tobytes() == pcm.tobytes() and ch["res"].tobytes() == res.tobytes() and np.array_equal(ch["bits"], bits)
+        assert np.concatenate([ch["cur"], ch["prev"], ch["enh"]]).tobytes() == st.tobytes()
