@@ -354,48 +354,84 @@ __device__ __forceinline__ void expand_ambe_body(const mbx_param_record* __restr
             }
             const int jsplit = (ji + 1) >> 1;
             const int j0 = half ? jsplit + 1 : 1, j1 = half ? ji : jsplit;
+            // the six cosines of an output are fetched one output ahead of the arithmetic (all waves of a launch move in
+            // step, so a look-up inside the sum would be paid in full)
+            float cosr[7], next[7];
+            if (j0 <= j1) {
+#pragma unroll
+                for (int k = 1; k <= 6; ++k) {
+                    cosr[k] = T->ambe_idct_cos[ji][j0][k];
+                }
+            }
             for (int j = j0; j <= j1; ++j) {
+                const int jn = j < j1 ? j + 1 : j;
+#pragma unroll
+                for (int k = 1; k <= 6; ++k) {
+                    next[k] = T->ambe_idct_cos[ji][jn][k];
+                }
                 float sum = 0;
 #pragma unroll
                 for (int k = 1; k <= 6; ++k) {
                     if (k <= ji) {
                         const float ak = (k == 1) ? 1.0f : 2.0f;
-                        sum = sum + (ak * C[k] * T->ambe_idct_cos[ji][j][k]);
+                        sum = sum + (ak * C[k] * cosr[k]);
                     }
                 }
                 row[l + j - 1] = sum;
+#pragma unroll
+                for (int k = 1; k <= 6; ++k) {
+                    cosr[k] = next[k];
+                }
             }
         }
     }
-    wave_lds_sync();   // the block lanes and the summary lane of a frame are in the same wave
-    if (i < n && sub == 0) {
-        uint32_t vlo = 0, vhi = 0;
-        float dg = 0.0f, sum42 = 0.0f;
-        if (bad == 0) {
-            if (!silence) {
-                const int b1 = k2400 ? pick(w, 38, 39, 40, 41) : pick(w, 4, 5, 6, 7, 35);
-                // the eight decisions of this codebook row as one bit mask (one 8-byte load, not L loads)
-                const uint2 vq = *reinterpret_cast<const uint2*>(k2400 ? &T->ambep_vuv[b1][0] : &T->ambe_vuv[b1][0]);
-                uint32_t vmask = 0;
+    // Voicing decisions: harmonic l takes entry (int)(l * 16 f0) & 7 of its codebook row.  The eight lanes of a frame
+    // share the harmonics (l = sub + 1, sub + 9, ...: at most seven each) and OR their bits together inside the group of
+    // eight lanes; every lane of the frame executes this, so the exchange needs no predicate.
+    uint32_t vlo = 0, vhi = 0;
+    if (i < n && bad == 0 && !silence) {
+        const int b1 = k2400 ? pick(w, 38, 39, 40, 41) : pick(w, 4, 5, 6, 7, 35);
+        // the eight decisions of this codebook row as one bit mask (one 8-byte load, not L loads)
+        const uint2 vq = *reinterpret_cast<const uint2*>(k2400 ? &T->ambep_vuv[b1][0] : &T->ambe_vuv[b1][0]);
+        uint32_t vmask = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint32_t byte = ((q < 4 ? vq.x : vq.y) >> (8 * (q & 3))) & 0xffu;
-                    vmask |= (byte & 1u) << q;
-                }
-                for (int l = 1; l <= L; ++l) {
-                    const int jl = (int)((float)l * (float)16.0 * f0);
-                    const uint32_t v = (vmask >> (jl & 7)) & 1u;
-                    if (l <= 32) {
-                        vlo |= v << (l - 1);
-                    } else {
-                        vhi |= v << (l - 33);
-                    }
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t byte = ((q < 4 ? vq.x : vq.y) >> (8 * (q & 3))) & 0xffu;
+            vmask |= (byte & 1u) << q;
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int l = sub + 1 + 8 * q;
+            if (l <= L) {
+                const int jl = (int)((float)l * (float)16.0 * f0);
+                const uint32_t v = (vmask >> (jl & 7)) & 1u;
+                if (l <= 32) {
+                    vlo |= v << (l - 1);
+                } else {
+                    vhi |= v << (l - 33);
                 }
             }
+        }
+    }
+    vlo |= (uint32_t)__shfl_xor((int)vlo, 1, kWave);
+    vhi |= (uint32_t)__shfl_xor((int)vhi, 1, kWave);
+    vlo |= (uint32_t)__shfl_xor((int)vlo, 2, kWave);
+    vhi |= (uint32_t)__shfl_xor((int)vhi, 2, kWave);
+    vlo |= (uint32_t)__shfl_xor((int)vlo, 4, kWave);
+    vhi |= (uint32_t)__shfl_xor((int)vhi, 4, kWave);
+    wave_lds_sync();   // the block lanes and the summary lane of a frame are in the same wave
+    if (i < n && sub == 0) {
+        float dg = 0.0f, sum42 = 0.0f;
+        if (bad == 0) {
             dg = k2400 ? T->ambep_dg[pick(w, 6, 7, 8, 9, 42, 43)] : T->ambe_dg[pick(w, 8, 9, 10, 11, 36)];
-            float tsum = 0.0f;   // Sum42 in the reference's order (l ascending)
-            for (int l = 1; l <= L; ++l) {
-                tsum += row[l];
+            float tsum = 0.0f;   // Sum42 in the reference's order (l ascending); rows past L hold zeros
+            const int L4 = (L + 3) & ~3;
+            for (int l = 1; l <= L4; l += 4) {
+                const float t0 = row[l], t1 = row[l + 1], t2 = row[l + 2], t3 = row[l + 3];   // four reads in flight
+                tsum += t0;
+                tsum += (l + 1 <= L) ? t1 : 0.0f;
+                tsum += (l + 2 <= L) ? t2 : 0.0f;
+                tsum += (l + 3 <= L) ? t3 : 0.0f;
             }
             sum42 = tsum / (float)L;
         }
