@@ -1873,6 +1873,10 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
     load_rng(rng, &rngs[slot]);
+    float row_now = 0.0f;
+    if constexpr (kPark) {
+        row_now = params[(size_t)s * (size_t)Tn].v[lane_in];
+    }
 
     for (int t = 0; t < Tn; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
@@ -1889,7 +1893,19 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             lane &= 63;
         }
         const DeviceTables& tabs = ft;
-        const float* fp = params[f].v;
+        const float* fp;
+        if constexpr (kPark) {
+            // The frame's FrameParams row goes through LDS, and the NEXT frame's row is requested now: with four waves per
+            // SIMD a global load in front of every decode is not hidden by the other waves.
+            scratch.x.fp[lane] = row_now;
+            wave_lds_sync();
+            fp = scratch.x.fp;
+            if (t + 1 < Tn) {
+                row_now = params[f + 1].v[lane];
+            }
+        } else {
+            fp = params[f].v;
+        }
         const uint32_t errw = uni(__float_as_uint(fp[62]));
         const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu);
         unsigned flags = (errw >> 24) & 0xffu;   // C0_VALID
