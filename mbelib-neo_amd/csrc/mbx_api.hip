@@ -780,7 +780,7 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
     }
     // (Long AMBE+2 launches used to need a second, register-padded instance to even out their rounds of waves -- config 5's
     // shard is 8 waves per SIMD on 6 slots: 6 + 2.  The LDS-resident instance runs 16 waves per CU: 2 x 16, and
-    // 8,192 streams x T = 128 went from 3.51 ms to 3.18 ms.)
+    // 8,192 streams x T = 128 went from 3.51 ms to 3.15 ms.)
     if (lds_resident) {
         hipLaunchKernelGGL(mbx::ambe_stream_kernel_lds, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
