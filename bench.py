@@ -21,7 +21,9 @@ Prints ONE JSON line on rank 0.  At N = 1 with the default workload the line als
 `other_configs` (the other three GPU configs of BASELINE.json, 10 steps each), `cpu_baseline` (+ the
 list `cpu_baselines`: the reference's scalar and SIMD builds, full path and its own bench_synth /
 bench_unvoiced recipes, one core and all cores), `host_path` (what a C host sees from host memory to
-host memory) and `no_reverse` (the headline with the alternating stream order switched off).
+host memory) and `infinity_cache_assisted` (the same workload in the library's default alternating stream order; the
+headline itself is timed in a FIXED order, i.e. against HBM).  The timed region is at least --steps steps and at
+least --min-time-ms (50 ms) of wall time: `steps_effective`.
 """
 import argparse
 import hashlib
@@ -125,6 +127,25 @@ def measured_traffic(workload, S, T):
     return None, stale or "no PMC summary for this workload and size"
 
 
+def measured_issue(workload, S, T):
+    """SQ-counter summary of the dominant kernel (profiles/rNN/<workload>_sq.json, written by tools/sq_profile.py on the GPU
+    box: instruction counts by class, busy / wait quad-cycles, clock) -- like the traffic figure only when it was taken
+    with the SAME build of libmbx_hip.so."""
+    import glob
+
+    sha = library_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_sq.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("streams_per_gpu") == S and d.get("frames_per_stream_per_step") == T and "issue_model" in d:
+            if d.get("libmbx_hip_sha256_16") == sha:
+                return dict(d["issue_model"], source=os.path.relpath(path, ROOT))
+            return {"source": os.path.relpath(path, ROOT), "stale": f"taken with another build of libmbx_hip.so ({d.get('libmbx_hip_sha256_16')} != {sha})"}
+    return None
+
+
 def unpack_cells(codec, frames):
     """packed wire frames [n, 18|9] -> the reference's char cell arrays [n, rows*cols] (int8)"""
     from mbelib_neo_amd.layout import FRAME_CELLS, ROW_WIDTHS
@@ -198,14 +219,15 @@ def reference_full_path(name, codec, T, simd, threads, budget_s):
 
 
 def reference_recipe(recipe, simd):
-    """bench/bench_synth.c:40-67 (recipe 0) / bench/bench_unvoiced.c:33-52,87-100 (recipe 1) of the reference, as
-    functions of oracle/tools/ref_bench.c: 2,000 frames of mbe_synthesizeSpeechf per run, best of 5, one core."""
+    """bench/bench_synth.c:40-67 (recipe 0) / bench/bench_unvoiced.c:33-52,87-100 (recipe 1) / bench/bench_convert.c:33-50
+    (recipe 2) of the reference, as functions of oracle/tools/ref_bench.c: 2,000 frames of mbe_synthesizeSpeechf per run,
+    best of 5 (200,000 conversions, best of 3, for bench_convert), one core."""
     import ctypes as C
 
     lib = _ref_lib(simd)
     if lib is None:
         return None
-    frames, runs = 2000, 5
+    frames, runs = (2000, 5) if recipe < 2 else (200000, 3)
     sink = C.c_float()
     lib.ref_bench_recipe(recipe, 200, 1, C.byref(sink))
     best = lib.ref_bench_recipe(recipe, frames, runs, C.byref(sink))
@@ -215,9 +237,10 @@ def reference_recipe(recipe, simd):
         "cores": 1,
         "kind": "reference",
         "build": "simd" if simd else "scalar",
-        "recipe": "bench_synth (L=40, mixed voicing, w0 alternating)" if recipe == 0 else "bench_unvoiced (L=36, all unvoiced)",
+        "recipe": ("bench_synth (L=40, mixed voicing, w0 alternating)", "bench_unvoiced (L=36, all unvoiced)",
+                   "bench_convert (mbe_floattoshort on one 160-sample ramp, bench/bench_convert.c:33-50)")[recipe],
         "us_per_frame": best / frames * 1e6,
-        "sample": f"{frames} frames of mbe_synthesizeSpeechf, best of {runs} runs ({best * 1e3:.1f} ms), single thread",
+        "sample": f"{frames} frames of {'mbe_synthesizeSpeechf' if recipe < 2 else 'mbe_floattoshort'}, best of {runs} runs ({best * 1e3:.1f} ms), single thread",
     }
 
 
@@ -288,7 +311,7 @@ def cpu_baselines(name, codec, T, full=True):
             r = reference_full_path(name, codec, T, simd=simd, threads=threads, budget_s=3.0)
             if r is not None:
                 out.append(r)
-        for recipe in (0, 1):
+        for recipe in (0, 1, 2):
             for simd in (True, False):
                 r = reference_recipe(recipe, simd)
                 if r is not None:
@@ -318,10 +341,19 @@ def self_launch(argv, n, script=None):
 
 
 # ---- one workload on this rank's GPU ----------------------------------------------------------------------------------
-def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args, use_dist=False, coll_device=None):
-    """Returns the measurements of one workload: wall time of `steps` steps (max over ranks), HIP-event time of the
-    dominant kernel, frame mix.  The launches of a step are what mbx_process_batch issues; they are issued one by one
-    here only so that the dominant kernel can be bracketed by events on the launch stream."""
+def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args, use_dist=False, coll_device=None,
+                 alternate=False, min_time_s=None):
+    """Returns the measurements of one workload: wall time of the timed steps (max over ranks), HIP-event time of the
+    dominant kernel per step (mean, median, spread), frame mix.  The launches of a step are what mbx_process_batch issues;
+    they are issued one by one here only so that the dominant kernel can be bracketed by events on the launch stream.
+
+    alternate = False (every reported headline): every launch walks the streams in the same direction, so a launch finds
+    nothing of the previous launch's state in the Infinity Cache -- what a decoder that ticks every 20 ms with other work
+    in between sees, and the timing the HBM roofline fraction is quoted on.  alternate = True is the library's default
+    order for back-to-back launches (reported separately as `infinity_cache_assisted`).
+
+    The timed region is at least `steps` steps and at least `min_time_s` of wall time (steps_effective, the same on
+    every rank): a 20-step region of a 0.28 ms step is 5.6 ms, too short to resolve effects of a few per cent."""
     import torch
 
     from mbelib_neo_amd import _native, decoder
@@ -369,28 +401,45 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
         if ev is not None and not soft:
             ev[1].record()
 
+    previous_order = L.mbx_set_stream_order(1 if alternate else 0)
     for _ in range(max(1, warmup)):  # the first pass also warms the model state
         step()
     if args.ablate:
         L.mbx_debug_set_ablation(args.ablate)  # development build only (tools/); never in a reported run
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    min_time_s = args.min_time_ms * 1e-3 if min_time_s is None else min_time_s
+    steps_eff = steps
+    if min_time_s > 0:   # size the timed region from three untimed steps (part of the warm-up)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        est = (time.perf_counter() - t0) / 3
+        steps_eff = max(steps, int(np.ceil(min_time_s / max(est, 1e-6))))
+        if use_dist:
+            t = torch.tensor([steps_eff], dtype=torch.int64, device=coll_device if coll_device is not None else torch.device("cuda", local_rank))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            steps_eff = int(t[0])
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps_eff)]
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(steps):
+    for k in range(steps_eff):
         step(events[k])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    dt_local = dt = time.perf_counter() - t0
+    per_step = np.array([a.elapsed_time(b) for a, b in events])
+    kernel_ms = float(per_step.mean())
     if use_dist:
         t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=coll_device if coll_device is not None else torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
+    L.mbx_set_stream_order(previous_order)
     flags = decoder.results_numpy(out["results"])["flags"]
     pcm_digest = int(out["pcm16"].to(torch.int64).sum().item())
     if soft:
@@ -404,7 +453,11 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     torch.cuda.empty_cache()
     return {
         "dt": dt, "kernel_ms": kernel_ms, "kernel": kernel, "alg_bytes": alg_bytes, "frames_per_step": world * n,
-        "value": world * n * steps / dt, "ms_per_step": dt / steps * 1e3, "pcm_digest": pcm_digest,
+        "value": world * n * steps_eff / dt, "ms_per_step": dt / steps_eff * 1e3, "pcm_digest": pcm_digest,
+        "steps_effective": steps_eff, "rank_value": n * steps_eff / dt_local,
+        "kernel_ms_stats": {"mean": float(per_step.mean()), "median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),
+                            "p90": float(np.percentile(per_step, 90)), "min": float(per_step.min()), "max": float(per_step.max()),
+                            "launches": int(per_step.size)},
         "frame_mix": {
             "repeat": float(np.mean((flags & 0x40) != 0)),
             "mute": float(np.mean((flags & 0x80) != 0)),
@@ -412,6 +465,32 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
             "tone": float(np.mean((flags & 0x10) != 0)),
         },
     }
+
+
+def convert_rate(local_rank, nframes=1 << 20, steps=20):
+    """floattoshort_kernel (mbe_floattoshort for a batch, ref src/core/mbelib.c:1148-1321; the reference's bench_convert
+    recipe is its CPU counterpart in cpu_baselines): frames/s and the HBM fraction of 960 B per frame."""
+    import torch
+
+    from mbelib_neo_amd import _native
+
+    L = _native.lib()
+    dev = torch.device("cuda", local_rank)
+    x = (torch.rand((nframes, 160), device=dev) - 0.5) * 12000.0
+    y = torch.empty((nframes, 160), dtype=torch.int16, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        _native.check(L.mbx_floattoshort(x.data_ptr(), y.data_ptr(), nframes, stream), "mbx_floattoshort")
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        _native.check(L.mbx_floattoshort(x.data_ptr(), y.data_ptr(), nframes, stream), "mbx_floattoshort")
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    return {"kernel": "floattoshort_kernel", "frames_per_launch": nframes, "kernel_ms": ms, "frames_per_s": nframes / (ms * 1e-3),
+            "bytes_per_frame": 960, "frac": nframes * 960 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "what": "float PCM resident in HBM -> int16 PCM, 1,048,576 frames per launch (the device counterpart of the reference's bench_convert)"}
 
 
 def roofline_of(name, S, T, m):
@@ -428,8 +507,10 @@ def roofline_of(name, S, T, m):
         "traffic_source": source,
         "algorithmic_bytes_per_launch": m["alg_bytes"],
         "kernel_ms": m["kernel_ms"],
+        "kernel_ms_stats": m["kernel_ms_stats"],
+        "stream_order": "fixed: every launch walks the streams forward, nothing of the previous launch's state is found in the Infinity Cache",
         "frac_on_counter_bytes": (traffic / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-        "binding_resource": "VALU issue and memory latency (DESIGN.md section 3); the HBM fraction is what BASELINE.json asks to be reported",
+        "issue": measured_issue(name, S, T),
     }
     if "_soft" in name:
         r["note"] = "dominant kernel of this workload is the soft-decision FEC kernel: algorithmic bytes = n * (2 B per soft cell + 16 B record)"
@@ -446,7 +527,7 @@ def main():
     ap.add_argument("--workload", default="imbe_voiced", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="headline (and cpu_baseline) only: no other_configs, host_path, no_reverse")
+    ap.add_argument("--no-extras", action="store_true", help="headline (and cpu_baseline) only: no other_configs, host_path, infinity_cache_assisted")
     ap.add_argument("--split-expand", action="store_true", help="run the parameter expansion as a separate launch")
     ap.add_argument("--fuse-expand", action="store_true", help="development aid: IMBE at T = 1 through the fused (one-launch) path")
     ap.add_argument("--force-dist", action="store_true",
@@ -455,6 +536,8 @@ def main():
                     help="collectives backend; gloo (CPU tensors) only to rehearse N > 1 on a box with fewer GPUs than ranks, "
                          "together with MBX_BENCH_SHARE_GPU=1 (every rank on device 0)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (development build of the library only); results invalid")
+    ap.add_argument("--min-time-ms", type=float, default=50.0,
+                    help="the timed region is at least --steps steps AND at least this much wall time (steps_effective in the line)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -492,11 +575,13 @@ def main():
     # rank 0 reads the blob, RCCL broadcasts it, every rank uploads it and the checksums are compared
     blob = broadcast_tables(mbx.load_tables_blob() if rank == 0 else None, coll_device, force=args.force_dist)
     checksum = decoder.ensure_init(local_rank, blob)
+    checksums = [checksum]
     if use_dist:
         cs = torch.tensor([checksum], dtype=torch.int64, device=coll_device)
         gathered = [torch.zeros_like(cs) for _ in range(world)]
         dist.all_gather(gathered, cs)
-        assert all(int(g) == checksum for g in gathered), "table checksum differs between ranks"
+        checksums = [int(g) for g in gathered]
+        assert all(g == checksum for g in checksums), "table checksum differs between ranks"
 
     codec, S, T, desc = WORKLOADS[args.workload]
     if args.streams:
@@ -504,6 +589,12 @@ def main():
     first, count = shard_range(S * world, world, rank)  # weak scaling: S streams on every rank
     assert count == S
     m = run_workload(args.workload, S, T, args.steps, args.warmup, rank, first, local_rank, blob, world, dist, args, use_dist, coll_device)
+    rank_values = [m["rank_value"]]
+    if use_dist:   # what every rank measured on its own clock (the line's value is the max-over-ranks time)
+        rv = torch.tensor([m["rank_value"]], dtype=torch.float64, device=coll_device)
+        gathered = [torch.zeros_like(rv) for _ in range(world)]
+        dist.all_gather(gathered, rv)
+        rank_values = [float(g) for g in gathered]
 
     line = {
         "metric": "20ms frames/sec (whole node), " + CODEC_NAME[codec],
@@ -511,6 +602,7 @@ def main():
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
+        "steps_effective": m["steps_effective"],
         "warmup": args.warmup,
         "ms_per_step": m["ms_per_step"],
         "higher_is_better": True,
@@ -529,6 +621,14 @@ def main():
             "frame_mix": m["frame_mix"],
         },
         "roofline": roofline_of(args.workload, S, T, m),
+        "distributed": {
+            "process_group": (dist.get_backend() if use_dist else None),
+            "world_size": (dist.get_world_size() if use_dist else 1),
+            "devices_visible": torch.cuda.device_count(),
+            "per_rank_frames_per_s": rank_values,
+            "table_checksums": checksums,
+            "tables": "rank 0 reads the blob, one broadcast over the process group, every rank uploads its copy" if use_dist else "read and uploaded by the only rank",
+        },
     }
     fpf, fpf_basis = nominal_flops_per_frame(args.workload)
     line["valu"] = {   # "also report valu.achieved"; the resource that binds this path
@@ -540,6 +640,16 @@ def main():
         "basis": fpf_basis,
     }
     extras = world == 1 and not args.no_extras and not args.ablate and not args.streams
+    if extras:
+        # the library's default order for back-to-back launches over the same state: a launch walks the streams in the
+        # direction opposite to the previous one and finds the tail of its state in the 256 MiB Infinity Cache
+        am = run_workload(args.workload, S, T, args.steps, 2, rank, first, local_rank, blob, world, dist, args, alternate=True)
+        line["infinity_cache_assisted"] = {
+            "value": am["value"], "ms_per_step": am["ms_per_step"], "kernel_ms": am["kernel_ms"], "kernel_ms_stats": am["kernel_ms_stats"],
+            "frac": am["alg_bytes"] / (am["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "what": "mbx_set_stream_order(1), the library default: successive launches walk the streams in opposite directions; "
+                    "NOT an HBM figure (part of the state comes out of the Infinity Cache), reported beside the headline only",
+        }
     if extras and args.workload == "imbe_voiced":
         # the other three GPU configs of BASELINE.json, driver-timed in the same line (10 steps each)
         line["other_configs"] = {}
@@ -548,11 +658,17 @@ def main():
             om = run_workload(other, oS, oT, 10, 2, rank, 0, local_rank, blob, 1, dist, args)
             orf = roofline_of(other, oS, oT, om)
             line["other_configs"][other] = {
-                "workload": odesc, "value": om["value"], "unit": "frames/s", "steps": 10, "ms_per_step": om["ms_per_step"],
-                "kernel": om["kernel"], "kernel_ms": om["kernel_ms"], "algorithmic_bytes_per_launch": om["alg_bytes"],
-                "frac": orf["frac"], "traffic": orf["traffic"], "frac_on_counter_bytes": orf["frac_on_counter_bytes"],
+                "workload": odesc, "value": om["value"], "unit": "frames/s", "steps": 10, "steps_effective": om["steps_effective"],
+                "ms_per_step": om["ms_per_step"],
+                "kernel": om["kernel"], "kernel_ms": om["kernel_ms"], "kernel_ms_stats": om["kernel_ms_stats"],
+                "algorithmic_bytes_per_launch": om["alg_bytes"],
+                "frac": orf["frac"], "traffic": orf["traffic"], "frac_on_counter_bytes": orf["frac_on_counter_bytes"], "issue": orf["issue"],
                 "frame_mix": om["frame_mix"],
             }
+        try:
+            line["convert"] = convert_rate(local_rank)
+        except Exception as e:   # noqa: BLE001 -- the headline must not depend on the extras
+            line["convert"] = {"error": str(e)[:300]}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # timed at N = 1 only, on rank 0
             lst, ncpu = cpu_baselines(args.workload, codec, T, full=extras)
@@ -587,17 +703,6 @@ def main():
                 }
             except Exception as e:   # noqa: BLE001 -- the headline must not depend on the extras
                 line["host_path"] = {"error": str(e)[:300]}
-            # the headline with the alternating stream order switched off (separate process: the switch is read once)
-            try:
-                env = dict(os.environ, MBX_NO_REVERSE="1")
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "30", "--no-cpu-baseline", "--no-extras"],
-                                   env=env, capture_output=True, text=True, timeout=600)
-                nr = json.loads(r.stdout.strip().splitlines()[-1])
-                line["no_reverse"] = {"value": nr["value"], "kernel_ms": nr["roofline"]["kernel_ms"], "frac": nr["roofline"]["frac"],
-                                      "what": "MBX_NO_REVERSE=1: every launch walks the streams in the same direction (no Infinity Cache reuse "
-                                              "between back-to-back launches over the same state)"}
-            except Exception as e:   # noqa: BLE001
-                line["no_reverse"] = {"error": str(e)[:300]}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

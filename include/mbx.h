@@ -53,6 +53,12 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes);
 void mbx_shutdown(void);
 /* 1 when mbx_init() has completed for `device` */
 int mbx_device_ready(int device);
+/* Walking order of successive stream-kernel launches over the same state, process-wide: alternate != 0 (the default;
+ * MBX_NO_REVERSE=1 in the environment starts with 0) = every other launch of a (device, stream) slot / session walks the
+ * streams backwards, so a launch that directly follows another over the same state finds the tail of it in the Infinity
+ * Cache; 0 = always forwards.  Results do not depend on it.  Returns the previous setting.  (No reference counterpart:
+ * the reference decodes one stream per call.) */
+int mbx_set_stream_order(int alternate);
 /* FNV-1a-32 of the table blob resident on the current device (for the per-rank checksum after the broadcast). */
 uint32_t mbx_table_checksum(void);
 /* message of the last failure on the calling thread */

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "mbx_release_stream": (C.c_int, [_vp]),
     "mbx_workspace_bytes": (_sz, [_sz]),
     "mbx_device_ready": (C.c_int, [C.c_int]),
+    "mbx_set_stream_order": (C.c_int, [C.c_int]),
     "mbx_table_checksum": (C.c_uint32, []),
     "mbx_last_error": (C.c_char_p, []),
     "mbx_pack_imbe7200x4400": (C.c_int, [_vp, _sz, _vp]),

@@ -149,10 +149,13 @@ bool lds_resident_enabled() {
     return on;
 }
 
-bool reverse_enabled() {
-    static const bool on = getenv("MBX_NO_REVERSE") == nullptr;   // read once (thread-safe static initialisation)
-    return on;
+// Walking order of successive stream-kernel launches (see launch_stream): alternating by default; MBX_NO_REVERSE=1 in the
+// environment or mbx_set_stream_order(0) fixes it (every launch walks the streams forward).
+std::atomic<int>& stream_order_flag() {
+    static std::atomic<int> flag{getenv("MBX_NO_REVERSE") == nullptr ? 1 : 0};   // thread-safe static initialisation
+    return flag;
 }
+bool reverse_enabled() { return stream_order_flag().load(std::memory_order_relaxed) != 0; }
 
 uint32_t fnv1a(const uint8_t* p, size_t n) {
     uint32_t h = 2166136261u;
@@ -452,6 +455,8 @@ void mbx_shutdown(void) {
         (void)hipSetDevice(before);
     }
 }
+
+int mbx_set_stream_order(int alternate) { return stream_order_flag().exchange(alternate ? 1 : 0, std::memory_order_relaxed); }
 
 int mbx_device_ready(int device) {
     return device >= 0 && device < kMaxDevices && g_ctx[device].ready.load(std::memory_order_acquire) ? 1 : 0;

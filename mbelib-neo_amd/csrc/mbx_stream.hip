@@ -1386,6 +1386,9 @@ struct ParkedState {};
 template <>
 struct ParkedState<true> {
     mbe_parms prev, enh;   // the ABI layout, so every load / store helper works on either home
+#ifdef MBX_EXP_LDS_PAD
+    char pad[MBX_EXP_LDS_PAD];   // occupancy experiments only (tools/variant.sh): fewer waves per CU
+#endif
 };
 
 template <bool kPark>

@@ -100,6 +100,7 @@ ref_process_batch_mt(int codec, int S, int T, const char* cells, int ncell, mbe_
 extern void mbe_initMbeParms(mbe_parms*, mbe_parms*, mbe_parms*);
 extern void mbe_moveMbeParms(const mbe_parms*, mbe_parms*);
 extern void mbe_synthesizeSpeechf(float*, mbe_parms*, mbe_parms*);
+extern void mbe_floattoshort(const float*, short*);
 
 static double
 wall(void) {
@@ -108,14 +109,37 @@ wall(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-/* recipe 0 = bench_synth (L = 40, w0 alternating 0.09 / 0.11, mixed voicing), 1 = bench_unvoiced (L = 36, all unvoiced);
- * returns seconds for `frames` calls of mbe_synthesizeSpeechf (best of `runs`), checksum of the output in *sink */
+/* recipe 0 = bench_synth (L = 40, w0 alternating 0.09 / 0.11, mixed voicing), 1 = bench_unvoiced (L = 36, all unvoiced):
+ * returns seconds for `frames` calls of mbe_synthesizeSpeechf (best of `runs`), checksum of the output in *sink;
+ * recipe 2 = bench_convert (bench/bench_convert.c:33-50: one 160-sample ramp converted `frames` times by mbe_floattoshort) */
 double
 ref_bench_recipe(int recipe, int frames, int runs, float* sink) {
     float out[160];
     mbe_parms cur, prev, enh;
     double best = 1e30;
     float acc = 0.0f;
+    if (recipe == 2) {
+        short s16[160];
+        for (int r = 0; r < runs; ++r) {
+            for (int i = 0; i < 160; ++i) {
+                out[i] = (float)i * 0.01f - 0.8f;
+            }
+            const double t0 = wall();
+            for (int i = 0; i < frames; ++i) {
+                mbe_floattoshort(out, s16);
+                out[0] += (float)(s16[0] & 1) * 1e-6f;   /* keeps the call alive, as the reference's bench does */
+            }
+            const double dt = wall() - t0;
+            if (dt < best) {
+                best = dt;
+            }
+            acc += (float)s16[0];
+        }
+        if (sink) {
+            *sink = acc;
+        }
+        return best;
+    }
     for (int r = 0; r < runs; ++r) {
         mbe_setThreadRngSeed(recipe == 0 ? 0x123456u : 0xBEEFu);
         mbe_initMbeParms(&cur, &prev, &enh);

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""sq_profile.py -- SQ / GRBM counter evidence for the issue model of the stream kernels (GPU box).
+
+    tools/sq_profile.py bench <workload> <out.json>     counters of the workload's dominant kernel under bench.py
+    tools/sq_profile.py calib <out.json>                the same counters on tools/bin/valu_issue (known instruction streams)
+
+Every pass is `rocprofv3 --kernel-trace --pmc <<= 8 SQ counters + GRBM_GUI_ACTIVE> -- python3 bench.py --no-extras ...`
+(the program itself after `--`; --no-extras: one workload, no child processes), counters only -- never together with a
+trace domain other than --kernel-trace.  This process never touches the GPU.  Counter names are filtered against
+`rocprofv3 -L`, so a name this ROCm does not know drops out instead of failing the pass.
+
+Units (MI355X_MICROARCH.md, rocprofv3 PMC slots): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed
+over waves; SQ_BUSY_CYCLES counts per SQ (shader engine) cycles; SQ_INSTS_* count wave-instructions; GRBM_GUI_ACTIVE counts
+cycles -- the calibration run pins each of them on instruction streams whose length and duration are known.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PASSES = [
+    ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"],
+    ["SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT",
+     "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE"],
+    ["SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_FMA_F64",
+     "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_INT32"],
+    ["SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT64", "SQ_THREAD_CYCLES_VALU",
+     "SQ_INST_CYCLES_VMEM"],
+    ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_F32", "SQ_IFETCH", "SQ_INSTS_FLAT", "SQ_INSTS_BRANCH", "SQ_INSTS_SENDMSG", "SQ_WAIT_INST_VALU",
+     "SQ_ACTIVE_INST_FLAT"],
+]
+
+
+def available():
+    try:
+        txt = subprocess.run(["rocprofv3", "-L"], capture_output=True, text=True, timeout=300).stdout
+    except Exception:   # noqa: BLE001
+        return None
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "rocprof_counters.txt"), "w").write(txt)
+    names = set(re.findall(r"\b((?:SQ|GRBM|TCC|TCP|TA|TD|SPI|CPC|CPF)_[A-Z0-9_]+)\b", txt))
+    return names or None
+
+
+def short(name):
+    return name.split("(")[0].split("::")[-1].strip()
+
+
+def run_pass(idx, counters, cmd):
+    d = f"/tmp/sqp_{idx}"
+    shutil.rmtree(d, ignore_errors=True)
+    full = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", d, "--"] + cmd
+    r = subprocess.run(full, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    vals = collections.defaultdict(dict)   # dispatch id -> counter -> value
+    kern = {}
+    for f in glob.glob(d + "/*/*_counter_collection.csv"):
+        for row in csv.DictReader(open(f)):
+            did = int(row["Dispatch_Id"])
+            kern[did] = row["Kernel_Name"]
+            vals[did][row["Counter_Name"]] = vals[did].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            vals[did]["_grid"] = float(row.get("Grid_Size", 0) or 0)
+            vals[did]["_wg"] = float(row.get("Workgroup_Size", 0) or 0)
+    dur = {}
+    for f in glob.glob(d + "/*/*_kernel_trace.csv"):
+        for row in csv.DictReader(open(f)):
+            dur[int(row["Dispatch_Id"])] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    return vals, kern, dur, r
+
+
+def main():
+    mode = sys.argv[1]
+    avail = available()
+    passes = [[c for c in p if avail is None or c in avail] for p in PASSES]
+    dropped = [c for p in PASSES for c in p if avail is not None and c not in avail]
+    out = {"mode": mode, "dropped_counters_unknown_to_this_rocm": dropped}
+    if mode == "bench":
+        workload, path = sys.argv[2], sys.argv[3]
+        steps = 4
+        cmd = ["python3", os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--workload", workload]
+        out["workload"] = workload
+        out["command"] = " ".join(cmd)
+        merged, durs = {}, []
+        target = None
+        for i, p in enumerate(passes):
+            if not p:
+                continue
+            vals, kern, dur, r = run_pass(i, p, cmd)
+            if target is None:
+                try:
+                    line = json.loads(r.stdout.strip().splitlines()[-1])
+                    target = line["roofline"]["kernel"]
+                    out["streams_per_gpu"] = line["config"]["streams_per_gpu"]
+                    out["frames_per_stream_per_step"] = line["config"]["frames_per_stream_per_step"]
+                except Exception:   # noqa: BLE001
+                    out.setdefault("errors", []).append({"pass": i, "stdout": r.stdout[-500:], "stderr": r.stderr[-1500:]})
+                    continue
+            ids = sorted(d for d, k in kern.items() if short(k) == target)[-steps:]   # the timed dispatches
+            if not ids:
+                out.setdefault("errors", []).append({"pass": i, "note": "no dispatch of " + str(target), "stderr": r.stderr[-800:]})
+                continue
+            for c in p + ["GRBM_GUI_ACTIVE"]:
+                xs = [vals[d].get(c) for d in ids if c in vals[d]]
+                if xs:
+                    merged.setdefault(c, []).append(sum(xs) / len(xs))
+            durs += [dur[d] for d in ids if d in dur]
+            out["grid_threads"] = vals[ids[-1]].get("_grid")
+        out["kernel"] = target
+        out["counters_per_dispatch"] = {k: sum(v) / len(v) for k, v in merged.items()}
+        out["kernel_ns_under_pmc"] = (sum(durs) / len(durs)) if durs else None
+    else:
+        path = sys.argv[2]
+        cmd = [os.path.join(ROOT, "tools", "bin", "valu_issue")]
+        rows = {}
+        text = None
+        for i, p in enumerate(passes[:2] + [passes[2]]):
+            if not p:
+                continue
+            vals, kern, dur, r = run_pass(i, p, cmd)
+            text = text or r.stdout
+            for did in sorted(vals):
+                e = rows.setdefault(did, {"dispatch": did, "kernel": short(kern[did]), "threads": vals[did].get("_grid"), "wg": vals[did].get("_wg"), "ns": dur.get(did)})
+                for c, v in vals[did].items():
+                    if not c.startswith("_"):
+                        e[c] = v
+        out["command"] = " ".join(cmd)
+        out["program_output"] = [json.loads(x) for x in (text or "").splitlines() if x.startswith("{")]
+        out["dispatches"] = [rows[k] for k in sorted(rows)]
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k not in ("dispatches", "program_output")})[:3000])
+
+
+if __name__ == "__main__":
+    main()
