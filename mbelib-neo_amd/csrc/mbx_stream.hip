@@ -204,7 +204,9 @@ __device__ __forceinline__ void load_continuity(Parms& r, const mbe_parms* __res
 typedef float v2f __attribute__((ext_vector_type(2)));   // two samples per lane: v_pk_{mul,fma}_f32
 __device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
 
-struct WaveScratch {
+template <int kParkColsT>
+struct WaveScratchT {
+    static constexpr int kParkCols = kParkColsT;
     union {
         struct {                       // voiced bank, harmonic l: g (cos psi, sin psi) and d g (sin psi, cos psi),
             alignas(16) float4 coef_amp[64];     //   each as (prev, cur) pairs = the operands of the packed FMAs
@@ -222,31 +224,42 @@ struct WaveScratch {
             float  bins[132];          //   |X(k)|^2, k = 0..128, then the per-bin scale in the same place
         };
     };
-    float park[MBX_PARK_N > 0 ? MBX_PARK_N : 1][64];                // per-lane values that only cross the unvoiced transform pair (see synth_core)
+    // per-lane values that only cross the unvoiced transform pair (see synth_core); none in the LDS-resident kernel
+    // instances: they run at the occupancy LDS allows and have the registers to carry those values themselves
+    float park[kParkColsT > 0 ? kParkColsT : 1][kParkColsT > 0 ? 64 : 4];
 };
+using WaveScratch = WaveScratchT<MBX_PARK_N>;
 
 // Sum of the per-lane terms v_1 .. v_L in INDEX ORDER with a float rounding after every addition -- the reference's
 // `for (l = 1; l <= L; l++) sum += v[l]`, bit for bit, returned wave-uniform.  Used where a sum feeds state that later
 // frames build on (the log-magnitude prediction memory, the local-energy filter): a wave-parallel tree sum is a few ulp
 // away from the sequential one, the difference is carried from frame to frame, and float-threshold decisions downstream
-// could then fall on the other side than the reference's.  The terms go through 64 floats of LDS and
-// come back as broadcast 16-byte reads, so the cost is L dependent v_add_f32 and L / 4 LDS reads.
-// v must be 0.0f in lanes outside 1..L; tmp is 16-byte aligned.
-__device__ __forceinline__ float seq_sum4(float v, int L, float* tmp, int lane) {
-    tmp[(lane - 1) & 63] = v;   // term l at index l - 1 (lane 0 holds a zero and lands on index 63)
-    wave_lds_sync();
-    float acc = 0.0f;
-    const int n4 = (L + 3) >> 2;
-    const float4* q = reinterpret_cast<const float4*>(tmp);
-    for (int k = 0; k < n4; ++k) {
-        const float4 t = q[k];   // wave-uniform address: one LDS broadcast per four terms
-        acc = acc + t.x;
-        acc = acc + t.y;         // terms past L are +0.0f: x + 0 == x
-        acc = acc + t.z;
-        acc = acc + t.w;
+// could then fall on the other side than the reference's.
+// The fold runs in registers: every step is ONE v_add_f32 whose first operand comes from the lane below (DPP wave_shr:1),
+// acc[l] <- acc[l-1] + v[l], so after t steps lane l holds the left fold of v[l-t .. l]; lane L after L - 1 steps holds
+// ((v_1 + v_2) + v_3) + ... + v_L (lanes below 1 contribute +0.0f, and 0 + v_1 is v_1), read back with one v_readlane.
+// L - 1 dependent additions like the reference's loop, and no LDS traffic at all (round 2 sent the terms through LDS and
+// read them back as broadcast ds_read_b128: 4 LDS-array cycles per 4 terms in a kernel whose LDS pipe is its busiest unit).
+// v must be 0.0f in lanes outside 1..L.  `tmp` (unused) keeps the call sites' shape.
+constexpr int kDppWaveShr1 = 0x138;   // gfx9 DPP: whole-wave shift right by one lane
+__device__ __forceinline__ float seq_sum4(float v, int L, float* /*tmp*/, int /*lane*/) {
+    float acc = v;
+    const int n = uni(L);
+    auto step = [&]() {
+        const float below = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), kDppWaveShr1, 0xf, 0xf, true));
+        acc = below + v;
+    };
+    int t = n - 1;
+    for (; t >= 4; t -= 4) {   // four steps per trip: the loop control is scalar work in the shadow of the DPP hazard slots
+        step();
+        step();
+        step();
+        step();
     }
-    wave_lds_sync();
-    return acc;
+    for (; t > 0; --t) {
+        step();
+    }
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), n & 63));   // every caller has 1 <= L <= 56
 }
 
 struct StreamRng {   // register copy of mbx_stream_rng (wave-uniform)
@@ -279,7 +292,8 @@ typedef const MBX_GLOBAL DerivedTables* GlobalDerived;
 typedef const MBX_GLOBAL float* GlobalFloats;
 __device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
 
-__device__ void expand_imbe_wave(const mbx_param_record* rp, WaveScratch& S, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane) {
+template <class Scratch>
+__device__ void expand_imbe_wave(const mbx_param_record* rp, Scratch& S, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane) {
     ConstTables T = (ConstTables)Tgen;
     GlobalTables Tg = (GlobalTables)Tgen;
     GlobalDerived Dg = (GlobalDerived)Dgen;
@@ -749,9 +763,10 @@ __device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
 // cur.PSIl are new), false when it left early (silence, comfort noise): the per-lane state is then still what
 // the snapshot holds.
 // kPark: the snapshot lives in LDS (the launch-resident copies of the T >= 4 kernel instances) instead of the stream's HBM slot.
-template <bool kSnap, bool kPark = false>
+template <bool kSnap, bool kPark = false, class Scratch = WaveScratch>
 __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
-                           WaveScratch& S, const DeviceTables& tabs, int lane, const mbe_parms* snap_ptr = nullptr) {
+                           Scratch& S, const DeviceTables& tabs, int lane, const mbe_parms* snap_ptr = nullptr) {
+    constexpr int kParkN = Scratch::kParkCols;
     // The HBM snapshot is read back through a pointer the compiler cannot trace to the stores that wrote it: otherwise it
     // forwards the stored registers to the loads and carries them across the voiced bank -- the very thing the read-back avoids.
     // (The LDS-resident instances run at four waves per SIMD with registers to spare: there the forwarding is welcome.)
@@ -1066,43 +1081,50 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         // Register diet: the transform pair is the kernel's register peak, and everything that merely crosses it
         // would cost a wave of occupancy for ALL frames.  Those values wait in the lane's own LDS column instead
         // (same lane writes and reads: no synchronisation).
-#if MBX_PARK_N > 2
-        S.park[2][lane] = acc[0];
-#endif
-#if MBX_PARK_N > 3
-        S.park[3][lane] = acc[1];
-#endif
-#if MBX_PARK_N > 4
-        if (lane < 32) {
-            S.park[4][lane] = acc[2];
-            S.park[4][lane + 32] = cur.ov[1];
+        if constexpr (kParkN > 2) {
+            S.park[2][lane] = acc[0];
         }
-#endif
-#if MBX_PARK_N > 5
-        S.park[5][lane] = cur.PHIl;
-#endif
-#if MBX_PARK_N > 6
-        S.park[6][lane] = cur.PSIl;
-#endif
-#if MBX_PARK_N > 7
-        S.park[7][lane] = cur.ov[0];
-#endif
-#if MBX_PARK_N > 8
-        S.park[8][lane] = prev.uw[2];
-#endif
-#if MBX_PARK_N > 9
-        S.park[9][lane] = prev.uw[3];
-#endif
-#if MBX_PARK_N > 0
-        S.park[0][lane] = cur.Ml;
-#endif
-#if MBX_PARK_N > 1
-        S.park[1][lane] = __int_as_float(cur.Vl);
-#endif
+        if constexpr (kParkN > 3) {
+            S.park[3][lane] = acc[1];
+        }
+        if constexpr (kParkN > 4) {
+            if (lane < 32) {
+                S.park[4][lane] = acc[2];
+                S.park[4][lane + 32] = cur.ov[1];
+            }
+        }
+        if constexpr (kParkN > 5) {
+            S.park[5][lane] = cur.PHIl;
+        }
+        if constexpr (kParkN > 6) {
+            S.park[6][lane] = cur.PSIl;
+        }
+        if constexpr (kParkN > 7) {
+            S.park[7][lane] = cur.ov[0];
+        }
+        if constexpr (kParkN > 0) {
+            S.park[0][lane] = cur.Ml;
+        }
+        if constexpr (kParkN > 1) {
+            S.park[1][lane] = __int_as_float(cur.Vl);
+        }
         asm volatile("" ::: "memory");
         // Complex values are (re, im) register pairs: a complex add is one v_pk_add_f32, a multiplication by -+i a
         // swap + sign the packed instructions take as operand modifiers, a complex product two packed instructions.
+        // Element e of the transform lives at F[fsw(e)].  Unswizzled, the middle stages collide in the LDS banks (a b64 read is
+        // served 32 lanes at a time from 64 dword banks, a b64 write 16 lanes at a time from 32: strides of 4 and 16 elements
+        // put 4 and 2 lanes on one bank -- measured on configs[3]: 302 of 1,308 LDS-array cycles per frame were conflicts).
+        // fsw is linear over GF(2) (e ^ two shifted bit fields of e), a bijection of 0..255, and conflict-free for EVERY
+        // access pattern below (first / last stage and the bin passes: lane + 64 r; stages with spans 16, 4, 1); being
+        // linear, fsw(base + r q) = fsw(base) ^ fsw(r q) whenever base has no bit in r q's digit: one swizzle per stage
+        // and three XORs with literals.  (tools/fft_swizzle.py searches the family and prints the conflict counts.)
         v2f* const F = reinterpret_cast<v2f*>(S.fft);
+        // Only in the LDS-resident instances: three more address registers across a butterfly are a spill under the 72 / 80
+        // register caps of the HBM-slot instances, which run one to three frames per stream and are not bound by the LDS pipe.
+        constexpr bool kSwz = kPark;
+        constexpr auto fsw = [](int e) constexpr -> int { return kSwz ? (e ^ ((e >> 2) & 3) ^ (((e >> 4) & 7) << 2)) : e; };
+        constexpr auto elem = [fsw](int base_sw, int c) constexpr -> int { return kSwz ? (base_sw ^ fsw(c)) : (base_sw + c); };   // element base + c
+        const int lane_sw = fsw(lane);   // lane + 64 r  ->  elem(lane_sw, 64 r)
         auto mul_mi = [](v2f a) -> v2f { return v2f{a.y, -a.x}; };   // -i a
         auto cmul = [](v2f u, v2f w) -> v2f {                         // u w
             return __builtin_elementwise_fma(v2f{u.y, u.y}, v2f{-w.y, w.x}, v2f{u.x, u.x} * w);
@@ -1126,31 +1148,32 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const float s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
             v2f w1, w2, w3;
             twiddles(lane, false, w1, w2, w3);
-            F[lane] = v2f{s02 + s13, 0.0f};
-            F[lane + 64] = cmul(v2f{d02, -d13}, w1);
-            F[lane + 128] = splat(s02 - s13) * w2;
-            F[lane + 192] = cmul(v2f{d02, d13}, w3);
+            F[lane_sw] = v2f{s02 + s13, 0.0f};
+            F[elem(lane_sw, 64)] = cmul(v2f{d02, -d13}, w1);
+            F[elem(lane_sw, 128)] = splat(s02 - s13) * w2;
+            F[elem(lane_sw, 192)] = cmul(v2f{d02, d13}, w3);
         }
         wave_lds_sync();
 #pragma unroll
         for (int q = 16; q >= 1; q >>= 2) {
             const int g = lane / q, jj = lane % q;
-            const int base = g * 4 * q + jj;
+            const int base = fsw(g * 4 * q + jj);
+            const int i1 = elem(base, q), i2 = elem(base, 2 * q), i3 = elem(base, 3 * q);
             const int tstep = 64 / q;   // 256 / (4q)
-            const v2f a0 = F[base], a1 = F[base + q], a2 = F[base + 2 * q], a3 = F[base + 3 * q];
+            const v2f a0 = F[base], a1 = F[i1], a2 = F[i2], a3 = F[i3];
             const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, md13 = mul_mi(a1 - a3);
             wave_lds_sync();
             F[base] = s02 + s13;
             if (q == 1) {   // last forward stage: all twiddles are 1
-                F[base + 1] = d02 + md13;   // d02 - i*d13
-                F[base + 2] = s02 - s13;
-                F[base + 3] = d02 - md13;   // d02 + i*d13
+                F[i1] = d02 + md13;   // d02 - i*d13
+                F[i2] = s02 - s13;
+                F[i3] = d02 - md13;   // d02 + i*d13
             } else {
                 v2f w1, w2, w3;
                 twiddles(jj * tstep, false, w1, w2, w3);
-                F[base + q] = cmul(d02 + md13, w1);
-                F[base + 2 * q] = cmul(s02 - s13, w2);
-                F[base + 3 * q] = cmul(d02 - md13, w3);
+                F[i1] = cmul(d02 + md13, w1);
+                F[i2] = cmul(s02 - s13, w2);
+                F[i3] = cmul(d02 - md13, w3);
             }
             wave_lds_sync();
         }
@@ -1158,7 +1181,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         const int kbase = rev4(lane & 63);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int pidx = lane + 64 * r;
+            const int pidx = elem(lane_sw, 64 * r);
             const int k = kbase + r;
             if (k <= 128) {
                 const v2f X = F[pidx];
@@ -1167,16 +1190,14 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         wave_lds_sync();
         // per-band scale: lane = band; a band spans at most 14 bins (w0 <= 4 pi / 39.5)
-#if MBX_PARK_N > 1
-        const bool band_unvoiced = __float_as_int(S.park[1][lane]) == 0;
-#else
-        const bool band_unvoiced = cur.Vl == 0;
-#endif
-#if MBX_PARK_N > 0
-        const float band_M = S.park[0][lane];
-#else
-        const float band_M = cur.Ml;
-#endif
+        bool band_unvoiced = cur.Vl == 0;
+        float band_M = cur.Ml;
+        if constexpr (kParkN > 1) {
+            band_unvoiced = __float_as_int(S.park[1][lane]) == 0;
+        }
+        if constexpr (kParkN > 0) {
+            band_M = S.park[0][lane];
+        }
         float band_sc = 0.0f;
         int band_a = 0, band_b = 0;
         if (lane >= 1 && lane <= cur.L && band_unvoiced) {
@@ -1218,7 +1239,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         wave_lds_sync();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int pidx = lane + 64 * r;
+            const int pidx = elem(lane_sw, 64 * r);
             const int k = kbase + r;
             const float sc = S.bins[k > 128 ? 256 - k : k];
             F[pidx] = F[pidx] * splat(sc);
@@ -1228,10 +1249,11 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
 #pragma unroll
         for (int q = 1; q <= 16; q <<= 2) {
             const int g = lane / q, jj = lane % q;
-            const int base = g * 4 * q + jj;
+            const int base = fsw(g * 4 * q + jj);
+            const int i1 = elem(base, q), i2 = elem(base, 2 * q), i3 = elem(base, 3 * q);
             const int tstep = 64 / q;
             const v2f x0 = F[base];
-            v2f z1 = F[base + q], z2 = F[base + 2 * q], z3 = F[base + 3 * q];
+            v2f z1 = F[i1], z2 = F[i2], z3 = F[i3];
             if (q != 1) {   // multiply by the conjugate twiddles
                 v2f w1, w2, w3;
                 twiddles(jj * tstep, true, w1, w2, w3);
@@ -1242,18 +1264,18 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const v2f s02 = x0 + z2, d02 = x0 - z2, s13 = z1 + z3, md13 = mul_mi(z1 - z3);
             wave_lds_sync();
             F[base] = s02 + s13;
-            F[base + q] = d02 - md13;       // d02 + i*d13
-            F[base + 2 * q] = s02 - s13;
-            F[base + 3 * q] = d02 + md13;   // d02 - i*d13
+            F[i1] = d02 - md13;       // d02 + i*d13
+            F[i2] = s02 - s13;
+            F[i3] = d02 + md13;   // d02 - i*d13
             wave_lds_sync();
         }
         {   // last inverse stage (span 64): only the real parts are needed, results stay in registers
             v2f w1, w2, w3;
             twiddles(lane, true, w1, w2, w3);
-            const v2f x0 = F[lane];
-            const v2f z1 = cmul(F[lane + 64], w1);
-            const v2f z2 = cmul(F[lane + 128], w2);
-            const v2f z3 = cmul(F[lane + 192], w3);
+            const v2f x0 = F[lane_sw];
+            const v2f z1 = cmul(F[elem(lane_sw, 64)], w1);
+            const v2f z2 = cmul(F[elem(lane_sw, 128)], w2);
+            const v2f z3 = cmul(F[elem(lane_sw, 192)], w3);
             const float s02 = x0.x + z2.x, d02 = x0.x - z2.x, s13 = z1.x + z3.x, d13y = z1.y - z3.y;
             cur.uw[0] = (s02 + s13) * (1.0f / 256.0f);
             cur.uw[1] = (d02 - d13y) * (1.0f / 256.0f);   // Re(d02 + i*d13)
@@ -1261,37 +1283,31 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             cur.uw[3] = (d02 + d13y) * (1.0f / 256.0f);   // Re(d02 - i*d13)
         }
         asm volatile("" ::: "memory");
-#if MBX_PARK_N > 2
-        acc[0] = S.park[2][lane];
-#endif
-#if MBX_PARK_N > 3
-        acc[1] = S.park[3][lane];
-#endif
-#if MBX_PARK_N > 4
-        acc[2] = (lane < 32) ? S.park[4][lane] : 0.0f;
-        cur.ov[1] = (lane < 32) ? S.park[4][lane + 32] : 0.0f;
-#endif
-#if MBX_PARK_N > 5
-        cur.PHIl = S.park[5][lane];
-#endif
-#if MBX_PARK_N > 6
-        cur.PSIl = S.park[6][lane];
-#endif
-#if MBX_PARK_N > 7
-        cur.ov[0] = S.park[7][lane];
-#endif
-#if MBX_PARK_N > 8
-        prev.uw[2] = S.park[8][lane];
-#endif
-#if MBX_PARK_N > 9
-        prev.uw[3] = S.park[9][lane];
-#endif
-#if MBX_PARK_N > 0
-        cur.Ml = S.park[0][lane];
-#endif
-#if MBX_PARK_N > 1
-        cur.Vl = __float_as_int(S.park[1][lane]);
-#endif
+        if constexpr (kParkN > 2) {
+            acc[0] = S.park[2][lane];
+        }
+        if constexpr (kParkN > 3) {
+            acc[1] = S.park[3][lane];
+        }
+        if constexpr (kParkN > 4) {
+            acc[2] = (lane < 32) ? S.park[4][lane] : 0.0f;
+            cur.ov[1] = (lane < 32) ? S.park[4][lane + 32] : 0.0f;
+        }
+        if constexpr (kParkN > 5) {
+            cur.PHIl = S.park[5][lane];
+        }
+        if constexpr (kParkN > 6) {
+            cur.PSIl = S.park[6][lane];
+        }
+        if constexpr (kParkN > 7) {
+            cur.ov[0] = S.park[7][lane];
+        }
+        if constexpr (kParkN > 0) {
+            cur.Ml = S.park[0][lane];
+        }
+        if constexpr (kParkN > 1) {
+            cur.Vl = __float_as_int(S.park[1][lane]);
+        }
     }
     if (!MBX_ABL(tabs, 32)) {
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
@@ -1390,6 +1406,16 @@ struct ParkedState<true> {
     char pad[MBX_EXP_LDS_PAD];   // occupancy experiments only (tools/variant.sh): fewer waves per CU
 #endif
 };
+// IMBE: prev_mp_enhanced needs no home inside the launch at all.  Every IMBE frame ends with prev_mp_enhanced := cur_mp
+// (ref src/imbe/imbe7200x4400.c:780-888), `cur` never leaves the registers, and synthesis reads only ten fields of the
+// enhanced model: they are copied register to register at the end of a frame (EnhView), the struct is loaded from HBM once
+// and written back once from `cur`.  2,604 B of LDS less per wave: 5,200 B = five allocation granules instead of eight.
+struct ParkedPrevOnly {
+    mbe_parms prev;
+#ifdef MBX_EXP_LDS_PAD
+    char pad[MBX_EXP_LDS_PAD];
+#endif
+};
 
 template <bool kPark>
 __device__ __forceinline__ void slot_fence() {   // the wave is about to re-read what it stored to its slots
@@ -1424,8 +1450,8 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
-    __shared__ WaveScratch scratch;
-    __shared__ ParkedState<kPark> park;
+    __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
+    __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;
     if ((int)blockIdx.x >= S) {
         return;
     }
@@ -1442,11 +1468,12 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     mbe_parms* const home_prev = &state[3 * slot + 1];
     mbe_parms* const home_enh = &state[3 * slot + 2];
     mbe_parms *slot_prev, *slot_enh;
+    Parms enh_keep;   // kPark: the fields of prev_mp_enhanced that synthesis reads, carried from frame to frame in registers
     if constexpr (kPark) {
         slot_prev = &park.prev;
-        slot_enh = &park.enh;
+        slot_enh = nullptr;
+        load_enh_view(enh_keep, home_enh, lane_in);
         copy_parms(slot_prev, home_prev, lane_in);
-        copy_parms(slot_enh, home_enh, lane_in);
         wave_lds_sync();
     } else {
         slot_prev = home_prev;
@@ -1479,7 +1506,11 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         // The parts of prev_mp_enhanced that synthesis reads are requested now, together with prev_mp,
         // so that one memory latency covers both (they are first used after the decode).
         Parms enh;
-        load_enh_view(enh, slot_enh, lane);
+        if constexpr (kPark) {
+            enh = enh_keep;
+        } else {
+            load_enh_view(enh, slot_enh, lane);
+        }
         Parms prev;
         load_prev_view(prev, slot_prev, lane);
         if (params) {
@@ -1561,7 +1592,21 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         if (muted) {
             flags |= MBE_PROCESS_FLAG_MUTE;
         }
-        if (!MBX_ABL(tabs, 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
+        if constexpr (kPark) {   // prev_mp_enhanced := cur_mp, as far as the next frame's synthesis reads it
+            enh_keep = Parms{};
+            enh_keep.w0 = cur.w0;
+            enh_keep.L = cur.L;
+            enh_keep.Vl = cur.Vl;
+            enh_keep.Ml = cur.Ml;
+            enh_keep.PHIl = cur.PHIl;
+            enh_keep.PSIl = cur.PSIl;
+            enh_keep.localEnergy = cur.localEnergy;
+            enh_keep.amplitudeThreshold = cur.amplitudeThreshold;
+            enh_keep.uw[2] = cur.uw[2];
+            enh_keep.uw[3] = cur.uw[3];
+        } else {
+            if (!MBX_ABL(tabs, 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
+        }
         if (t + 1 < Tn) {
             slot_fence<kPark>();             // the next frame of this wave reloads both slots
         }
@@ -1580,10 +1625,10 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 
     if (!MBX_ABL(tabs_in, 1024)) store_parms(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
-    if constexpr (kPark) {   // the two structs go home
+    if constexpr (kPark) {   // prev_mp goes home from LDS; prev_mp_enhanced IS cur_mp after the last frame
+        store_parms(cur, home_enh, lane_in);
         wave_lds_sync();
         copy_parms(home_prev, slot_prev, lane_in);
-        copy_parms(home_enh, slot_enh, lane_in);
     }
 }
 
@@ -1601,7 +1646,10 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
 // (The compiler notes that the occupancy asked for is not reached -- LDS allows four waves per SIMD -- and relaxes the
 // register budget accordingly; -Wno-pass-failed in the Makefile silences exactly that remark.)
 #define MBX_LDS_KERNEL_ATTR(waves) __launch_bounds__(64, waves)
-__global__ void MBX_LDS_KERNEL_ATTR(MBX_STREAM_WAVES_PER_SIMD)
+#ifndef MBX_IMBE_LDS_WAVES_PER_SIMD
+#define MBX_IMBE_LDS_WAVES_PER_SIMD 6   // 5,200 B of LDS per wave = 25 waves per CU: the register file decides (80 VGPRs)
+#endif
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_IMBE_LDS_WAVES_PER_SIMD)
 imbe_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
@@ -1847,7 +1895,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
-    __shared__ WaveScratch scratch;
+    __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ ParkedState<kPark> park;   // T >= 4: prev_mp / prev_mp_enhanced resident in LDS (see the IMBE kernel)
     if ((int)blockIdx.x >= S) {
         return;
