@@ -1896,7 +1896,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
-    __shared__ ParkedState<kPark> park;   // T >= 4: prev_mp / prev_mp_enhanced resident in LDS (see the IMBE kernel)
+    __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;   // T >= 4: prev_mp resident in LDS
     if ((int)blockIdx.x >= S) {
         return;
     }
@@ -1909,17 +1909,37 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     mbe_parms* const slot_cur = &state[3 * slot + 0];
     mbe_parms* const home_prev = &state[3 * slot + 1];
     mbe_parms* const home_enh = &state[3 * slot + 2];
-    mbe_parms *slot_prev, *slot_enh;
+    mbe_parms* const slot_enh = home_enh;
+    mbe_parms* slot_prev;
+    // kPark: prev_mp_enhanced has no copy in LDS.  The fields synthesis reads travel from frame to frame in registers
+    // (enh_keep), and the struct itself is only ever needed whole by the rare invalid-tone replay.  `synced` says that
+    // prev_mp_enhanced == cur_mp field for field (true after every frame that ends with prev_mp_enhanced := cur_mp: voice,
+    // erasure, re-initialisation); while it holds, the HBM home of prev_mp_enhanced is stale and `cur` is its only copy.
+    // A tone frame leaves prev_mp_enhanced alone while it changes cur_mp, so a synced wave first writes `cur` to the home
+    // (before the frame touches it); from then on the home is current until the next frame that syncs again.
+    Parms enh_keep;
+    bool synced = false;
     if constexpr (kPark) {
         slot_prev = &park.prev;
-        slot_enh = &park.enh;
+        load_enh_view(enh_keep, home_enh, lane_in);
         copy_parms(slot_prev, home_prev, lane_in);
-        copy_parms(slot_enh, home_enh, lane_in);
         wave_lds_sync();
     } else {
         slot_prev = home_prev;
-        slot_enh = home_enh;
     }
+    auto keep_enh_view = [&](const Parms& from) {
+        enh_keep = Parms{};
+        enh_keep.w0 = from.w0;
+        enh_keep.L = from.L;
+        enh_keep.Vl = from.Vl;
+        enh_keep.Ml = from.Ml;
+        enh_keep.PHIl = from.PHIl;
+        enh_keep.PSIl = from.PSIl;
+        enh_keep.localEnergy = from.localEnergy;
+        enh_keep.amplitudeThreshold = from.amplitudeThreshold;
+        enh_keep.uw[2] = from.uw[2];
+        enh_keep.uw[3] = from.uw[3];
+    };
     Parms cur;
     load_parms(cur, slot_cur, lane_in);
     StreamRng rng;
@@ -1946,7 +1966,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         const DeviceTables& tabs = ft;
         const float* fp;
         if constexpr (kPark) {
-            // The frame's FrameParams row goes through LDS, and the NEXT frame's row is requested now: with four waves per
+            // The frame's FrameParams row goes through LDS, and the NEXT frame's row is requested now: with few waves per
             // SIMD a global load in front of every decode is not hidden by the other waves.
             scratch.x.fp[lane] = row_now;
             wave_lds_sync();
@@ -1966,7 +1986,11 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         // The parts of prev_mp_enhanced that synthesis reads are requested together with prev_mp, so that one
         // memory latency covers both (as in the IMBE kernel).
         Parms enh;
-        load_enh_view(enh, slot_enh, lane);
+        if constexpr (kPark) {
+            enh = enh_keep;
+        } else {
+            load_enh_view(enh, slot_enh, lane);
+        }
         {
             Parms prev;
             load_prev_view(prev, slot_prev, lane);
@@ -1976,9 +2000,27 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 init_ambe_parms(prev, lane);
                 cur = prev;
                 store_parms(prev, slot_prev, lane);
-                store_parms(prev, slot_enh, lane);
+                if constexpr (kPark) {
+                    keep_enh_view(prev);
+                    enh = enh_keep;
+                    synced = true;
+                } else {
+                    store_parms(prev, slot_enh, lane);
+                    slot_fence<kPark>();
+                    load_enh_view(enh, slot_enh, lane);
+                }
                 slot_fence<kPark>();
-                load_enh_view(enh, slot_enh, lane);
+            }
+            if constexpr (kPark) {
+                // a frame that will leave prev_mp_enhanced alone (AMBE+2 tone class, valid D-STAR tone) while it changes cur_mp:
+                // `cur` is still prev_mp_enhanced field for field here (see `synced` above) -- write it home first
+                const int cls = uni(__float_as_int(fp[63]));
+                const int c0v_early = ((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? c0 : 0;
+                const bool keeps_enh = k2400 ? ((cls >= 7) && (cls <= 122) && (c0v_early < 2) && (total < 3)) : (cls == 7);
+                if (keeps_enh && synced) {
+                    store_parms(cur, home_enh, lane);
+                    synced = false;
+                }
             }
             cur.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
             cur.errorCountTotal = total;
@@ -2058,15 +2100,25 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             // invalid tone id: run the synthesiser on a copy of the enhanced model.  `cur` is parked in
             // its slot meanwhile so that still only two structs are live.
             store_parms(cur, slot_cur, lane);
-            __threadfence_block();               // (slot_cur is always the HBM slot)
-            slot_fence<kPark>();
-            load_parms(cur, slot_enh, lane);     // the copy that is synthesised ...
-            load_enh_view(enh, slot_enh, lane);  // ... against the enhanced model itself (only the fields synthesis reads)
+            if constexpr (kPark) {
+                // The copy takes the LDS home of prev_mp for the duration (it is the synthesiser's snapshot), prev_mp waits in
+                // its HBM home.  prev_mp_enhanced is current in ITS home: this is a tone-class frame (see `synced`).
+                wave_lds_sync();
+                copy_parms(home_prev, slot_prev, lane);
+                __threadfence_block();
+                copy_parms(slot_prev, home_enh, lane);
+                slot_fence<kPark>();
+                load_parms(cur, slot_prev, lane);
+            } else {
+                __threadfence_block();               // (slot_cur is always the HBM slot)
+                load_parms(cur, slot_enh, lane);     // the copy that is synthesised ...
+                load_enh_view(enh, slot_enh, lane);  // ... against the enhanced model itself (only the fields synthesis reads)
+            }
             cur.log2Ml = 0.0f;   // slot_enh itself is the snapshot of this copy
             cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
         }
         if (action == kVoice || action == kToneFallback) {
-            const mbe_parms* snap = (action == kVoice) ? slot_prev : slot_enh;
+            const mbe_parms* snap = (kPark || action == kVoice) ? slot_prev : slot_enh;
             const bool fresh = synth_core<true, kPark>(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane, snap);
             {
                 slot_fence<kPark>();
@@ -2086,7 +2138,19 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     cur.ov[1] = (lane < 32) ? slot_read<kPark>(f, O_OVERLAP + 64 + lane) : 0.0f;
                 }
             }
-            store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := synthesised model
+            if constexpr (kPark) {   // prev_mp_enhanced := synthesised model
+                keep_enh_view(cur);
+                if (action == kVoice) {
+                    synced = true;
+                } else {
+                    store_parms(cur, home_enh, lane);    // the replayed copy is NOT cur_mp: it goes to the home (synced stays false)
+                    wave_lds_sync();
+                    __threadfence_block();
+                    copy_parms(slot_prev, home_prev, lane);   // prev_mp returns to LDS
+                }
+            } else {
+                store_parms(cur, slot_enh, lane);
+            }
             if (action == kToneFallback) {
                 __threadfence_block();
                 load_parms(cur, slot_cur, lane);
@@ -2102,7 +2166,12 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 init_ambe_parms(cur, lane);
             }
             store_parms(cur, slot_prev, lane);
-            store_parms(cur, slot_enh, lane);
+            if constexpr (kPark) {
+                keep_enh_view(cur);
+                synced = true;
+            } else {
+                store_parms(cur, slot_enh, lane);
+            }
         }
         if (t + 1 < Tn) {
             slot_fence<kPark>();   // the next frame of this wave reloads the parked structs
@@ -2122,10 +2191,12 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 
     store_parms(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
-    if constexpr (kPark) {   // the two structs go home
+    if constexpr (kPark) {   // prev_mp goes home from LDS; prev_mp_enhanced from `cur` unless its home is already current
+        if (synced) {
+            store_parms(cur, home_enh, lane_in);
+        }
         wave_lds_sync();
         copy_parms(home_prev, slot_prev, lane_in);
-        copy_parms(home_enh, slot_enh, lane_in);
     }
 }
 
@@ -2146,14 +2217,17 @@ ambe2400_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ recor
 }
 
 // T >= 4: prev_mp / prev_mp_enhanced resident in LDS (see the IMBE kernel)
-__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_WAVES_PER_SIMD)
+#ifndef MBX_AMBE_LDS_WAVES_PER_SIMD
+#define MBX_AMBE_LDS_WAVES_PER_SIMD 5   // 5,200 B of LDS per wave = 25 waves per CU; 80 registers (six waves) would spill
+#endif
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
 ambe_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     ambe_stream_body<false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
-__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE2400_WAVES_PER_SIMD)
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
 ambe2400_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                            mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                            float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
