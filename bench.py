@@ -377,10 +377,10 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
         fec = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400, 3: L.mbx_fec_ambe3600x2450}[codec]
     n = S * T
     stream_codec = 0 if codec == 2 else codec   # 7100x4400 records are in 7200x4400 order after its FEC stage
-    # mbx_process_records is ONE launch for IMBE at T > 1 (expansion fused into the stream kernel); otherwise it is the
-    # expand launch + the stream launch.  --split-expand forces the separate launch for IMBE at T > 1 (development aid).
-    split = (codec in (1, 3)) or (T == 1 and not args.fuse_expand) or args.split_expand
-
+    # mbx_process_records is ONE launch where the stream kernel expands the records itself (IMBE at T > 1, the AMBE codecs
+    # at T >= 4); otherwise it is the expand launch + the stream launch, issued separately here so that the events bracket
+    # the stream kernel alone.  --split-expand forces the separate launch everywhere (development aid).
+    split = bool(L.mbx_uses_expand_launch(stream_codec, S, T)) and not (T == 1 and args.fuse_expand) or args.split_expand
     def step(ev=None):
         if ev is not None and soft:
             ev[0].record()

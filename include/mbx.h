@@ -76,6 +76,10 @@ const char* mbx_last_error(void);
  * Alternatively the caller owns the workspace: the *_ws launchers take a device buffer of mbx_workspace_bytes(S*T)
  * bytes and touch no internal buffer at all. */
 int mbx_reserve(size_t max_frames);
+/* 1 when mbx_process_records / mbx_process_batch issue the parameter expansion of an S x T batch of `codec` as a separate
+ * launch through the workspace (one-frame-per-stream IMBE launches of more than 256 streams, AMBE launches with fewer than
+ * four frames per stream), 0 when the stream kernel expands the records itself. */
+int mbx_uses_expand_launch(int codec, int S, int T);
 int mbx_reserve_stream(void* stream, size_t max_frames);
 int mbx_release_stream(void* stream);
 size_t mbx_workspace_bytes(size_t max_frames);

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "mbx_shutdown": (None, []),
     "mbx_reserve": (C.c_int, [_sz]),
     "mbx_reserve_stream": (C.c_int, [_vp, _sz]),
+    "mbx_uses_expand_launch": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mbx_release_stream": (C.c_int, [_vp]),
     "mbx_workspace_bytes": (_sz, [_sz]),
     "mbx_device_ready": (C.c_int, [C.c_int]),

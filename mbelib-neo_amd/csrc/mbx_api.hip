@@ -804,7 +804,7 @@ static bool stream_args_ok(int codec, int S, int T, const void* d_records, const
 // trip and a launch (+4 % at T = 16).  With ONE frame per stream the whole-job rate is the same either way (measured
 // 0.296 vs 0.292 ms per 65,536 frames): the table look-ups of the expansion are a latency chain a one-frame wave cannot
 // hide, and the 8-lanes-per-frame expand kernel costs as much as it saves -- there the expansion stays a separate
-// launch, which keeps the dominant kernel to the stream stage proper.  The AMBE stream kernels always read rows.
+// launch, which keeps the dominant kernel to the stream stage proper.  The AMBE HBM-slot instances always read rows.
 // ... except for small batches (the synchronous per-frame API is S = T = 1): there a launch less is worth more than the
 // last few per cent of kernel efficiency, and the IMBE stream kernel expands the record itself.
 constexpr int kSmallBatchFrames = 256;
@@ -812,8 +812,12 @@ static bool needs_workspace(int codec, int S, int T) {
     if (codec == MBX_CODEC_IMBE7200X4400) {
         return T == 1 && S > kSmallBatchFrames;
     }
-    return true;   // the AMBE stream kernels always read rows
+    // AMBE codecs: the LDS-resident instances (T >= 4) expand eight frames of their stream at a time into LDS rows;
+    // the HBM-slot instances read rows from the workspace
+    return !(T >= kLdsResidentMinFrames && lds_resident_enabled());
 }
+
+extern "C" int mbx_uses_expand_launch(int codec, int S, int T) { return needs_workspace(codec == MBX_CODEC_IMBE7100X4400 ? MBX_CODEC_IMBE7200X4400 : codec, S, T) ? 1 : 0; }
 
 // expand (where needed) + stream kernel with the workspace at `ws` (nullptr when none is needed); `order` = the launch
 // counter that decides the walking direction

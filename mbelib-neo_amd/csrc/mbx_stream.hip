@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "mbx_device.h"
+#include "mbx_expand_ambe.h"
 
 #ifndef MBX_PARK_N
 #define MBX_PARK_N 8   // how many per-lane values wait in LDS across the unvoiced transform pair (synth_core)
@@ -1897,6 +1898,12 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;   // T >= 4: prev_mp resident in LDS
+    // kPark without a workspace (params == nullptr, the normal case): the wave expands the records of its next EIGHT frames
+    // itself, eight lanes per frame exactly like the expand kernels (mbx_expand_ambe.h), into eight LDS rows -- no
+    // expand launch, no 256-byte row per frame through HBM.  (One frame at a time fills 8 of 64 lanes: round 2 measured
+    // that slower than the separate launch.)  Row stride 65 dwords: the eight frames write the same columns at once.
+    constexpr int kXRows = 8, kXStride = 65;
+    __shared__ float xrows[kPark ? kXRows : 1][kPark ? kXStride : 1];
     if ((int)blockIdx.x >= S) {
         return;
     }
@@ -1946,7 +1953,9 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     load_rng(rng, &rngs[slot]);
     float row_now = 0.0f;
     if constexpr (kPark) {
-        row_now = params[(size_t)s * (size_t)Tn].v[lane_in];
+        if (params) {
+            row_now = params[(size_t)s * (size_t)Tn].v[lane_in];
+        }
     }
 
     for (int t = 0; t < Tn; ++t) {
@@ -1966,13 +1975,24 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         const DeviceTables& tabs = ft;
         const float* fp;
         if constexpr (kPark) {
-            // The frame's FrameParams row goes through LDS, and the NEXT frame's row is requested now: with few waves per
-            // SIMD a global load in front of every decode is not hidden by the other waves.
-            scratch.x.fp[lane] = row_now;
-            wave_lds_sync();
-            fp = scratch.x.fp;
-            if (t + 1 < Tn) {
-                row_now = params[f + 1].v[lane];
+            if (params) {
+                // rows from a workspace (mbx_stream_expanded): the frame's row goes through LDS, and the NEXT frame's row is
+                // requested now -- with few waves per SIMD a global load in front of every decode is not hidden
+                scratch.x.fp[lane] = row_now;
+                wave_lds_sync();
+                fp = scratch.x.fp;
+                if (t + 1 < Tn) {
+                    row_now = params[f + 1].v[lane];
+                }
+            } else {
+                if ((t & (kXRows - 1)) == 0) {
+                    const int q = lane >> 3;
+                    const bool have = (t + q) < Tn;
+                    wave_lds_sync();   // the previous eight rows have been read
+                    xp::expand_ambe_frame<k2400>(have, &records[have ? f + (size_t)q : f], xrows[q], lane & 7, tabs);
+                    wave_lds_sync();
+                }
+                fp = xrows[t & (kXRows - 1)];
             }
         } else {
             fp = params[f].v;
