@@ -3,7 +3,7 @@
 build and the REFERENCE's own SIMD build (`make -C oracle ref simd`) on the same seeded random-bit frames and count
 where the two builds of the reference part: int16 differences, and frames that differ grossly (a float threshold
 decision -- adaptive smoothing's Ml > VM -- taken the other way because the builds order their sums differently).
-usage: oracle/tools/ref_simd_vs_scalar.py [rounds] [codec ...]"""
+usage: oracle/tools/ref_simd_vs_scalar.py [simd|fma] [rounds] [codec ...]   (fma: the x86-64-v3 build of `make -C oracle fma`)"""
 import ctypes as C
 import os
 import sys
@@ -21,7 +21,7 @@ def run(args):
     from mbelib_neo_amd import framegen
     from mbelib_neo_amd.layout import FRAME_CELLS, init_state
 
-    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_bench_simd.so" if build == "simd" else "libref_bench.so"))
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", {"simd": "libref_bench_simd.so", "fma": "libref_bench_fma.so"}.get(build, "libref_bench.so")))
     lib.ref_process_batch.restype = C.c_int
     lib.ref_process_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
     S, T = 2048, 8
@@ -37,9 +37,12 @@ def run(args):
 
 
 def main():
+    other = "simd"
+    if len(sys.argv) > 1 and sys.argv[1] in ("simd", "fma"):   # which second build: SIMD (`make -C oracle simd`) or FMA target (`make -C oracle fma`)
+        other = sys.argv.pop(1)
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     codecs = [int(c) for c in sys.argv[2:]] or [0, 1, 2, 3]
-    tasks = [(b, r, c) for r in range(rounds) for c in codecs for b in ("scalar", "simd")]
+    tasks = [(b, r, c) for r in range(rounds) for c in codecs for b in ("scalar", other)]
     hist = {c: np.zeros(8, dtype=np.int64) for c in codecs}
     gross = {c: [] for c in codecs}
     frames = {c: 0 for c in codecs}
@@ -54,7 +57,7 @@ def main():
         gross[c] += [(r, int(f)) for f in far]
         frames[c] += a.shape[0]
     for c in codecs:
-        print(f"codec {c}: {frames[c]} frames; int16 |scalar - simd| histogram 0,1,..,6,>=7: {hist[c].tolist()}; "
+        print(f"codec {c}: {frames[c]} frames; int16 |scalar - {other}| histogram 0,1,..,6,>=7: {hist[c].tolist()}; "
               f"frames differing by more than 64: {len(gross[c])} {gross[c][:12]}")
 
 
