@@ -1045,3 +1045,63 @@ def test_int16_tail_over_ten_million_samples(mbx, oracle, codec):
     assert d.size >= 10_000_000
     assert float(np.mean(d <= 1)) >= 0.9999
     print(f"codec {codec} tail:", m, np.bincount(np.minimum(d, 7), minlength=8).tolist())
+
+
+# ---- AMBE+2 frame classes inside LDS-resident launches ---------------------------------------------------------------
+def _ambe_class_frames(classes, rng):
+    """clean AMBE+2 wire frames of the given classes: 'v' voice, 't' valid tone, 'i' tone frame with an invalid id,
+    'e' erasure (ref src/ambe/ambe3600x2450.c:176-240 classification)"""
+    from mbelib_neo_amd import framegen
+
+    n = len(classes)
+    bits = framegen.ambe_voice_param_bits(n, rng)
+    for k, c in enumerate(classes):
+        if c in "ti":
+            bits[k, 0:6] = 1                       # u0 >> 6 == 63: the tone signature ...
+            bits[k, 45:49] = 0                     # ... with u3 & 0xf == 0
+            tone_id = int(rng.integers(7, 123)) if c == "t" else int(rng.choice([0, 3, 124, 127, 200, 255]))
+            for j in range(8):
+                bits[k, 12 + j] = (tone_id >> (7 - j)) & 1
+        elif c == "e":
+            bits[k, 0:4] = 1                       # b0 = 120..123
+            bits[k, 4] = 0                         # (not the tone signature)
+            bits[k, 37] = 0
+    return framegen.encode_ambe3600x2450(bits)
+
+
+def test_ambe_tone_and_erasure_classes_in_lds_resident_launches(mbx, oracle):
+    """prev_mp_enhanced has no LDS home in the LDS-resident AMBE instances: it travels in registers and is written to HBM
+    only around tone-class frames (mbx_stream.hip, `synced`).  Scripted class sequences -- a tone as the very first frame
+    of a stream, invalid tones (which replay prev_mp_enhanced whole) before and after voice, runs of invalid tones,
+    erasures in between -- as ONE launch of T = 12 (LDS-resident) against the oracle and against twelve T = 1 launches
+    (HBM-slot instance): integer state and results exact, PCM in tolerance, both instances bit-identical."""
+    from mbelib_neo_amd import framegen
+    from mbelib_neo_amd.layout import init_state, rng_seeded
+
+    rng = framegen.rng_for(4711)
+    scripts = ["tvvivvtvvevv", "ivvvvvvvvvvv", "vvviiivvtvie", "evtvivvvviiv", "vvvvvvvvvvvi", "tttvvviveevi", "viviviviviei", "vvetvivtveiv"]
+    S, T = 256, 12
+    rows = []
+    for s_ in range(S):
+        sc = scripts[s_ % len(scripts)] if s_ < 64 else "".join(rng.choice(list("vvvvvtie"), size=T))
+        rows.append(_ambe_class_frames(sc, rng))
+    frames = np.stack(rows).reshape(S * T, 9)
+    seeds = [4000 + s_ for s_ in range(S)]
+    ref = oracle.process_batch(1, S, T, frames, oracle.init_state(S), oracle.rng_seeded(seeds))
+    flags = np.asarray(ref["results"]["flags"])
+    assert (flags & 0x10).any() and (flags & 0x20).any()   # tone and erasure frames are really there
+    got = _host_batch(mbx, 1, S, T, frames, init_state(S), rng_seeded(seeds))
+    parity.check_results(ref["results"], got["results"])
+    parity.check_pcm(ref["pcmf"], got["pcmf"], ref["pcm16"], got["pcm16"])
+    parity.check_state(ref["state"], got["state"])
+    assert np.array_equal(ref["rng"], got["rng"])
+    # the same streams tick by tick (T = 1: the HBM-slot instance)
+    state, rg = init_state(S), rng_seeded(seeds)
+    pcm = np.zeros((S, T, 160), dtype=np.int16)
+    fr = frames.reshape(S, T, 9)
+    for t in range(T):
+        out = _host_batch(mbx, 1, S, 1, np.ascontiguousarray(fr[:, t]), state, rg)
+        state, rg = out["state"], out["rng"]
+        pcm[:, t] = np.asarray(out["pcm16"]).reshape(S, 160)
+    assert np.array_equal(pcm.reshape(-1, 160), np.asarray(got["pcm16"]).reshape(-1, 160))
+    assert np.array_equal(np.asarray(state).view(np.uint8), np.asarray(got["state"]).view(np.uint8))
