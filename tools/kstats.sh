@@ -2,7 +2,7 @@
 # development aid (GPU box): per-kernel average durations of one bench run (rocprofv3 --kernel-trace --stats)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks
-rocprofv3 --kernel-trace --stats -d /tmp/ks --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/ks --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras "$@" > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob
 for f in glob.glob('/tmp/ks/*/*kernel_stats.csv'):

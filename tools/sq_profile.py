@@ -16,6 +16,7 @@ cycles -- the calibration run pins each of them on instruction streams whose len
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
@@ -74,6 +75,45 @@ def run_pass(idx, counters, cmd):
     return vals, kern, dur, r
 
 
+SIMDS, CUS, XCDS = 1024, 256, 8   # MI355X: 256 CUs x 4 SIMD-32, 8 XCDs (GRBM_GUI_ACTIVE is summed over the XCDs)
+# cycles of SIMD time per wave-instruction at four waves per SIMD, measured by tools/valu_issue.hip (profiles/r03/valu_issue.jsonl):
+# 8-byte VALU encodings (v_fma_f32, v_pk_*, DPP, v_fma_f64, v_mul_lo_u32) 2.9-3.3, v_mov_b32 2.07, transcendentals 6.06
+COST_VALU, COST_TRANS = 3.1, 6.06
+
+
+def issue_model(c, kernel_ns, frames):
+    """derived figures of one dispatch from its counters (c), duration and the frames it decoded"""
+    g = c.get
+    cycles = g("GRBM_GUI_ACTIVE", 0.0) / XCDS
+    if not cycles or not kernel_ns:
+        return None
+    valu, trans = g("SQ_INSTS_VALU", 0.0), g("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    wave_q = g("SQ_WAVE_CYCLES", 0.0)
+    m = {
+        "clock_ghz": cycles / kernel_ns,
+        "kernel_cycles": cycles,
+        "waves_per_simd_resident": wave_q * 4 / (SIMDS * cycles),
+        "per_frame": {k: g(n, 0.0) / frames for k, n in (("valu", "SQ_INSTS_VALU"), ("valu_trans", "SQ_INSTS_VALU_TRANS_F32"),
+                                                           ("valu_f64", None), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"),
+                                                           ("vmem_rd", "SQ_INSTS_VMEM_RD"), ("vmem_wr", "SQ_INSTS_VMEM_WR"),
+                                                           ("branch", "SQ_INSTS_BRANCH"), ("lds_array_cycles", "SQ_LDS_IDX_ACTIVE"),
+                                                           ("lds_bank_conflict_cycles", "SQ_LDS_BANK_CONFLICT")) if n},
+        # the SQ books 4 cycles per VALU instruction (8 per transcendental) whatever the SIMD needed: tools/valu_issue.hip
+        # shows 4.00 / 7.96 on every stream, including ones that retire an instruction every 2.1-3.2 cycles
+        "valu_busy_sq_accounting": g("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (SIMDS * cycles),
+        # the same instructions priced at what the SIMD measurably needs at this occupancy
+        "valu_issue_utilisation": ((valu - trans) * COST_VALU + trans * COST_TRANS) / (SIMDS * cycles),
+        "valu_cost_model": {"plain_or_packed_cycles": COST_VALU, "transcendental_cycles": COST_TRANS, "source": "tools/valu_issue.hip at 4 waves per SIMD"},
+        "lds_array_busy": g("SQ_LDS_IDX_ACTIVE", 0.0) / (CUS * cycles),
+        "lds_bank_conflict_share": (g("SQ_LDS_BANK_CONFLICT", 0.0) / g("SQ_LDS_IDX_ACTIVE", 1.0)) if g("SQ_LDS_IDX_ACTIVE") else None,
+        "wave_time": ({"parked_in_waitcnt": g("SQ_WAIT_ANY", 0.0) / wave_q, "issue_stalled": g("SQ_WAIT_INST_ANY", 0.0) / wave_q,
+                       "issuing": g("SQ_ACTIVE_INST_ANY", 0.0) / wave_q} if wave_q else None),
+    }
+    m["per_frame"]["valu_f64"] = (g("SQ_INSTS_VALU_FMA_F64", 0.0) + g("SQ_INSTS_VALU_MUL_F64", 0.0) + g("SQ_INSTS_VALU_ADD_F64", 0.0)) / frames
+    m["measured_busy"] = m["valu_issue_utilisation"]
+    return m
+
+
 def main():
     mode = sys.argv[1]
     avail = available()
@@ -83,7 +123,7 @@ def main():
     if mode == "bench":
         workload, path = sys.argv[2], sys.argv[3]
         steps = 4
-        cmd = ["python3", os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--workload", workload]
+        cmd = ["python3", os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "2", "--min-time-ms", "0", "--no-cpu-baseline", "--no-extras", "--workload", workload]
         out["workload"] = workload
         out["command"] = " ".join(cmd)
         merged, durs = {}, []
@@ -114,6 +154,10 @@ def main():
         out["kernel"] = target
         out["counters_per_dispatch"] = {k: sum(v) / len(v) for k, v in merged.items()}
         out["kernel_ns_under_pmc"] = (sum(durs) / len(durs)) if durs else None
+        out["libmbx_hip_sha256_16"] = hashlib.sha256(open(os.path.join(ROOT, "mbelib-neo_amd", "libmbx_hip.so"), "rb").read()).hexdigest()[:16]
+        if "streams_per_gpu" in out:
+            out["issue_model"] = issue_model(out["counters_per_dispatch"], out["kernel_ns_under_pmc"],
+                                             out["streams_per_gpu"] * out["frames_per_stream_per_step"])
     else:
         path = sys.argv[2]
         cmd = [os.path.join(ROOT, "tools", "bin", "valu_issue")]
@@ -131,7 +175,12 @@ def main():
                         e[c] = v
         out["command"] = " ".join(cmd)
         out["program_output"] = [json.loads(x) for x in (text or "").splitlines() if x.startswith("{")]
-        out["dispatches"] = [rows[k] for k in sorted(rows)]
+        out["dispatches"] = [rows[k] for k in sorted(rows) if "issue_kernel" in rows[k]["kernel"]]
+        for e in out["dispatches"]:   # what the counters say per instruction on streams of known length
+            if e.get("SQ_INSTS_VALU"):
+                e["active_valu_cycles_per_valu_inst"] = e.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / e["SQ_INSTS_VALU"]
+            if e.get("GRBM_GUI_ACTIVE") and e.get("ns"):
+                e["waves_per_simd"] = e["wg"] / 256.0
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k not in ("dispatches", "program_output")})[:3000])
 
