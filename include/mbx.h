@@ -195,6 +195,20 @@ int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_recor
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream);
 
+/* ONE frame of ONE stream as one launch of one wavefront (FEC + parameter decode + policy + synthesis + float->int16):
+ * what the synchronous mbe_process*Frame[f] of libmbe_neo_amd.so issue.
+ *   ref: mbe_processImbe7200x4400Frame[f]  include/mbelib-neo/mbelib.h:429-441, mbe_processAmbe3600x2450Frame[f] :505-517,
+ *        mbe_processImbe7100x4400Frame[f] :564-576, mbe_processAmbe3600x2400Frame[f] :352-364
+ * Every pointer must be device-accessible -- device memory, or PINNED host memory (hipHostMalloc / mbx_host_alloc): the
+ * kernel reads the three structs at its start and writes them at its end, nothing in between touches them, so with the
+ * caller's structs in pinned memory the call needs no copy in either direction.  d_frame: one wire frame (18 | 9 bytes);
+ * d_state: {cur, prev, prev_enhanced}; d_pcm16 / d_pcmf: 160 samples, either may be NULL; d_result may be NULL; d_record:
+ * the 16-byte parameter record (out).  d_done (may be NULL): after everything else has been written the kernel stores
+ * `token` there with system scope -- a host that polls a word of pinned memory for the token needs no stream
+ * synchronisation to know that the outputs are complete. */
+int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                      mbe_process_result* d_result, mbx_param_record* d_record, uint32_t* d_done, uint32_t token, void* stream);
+
 /* FEC stage + stream stage back to back:
  * ref: mbe_processImbe7200x4400Frame[f] include/mbelib-neo/mbelib.h:505-511,
  *      mbe_processAmbe3600x2450Frame[f] include/mbelib-neo/mbelib.h:429-435.

@@ -85,6 +85,8 @@ struct Slot {
     int16_t*          pcm16 = nullptr;    // 160
     mbe_process_result* res = nullptr;
     uint32_t*         words = nullptr;    // 4: in, out, errs
+    uint32_t*         done = nullptr;     // completion word of the single-frame kernel (mbx_process_frame), polled by the host
+    uint32_t          token = 0;
     uint8_t*          frame_out = nullptr; // 18 bytes: a frame after one of the in-place sub-stages
     mbe_soft_bit*     soft = nullptr;     // one soft frame (184 cells)
     struct Pending {
@@ -105,10 +107,13 @@ struct Slot {
         };
         const size_t o_frame = take(32), o_rec = take(sizeof(mbx_param_record)), o_state = take(3 * sizeof(mbe_parms)),
                      o_rng = take(sizeof(mbx_stream_rng)), o_pcmf = take(160 * sizeof(float)), o_pcm16 = take(160 * sizeof(int16_t)),
-                     o_res = take(sizeof(mbe_process_result)), o_words = take(4 * sizeof(uint32_t)), o_fout = take(32),
+                     o_res = take(sizeof(mbe_process_result)), o_words = take(4 * sizeof(uint32_t)), o_done = take(64), o_fout = take(32),
                      o_soft = take(MBX_IMBE_SOFT_BITS * sizeof(mbe_soft_bit));   // the largest soft frame (184 cells)
         block_bytes = off;
-        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&block), block_bytes, hipHostMallocDefault));   // coherent, device-visible
+        // fine-grained (coherent) pinned memory: what a kernel writes here is visible to the host while the kernel is still
+        // running, in program order behind a system-scope fence -- the completion word below relies on that
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&block), block_bytes, hipHostMallocCoherent));
+        memset(block, 0, block_bytes);
         frame = block + o_frame;
         rec = reinterpret_cast<mbx_param_record*>(block + o_rec);
         state = reinterpret_cast<mbe_parms*>(block + o_state);
@@ -117,6 +122,7 @@ struct Slot {
         pcm16 = reinterpret_cast<int16_t*>(block + o_pcm16);
         res = reinterpret_cast<mbe_process_result*>(block + o_res);
         words = reinterpret_cast<uint32_t*>(block + o_words);
+        done = reinterpret_cast<uint32_t*>(block + o_done);
         frame_out = block + o_fout;
         soft = reinterpret_cast<mbe_soft_bit*>(block + o_soft);
     }
@@ -140,6 +146,31 @@ struct Slot {
             pending[npending++] = Pending{dst, src, n};   // the kernels have not run yet: copied by sync()
         } else {
             HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));
+        }
+    }
+    // Wait for the single-frame kernel by polling its completion word (a few microseconds less than waking up on the
+    // stream's completion signal).  The stream is queried now and then so that a faulted launch cannot spin forever.
+    void wait_token(uint32_t want) {
+        for (unsigned spins = 1;; ++spins) {
+            if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == want) {
+                return;
+            }
+            if ((spins & 0x3fffu) == 0u) {
+                const hipError_t e = hipStreamQuery(stream);
+                if (e == hipSuccess) {   // the kernel has retired: the word is there (or the launch never ran)
+                    if (__atomic_load_n(done, __ATOMIC_ACQUIRE) != want) {
+                        fprintf(stderr, "libmbe_neo_amd: single-frame kernel retired without its completion word\n");
+                        abort();
+                    }
+                    return;
+                }
+                if (e != hipErrorNotReady) {
+                    HIP_OK(e);
+                }
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
         }
     }
     void sync() {
@@ -805,8 +836,9 @@ int queue_frame(int codec, float* aout_f, short* aout_s, mbe_process_result* res
 
 bool queueing() { return batch().active; }
 
-// mbe_process*Frame[f], synchronous: frame decode + parameter processing in ONE device round trip (FEC, expand and stream
-// kernel back to back on the thread's stream, what mbx_process_batch does for S = T = 1).  The record the FEC kernel hands
+// mbe_process*Frame[f], synchronous: frame decode + parameter processing as ONE launch of one wavefront (mbx_process_frame:
+// FEC by lane 0, then the LDS-resident stream body) on the caller's structs copied into the thread's pinned block; the
+// host waits on the kernel's completion word, not on the stream.  The record the FEC kernel hands
 // to the stream stage is the one the reference's two calls hand over through imbe_d / result (c0, protected, c4, context
 // flags), so the outcome is that of mbe_decode*Frame followed by mbe_process*Dataf.  Argument errors that the reference
 // reports only AFTER the frame decode has written imbe_d / result take the two-call path below, which does the same.
@@ -842,10 +874,11 @@ int process_frame(int codec, float* aout_f, short* aout_s, mbe_process_result* r
     s.up(&s.state[1], prev, sizeof(mbe_parms));
     s.up(&s.state[2], enh, sizeof(mbe_parms));
     s.up(s.rng, &t_rng.r, sizeof(mbx_stream_rng));
-    must(mbx_process_batch(codec, 1, 1, s.frame, s.state, s.rng, aout_s ? s.pcm16 : nullptr, aout_f ? s.pcmf : nullptr, s.res, s.rec,
-                           s.stream),
-         "mbx_process_batch");
-    s.sync();
+    const uint32_t token = ++s.token;
+    must(mbx_process_frame(codec, s.frame, s.state, s.rng, aout_s ? s.pcm16 : nullptr, aout_f ? s.pcmf : nullptr, s.res, s.rec, s.done,
+                           token, s.stream),
+         "mbx_process_frame");
+    s.wait_token(token);
     if (aout_f) {
         memcpy(aout_f, s.pcmf, 160 * sizeof(float));
     }

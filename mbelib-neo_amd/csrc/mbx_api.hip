@@ -36,6 +36,12 @@ __global__ void ambe_stream_kernel(int, int, const mbx_param_record*, const Fram
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe2400_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void imbe_frame_kernel(int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                  mbe_process_result*, uint32_t*, uint32_t, DeviceTables);
+__global__ void ambe_frame_kernel(const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*, mbe_process_result*,
+                                  uint32_t*, uint32_t, DeviceTables);
+__global__ void ambe2400_frame_kernel(const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                      mbe_process_result*, uint32_t*, uint32_t, DeviceTables);
 __global__ void synth_speech_kernel(int, mbe_parms*, mbe_parms*, mbx_stream_rng*, float*, int16_t*, DeviceTables);
 __global__ void enhance_kernel(int, mbe_parms*);
 __global__ void smoothing_kernel(int, mbe_parms*, const mbe_parms*);
@@ -953,6 +959,28 @@ int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parm
         return rc;
     }
     return mbx_process_records(stream_codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+}
+
+int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                      mbe_process_result* d_result, mbx_param_record* d_record, uint32_t* d_done, uint32_t token, void* stream) {
+    REQUIRE_CTX(c);
+    if (!d_frame || !d_state || !d_rng || !d_record || codec < MBX_CODEC_IMBE7200X4400 || codec > MBX_CODEC_AMBE3600X2400) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbx::DeviceTables tabs = c->tabs;
+    tabs.reverse = 0;
+    tabs.stream_map = nullptr;
+    if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {
+        hipLaunchKernelGGL(mbx::imbe_frame_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, codec, d_frame, d_record, d_state, d_rng,
+                           d_pcm16, d_pcmf, d_result, d_done, token, tabs);
+    } else if (codec == MBX_CODEC_AMBE3600X2400) {
+        hipLaunchKernelGGL(mbx::ambe2400_frame_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_frame, d_record, d_state, d_rng,
+                           d_pcm16, d_pcmf, d_result, d_done, token, tabs);
+    } else {
+        hipLaunchKernelGGL(mbx::ambe_frame_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_frame, d_record, d_state, d_rng, d_pcm16,
+                           d_pcmf, d_result, d_done, token, tabs);
+    }
+    return check_launch("frame_kernel");
 }
 
 int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,

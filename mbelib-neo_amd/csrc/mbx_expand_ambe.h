@@ -34,9 +34,11 @@ __device__ __forceinline__ int pick(const uint32_t w[3], int i0, int i1, int i2,
 // parameter record; row: the frame's 64 (+ pad) dwords in LDS; sub: 0..7, the lane's place in its group of eight.
 // All 64 lanes of the wave must call this together (it exchanges data inside each group of eight lanes and uses a
 // wavefront-scope LDS fence between the block lanes and the summary lane of a frame).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 class has no address-space-aware copy)
+
+// the record by value (wherever it came from); `rec` is ignored when !have
 template <bool k2400>
-__device__ __forceinline__ void expand_ambe_frame(bool have, const mbx_param_record* __restrict__ rec_ptr, float* row, int sub,
-                                                  const DeviceTables& tabs) {
+__device__ __forceinline__ void expand_ambe_frame_rec(bool have, const u32x4 rec, float* row, int sub, const DeviceTables& tabs) {
     // explicit global address space: inside the stream kernels the table pointers have passed an asm barrier and would
     // otherwise be read with FLAT loads, which also count against the LDS counter
     const MBX_GLOBAL mbx_tables* T = (const MBX_GLOBAL mbx_tables*)tabs.t;
@@ -46,8 +48,6 @@ __device__ __forceinline__ void expand_ambe_frame(bool have, const mbx_param_rec
     bool silence = false;
     uint32_t w[3] = {0, 0, 0}, errw = 0;
     if (have) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 class has no address-space-aware copy)
-        const u32x4 rec = *reinterpret_cast<const MBX_GLOBAL u32x4*>((const MBX_GLOBAL mbx_param_record*)rec_ptr);
         w[0] = rec.x;
         w[1] = rec.y;
         w[2] = rec.z;
@@ -232,6 +232,17 @@ __device__ __forceinline__ void expand_ambe_frame(bool have, const mbx_param_rec
         row[62] = __uint_as_float(errw);
         row[63] = __int_as_float(bad);
     }
+}
+
+// the record from memory (rec_ptr must be dereferenceable even when !have)
+template <bool k2400>
+__device__ __forceinline__ void expand_ambe_frame(bool have, const mbx_param_record* __restrict__ rec_ptr, float* row, int sub,
+                                                  const DeviceTables& tabs) {
+    u32x4 rec = {0u, 0u, 0u, 0u};
+    if (have) {
+        rec = *reinterpret_cast<const MBX_GLOBAL u32x4*>((const MBX_GLOBAL mbx_param_record*)rec_ptr);
+    }
+    expand_ambe_frame_rec<k2400>(have, rec, row, sub, tabs);
 }
 
 }  // namespace xp

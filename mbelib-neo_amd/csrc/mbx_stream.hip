@@ -34,6 +34,7 @@
 
 #include "mbx_device.h"
 #include "mbx_expand_ambe.h"
+#include "mbx_fec_frame.h"
 
 #ifndef MBX_PARK_N
 #define MBX_PARK_N 8   // how many per-lane values wait in LDS across the unvoiced transform pair (synth_core)
@@ -293,13 +294,17 @@ typedef const MBX_GLOBAL DerivedTables* GlobalDerived;
 typedef const MBX_GLOBAL float* GlobalFloats;
 __device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
 
+// a frame's parameter record by SCALAR loads (wave-uniform address)
+__device__ __forceinline__ uint4 load_record_scalar(const mbx_param_record* rp) {
+    const __attribute__((address_space(4))) uint32_t* rq = (const __attribute__((address_space(4))) uint32_t*)rp;
+    return make_uint4(rq[0], rq[1], rq[2], rq[3]);
+}
+
 template <class Scratch>
-__device__ void expand_imbe_wave(const mbx_param_record* rp, Scratch& S, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane) {
+__device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane) {
     ConstTables T = (ConstTables)Tgen;
     GlobalTables Tg = (GlobalTables)Tgen;
     GlobalDerived Dg = (GlobalDerived)Dgen;
-    const __attribute__((address_space(4))) uint32_t* rq = (const __attribute__((address_space(4))) uint32_t*)rp;
-    const uint4 rec = make_uint4(rq[0], rq[1], rq[2], rq[3]);
     int b0 = (int)(rec.x >> 26);
     b0 = (b0 << 2) | (int)((rec.z >> 9) & 3u);   // payload bits 85, 86
     int bad = 1, L = 0, K = 0;
@@ -1445,12 +1450,14 @@ __device__ __forceinline__ void copy_parms(mbe_parms* dst, const mbe_parms* src,
 // ------------------------------------------------------------------------------------------
 // IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
 // ------------------------------------------------------------------------------------------
-template <bool kPark>
+// kFrame: the single-frame kernels behind the synchronous per-frame API (S = T = 1): the record comes in registers from
+// the FEC the same wave has just run (rec_in), not from memory.
+template <bool kPark, bool kFrame = false>
 __device__ __forceinline__ void
 imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                 mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+                 mbe_process_result* __restrict__ results, DeviceTables tabs_in, uint4 rec_in = make_uint4(0u, 0u, 0u, 0u)) {
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;
     if ((int)blockIdx.x >= S) {
@@ -1518,7 +1525,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             scratch.x.fp[lane] = params[f].v[lane];
             wave_lds_sync();
         } else {
-            expand_imbe_wave(&records[f], scratch, tabs.t, tabs.d, lane);
+            expand_imbe_wave(kFrame ? rec_in : load_record_scalar(&records[f]), scratch, tabs.t, tabs.d, lane);
         }
         const float* fp = scratch.x.fp;
         const uint32_t errw = uni(__float_as_uint(fp[62]));
@@ -1890,12 +1897,12 @@ __device__ void tone_dstar_frame(float out[3], int id1, Parms& cur, int lane) {
 
 // k2400: AMBE 3600x2400 (D-STAR) frame policy, ref src/ambe/ambe3600x2400.c:629-763 -- no erasure class, D-STAR
 // tones, repeats decided by the total error count alone.  The prediction (decode_ambe) is common.
-template <bool k2400, bool kPark>
+template <bool k2400, bool kPark, bool kFrame = false>
 __device__ __forceinline__ void
 ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                 mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+                 mbe_process_result* __restrict__ results, DeviceTables tabs_in, uint4 rec_in = make_uint4(0u, 0u, 0u, 0u)) {
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;   // T >= 4: prev_mp resident in LDS
     // kPark without a workspace (params == nullptr, the normal case): the wave expands the records of its next EIGHT frames
@@ -1989,7 +1996,11 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     const int q = lane >> 3;
                     const bool have = (t + q) < Tn;
                     wave_lds_sync();   // the previous eight rows have been read
-                    xp::expand_ambe_frame<k2400>(have, &records[have ? f + (size_t)q : f], xrows[q], lane & 7, tabs);
+                    if constexpr (kFrame) {
+                        xp::expand_ambe_frame_rec<k2400>(q == 0, xp::u32x4{rec_in.x, rec_in.y, rec_in.z, rec_in.w}, xrows[q], lane & 7, tabs);
+                    } else {
+                        xp::expand_ambe_frame<k2400>(have, &records[have ? f + (size_t)q : f], xrows[q], lane & 7, tabs);
+                    }
                     wave_lds_sync();
                 }
                 fp = xrows[t & (kXRows - 1)];
@@ -2098,7 +2109,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 flags |= MBE_PROCESS_FLAG_MUTE;
             }
         } else if (bad == 7) {
-            const uint4 rec = *reinterpret_cast<const uint4*>(&records[f]);
+            const uint4 rec = kFrame ? rec_in : *reinterpret_cast<const uint4*>(&records[f]);
             tw[0] = rec.x;
             tw[1] = rec.y;
             tw[2] = rec.z;
@@ -2218,6 +2229,74 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         wave_lds_sync();
         copy_parms(home_prev, slot_prev, lane_in);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-frame kernels: mbe_process*Frame[f] of the synchronous per-frame API as ONE launch of ONE wavefront.
+//   FEC by lane 0 (mbx_fec_frame.h; the record stays in registers and is also written out), then the LDS-resident stream
+//   body with S = T = 1: every read of the three structs is issued at the start and every write at the end, nothing in
+//   between waits on the state's memory -- which for this path is pinned HOST memory behind PCIe (libmbe_neo_amd.so hands
+//   the caller's structs over in place).  The last thing the wave does is store `token` to *done with system scope after a
+//   system-scope fence: the host polls that word instead of paying a stream synchronisation.
+//   ref include/mbelib-neo/mbelib.h:429,505,564,352 (mbe_process*Frame[f]); the two calls they make,
+//       mbe_decode*Frame + mbe_process*Dataf: src/imbe/imbe7200x4400.c:709-744,780-888 and counterparts.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void frame_done(uint32_t* done, uint32_t token, int lane) {
+    __threadfence_system();   // the wave's stores (one wave: s_waitcnt vmcnt(0) covers every lane) are visible to the host ...
+    if (done && lane == 0) {
+        __hip_atomic_store(done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag is
+    }
+}
+
+__device__ __forceinline__ uint4 broadcast_record(uint4 r, mbx_param_record* out, int lane) {
+    if (lane == 0) {
+        *reinterpret_cast<uint4*>(out) = r;
+    }
+    return make_uint4(uni(r.x), uni(r.y), uni(r.z), uni(r.w));
+}
+
+__global__ void __launch_bounds__(64)
+imbe_frame_kernel(int codec, const uint8_t* __restrict__ frame, mbx_param_record* __restrict__ record, mbe_parms* __restrict__ state,
+                  mbx_stream_rng* __restrict__ rng, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                  mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs) {
+    const int lane = lane_id();
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (lane == 0) {
+        r = (codec == MBX_CODEC_IMBE7100X4400) ? fec_imbe7100x4400_frame(tabs.t, frame) : fec_imbe7200x4400_frame(tabs.t, frame);
+    }
+    r = broadcast_record(r, record, lane);
+    imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, r);
+    frame_done(done, token, lane);
+}
+
+template <bool k2400>
+__device__ __forceinline__ void ambe_frame_body(const uint8_t* __restrict__ frame, mbx_param_record* __restrict__ record,
+                                                mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rng,
+                                                int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                                                mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token,
+                                                const DeviceTables& tabs) {
+    const int lane = lane_id();
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (lane == 0) {
+        r = fec_ambe3600x2450_frame(tabs.t, frame);   // both AMBE codecs share the FEC front end
+    }
+    r = broadcast_record(r, record, lane);
+    ambe_stream_body<k2400, true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, r);
+    frame_done(done, token, lane);
+}
+
+__global__ void __launch_bounds__(64)
+ambe_frame_kernel(const uint8_t* __restrict__ frame, mbx_param_record* __restrict__ record, mbe_parms* __restrict__ state,
+                  mbx_stream_rng* __restrict__ rng, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                  mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs) {
+    ambe_frame_body<false>(frame, record, state, rng, pcm16, pcmf, result, done, token, tabs);
+}
+
+__global__ void __launch_bounds__(64)
+ambe2400_frame_kernel(const uint8_t* __restrict__ frame, mbx_param_record* __restrict__ record, mbe_parms* __restrict__ state,
+                      mbx_stream_rng* __restrict__ rng, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                      mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs) {
+    ambe_frame_body<true>(frame, record, state, rng, pcm16, pcmf, result, done, token, tabs);
 }
 
 // mbe_synthesizeSpeechf for S independent (cur, prev) pairs.
