@@ -1450,6 +1450,31 @@ __device__ __forceinline__ void copy_parms(mbe_parms* dst, const mbe_parms* src,
 // ------------------------------------------------------------------------------------------
 // IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void frame_done(uint32_t* done, uint32_t token, int lane) {
+    __threadfence_system();   // the wave's stores (one wave: s_waitcnt vmcnt(0) covers every lane) are visible to the host ...
+    if (done && lane == 0) {
+        __hip_atomic_store(done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag is
+    }
+}
+
+__device__ __forceinline__ uint4 broadcast_record(uint4 r, mbx_param_record* out, int lane) {
+    if (lane == 0) {
+        *reinterpret_cast<uint4*>(out) = r;
+    }
+    return make_uint4(uni(r.x), uni(r.y), uni(r.z), uni(r.w));
+}
+
+// the frame's record by lane 0 of the wave (kFrame kernels); fec_codec: MBX_CODEC_* of the FRONT END (both AMBE codecs share one)
+__device__ __forceinline__ uint4 frame_record(int fec_codec, const uint8_t* frame, mbx_param_record* record, const mbx_tables* T, int lane) {
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (lane == 0) {
+        r = (fec_codec == MBX_CODEC_IMBE7200X4400)   ? fec_imbe7200x4400_frame(T, frame)
+            : (fec_codec == MBX_CODEC_IMBE7100X4400) ? fec_imbe7100x4400_frame(T, frame)
+                                                     : fec_ambe3600x2450_frame(T, frame);
+    }
+    return broadcast_record(r, record, lane);
+}
+
 // kFrame: the single-frame kernels behind the synchronous per-frame API (S = T = 1): the record comes in registers from
 // the FEC the same wave has just run (rec_in), not from memory.
 template <bool kPark, bool kFrame = false>
@@ -1457,9 +1482,11 @@ __device__ __forceinline__ void
 imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                 mbe_process_result* __restrict__ results, DeviceTables tabs_in, uint4 rec_in = make_uint4(0u, 0u, 0u, 0u)) {
+                 mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr,
+                 int fec_codec = 0) {
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;
+    uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
     if ((int)blockIdx.x >= S) {
         return;
     }
@@ -1477,20 +1504,27 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     mbe_parms* const home_enh = &state[3 * slot + 2];
     mbe_parms *slot_prev, *slot_enh;
     Parms enh_keep;   // kPark: the fields of prev_mp_enhanced that synthesis reads, carried from frame to frame in registers
+    Parms cur;
+    StreamRng rng;
     if constexpr (kPark) {
         slot_prev = &park.prev;
         slot_enh = nullptr;
         load_enh_view(enh_keep, home_enh, lane_in);
-        copy_parms(slot_prev, home_prev, lane_in);
+        Parms home;
+        load_parms(home, home_prev, lane_in);
+        load_parms(cur, slot_cur, lane_in);
+        load_rng(rng, &rngs[slot]);
+        if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
+            rec_in = frame_record(fec_codec, frame_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+        }
+        store_parms(home, slot_prev, lane_in);
         wave_lds_sync();
     } else {
         slot_prev = home_prev;
         slot_enh = home_enh;
+        load_parms(cur, slot_cur, lane_in);
+        load_rng(rng, &rngs[slot]);
     }
-    Parms cur;
-    load_parms(cur, slot_cur, lane_in);
-    StreamRng rng;
-    load_rng(rng, &rngs[slot]);
 
     for (int t = 0; t < Tn; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
@@ -1902,7 +1936,8 @@ __device__ __forceinline__ void
 ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                 mbe_process_result* __restrict__ results, DeviceTables tabs_in, uint4 rec_in = make_uint4(0u, 0u, 0u, 0u)) {
+                 mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr) {
+    uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;   // T >= 4: prev_mp resident in LDS
     // kPark without a workspace (params == nullptr, the normal case): the wave expands the records of its next EIGHT frames
@@ -1933,13 +1968,24 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     // (before the frame touches it); from then on the home is current until the next frame that syncs again.
     Parms enh_keep;
     bool synced = false;
+    Parms cur;
+    StreamRng rng;
     if constexpr (kPark) {
         slot_prev = &park.prev;
         load_enh_view(enh_keep, home_enh, lane_in);
-        copy_parms(slot_prev, home_prev, lane_in);
+        Parms home;
+        load_parms(home, home_prev, lane_in);
+        load_parms(cur, slot_cur, lane_in);
+        load_rng(rng, &rngs[slot]);
+        if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
+            rec_in = frame_record(MBX_CODEC_AMBE3600X2450, frame_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+        }
+        store_parms(home, slot_prev, lane_in);
         wave_lds_sync();
     } else {
         slot_prev = home_prev;
+        load_parms(cur, slot_cur, lane_in);
+        load_rng(rng, &rngs[slot]);
     }
     auto keep_enh_view = [&](const Parms& from) {
         enh_keep = Parms{};
@@ -1954,10 +2000,6 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         enh_keep.uw[2] = from.uw[2];
         enh_keep.uw[3] = from.uw[3];
     };
-    Parms cur;
-    load_parms(cur, slot_cur, lane_in);
-    StreamRng rng;
-    load_rng(rng, &rngs[slot]);
     float row_now = 0.0f;
     if constexpr (kPark) {
         if (params) {
@@ -2241,32 +2283,12 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 //   ref include/mbelib-neo/mbelib.h:429,505,564,352 (mbe_process*Frame[f]); the two calls they make,
 //       mbe_decode*Frame + mbe_process*Dataf: src/imbe/imbe7200x4400.c:709-744,780-888 and counterparts.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void frame_done(uint32_t* done, uint32_t token, int lane) {
-    __threadfence_system();   // the wave's stores (one wave: s_waitcnt vmcnt(0) covers every lane) are visible to the host ...
-    if (done && lane == 0) {
-        __hip_atomic_store(done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag is
-    }
-}
-
-__device__ __forceinline__ uint4 broadcast_record(uint4 r, mbx_param_record* out, int lane) {
-    if (lane == 0) {
-        *reinterpret_cast<uint4*>(out) = r;
-    }
-    return make_uint4(uni(r.x), uni(r.y), uni(r.z), uni(r.w));
-}
-
 __global__ void __launch_bounds__(64)
 imbe_frame_kernel(int codec, const uint8_t* __restrict__ frame, mbx_param_record* __restrict__ record, mbe_parms* __restrict__ state,
                   mbx_stream_rng* __restrict__ rng, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                   mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs) {
-    const int lane = lane_id();
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
-    if (lane == 0) {
-        r = (codec == MBX_CODEC_IMBE7100X4400) ? fec_imbe7100x4400_frame(tabs.t, frame) : fec_imbe7200x4400_frame(tabs.t, frame);
-    }
-    r = broadcast_record(r, record, lane);
-    imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, r);
-    frame_done(done, token, lane);
+    imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, frame, codec);
+    frame_done(done, token, lane_id());
 }
 
 template <bool k2400>
@@ -2275,14 +2297,8 @@ __device__ __forceinline__ void ambe_frame_body(const uint8_t* __restrict__ fram
                                                 int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                                                 mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token,
                                                 const DeviceTables& tabs) {
-    const int lane = lane_id();
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
-    if (lane == 0) {
-        r = fec_ambe3600x2450_frame(tabs.t, frame);   // both AMBE codecs share the FEC front end
-    }
-    r = broadcast_record(r, record, lane);
-    ambe_stream_body<k2400, true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, r);
-    frame_done(done, token, lane);
+    ambe_stream_body<k2400, true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, frame);
+    frame_done(done, token, lane_id());
 }
 
 __global__ void __launch_bounds__(64)
