@@ -69,8 +69,9 @@ const char* mbx_last_error(void);
  * need none).
  * Each (device, hipStream_t) owns one, grown on demand -- growth waits for that stream and allocates, so size it up
  * front where that matters (required before stream capture):
- *   mbx_reserve(n)            every stream already known to the current device now, and every stream first used later,
- *                             holds >= n frames (n = the largest S*T of one launch)
+ *   mbx_reserve(n)            the default stream's workspace holds >= n frames now, and every other stream's at least
+ *                             that much from the next time it has to grow (n = the largest S*T of one launch); streams
+ *                             seen earlier are not touched -- their handles may be gone
  *   mbx_reserve_stream(s, n)  the same for one stream, creating its slot
  *   mbx_release_stream(s)     waits for `s` and frees its slot (call before hipStreamDestroy on long-lived processes)
  * Alternatively the caller owns the workspace: the *_ws launchers take a device buffer of mbx_workspace_bytes(S*T)

@@ -182,8 +182,28 @@ struct Slot {
     }
 };
 
+// What a decoding thread owns (stream, pinned block, the stream's expand workspace inside libmbx_hip) goes back when the
+// thread ends: a host that spawns short-lived decode threads must not leak one of each per thread.
+struct SlotHolder {
+    Slot* p = nullptr;
+    ~SlotHolder() {
+        if (p) {
+            (void)hipStreamSynchronize(p->stream);
+            (void)mbx_release_stream(p->stream);
+            (void)hipStreamDestroy(p->stream);
+            (void)hipHostFree(p->block);
+            (void)hipGetLastError();
+            delete p;
+        }
+    }
+};
+
 Slot& slot() {
-    thread_local Slot* s = new Slot();   // lives as long as the thread's HIP context; never freed
+    thread_local SlotHolder holder;
+    if (!holder.p) {
+        holder.p = new Slot();
+    }
+    Slot* s = holder.p;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev != g_device) {   // the host application switched devices on this thread
         HIP_OK(hipSetDevice(g_device));
@@ -463,6 +483,14 @@ template <class U>
 struct DevArr {   // grow-only device array
     U*     p = nullptr;
     size_t cap = 0;
+    DevArr() = default;
+    DevArr(const DevArr&) = delete;
+    DevArr& operator=(const DevArr&) = delete;
+    ~DevArr() {
+        if (p) {
+            (void)hipFree(p);
+        }
+    }
     void need(size_t n) {
         if (n > cap) {
             if (p) {
@@ -478,6 +506,14 @@ template <class U>
 struct PinArr {   // grow-only pinned host array
     U*     p = nullptr;
     size_t cap = 0;
+    PinArr() = default;
+    PinArr(const PinArr&) = delete;
+    PinArr& operator=(const PinArr&) = delete;
+    ~PinArr() {
+        if (p) {
+            (void)hipHostFree(p);
+        }
+    }
     void need(size_t n) {
         if (n > cap) {
             if (p) {
@@ -495,6 +531,7 @@ struct Batch {
     std::vector<QEntry>   q;
     std::vector<QChannel> channels;                       // pool slot = index
     std::unordered_map<const mbe_parms*, int> index;      // cur_mp -> channel
+    std::unordered_map<const mbe_parms*, int> aux;        // prev_mp / prev_mp_enhanced -> channel (direct use of either struct)
     DevArr<mbe_parms>      d_state;                       // [channels][3]
     DevArr<mbx_stream_rng> d_rng;
     size_t                 resident = 0;                  // channels [0, resident) hold their state on the device
@@ -514,9 +551,17 @@ struct Batch {
     PinArr<mbx_stream_rng>     h_rng;
 };
 
+struct BatchHolder {   // freed with the thread (the arrays' destructors return the device and pinned memory)
+    Batch* p = nullptr;
+    ~BatchHolder() { delete p; }
+};
+
 Batch& batch() {
-    thread_local Batch* b = new Batch();
-    return *b;
+    thread_local BatchHolder holder;
+    if (!holder.p) {
+        holder.p = new Batch();
+    }
+    return *holder.p;
 }
 
 size_t frame_bytes_of(int codec) {
@@ -755,24 +800,39 @@ void release_channel(Batch& b, int c) {
         b.resident = last;
     }
     b.index.erase(ch.cur);
+    b.aux.erase(ch.prev);
+    b.aux.erase(ch.enh);
     if ((size_t)c != last) {
         b.channels[(size_t)c] = b.channels[last];
         if (b.channels[(size_t)c].on_device) {
             b.channels[(size_t)c].slot = c;
         }
         b.index[b.channels[(size_t)c].cur] = c;
+        b.aux[b.channels[(size_t)c].prev] = c;
+        b.aux[b.channels[(size_t)c].enh] = c;
     }
     b.channels.pop_back();
 }
 
-// a synchronous call is about to use these structs: make sure the host copy is the current one
-void sync_channel_for_direct_use(const mbe_parms* cur) {
+// a synchronous call is about to use this struct (any of a channel's three): make sure the host copy is the current one.
+// Outside queue mode, and for structs that belong to no queued channel, this is two look-ups in empty / small maps.
+void sync_channel_for_direct_use(const mbe_parms* any) {
     Batch& b = batch();
-    if (!b.active || b.index.empty()) {
+    if (!any || !b.active || b.index.empty()) {
         return;
     }
-    auto it = b.index.find(cur);
+    auto it = b.index.find(any);
+    int c = -1;
     if (it != b.index.end()) {
+        c = it->second;
+    } else {
+        auto ia = b.aux.find(any);
+        if (ia != b.aux.end()) {
+            c = ia->second;
+        }
+    }
+    if (c >= 0) {
+        const mbe_parms* cur = b.channels[(size_t)c].cur;
         (void)flush_batch(b);
         release_channel(b, b.index.find(cur)->second);
     }
@@ -801,6 +861,8 @@ int queue_frame(int codec, float* aout_f, short* aout_s, mbe_process_result* res
         ch.rng = t_rng.r;
         b.channels.push_back(ch);
         b.index.emplace(cur, c);
+        b.aux[prev] = c;
+        b.aux[enh] = c;
     } else {
         c = it->second;
         QChannel& ch = b.channels[(size_t)c];
@@ -912,12 +974,16 @@ void mbe_initProcessResult(mbe_process_result* result) {
 void mbe_setThreadRngSeed(uint32_t seed) { mbx_rng_seed(&t_rng.r, seed); }
 
 void mbe_moveMbeParms(const mbe_parms* source_mp, mbe_parms* destination_mp) {
+    sync_channel_for_direct_use(source_mp);        // queue mode: a struct of a resident channel is stale on the host
+    sync_channel_for_direct_use(destination_mp);
     if (source_mp && destination_mp) {
         *destination_mp = *source_mp;
     }
 }
 
 void mbe_useLastMbeParms(mbe_parms* cur_mp, const mbe_parms* prev_mp) {
+    sync_channel_for_direct_use(cur_mp);
+    sync_channel_for_direct_use(prev_mp);
     if (cur_mp && prev_mp) {
         *cur_mp = *prev_mp;
     }
@@ -928,6 +994,11 @@ void mbe_initMbeParms(mbe_parms* cur_mp, mbe_parms* prev_mp, mbe_parms* prev_mp_
     if (!cur_mp || !prev_mp || !prev_mp_enhanced) {
         return;
     }
+    // queue mode: a host that resets a channel at call start gets a reset -- the channel leaves the device pool first,
+    // otherwise mbe_batchEnd / mbe_batchRelease would write the old device state over these defaults
+    sync_channel_for_direct_use(cur_mp);
+    sync_channel_for_direct_use(prev_mp);
+    sync_channel_for_direct_use(prev_mp_enhanced);
     mbe_parms p;
     memset(&p, 0, sizeof(p));
     p.w0 = (float)((4.0 * M_PI) / (134.0 + 39.5));
@@ -1230,6 +1301,7 @@ int mbe_batchEnd(void) {
     }
     b.channels.clear();
     b.index.clear();
+    b.aux.clear();
     b.resident = 0;
     b.active = false;
     return ran;
@@ -1315,6 +1387,8 @@ void mbe_synthesizeSpeechf(float* aout_buf, mbe_parms* cur_mp, mbe_parms* prev_m
     if (!aout_buf) {
         return;
     }
+    sync_channel_for_direct_use(cur_mp);
+    sync_channel_for_direct_use(prev_mp);
     if (!cur_mp || !prev_mp || !valid_L(cur_mp->L) || !valid_L(prev_mp->L)) {
         mbe_synthesizeSilencef(aout_buf);
         return;
@@ -1326,6 +1400,8 @@ void mbe_synthesizeSpeech(short* aout_buf, mbe_parms* cur_mp, mbe_parms* prev_mp
     if (!aout_buf) {
         return;
     }
+    sync_channel_for_direct_use(cur_mp);
+    sync_channel_for_direct_use(prev_mp);
     if (!cur_mp || !prev_mp || !valid_L(cur_mp->L) || !valid_L(prev_mp->L)) {
         mbe_synthesizeSilence(aout_buf);
         return;
@@ -1334,6 +1410,7 @@ void mbe_synthesizeSpeech(short* aout_buf, mbe_parms* cur_mp, mbe_parms* prev_mp
 }
 
 void mbe_spectralAmpEnhance(mbe_parms* cur_mp) {
+    sync_channel_for_direct_use(cur_mp);
     if (!cur_mp || !valid_L(cur_mp->L)) {
         return;
     }
@@ -1345,6 +1422,8 @@ void mbe_spectralAmpEnhance(mbe_parms* cur_mp) {
 }
 
 void mbe_applyAdaptiveSmoothing(mbe_parms* cur_mp, const mbe_parms* prev_mp) {
+    sync_channel_for_direct_use(cur_mp);
+    sync_channel_for_direct_use(prev_mp);
     if (!cur_mp || !prev_mp || !valid_L(cur_mp->L) || !valid_L(prev_mp->L)) {
         return;
     }

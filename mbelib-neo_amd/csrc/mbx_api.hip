@@ -587,16 +587,12 @@ int mbx_reserve(size_t max_frames) {
     REQUIRE_CTX(c);
     std::lock_guard<std::mutex> lock(c->mu);
     if (max_frames > c->reserve_frames) {
-        c->reserve_frames = max_frames;   // every stream first used from now on starts with this much
+        c->reserve_frames = max_frames;   // every slot grows to at least this much the next time it has to grow at all
     }
-    (void)c->slots[nullptr];
-    for (auto& kv : c->slots) {
-        int rc = ensure_workspace(c, kv.second, max_frames, kv.first);
-        if (rc < 0) {
-            return rc;
-        }
-    }
-    return 0;
+    // Only the default stream's slot is sized here.  The slots of other streams are NOT walked: the library cannot know
+    // whether a hipStream_t it saw earlier still exists, and synchronising a destroyed handle is undefined -- a stream
+    // that must not allocate at its next launch (stream capture) is sized with mbx_reserve_stream() by its owner.
+    return ensure_workspace(c, c->slots[nullptr], max_frames, nullptr);
 }
 
 int mbx_release_stream(void* stream) {

@@ -94,6 +94,7 @@ struct mbx_session {
     hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
     Slot     slot[kDepth];
     unsigned long long submitted = 0;
+    std::vector<uint8_t> seen;   // submit_indexed: one mark per stream, to refuse an index that names a stream twice
 };
 
 namespace {
@@ -154,6 +155,9 @@ bool range_ok(const mbx_session* s, int first, int count) {
     return s && first >= 0 && count >= 0 && (long long)first + count <= s->streams;
 }
 
+int enqueue(mbx_session* s, Slot& sl, int n, int T, const int32_t* index, const uint8_t* frames, int16_t* pcm16, float* pcmf,
+            mbe_process_result* results, mbx_param_record* records);
+
 int submit(mbx_session* s, int n, int T, const int32_t* index, const uint8_t* frames, int16_t* pcm16, float* pcmf,
            mbe_process_result* results, mbx_param_record* records) {
     if (!s || !frames || n < 0 || T < 0 || n > s->streams || (size_t)n * (size_t)T > s->max_frames) {
@@ -166,11 +170,14 @@ int submit(mbx_session* s, int n, int T, const int32_t* index, const uint8_t* fr
     if (n == 0 || T == 0) {
         return 0;
     }
-    if (index) {
+    if (index) {   // every row must name its own stream: two rows on one stream would race on its state
+        s->seen.assign((size_t)s->streams, 0);
         for (int i = 0; i < n; ++i) {
-            if (index[i] < 0 || index[i] >= s->streams) {
+            if (index[i] < 0 || index[i] >= s->streams || s->seen[(size_t)index[i]]) {
+                mbx_set_error_text("session: stream index out of range or listed twice");
                 return MBE_STATUS_INVALID_ARGUMENT;
             }
+            s->seen[(size_t)index[i]] = 1;
         }
     }
     DeviceGuard guard(s->device);
@@ -179,6 +186,25 @@ int submit(mbx_session* s, int n, int T, const int32_t* index, const uint8_t* fr
     if (rc < 0) {
         return rc;
     }
+    // From here on work is queued on the three streams against this slot's buffers.  If anything fails halfway the slot is
+    // NOT marked busy, so before the error goes back the streams are drained: the next submit may reuse the slot at once.
+    rc = enqueue(s, sl, n, T, index, frames, pcm16, pcmf, results, records);
+    if (rc < 0) {
+        (void)hipStreamSynchronize(s->s_in);
+        (void)hipStreamSynchronize(s->s_comp);
+        (void)hipStreamSynchronize(s->s_out);
+        (void)hipGetLastError();
+        sl.nout = 0;
+        return rc;
+    }
+    sl.busy = true;
+    ++s->submitted;
+    return 0;
+}
+
+int enqueue(mbx_session* s, Slot& sl, int n, int T, const int32_t* index, const uint8_t* frames, int16_t* pcm16, float* pcmf,
+            mbe_process_result* results, mbx_param_record* records) {
+    int rc = 0;
     const size_t nf = (size_t)n * (size_t)T;
     // ---- in ----
     const uint8_t* src = frames;
@@ -241,8 +267,6 @@ int submit(mbx_session* s, int n, int T, const int32_t* index, const uint8_t* fr
         return rc;
     }
     S_TRY(hipEventRecord(sl.done, s->s_out));
-    sl.busy = true;
-    ++s->submitted;
     return 0;
 }
 
@@ -409,6 +433,7 @@ int mbx_session_set_state(mbx_session* s, int first, int count, const mbe_parms*
         return rc;
     }
     DeviceGuard guard(s->device);
+    S_TRY(hipStreamSynchronize(s->s_comp));   // (a submit that failed halfway leaves no busy slot to wait on)
     if (state) {
         S_TRY(hipMemcpy(s->d_state + 3 * (size_t)first, state, (size_t)count * 3 * sizeof(mbe_parms), hipMemcpyHostToDevice));
     }

@@ -856,3 +856,48 @@ def test_queue_mode_other_codecs_equal_synchronous_calls(mbe):
         assert all(r == 0 for r in ch["rets"])
         assert ch["pcm"].tobytes() == pcm.tobytes() and ch["res"].tobytes() == res.tobytes() and np.array_equal(ch["bits"], bits)
         assert np.concatenate([ch["cur"], ch["prev"], ch["enh"]]).tobytes() == st.tobytes()
+
+
+def test_queue_mode_resident_channel_reset_and_copied_by_direct_calls(mbe):
+    """A host that resets a resident channel with mbe_initMbeParms, or copies one of its structs with mbe_moveMbeParms,
+    works on the CURRENT state: the channel is flushed and released first (before round 3 the reset was silently overwritten
+    by the device state at mbe_batchEnd, and the copy returned the stale host struct)."""
+    S, T, fx = golden_io.stream(0)
+    fn = mbe.mbe_processImbe7200x4400Framef
+
+    def frame(s, t):
+        return fx["frames"][s, t]["cells"].copy(), np.zeros(88, dtype=np.int8)
+
+    # reference behaviour by synchronous calls: three frames, reset, three frames again
+    cur, prev, enh = new_state(mbe)
+    mbe.mbe_setThreadRngSeed(77)
+    want = np.zeros((6, 160), dtype=np.float32)
+    snap = None
+    for t in range(6):
+        if t == 3:
+            snap = np.concatenate([cur, prev, enh]).copy()
+            mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))
+            mbe.mbe_setThreadRngSeed(78)
+        cells, d = frame(0, t)
+        fn(p(want[t]), None, p(cells), p(d), p(cur), p(prev), p(enh))
+    want_state = np.concatenate([cur, prev, enh]).copy()
+
+    cur, prev, enh = new_state(mbe)
+    copy_of_prev = new_state(mbe)[0]
+    got = np.zeros((6, 160), dtype=np.float32)
+    keep = []
+    mbe.mbe_setThreadRngSeed(77)
+    assert mbe.mbe_batchBegin(1) == 0   # resident: the state stays on the device between flushes
+    for t in range(6):
+        if t == 3:
+            mbe.mbe_moveMbeParms(p(prev), p(copy_of_prev))          # reads a struct of a resident channel
+            assert copy_of_prev.tobytes() == snap[1:2].tobytes()
+            mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))           # resets it
+            mbe.mbe_setThreadRngSeed(78)                            # (a channel copies the thread's RNG state at its first queued frame)
+        cells, d = frame(0, t)
+        keep.append((cells, d))
+        assert fn(p(got[t]), None, p(cells), p(d), p(cur), p(prev), p(enh)) == 0
+        assert mbe.mbe_flush() >= 0
+    assert mbe.mbe_batchEnd() >= 0
+    assert got.tobytes() == want.tobytes()
+    assert np.concatenate([cur, prev, enh]).tobytes() == want_state.tobytes()
