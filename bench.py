@@ -690,6 +690,8 @@ def main():
                             "(int16 PCM), state resident on the device; end to end from host memory to host memory",
                     "with_results_frames_per_s": hp["session_pinned_with_results_frames_per_s"],
                     "pageable_buffers_frames_per_s": hp["session_pageable_frames_per_s"],
+                    "frames_per_s_by_host_threads": dict(zip(map(str, hp.get("threads", [])), hp.get("session_pinned_frames_per_s_by_threads", []))),
+                    "devices": hp.get("devices"), "all_devices_frames_per_s": hp.get("session_all_devices_frames_per_s"),
                     "per_frame_api": {
                         "sync_call_us": hp["sync_call_us"],
                         "reference_call_us": (1e6 / one_core[0]["value"]) if one_core else None,
@@ -697,6 +699,7 @@ def main():
                         "queue_mode_writeback_frames_per_s": hp["queue_writeback_frames_per_s"],
                         "queue_mode_host_ns_per_call": hp["queue_resident_call_ns"],
                         "queue_channels": hp["queue_channels"],
+                        "queue_mode_resident_frames_per_s_by_host_threads": dict(zip(map(str, hp.get("threads", [])), hp.get("queue_resident_frames_per_s_by_threads", []))),
                         "what": "mbe_processImbe7200x4400Frame through libmbe_neo_amd.so from one host thread: synchronous "
                                 "(S=T=1 round trip per call) and in queue mode (mbe_batchBegin / mbe_flush, one frame per channel and flush)",
                     },

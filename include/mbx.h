@@ -85,6 +85,29 @@ int mbx_reserve_stream(void* stream, size_t max_frames);
 int mbx_release_stream(void* stream);
 size_t mbx_workspace_bytes(size_t max_frames);
 
+/* ---- multi-GPU start-up: the ONE collective of the path --------------------------------- */
+
+/* Streams shard across the GPUs of a node with no data-path collective (frames of a stream stay on one wavefront); what
+ * the ranks share is the constant-table blob.  SURVEY.md §8(e) / north_star: "RCCL broadcast of the shared codebook
+ * tables over xGMI only".  The reference has no counterpart (single-process CPU library; ref include/mbelib-neo/mbelib.h
+ * has no communication API).  RCCL is bound at run time (librccl.so.1): a host that never calls these needs none.
+ *
+ *   mbx_init_broadcast(comm, root, device, blob, bytes, minmax, stream)
+ *       comm = an ncclComm_t of the caller's (RCCL / NCCL API) or one made by mbx_comm_init() below; every rank calls it.
+ *       Rank `root` passes the blob (mbx_tables.bin, sizeof(mbx_tables) bytes); every other rank passes a buffer of the
+ *       same size that RECEIVES it.  One ncclBroadcast moves the bytes GPU to GPU, every rank then runs
+ *       mbx_init(device, blob, bytes) on its copy, and an ncclAllReduce (min, max) of the per-rank mbx_table_checksum()
+ *       must coincide -- MBX_EBADTABLE otherwise.  minmax (may be NULL) receives {min, max}.
+ *   mbx_comm_unique_id(id)  rank 0 makes the 128-byte id and hands it to the other ranks by whatever channel the host has
+ *   mbx_comm_init(&comm, nranks, id, rank, device) / mbx_comm_destroy(comm)
+ *       ncclCommInitRank / ncclCommDestroy for hosts that do not want the RCCL headers; one rank per GPU. */
+#define MBX_COMM_ID_BYTES 128
+int mbx_comm_unique_id(void* id128);
+int mbx_comm_init(void** comm, int nranks, const void* id128, int rank, int device);
+int mbx_comm_destroy(void* comm);
+int mbx_init_broadcast(void* comm, int root, int device, void* table_blob, size_t table_bytes, uint32_t* checksums_min_max,
+                       void* stream);
+
 /* ---- host-side frame packing (no device work) ----------------------------------------- */
 
 /* imbe_fr[8][23] / ambe_fr[4][24] arrays of 0/1 chars -> 18 / 9 byte wire frames.

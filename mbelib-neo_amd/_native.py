@@ -33,6 +33,10 @@ _SIGNATURES = {
     "mbx_set_stream_order": (C.c_int, [C.c_int]),
     "mbx_table_checksum": (C.c_uint32, []),
     "mbx_last_error": (C.c_char_p, []),
+    "mbx_comm_unique_id": (C.c_int, [_vp]),
+    "mbx_comm_init": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
+    "mbx_comm_destroy": (C.c_int, [_vp]),
+    "mbx_init_broadcast": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
     "mbx_pack_imbe7200x4400": (C.c_int, [_vp, _sz, _vp]),
     "mbx_pack_ambe3600x2450": (C.c_int, [_vp, _sz, _vp]),
     "mbx_pack_cells": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp]),

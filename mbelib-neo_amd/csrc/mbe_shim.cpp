@@ -87,6 +87,7 @@ struct Slot {
     uint32_t*         words = nullptr;    // 4: in, out, errs
     uint32_t*         done = nullptr;     // completion word of the single-frame kernel (mbx_process_frame), polled by the host
     uint32_t          token = 0;
+    hipEvent_t        batch_done = nullptr;
     uint8_t*          frame_out = nullptr; // 18 bytes: a frame after one of the in-place sub-stages
     mbe_soft_bit*     soft = nullptr;     // one soft frame (184 cells)
     struct Pending {
@@ -173,6 +174,20 @@ struct Slot {
 #endif
         }
     }
+    // the end of a queued batch (mbe_flush): the thread SLEEPS until the stream is done instead of spinning -- a flush takes
+    // a millisecond, a wake-up tens of microseconds, and a host with one decoder thread per core must not have all of
+    // them burning their cores (and the container's CPU quota) in wait loops
+    void sync_blocking() {
+        if (!batch_done) {
+            HIP_OK(hipEventCreateWithFlags(&batch_done, hipEventDisableTiming | hipEventBlockingSync));
+        }
+        HIP_OK(hipEventRecord(batch_done, stream));
+        HIP_OK(hipEventSynchronize(batch_done));
+        for (int i = 0; i < npending; ++i) {
+            memcpy(pending[i].dst, pending[i].src, pending[i].n);
+        }
+        npending = 0;
+    }
     void sync() {
         HIP_OK(hipStreamSynchronize(stream));
         for (int i = 0; i < npending; ++i) {
@@ -190,6 +205,9 @@ struct SlotHolder {
         if (p) {
             (void)hipStreamSynchronize(p->stream);
             (void)mbx_release_stream(p->stream);
+            if (p->batch_done) {
+                (void)hipEventDestroy(p->batch_done);
+            }
             (void)hipStreamDestroy(p->stream);
             (void)hipHostFree(p->block);
             (void)hipGetLastError();
@@ -751,7 +769,11 @@ int flush_batch(Batch& b) {
     }
     s.down(b.h_results.p, b.d_results.p, rows * sizeof(mbe_process_result));
     s.down(b.h_records.p, b.d_records.p, rows * sizeof(mbx_param_record));
-    s.sync();
+    if (rows >= 256) {
+        s.sync_blocking();
+    } else {
+        s.sync();
+    }
     // ---- hand the outputs to the callers' buffers ----
     for (size_t e = 0; e < n; ++e) {
         const QEntry& qe = b.q[e];

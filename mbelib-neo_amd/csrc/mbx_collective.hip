@@ -1,0 +1,203 @@
+// mbx_collective.hip -- the one collective of the path: RCCL broadcast of the constant-table blob at start-up, for hosts
+// that are not Python (north_star: "RCCL broadcast of the shared codebook tables over xGMI only").
+// bench.py does the same through torch.distributed (mbelib-neo_amd/parallel.py); a C host gets it from here.
+//
+// Frames are embarrassingly parallel, streams shard across ranks with no data-path collective, so this is ALL the
+// communication there is: rank `root` holds the blob (71,908 bytes), one ncclBroadcast hands it to every rank's GPU over
+// xGMI, every rank uploads its copy with mbx_init() and an ncclAllReduce (min, max) of the per-rank table checksums
+// proves that all ranks decode with the same tables.  The reference has no counterpart (single-process CPU library).
+//
+// RCCL is bound at RUN TIME (dlopen "librccl.so.1"): libmbx_hip.so carries no link-time dependency on it, so a
+// single-GPU host that never calls these entry points needs no RCCL at all, and inside a process that already has one
+// loaded (PyTorch) the same instance is used.  Host code only.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and enumerators only
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "mbx.h"
+
+void mbx_set_error_text(const char* text);   // mbx_api.hip
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+int cfail(int code, const char* what, const char* detail = nullptr) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "collective: %s%s%s", what, detail ? ": " : "", detail ? detail : "");
+    mbx_set_error_text(buf);
+    return code;
+}
+
+const Rccl* rccl() {   // nullptr (with the error text set) when RCCL cannot be loaded
+    static Rccl r;
+    static std::once_flag once;
+    static bool ok = false;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) {
+                break;
+            }
+        }
+        if (!r.handle) {
+            return;
+        }
+        auto sym = [&](const char* n) { return dlsym(r.handle, n); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.CommCount && r.CommUserRank && r.Broadcast && r.AllReduce
+             && r.GetErrorString;
+    });
+    if (!ok) {
+        (void)cfail(MBX_ENODEVICE, "RCCL (librccl.so.1) could not be loaded", dlerror());
+        return nullptr;
+    }
+    return &r;
+}
+
+#define N_TRY(R, expr)                                                   \
+    do {                                                                 \
+        ncclResult_t n_ = (expr);                                        \
+        if (n_ != ncclSuccess) {                                         \
+            return cfail(MBX_ENODEVICE, #expr, (R)->GetErrorString(n_)); \
+        }                                                                \
+    } while (0)
+#define H_TRY(expr)                                                      \
+    do {                                                                 \
+        hipError_t e_ = (expr);                                          \
+        if (e_ != hipSuccess) {                                          \
+            return cfail(MBX_ENODEVICE, #expr, hipGetErrorString(e_));   \
+        }                                                                \
+    } while (0)
+
+struct DevBytes {
+    void* p = nullptr;
+    ~DevBytes() {
+        if (p) {
+            (void)hipFree(p);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mbx_comm_unique_id(void* id128) {
+    const Rccl* R = rccl();
+    if (!R) {
+        return MBX_ENODEVICE;
+    }
+    if (!id128) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    ncclUniqueId id;
+    N_TRY(R, R->GetUniqueId(&id));
+    static_assert(sizeof(id) == MBX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int mbx_comm_init(void** comm, int nranks, const void* id128, int rank, int device) {
+    const Rccl* R = rccl();
+    if (!R) {
+        return MBX_ENODEVICE;
+    }
+    if (!comm || !id128 || nranks < 1 || rank < 0 || rank >= nranks) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    H_TRY(hipSetDevice(device));   // the communicator binds to the calling thread's current device
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    N_TRY(R, R->CommInitRank(&c, nranks, id, rank));
+    *comm = c;
+    return 0;
+}
+
+int mbx_comm_destroy(void* comm) {
+    const Rccl* R = rccl();
+    if (!R) {
+        return MBX_ENODEVICE;
+    }
+    if (comm) {
+        N_TRY(R, R->CommDestroy(static_cast<ncclComm_t>(comm)));
+    }
+    return 0;
+}
+
+int mbx_init_broadcast(void* comm, int root, int device, void* table_blob, size_t table_bytes, uint32_t* checksums_min_max, void* stream) {
+    const Rccl* R = rccl();
+    if (!R) {
+        return MBX_ENODEVICE;
+    }
+    if (!comm || !table_blob || table_bytes != sizeof(mbx_tables)) {
+        return cfail(MBE_STATUS_INVALID_ARGUMENT, "mbx_init_broadcast: communicator, a blob buffer of sizeof(mbx_tables) bytes on every rank");
+    }
+    ncclComm_t c = static_cast<ncclComm_t>(comm);
+    int nranks = 0, rank = -1;
+    N_TRY(R, R->CommCount(c, &nranks));
+    N_TRY(R, R->CommUserRank(c, &rank));
+    if (root < 0 || root >= nranks) {
+        return cfail(MBE_STATUS_INVALID_ARGUMENT, "mbx_init_broadcast: root is not a rank of the communicator");
+    }
+    H_TRY(hipSetDevice(device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DevBytes blob, sums;
+    H_TRY(hipMalloc(&blob.p, table_bytes));
+    H_TRY(hipMalloc(&sums.p, 4 * sizeof(uint32_t)));
+    if (rank == root) {
+        H_TRY(hipMemcpyAsync(blob.p, table_blob, table_bytes, hipMemcpyHostToDevice, st));
+    }
+    // the one collective of the path: 71,908 bytes, root's GPU -> every GPU
+    N_TRY(R, R->Broadcast(blob.p, blob.p, table_bytes, ncclUint8, root, c, st));
+    if (rank != root) {
+        H_TRY(hipMemcpyAsync(table_blob, blob.p, table_bytes, hipMemcpyDeviceToHost, st));
+    }
+    H_TRY(hipStreamSynchronize(st));
+    int rc = mbx_init(device, table_blob, table_bytes);   // validates magic / version / checksum of what arrived
+    if (rc < 0) {
+        return rc;
+    }
+    // every rank decodes with the same tables: min and max of the per-rank checksums must coincide
+    const uint32_t mine = mbx_table_checksum();
+    const uint32_t in[2] = {mine, mine};
+    uint32_t out[2] = {0u, 0u};
+    uint32_t* d = static_cast<uint32_t*>(sums.p);
+    H_TRY(hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, st));
+    N_TRY(R, R->AllReduce(d, d + 2, 1, ncclUint32, ncclMin, c, st));
+    N_TRY(R, R->AllReduce(d + 1, d + 3, 1, ncclUint32, ncclMax, c, st));
+    H_TRY(hipMemcpyAsync(out, d + 2, sizeof(out), hipMemcpyDeviceToHost, st));
+    H_TRY(hipStreamSynchronize(st));
+    if (checksums_min_max) {
+        checksums_min_max[0] = out[0];
+        checksums_min_max[1] = out[1];
+    }
+    if (out[0] != out[1] || out[0] != mine) {
+        return cfail(MBX_EBADTABLE, "mbx_init_broadcast: the table checksums differ between ranks");
+    }
+    return 0;
+}
+
+}  // extern "C"

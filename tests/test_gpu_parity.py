@@ -1105,3 +1105,51 @@ def test_ambe_tone_and_erasure_classes_in_lds_resident_launches(mbx, oracle):
         pcm[:, t] = np.asarray(out["pcm16"]).reshape(S, 160)
     assert np.array_equal(pcm.reshape(-1, 160), np.asarray(got["pcm16"]).reshape(-1, 160))
     assert np.array_equal(np.asarray(state).view(np.uint8), np.asarray(got["state"]).view(np.uint8))
+
+
+# ---- multi-GPU readiness -----------------------------------------------------------------------------
+def test_c_abi_rccl_table_broadcast_one_rank(mbx):
+    """The C library's own collective (mbx_comm_* / mbx_init_broadcast: ncclBroadcast of the table blob + min/max all-reduce
+    of the per-rank checksums), with the one rank a one-GPU box has: communicator from a unique id, broadcast, upload,
+    checksum agreement.  RCCL is bound at run time; libmbx_hip.so must not carry a link-time dependency on it."""
+    import ctypes as C
+    import subprocess
+
+    from mbelib_neo_amd import _native
+
+    L = _native.lib()
+    needed = subprocess.run(["objdump", "-p", _native.library_path()], capture_output=True, text=True).stdout
+    assert "librccl" not in needed
+    blob = mbx.load_tables_blob()
+    ident = C.create_string_buffer(128)
+    _native.check(L.mbx_comm_unique_id(ident), "mbx_comm_unique_id")
+    comm = C.c_void_p()
+    _native.check(L.mbx_comm_init(C.byref(comm), 1, ident, 0, 0), "mbx_comm_init")
+    buf = C.create_string_buffer(bytes(blob), len(blob))
+    minmax = (C.c_uint32 * 2)()
+    _native.check(L.mbx_init_broadcast(comm, 0, 0, buf, len(blob), minmax, None), "mbx_init_broadcast")
+    assert minmax[0] == minmax[1] == L.mbx_table_checksum() != 0
+    assert L.mbx_init_broadcast(comm, 1, 0, buf, len(blob), minmax, None) < 0      # root outside the communicator
+    assert L.mbx_init_broadcast(comm, 0, 0, buf, len(blob) - 4, minmax, None) < 0  # not a table blob
+    _native.check(L.mbx_comm_destroy(comm), "mbx_comm_destroy")
+
+
+def test_every_visible_device_decodes(mbx, oracle):
+    """One context per device: every device torch can see (one on the test box, eight on a node) is initialised and decodes
+    a small batch against the oracle -- device index > 0 is exercised the moment a box has it."""
+    import torch
+
+    from mbelib_neo_amd import decoder, framegen
+
+    S, T = 64, 4
+    frames = framegen.random_frames(0, S * T, framegen.rng_for(8080))
+    seeds = np.arange(S) + 5
+    ref = oracle.process_batch(0, S, T, frames, oracle.init_state(S), oracle.rng_seeded(seeds))
+    for dev in range(torch.cuda.device_count()):
+        dec = decoder.BatchDecoder(0, S, device=dev, seeds=seeds)
+        out = dec.decode(frames, T, want_float=True)
+        torch.cuda.synchronize(dev)
+        parity.check_results(ref["results"], decoder.results_numpy(out["results"]))
+        parity.check_pcm(ref["pcmf"], out["pcmf"].cpu().numpy(), ref["pcm16"], out["pcm16"].cpu().numpy())
+        parity.check_state(ref["state"], dec.state_numpy())
+    torch.cuda.set_device(0)
