@@ -88,6 +88,7 @@ struct Slot {
     uint32_t*         done = nullptr;     // completion word of the single-frame kernel (mbx_process_frame), polled by the host
     uint32_t          token = 0;
     hipEvent_t        batch_done = nullptr;
+    hipEvent_t        chunk_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // mbe_flush: small outputs, then four PCM chunks
     uint8_t*          frame_out = nullptr; // 18 bytes: a frame after one of the in-place sub-stages
     mbe_soft_bit*     soft = nullptr;     // one soft frame (184 cells)
     struct Pending {
@@ -207,6 +208,11 @@ struct SlotHolder {
             (void)mbx_release_stream(p->stream);
             if (p->batch_done) {
                 (void)hipEventDestroy(p->batch_done);
+            }
+            for (hipEvent_t e : p->chunk_done) {
+                if (e) {
+                    (void)hipEventDestroy(e);
+                }
             }
             (void)hipStreamDestroy(p->stream);
             (void)hipHostFree(p->block);
@@ -636,6 +642,32 @@ void pool_download(Batch& b, Slot& s, size_t first, const std::vector<int>& owne
     }
 }
 
+// parameter record -> the reference's imbe_d[88] / ambe_d[49] chars, eight cells per table look-up (the bit order of
+// mbx_unpack_records: bit i of the record is bit 31 - (i & 31) of word i >> 5)
+void unpack_bits_fast(const mbx_param_record& r, int nbits, char* out) {
+    static const struct Lut {
+        uint64_t v[256];
+        Lut() {
+            for (int b = 0; b < 256; ++b) {
+                uint64_t x = 0;
+                for (int k = 0; k < 8; ++k) {
+                    x |= (uint64_t)((b >> (7 - k)) & 1) << (8 * k);   // little-endian: cell k of the byte is byte k of x
+                }
+                v[b] = x;
+            }
+        }
+    } lut;
+    int i = 0;
+    for (; i + 8 <= nbits; i += 8) {
+        const int j = i >> 3;
+        const uint64_t x = lut.v[(r.w[j >> 2] >> (24 - 8 * (j & 3))) & 0xffu];
+        memcpy(out + i, &x, 8);
+    }
+    for (; i < nbits; ++i) {
+        out[i] = (char)((r.w[i >> 5] >> (31 - (i & 31))) & 1u);
+    }
+}
+
 int flush_batch(Batch& b) {
     const size_t n = b.q.size();
     if (n == 0) {
@@ -761,34 +793,62 @@ int flush_batch(Batch& b) {
                                        b.d_records.p + g.row0, s.stream),
              "mbx_process_batch_indexed");
     }
-    if (any_short) {
-        s.down(b.h_pcm16.p, b.d_pcm16.p, rows * 160 * sizeof(int16_t));
+    // ---- outputs: the small arrays first, then the PCM in chunks -- the host hands chunk k to the callers' buffers while
+    //      chunk k + 1 is still crossing PCIe (the scatter is as long as the copy: 5 MB per 16,384 frames each) ----
+    constexpr int kChunks = 4;
+    if (!s.chunk_done[0]) {
+        HIP_OK(hipEventCreateWithFlags(&s.chunk_done[0], hipEventDisableTiming | hipEventBlockingSync));   // the long wait sleeps
+        for (int k = 1; k <= kChunks; ++k) {
+            HIP_OK(hipEventCreateWithFlags(&s.chunk_done[k], hipEventDisableTiming));
+        }
     }
-    if (any_float) {
-        s.down(b.h_pcmf.p, b.d_pcmf.p, rows * 160 * sizeof(float));
+    HIP_OK(hipMemcpyAsync(b.h_results.p, b.d_results.p, rows * sizeof(mbe_process_result), hipMemcpyDeviceToHost, s.stream));
+    HIP_OK(hipMemcpyAsync(b.h_records.p, b.d_records.p, rows * sizeof(mbx_param_record), hipMemcpyDeviceToHost, s.stream));
+    HIP_OK(hipEventRecord(s.chunk_done[0], s.stream));
+    const size_t per_chunk = (rows + kChunks - 1) / kChunks;
+    for (int k = 0; k < kChunks; ++k) {
+        const size_t r0 = (size_t)k * per_chunk, r1 = r0 + per_chunk < rows ? r0 + per_chunk : rows;
+        if (r0 < r1) {
+            if (any_short) {
+                HIP_OK(hipMemcpyAsync(b.h_pcm16.p + r0 * 160, b.d_pcm16.p + r0 * 160, (r1 - r0) * 160 * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
+            }
+            if (any_float) {
+                HIP_OK(hipMemcpyAsync(b.h_pcmf.p + r0 * 160, b.d_pcmf.p + r0 * 160, (r1 - r0) * 160 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+            }
+        }
+        HIP_OK(hipEventRecord(s.chunk_done[k + 1], s.stream));
     }
-    s.down(b.h_results.p, b.d_results.p, rows * sizeof(mbe_process_result));
-    s.down(b.h_records.p, b.d_records.p, rows * sizeof(mbx_param_record));
-    if (rows >= 256) {
-        s.sync_blocking();
-    } else {
-        s.sync();
-    }
-    // ---- hand the outputs to the callers' buffers ----
+    std::vector<uint32_t> by_row(rows);
     for (size_t e = 0; e < n; ++e) {
+        by_row[row_of[e]] = (uint32_t)e;
+    }
+    if (rows < 256) {
+        HIP_OK(hipStreamSynchronize(s.stream));   // a small flush: spin, the sleeping wait's wake-up would be most of it
+    } else {
+        HIP_OK(hipEventSynchronize(s.chunk_done[0]));
+    }
+    for (size_t e = 0; e < n; ++e) {   // results and parameter bits
         const QEntry& qe = b.q[e];
         const size_t r = row_of[e];
-        if (qe.want_short) {
-            memcpy(qe.aout, b.h_pcm16.p + r * 160, 160 * sizeof(int16_t));
-        } else {
-            memcpy(qe.aout, b.h_pcmf.p + r * 160, 160 * sizeof(float));
-        }
         if (qe.result) {
             *qe.result = b.h_results.p[r];
         }
         const int nbits = (qe.codec == MBX_CODEC_AMBE3600X2450 || qe.codec == MBX_CODEC_AMBE3600X2400) ? 49 : 88;
-        mbx_unpack_records(&b.h_records.p[r], 1, nbits, qe.bits_out, nullptr);
+        unpack_bits_fast(b.h_records.p[r], nbits, qe.bits_out);
     }
+    for (int k = 0; k < kChunks; ++k) {   // PCM, chunk by chunk
+        const size_t r0 = (size_t)k * per_chunk, r1 = r0 + per_chunk < rows ? r0 + per_chunk : rows;
+        HIP_OK(hipEventSynchronize(s.chunk_done[k + 1]));
+        for (size_t r = r0; r < r1; ++r) {
+            const QEntry& qe = b.q[by_row[r]];
+            if (qe.want_short) {
+                memcpy(qe.aout, b.h_pcm16.p + r * 160, 160 * sizeof(int16_t));
+            } else {
+                memcpy(qe.aout, b.h_pcmf.p + r * 160, 160 * sizeof(float));
+            }
+        }
+    }
+    s.npending = 0;
     b.q.clear();
     for (QChannel& ch : b.channels) {
         ch.pending = 0;
