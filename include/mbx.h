@@ -219,6 +219,10 @@ int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_recor
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream);
 
+/* pinned host memory -> device memory by a kernel on `stream` (16-byte aligned buffers): what the sessions use for the wire
+ * frames of a batch instead of a DMA copy, which would queue behind the previous batch's PCM on the copy engine */
+int mbx_stage_in(void* d_dst, const void* pinned_src, size_t bytes, void* stream);
+
 /* ONE frame of ONE stream as one launch of one wavefront (FEC + parameter decode + policy + synthesis + float->int16):
  * what the synchronous mbe_process*Frame[f] of libmbe_neo_amd.so issue.
  *   ref: mbe_processImbe7200x4400Frame[f]  include/mbelib-neo/mbelib.h:429-441, mbe_processAmbe3600x2450Frame[f] :505-517,

@@ -21,6 +21,7 @@ __global__ void fec_imbe7200x4400_kernel(const uint8_t*, size_t, mbx_param_recor
 __global__ void fec_ambe3600x2450_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
 __global__ void fec_imbe7100x4400_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
 __global__ void floattoshort_kernel(const float*, int16_t*, size_t);
+__global__ void stage_in_kernel(const uint8_t*, uint8_t*, size_t);
 __global__ void expand_imbe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void expand_ambe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void expand_ambe2400_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
@@ -955,6 +956,22 @@ int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parm
         return rc;
     }
     return mbx_process_records(stream_codec, S, T, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream);
+}
+
+int mbx_stage_in(void* d_dst, const void* pinned_src, size_t bytes, void* stream) {
+    if (!d_dst || !pinned_src) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (bytes == 0) {
+        return 0;
+    }
+    if ((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(pinned_src)) & 15u) {
+        return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_stage_in: both buffers must be 16-byte aligned");
+    }
+    const size_t threads = (bytes >> 4) + 1;
+    hipLaunchKernelGGL(mbx::stage_in_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const uint8_t*>(pinned_src), static_cast<uint8_t*>(d_dst), bytes);
+    return check_launch("stage_in_kernel");
 }
 
 int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,

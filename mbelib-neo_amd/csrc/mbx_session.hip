@@ -4,11 +4,14 @@
 // What crosses PCIe per 20 ms frame is the wire frame in (18 B / 9 B) and the PCM out (320 B int16, + 20 B when the
 // mbe_process_result is asked for) -- not the 15.6 KB of state the per-call conveniences (mbx_process_batch_host) move.
 //
-// Pipeline: kDepth slots of device buffers, three HIP streams.  Batch k uses slot k % kDepth:
-//     copy-in stream   H2D frames(k)                      -> event in(k)
-//     compute stream   wait in(k);  FEC + stream kernels  -> event comp(k)      (batches run in submission order: the
-//     copy-out stream  wait comp(k); D2H PCM / results    -> event done(k)       state of batch k+1 depends on batch k)
-// so H2D(k+1), kernels(k) and D2H(k-1) overlap.  The host blocks only when it is kDepth batches ahead of the device.
+// Pipeline: kDepth slots of device buffers, two HIP streams.  Batch k uses slot k % kDepth:
+//     compute stream   stage-in kernel (frames(k) read from pinned host memory), FEC + stream kernels -> event comp(k)
+//     copy-out stream  wait comp(k); D2H PCM / results (DMA)                                          -> event done(k)
+// Batches run in submission order (the state of batch k+1 depends on batch k); kernels(k+1) overlap D2H(k).  The frames
+// are NOT brought in by a DMA copy: on this stack a host-to-device copy of batch k+1 queues behind the device-to-host copy
+// of batch k on the copy engine, which put the next batch's kernels behind that transfer (65,536 frames: 0.257 ms of
+// kernels + 0.379 ms of PCM back to back = 103 M frames/s; overlapped the PCM transfer alone bounds the rate).
+// The host blocks only when it is kDepth batches ahead of the device.
 // Host buffers that are pinned (mbx_host_alloc / hipHostMalloc / hipHostRegister) are DMA targets as they are; pageable
 // buffers are staged through pinned memory owned by the slot (one extra host memcpy each way).
 //
@@ -74,7 +77,7 @@ struct Slot {
     float*              h_pcmf = nullptr;
     mbe_process_result* h_results = nullptr;
     mbx_param_record*   h_records = nullptr;
-    hipEvent_t          in = nullptr, comp = nullptr, done = nullptr;
+    hipEvent_t          comp = nullptr, done = nullptr;
     bool                busy = false;
     CopyOut             out[4];
     int                 nout = 0;
@@ -91,7 +94,7 @@ struct mbx_session {
     size_t   frame_bytes = 0;
     mbe_parms*      d_state = nullptr;   // [streams][3]
     mbx_stream_rng* d_rng = nullptr;     // [streams]
-    hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+    hipStream_t s_comp = nullptr, s_out = nullptr;
     Slot     slot[kDepth];
     unsigned long long submitted = 0;
     std::vector<uint8_t> seen;   // submit_indexed: one mark per stream, to refuse an index that names a stream twice
@@ -190,7 +193,6 @@ int submit(mbx_session* s, int n, int T, const int32_t* index, const uint8_t* fr
     // NOT marked busy, so before the error goes back the streams are drained: the next submit may reuse the slot at once.
     rc = enqueue(s, sl, n, T, index, frames, pcm16, pcmf, results, records);
     if (rc < 0) {
-        (void)hipStreamSynchronize(s->s_in);
         (void)hipStreamSynchronize(s->s_comp);
         (void)hipStreamSynchronize(s->s_out);
         (void)hipGetLastError();
@@ -216,18 +218,32 @@ int enqueue(mbx_session* s, Slot& sl, int n, int T, const int32_t* index, const 
         memcpy(sl.h_in, frames, nf * s->frame_bytes);
         src = sl.h_in;
     }
-    S_TRY(hipMemcpyAsync(sl.d_frames, src, nf * s->frame_bytes, hipMemcpyHostToDevice, s->s_in));
+    // The frames (and the stream index) are fetched by a kernel on the COMPUTE stream, not by a DMA copy: see stage_in_kernel
+    // (mbx_fec.hip).  A pinned buffer that is not 16-byte aligned goes through the slot's own pinned staging like a pageable one.
+    if (reinterpret_cast<uintptr_t>(src) & 15u) {
+        rc = pinned(sl.h_in, s->max_frames * s->frame_bytes);
+        if (rc < 0) {
+            return rc;
+        }
+        memcpy(sl.h_in, frames, nf * s->frame_bytes);
+        src = sl.h_in;
+    }
+    rc = mbx_stage_in(sl.d_frames, src, nf * s->frame_bytes, s->s_comp);
+    if (rc < 0) {
+        return rc;
+    }
     if (index) {
         rc = pinned(sl.h_index, (size_t)s->streams);   // always staged: 4 B per stream, and the caller may reuse its array at once
         if (rc < 0) {
             return rc;
         }
         memcpy(sl.h_index, index, (size_t)n * sizeof(int32_t));
-        S_TRY(hipMemcpyAsync(sl.d_index, sl.h_index, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s->s_in));
+        rc = mbx_stage_in(sl.d_index, sl.h_index, (size_t)n * sizeof(int32_t), s->s_comp);
+        if (rc < 0) {
+            return rc;
+        }
     }
-    S_TRY(hipEventRecord(sl.in, s->s_in));
     // ---- compute ----
-    S_TRY(hipStreamWaitEvent(s->s_comp, sl.in, 0));
     int16_t* d16 = pcm16 ? sl.d_pcm16 : nullptr;
     float*   dfl = pcmf ? sl.d_pcmf : nullptr;
     mbe_process_result* dres = results ? sl.d_results : nullptr;
@@ -321,7 +337,6 @@ int mbx_session_create(mbx_session** out, int codec, int streams, size_t max_fra
     } while (0)
     C_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_state), (size_t)streams * 3 * sizeof(mbe_parms)));
     C_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_rng), (size_t)streams * sizeof(mbx_stream_rng)));
-    C_TRY(hipStreamCreateWithFlags(&s->s_in, hipStreamNonBlocking));
     C_TRY(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking));
     C_TRY(hipStreamCreateWithFlags(&s->s_out, hipStreamNonBlocking));
     const size_t mf = s->max_frames;
@@ -339,7 +354,6 @@ int mbx_session_create(mbx_session** out, int codec, int streams, size_t max_fra
         if (s->outputs & MBX_SESSION_RESULTS) {
             C_TRY(hipMalloc(reinterpret_cast<void**>(&sl.d_results), mf * sizeof(mbe_process_result)));
         }
-        C_TRY(hipEventCreateWithFlags(&sl.in, hipEventDisableTiming));
         C_TRY(hipEventCreateWithFlags(&sl.comp, hipEventDisableTiming));
         // (a blocking wait -- hipEventBlockingSync -- was measured here and costs more than it saves: the wake-up latency of every
         // submit that has to wait is exposed, 155 -> 113 M frames/s with two session threads, 117 -> 78 M with four)
@@ -360,9 +374,6 @@ int mbx_session_destroy(mbx_session* s) {
         return 0;
     }
     DeviceGuard guard(s->device);
-    if (s->s_in) {
-        (void)hipStreamSynchronize(s->s_in);
-    }
     if (s->s_comp) {
         (void)hipStreamSynchronize(s->s_comp);
         (void)mbx_release_stream(s->s_comp);
@@ -384,9 +395,6 @@ int mbx_session_destroy(mbx_session* s) {
         (void)hipHostFree(sl.h_pcmf);
         (void)hipHostFree(sl.h_results);
         (void)hipHostFree(sl.h_records);
-        if (sl.in) {
-            (void)hipEventDestroy(sl.in);
-        }
         if (sl.comp) {
             (void)hipEventDestroy(sl.comp);
         }
@@ -396,9 +404,6 @@ int mbx_session_destroy(mbx_session* s) {
     }
     (void)hipFree(s->d_state);
     (void)hipFree(s->d_rng);
-    if (s->s_in) {
-        (void)hipStreamDestroy(s->s_in);
-    }
     if (s->s_comp) {
         (void)hipStreamDestroy(s->s_comp);
     }
