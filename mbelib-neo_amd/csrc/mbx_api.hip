@@ -150,7 +150,11 @@ void free_context(Context& c) {   // caller holds g_init_mu and c.mu
     c.device = -1;
 }
 
-constexpr int kLdsResidentMinFrames = 4;
+int lds_min_frames() {   // frames per stream from which the LDS-resident instances are used (MBX_LDS_MIN_FRAMES: A/B timing)
+    static const int v = getenv("MBX_LDS_MIN_FRAMES") ? atoi(getenv("MBX_LDS_MIN_FRAMES")) : 4;
+    return v;
+}
+#define kLdsResidentMinFrames lds_min_frames()
 bool lds_resident_enabled() {
     static const bool on = getenv("MBX_NO_LDS_RESIDENT") == nullptr;   // development switch for A/B timing; read once
     return on;
