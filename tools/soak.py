@@ -88,6 +88,16 @@ def main():
                 print(f"round {r} codec {codec} {kind:6s}: {S*T} frames ok  rel_rms {m['rel_rms']:.2e} worst {m['worst_frame']:.2e} "
                       f"int16_max {m['int16_max']}  ({time.perf_counter()-t0:.1f} s)", flush=True)
     print("worst over all rounds:", worst)
+    import hashlib
+    import json
+
+    from mbelib_neo_amd import _native
+    summary = {"first_round": first, "rounds": rounds, "cases": rounds * 16,
+               "frames": rounds * 4 * (2 * 2048 * 8 + 256 * 4 + 1024 * 12),
+               "libmbx_hip_sha256_16": hashlib.sha256(open(_native.library_path(), "rb").read()).hexdigest()[:16],
+               "worst": {f"codec{c}_{k}": v for (c, k), v in worst.items()}}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(summary, open(os.path.join(ROOT, "gpurun_out", f"soak_r03_{first}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
