@@ -2047,8 +2047,24 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 }
                 fp = xrows[t & (kXRows - 1)];
             }
+        }
+        // The parts of prev_mp_enhanced that synthesis reads are requested together with prev_mp, so that one
+        // memory latency covers both (as in the IMBE kernel) -- and, in the HBM-slot instances, together with the frame's
+        // FrameParams row: the row is requested FIRST, the two views right behind it, and the row then goes through LDS, so the
+        // first wave-uniform read of it (the error word) waits for one load, not for a round trip before the views are even
+        // requested.
+        Parms enh;
+        Parms prev;
+        if constexpr (kPark) {
+            enh = enh_keep;
+            load_prev_view(prev, slot_prev, lane);
         } else {
-            fp = params[f].v;
+            const float row = params[f].v[lane];
+            load_enh_view(enh, slot_enh, lane);
+            load_prev_view(prev, slot_prev, lane);
+            scratch.x.fp[lane] = row;
+            wave_lds_sync();
+            fp = scratch.x.fp;
         }
         const uint32_t errw = uni(__float_as_uint(fp[62]));
         const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu);
@@ -2056,17 +2072,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         const int total = c0 + prot;
         int bad;
         bool prev_max_repeat, valid_tone = false;
-        // The parts of prev_mp_enhanced that synthesis reads are requested together with prev_mp, so that one
-        // memory latency covers both (as in the IMBE kernel).
-        Parms enh;
-        if constexpr (kPark) {
-            enh = enh_keep;
-        } else {
-            load_enh_view(enh, slot_enh, lane);
-        }
         {
-            Parms prev;
-            load_prev_view(prev, slot_prev, lane);
             // prepare (ambe2450_prepare_process): state that came from the generic initialiser is
             // replaced by the AMBE defaults in all three structs
             if (fabsf(prev.mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f) {
