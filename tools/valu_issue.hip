@@ -34,12 +34,13 @@ constexpr int kBody = 64;     // instructions per trip (8 accumulators x 8)
     op " %0, %0" tail "\n" op " %1, %1" tail "\n" op " %2, %2" tail "\n" op " %3, %3" tail "\n" op " %4, %4" tail "\n" \
        op " %5, %5" tail "\n" op " %6, %6" tail "\n" op " %7, %7" tail "\n"
 
-enum Op { kFma, kPkFma, kPkMul, kCos, kFma64, kAddDpp, kMulLoU32, kMov, kReadlane, kDsReadB128, kBankLoop, kNumOps };
+enum Op { kFma, kPkFma, kPkMul, kCos, kFma64, kAddDpp, kMulLoU32, kMov, kReadlane, kDsReadB128, kBankLoop, kAddE32, kMulE32, kFmacE32, kCndmaskE32, kNumOps };
 static const char* kNames[kNumOps] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cos_f32", "v_fma_f64", "v_add_f32 dpp",
                                       "v_mul_lo_u32", "v_mov_b32", "v_readlane_b32", "ds_read_b128 (broadcast)",
-                                      "bank loop body (8 pk + 2 ds_read_b128)"};
+                                      "bank loop body (8 pk + 2 ds_read_b128)", "v_add_f32_e32 (VOP2, 4 B)", "v_mul_f32_e32 (VOP2, 4 B)",
+                                      "v_fmac_f32_e32 (VOP2, 4 B)", "v_cndmask_b32_e32 (VOP2, 4 B)"};
 // instructions of the measured class per loop trip
-static const int kPerTrip[kNumOps] = {kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, 8 * 8};
+static const int kPerTrip[kNumOps] = {kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, 8 * 8, kBody, kBody, kBody, kBody};
 
 template <int kOp>
 __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* cycles, float* sink, float seed) {
@@ -92,6 +93,24 @@ __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* cycles,
                             "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n")
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                          : "v"(k));
+        } else if constexpr (kOp == kAddE32) {
+            asm volatile(R8(OPS8("v_add_f32_e32", ", %8"))
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(k));
+        } else if constexpr (kOp == kMulE32) {
+            asm volatile(R8(OPS8("v_mul_f32_e32", ", %8"))
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(k));
+        } else if constexpr (kOp == kFmacE32) {
+            asm volatile(R8("v_fmac_f32_e32 %0, %8, %8\n v_fmac_f32_e32 %1, %8, %8\n v_fmac_f32_e32 %2, %8, %8\n v_fmac_f32_e32 %3, %8, %8\n"
+                            "v_fmac_f32_e32 %4, %8, %8\n v_fmac_f32_e32 %5, %8, %8\n v_fmac_f32_e32 %6, %8, %8\n v_fmac_f32_e32 %7, %8, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(k));
+        } else if constexpr (kOp == kCndmaskE32) {
+            asm volatile(R8(OPS8("v_cndmask_b32_e32", ", %8, vcc"))
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(k)
+                         : "vcc");
         } else if constexpr (kOp == kReadlane) {
             int s0, s1, s2, s3, s4, s5, s6, s7;
             asm volatile(R8("v_readlane_b32 %0, %8, 1\n v_readlane_b32 %1, %9, 2\n v_readlane_b32 %2, %10, 3\n v_readlane_b32 %3, %11, 4\n"
@@ -189,5 +208,9 @@ int main(int argc, char** argv) {
     run<kReadlane>(cus, d_cycles, d_sink, only_w);
     run<kDsReadB128>(cus, d_cycles, d_sink, only_w);
     run<kBankLoop>(cus, d_cycles, d_sink, only_w);
+    run<kAddE32>(cus, d_cycles, d_sink, only_w);
+    run<kMulE32>(cus, d_cycles, d_sink, only_w);
+    run<kFmacE32>(cus, d_cycles, d_sink, only_w);
+    run<kCndmaskE32>(cus, d_cycles, d_sink, only_w);
     return 0;
 }
