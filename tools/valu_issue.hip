@@ -34,13 +34,15 @@ constexpr int kBody = 64;     // instructions per trip (8 accumulators x 8)
     op " %0, %0" tail "\n" op " %1, %1" tail "\n" op " %2, %2" tail "\n" op " %3, %3" tail "\n" op " %4, %4" tail "\n" \
        op " %5, %5" tail "\n" op " %6, %6" tail "\n" op " %7, %7" tail "\n"
 
-enum Op { kFma, kPkFma, kPkMul, kCos, kFma64, kAddDpp, kMulLoU32, kMov, kReadlane, kDsReadB128, kBankLoop, kAddE32, kMulE32, kFmacE32, kCndmaskE32, kNumOps };
+enum Op { kFma, kPkFma, kPkMul, kCos, kFma64, kAddDpp, kMulLoU32, kMov, kReadlane, kDsReadB128, kBankLoop, kAddE32, kMulE32, kFmacE32, kCndmaskE32, kMulSgpr, kFmaSgpr, kPkFmaSgpr, kCndmaskE64, kNumOps };
 static const char* kNames[kNumOps] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cos_f32", "v_fma_f64", "v_add_f32 dpp",
                                       "v_mul_lo_u32", "v_mov_b32", "v_readlane_b32", "ds_read_b128 (broadcast)",
                                       "bank loop body (8 pk + 2 ds_read_b128)", "v_add_f32_e32 (VOP2, 4 B)", "v_mul_f32_e32 (VOP2, 4 B)",
-                                      "v_fmac_f32_e32 (VOP2, 4 B)", "v_cndmask_b32_e32 (VOP2, 4 B)"};
+                                      "v_fmac_f32_e32 (VOP2, 4 B)", "v_cndmask_b32_e32 (VOP2, 4 B, mask in VCC)",
+                                      "v_mul_f32_e32 with an SGPR source", "v_fma_f32 with an SGPR source", "v_pk_fma_f32 with an SGPR-pair source",
+                                      "v_cndmask_b32_e64 (mask in an SGPR pair)"};
 // instructions of the measured class per loop trip
-static const int kPerTrip[kNumOps] = {kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, 8 * 8, kBody, kBody, kBody, kBody};
+static const int kPerTrip[kNumOps] = {kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, 8 * 8, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody};
 
 template <int kOp>
 __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* cycles, float* sink, float seed) {
@@ -111,6 +113,24 @@ __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* cycles,
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                          : "v"(k)
                          : "vcc");
+        } else if constexpr (kOp == kMulSgpr) {
+            asm volatile(R8("v_mul_f32_e32 %0, %8, %0\n v_mul_f32_e32 %1, %8, %1\n v_mul_f32_e32 %2, %8, %2\n v_mul_f32_e32 %3, %8, %3\n"
+                            "v_mul_f32_e32 %4, %8, %4\n v_mul_f32_e32 %5, %8, %5\n v_mul_f32_e32 %6, %8, %6\n v_mul_f32_e32 %7, %8, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "s"(k));
+        } else if constexpr (kOp == kFmaSgpr) {
+            asm volatile(R8(OPS8("v_fma_f32", ", %8, %9"))
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "s"(k), "v"(seed));
+        } else if constexpr (kOp == kPkFmaSgpr) {
+            asm volatile(R8(OPS8("v_pk_fma_f32", ", %8, %9"))
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                         : "s"(pk), "v"(pk));
+        } else if constexpr (kOp == kCndmaskE64) {
+            const unsigned long long m = 0x5555aaaa3333ccccULL ^ (unsigned long long)it;
+            asm volatile(R8(OPS8("v_cndmask_b32_e64", ", %8, %9"))
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(k), "s"(m));
         } else if constexpr (kOp == kReadlane) {
             int s0, s1, s2, s3, s4, s5, s6, s7;
             asm volatile(R8("v_readlane_b32 %0, %8, 1\n v_readlane_b32 %1, %9, 2\n v_readlane_b32 %2, %10, 3\n v_readlane_b32 %3, %11, 4\n"
@@ -212,5 +232,9 @@ int main(int argc, char** argv) {
     run<kMulE32>(cus, d_cycles, d_sink, only_w);
     run<kFmacE32>(cus, d_cycles, d_sink, only_w);
     run<kCndmaskE32>(cus, d_cycles, d_sink, only_w);
+    run<kMulSgpr>(cus, d_cycles, d_sink, only_w);
+    run<kFmaSgpr>(cus, d_cycles, d_sink, only_w);
+    run<kPkFmaSgpr>(cus, d_cycles, d_sink, only_w);
+    run<kCndmaskE64>(cus, d_cycles, d_sink, only_w);
     return 0;
 }
