@@ -79,6 +79,11 @@ SIMDS, CUS, XCDS = 1024, 256, 8   # MI355X: 256 CUs x 4 SIMD-32, 8 XCDs (GRBM_GU
 # cycles of SIMD time per wave-instruction at four waves per SIMD, measured by tools/valu_issue.hip (profiles/r03/valu_issue.jsonl):
 # 8-byte VALU encodings (v_fma_f32, v_pk_*, DPP, v_fma_f64, v_mul_lo_u32) 2.9-3.3, v_mov_b32 2.07, transcendentals 6.06
 COST_VALU, COST_TRANS = 3.1, 6.06
+# VOP1 / VOP2 instructions with two VGPR sources and no SGPR operand retire every 2.07 cycles (v_mov, v_add_f32_e32, v_mul_f32_e32);
+# the counters cannot tell them apart.  About half of the VALU instructions of the stream kernels are 4-byte encodings
+# statically (an over-estimate of the cheap class: a 4-byte v_mul with an SGPR source already costs 3.03), so pricing half
+# of the non-transcendental instructions at 2.07 gives a LOWER bound of the utilisation.
+COST_VALU_CHEAP, CHEAP_SHARE = 2.07, 0.5
 
 
 def issue_model(c, kernel_ns, frames):
@@ -103,7 +108,10 @@ def issue_model(c, kernel_ns, frames):
         "valu_busy_sq_accounting": g("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (SIMDS * cycles),
         # the same instructions priced at what the SIMD measurably needs at this occupancy
         "valu_issue_utilisation": ((valu - trans) * COST_VALU + trans * COST_TRANS) / (SIMDS * cycles),
-        "valu_cost_model": {"plain_or_packed_cycles": COST_VALU, "transcendental_cycles": COST_TRANS, "source": "tools/valu_issue.hip at 4 waves per SIMD"},
+        "valu_issue_utilisation_lower_bound": ((valu - trans) * (CHEAP_SHARE * COST_VALU_CHEAP + (1 - CHEAP_SHARE) * COST_VALU)
+                                               + trans * COST_TRANS) / (SIMDS * cycles),
+        "valu_cost_model": {"two_vgpr_source_vop2_cycles": COST_VALU_CHEAP, "assumed_share_of_those_for_the_lower_bound": CHEAP_SHARE,
+                            "plain_or_packed_cycles": COST_VALU, "transcendental_cycles": COST_TRANS, "source": "tools/valu_issue.hip at 4 waves per SIMD"},
         "lds_array_busy": g("SQ_LDS_IDX_ACTIVE", 0.0) / (CUS * cycles),
         "lds_bank_conflict_share": (g("SQ_LDS_BANK_CONFLICT", 0.0) / g("SQ_LDS_IDX_ACTIVE", 1.0)) if g("SQ_LDS_IDX_ACTIVE") else None,
         "wave_time": ({"parked_in_waitcnt": g("SQ_WAIT_ANY", 0.0) / wave_q, "issue_stalled": g("SQ_WAIT_INST_ANY", 0.0) / wave_q,
