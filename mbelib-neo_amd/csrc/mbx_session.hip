@@ -228,7 +228,14 @@ int enqueue(mbx_session* s, Slot& sl, int n, int T, const int32_t* index, const 
         memcpy(sl.h_in, frames, nf * s->frame_bytes);
         src = sl.h_in;
     }
-    rc = mbx_stage_in(sl.d_frames, src, nf * s->frame_bytes, s->s_comp);
+    const void* dev_view = src;   // what the GPU dereferences: the same address for hipHostMalloc memory, possibly another one for
+    void* mapped = nullptr;       // memory the host registered itself (hipHostRegister)
+    if (hipHostGetDevicePointer(&mapped, const_cast<uint8_t*>(src), 0) == hipSuccess && mapped) {
+        dev_view = mapped;
+    } else {
+        (void)hipGetLastError();
+    }
+    rc = mbx_stage_in(sl.d_frames, dev_view, nf * s->frame_bytes, s->s_comp);
     if (rc < 0) {
         return rc;
     }

@@ -1153,3 +1153,36 @@ def test_every_visible_device_decodes(mbx, oracle):
         parity.check_pcm(ref["pcmf"], out["pcmf"].cpu().numpy(), ref["pcm16"], out["pcm16"].cpu().numpy())
         parity.check_state(ref["state"], dec.state_numpy())
     torch.cuda.set_device(0)
+
+
+def test_ambe_rows_from_a_workspace_equal_in_kernel_expansion(mbx, oracle):
+    """T >= 4 AMBE launches expand the records inside the stream kernel (eight frames of a stream at a time); the same
+    kernel still accepts FrameParams rows made by mbx_expand_records (mbx_stream_expanded).  Both ways, both AMBE codecs:
+    identical PCM, results and state."""
+    import torch
+
+    from mbelib_neo_amd import _native, decoder, framegen
+
+    L = _native.lib()
+    S, T = 256, 11   # T not a multiple of eight: the last group of rows is partial
+    for codec in (1, 3):
+        frames = framegen.random_frames(codec, S * T, framegen.rng_for(6060 + codec))
+        outs = []
+        for split in (False, True):
+            dec = decoder.BatchDecoder(codec, S, seeds=np.arange(S) + 9)
+            d_frames = dec.to_device(frames)
+            out = dec.make_outputs(T, want_pcm16=True, want_float=True, want_results=True)
+            stream = torch.cuda.current_stream().cuda_stream
+            _native.check(L.mbx_fec_ambe3600x2450(d_frames.data_ptr(), S * T, out["records"].data_ptr(), stream), "fec")
+            if split:
+                assert L.mbx_uses_expand_launch(codec, S, T) == 0
+                _native.check(L.mbx_expand_records(codec, out["records"].data_ptr(), S * T, stream), "expand")
+                run = L.mbx_stream_expanded
+            else:
+                run = L.mbx_process_records
+            _native.check(run(codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(), out["pcm16"].data_ptr(),
+                              out["pcmf"].data_ptr(), out["results"].data_ptr(), stream), "stream")
+            torch.cuda.synchronize()
+            outs.append((out["pcmf"].cpu().numpy().tobytes(), out["pcm16"].cpu().numpy().tobytes(), out["results"].cpu().numpy().tobytes(),
+                         dec.state.cpu().numpy().tobytes()))
+        assert outs[0] == outs[1], f"codec {codec}"
