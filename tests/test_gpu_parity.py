@@ -1186,3 +1186,52 @@ def test_ambe_rows_from_a_workspace_equal_in_kernel_expansion(mbx, oracle):
             outs.append((out["pcmf"].cpu().numpy().tobytes(), out["pcm16"].cpu().numpy().tobytes(), out["results"].cpu().numpy().tobytes(),
                          dec.state.cpu().numpy().tobytes()))
         assert outs[0] == outs[1], f"codec {codec}"
+
+
+def test_single_frame_kernel_equals_batch_launch(mbx, oracle):
+    """mbx_process_frame (one launch of one wavefront: FEC by lane 0 + the LDS-resident stream body + completion word) against
+    mbx_process_batch with S = T = 1 on the same frames and state, all four codecs, twenty frames of one stream each: PCM,
+    result, record and the three structs bit for bit; the completion word carries the token."""
+    import torch
+
+    from mbelib_neo_amd import _native, framegen
+    from mbelib_neo_amd.layout import FRAME_BYTES, init_state, rng_seeded
+
+    L = _native.lib()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for codec in (0, 1, 2, 3):
+        T = 20
+        frames = framegen.random_frames(codec, T, framegen.rng_for(7000 + codec))
+        if codec in (1, 3):
+            frames[::2] = framegen.encode_ambe3600x2450(framegen.ambe_voice_param_bits(T // 2, framegen.rng_for(7100 + codec)))
+        d_frames = torch.from_numpy(np.ascontiguousarray(frames).reshape(-1)).to(dev)
+        fb = FRAME_BYTES[codec]
+
+        def fresh():
+            st = torch.from_numpy(init_state(1).view(np.uint8).reshape(-1).copy()).to(dev)
+            rg = torch.from_numpy(rng_seeded([4321]).view(np.uint8).reshape(-1).copy()).to(dev)
+            return st, rg
+
+        outs = []
+        for single in (True, False):
+            st, rg = fresh()
+            pcm16 = torch.zeros((T, 160), dtype=torch.int16, device=dev)
+            pcmf = torch.zeros((T, 160), dtype=torch.float32, device=dev)
+            res = torch.zeros((T, 5), dtype=torch.int32, device=dev)
+            rec = torch.zeros((T, 4), dtype=torch.int32, device=dev)
+            done = torch.zeros(1, dtype=torch.int32, device=dev)
+            for t in range(T):
+                fptr = d_frames.data_ptr() + t * fb
+                if single:
+                    _native.check(L.mbx_process_frame(codec, fptr, st.data_ptr(), rg.data_ptr(), pcm16[t].data_ptr(), pcmf[t].data_ptr(),
+                                                      res[t].data_ptr(), rec[t].data_ptr(), done.data_ptr(), 1000 + t, stream), "mbx_process_frame")
+                else:
+                    _native.check(L.mbx_process_batch(codec, 1, 1, fptr, st.data_ptr(), rg.data_ptr(), pcm16[t].data_ptr(), pcmf[t].data_ptr(),
+                                                      res[t].data_ptr(), rec[t].data_ptr(), stream), "mbx_process_batch")
+            torch.cuda.synchronize()
+            if single:
+                assert int(done.item()) == 1000 + T - 1
+            outs.append(tuple(x.cpu().numpy().tobytes() for x in (pcm16, pcmf, res, rec, st, rg)))
+        for a, b, name in zip(outs[0], outs[1], ("pcm16", "pcmf", "results", "records", "state", "rng")):
+            assert a == b, f"codec {codec}: {name}"
