@@ -4,8 +4,9 @@
 // array (Vl, Ml, log2Ml, PHIl, PSIl; L <= 56 < 64), previousUw[256] is four registers per lane, noiseOverlap[96] two.
 // The T frames of the stream are processed in order inside the kernel.  `cur` stays in registers for the whole launch;
 // `prev` and `prev_enhanced` are live only where the reference reads them and are parked in between: in their own HBM/L2
-// slots (the loads and stores a T = 1 launch needs anyway; launches with one to three frames per stream), or in LDS for
-// the whole launch (the *_lds kernel instances, T >= 4: see ParkedState); what the snapshot already holds is read back
+// slots (the loads and stores a T = 1 launch needs anyway; launches with one to three frames per stream), or -- the *_lds
+// kernel instances, T >= 4, and the single-frame kernels -- `prev` in LDS for the whole launch and the ten fields of
+// `prev_enhanced` that synthesis reads in registers (see ParkedPrevOnly); what the snapshot already holds is read back
 // from it instead of being carried across the synthesiser.  A struct is 651 consecutive dwords: coalesced dword accesses.
 //
 // Stages and the reference code they replace (ref = arancormonk/mbelib-neo v2.0.0):
@@ -775,7 +776,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     constexpr int kParkN = Scratch::kParkCols;
     // The HBM snapshot is read back through a pointer the compiler cannot trace to the stores that wrote it: otherwise it
     // forwards the stored registers to the loads and carries them across the voiced bank -- the very thing the read-back avoids.
-    // (The LDS-resident instances run at four waves per SIMD with registers to spare: there the forwarding is welcome.)
+    // (In the LDS-resident instances the snapshot is in LDS and read with ds_read: nothing to hide from the compiler.)
     if (kSnap && !kPark) {
         asm volatile("" : "+s"(snap_ptr));
     }
@@ -1398,24 +1399,18 @@ __device__ __forceinline__ void store_rng(const StreamRng& r, mbx_stream_rng* p,
 // Where prev_mp and prev_mp_enhanced live between the frames of a launch.
 //   kPark = false (launches with few frames per stream): in their HBM slots -- the loads and stores a one-frame launch
 //           needs anyway; seven / six waves per SIMD.
-//   kPark = true  (T >= 4): in LDS for the whole launch, copied in once and written back once, so a launch moves each
-//           struct over HBM exactly twice whatever T is (at T = 16 the HBM-slot scheme wrote 5.2 KB per FRAME: 5.8x the
-//           algorithmic bytes).  2 x 2,604 B on top of the 4,624 B of scratch = 16 waves per CU = four per SIMD, which
-//           costs nothing there: with many frames per stream the kernel is bound by VALU issue, not by latency.
+//   kPark = true  (T >= 4, and the single-frame kernels): prev_mp in LDS for the whole launch, copied in once and written back
+//           once, so a launch moves each struct over HBM exactly twice whatever T is (at T = 16 the HBM-slot scheme wrote
+//           5.2 KB per FRAME: 5.8x the algorithmic bytes); prev_mp_enhanced not in LDS at all (below).  Round 2 kept both
+//           structs in LDS: 9,840 B per wave = four waves per SIMD, and the counters showed a kernel starved of waves.
 // ------------------------------------------------------------------------------------------
 template <bool kPark>
-struct ParkedState {};
-template <>
-struct ParkedState<true> {
-    mbe_parms prev, enh;   // the ABI layout, so every load / store helper works on either home
-#ifdef MBX_EXP_LDS_PAD
-    char pad[MBX_EXP_LDS_PAD];   // occupancy experiments only (tools/variant.sh): fewer waves per CU
-#endif
-};
-// IMBE: prev_mp_enhanced needs no home inside the launch at all.  Every IMBE frame ends with prev_mp_enhanced := cur_mp
-// (ref src/imbe/imbe7200x4400.c:780-888), `cur` never leaves the registers, and synthesis reads only ten fields of the
-// enhanced model: they are copied register to register at the end of a frame (EnhView), the struct is loaded from HBM once
-// and written back once from `cur`.  2,604 B of LDS less per wave: 5,200 B = five allocation granules instead of eight.
+struct ParkedState {};   // kPark = false: nothing in LDS
+// prev_mp_enhanced needs no home inside the launch at all.  Every voice frame ends with prev_mp_enhanced := cur_mp
+// (ref src/imbe/imbe7200x4400.c:780-888, src/ambe/ambe3600x2450.c:790-800), `cur` never leaves the registers, and synthesis
+// reads only ten fields of the enhanced model: they are copied register to register at the end of a frame (enh_keep), the
+// struct is loaded from HBM once and written back once from `cur` (AMBE tone-class frames: see `synced` in ambe_stream_body).
+// 2,604 B of LDS less per wave: 5,200 B = five allocation granules instead of eight.
 struct ParkedPrevOnly {
     mbe_parms prev;
 #ifdef MBX_EXP_LDS_PAD
@@ -1681,12 +1676,9 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
     imbe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
-// T >= 4: prev_mp / prev_mp_enhanced resident in LDS, four waves per SIMD (see ParkedState)
-// Occupancy is set by LDS here (9,840 B per wave = 16 waves per CU); the register budget stays that of the HBM-slot
-// instance.  Measured on configs[3] (65,536 x T=16): register allocation padded to exactly four waves per SIMD
-// (amdgpu_waves_per_eu(4, 4)) 3.47 ms, launch bounds as below 3.37 ms, HBM-slot instance 3.31-3.36 ms.
-// (The compiler notes that the occupancy asked for is not reached -- LDS allows four waves per SIMD -- and relaxes the
-// register budget accordingly; -Wno-pass-failed in the Makefile silences exactly that remark.)
+// T >= 4: prev_mp resident in LDS (see ParkedPrevOnly).  5,200 B of LDS per wave allow 25 waves per CU, so the register
+// file decides the occupancy: 79 VGPRs = six waves per SIMD.  Measured on configs[3] (65,536 x T=16) with padded LDS:
+// two waves per SIMD 5.15 ms, three 3.91, four (round 2) 3.40, five 2.86, six 2.76.
 #define MBX_LDS_KERNEL_ATTR(waves) __launch_bounds__(64, waves)
 #ifndef MBX_IMBE_LDS_WAVES_PER_SIMD
 #define MBX_IMBE_LDS_WAVES_PER_SIMD 6   // 5,200 B of LDS per wave = 25 waves per CU: the register file decides (80 VGPRs)
