@@ -283,3 +283,24 @@ int main(void) {
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", ref_inc, "-I", gen_inc, str(src), "-o", str(exe), "-L", libdir, "-lmbe_neo_amd",
                         "-Wl,--no-undefined", "-Wl,--allow-shlib-undefined", "-Wl,-rpath," + libdir], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_fft_swizzle_of_the_kernel_is_conflict_free_in_the_bank_model():
+    """The LDS-resident stream kernels address the unvoiced transform through an XOR swizzle (mbx_stream.hip, fsw).  Under
+    the gfx950 banking rules of MI355X_MICROARCH.md (ds_read_b64: 2 x 32 lanes on 64 dword banks; ds_write_b64: 4 x 16 lanes
+    on 32) every access pattern of the transform pair is conflict-free with it (200 lane-group cycles = the minimum), the
+    plain indices are not (504), and the map is a bijection of 0..255 that is linear over GF(2) -- which is what lets the
+    kernel form fsw(base + r q) as fsw(base) ^ fsw(r q)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fft_swizzle", os.path.join(ROOT, "tools", "fft_swizzle.py"))
+    fs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fs)
+    assert fs.cost(lambda e: e) == (504, 200)
+    assert fs.cost(fs.kernel_map) == (200, 200)
+    assert sorted(fs.kernel_map(e) for e in range(256)) == list(range(256))
+    for a in range(256):
+        for b in (1, 2, 3, 4, 8, 12, 16, 32, 48, 64, 128, 192):
+            assert fs.kernel_map(a ^ b) == fs.kernel_map(a) ^ fs.kernel_map(b)
+    src = open(os.path.join(ROOT, "mbelib-neo_amd", "csrc", "mbx_stream.hip")).read()
+    assert "(e ^ ((e >> 2) & 3) ^ (((e >> 4) & 7) << 2))" in src   # the kernel's map is the one checked here

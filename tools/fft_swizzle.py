@@ -35,19 +35,34 @@ def cost(m):
                 e=m(idx[l]); banks.setdefault(e%nb,set()).add(e)
             tot+=max(len(v) for v in banks.values()); base+=1
     return tot,base
-print("identity",cost(lambda e:e))
-best=[]
-for c4,c5,c6,c7 in itertools.product(range(0,5),repeat=4):
-    m=lambda e:e+c4*(e>>4)+c5*(e>>5)+c6*(e>>6)+c7*(e>>7)
-    t,b=cost(m); size=m(255)+1
-    best.append((t,size,(c4,c5,c6,c7)))
-best.sort(); print(best[:10])
-# xor swizzles
-res=[]
-for s1,t1,m1 in itertools.product(range(1,8),range(0,8),(1,3,7,15)):
-  for s2,t2,m2 in itertools.product(range(1,8),range(0,8),(0,1,3,7)):
-    def m(e,s1=s1,t1=t1,m1=m1,s2=s2,t2=t2,m2=m2):
-        return (e ^ (((e>>s1)&m1)<<t1) ^ (((e>>s2)&m2)<<t2)) & 255
-    if len({m(e) for e in range(256)})!=256: continue
-    t,b=cost(m); res.append((t,(s1,t1,m1,s2,t2,m2)))
-res.sort(); print(res[:10])
+def kernel_map(e):
+    """the map mbx_stream.hip uses (synth_core, fsw)"""
+    return e ^ ((e >> 2) & 3) ^ (((e >> 4) & 7) << 2)
+
+
+def main():
+    print("identity",cost(lambda e:e))
+    print("kernel map",cost(kernel_map))
+    search()
+
+
+def search():
+    best=[]
+    for c4,c5,c6,c7 in itertools.product(range(0,5),repeat=4):
+        m=lambda e:e+c4*(e>>4)+c5*(e>>5)+c6*(e>>6)+c7*(e>>7)
+        t,b=cost(m); size=m(255)+1
+        best.append((t,size,(c4,c5,c6,c7)))
+    best.sort(); print(best[:10])
+    # xor swizzles
+    res=[]
+    for s1,t1,m1 in itertools.product(range(1,8),range(0,8),(1,3,7,15)):
+      for s2,t2,m2 in itertools.product(range(1,8),range(0,8),(0,1,3,7)):
+        def m(e,s1=s1,t1=t1,m1=m1,s2=s2,t2=t2,m2=m2):
+            return (e ^ (((e>>s1)&m1)<<t1) ^ (((e>>s2)&m2)<<t2)) & 255
+        if len({m(e) for e in range(256)})!=256: continue
+        t,b=cost(m); res.append((t,(s1,t1,m1,s2,t2,m2)))
+    res.sort(); print(res[:10])
+
+
+if __name__ == "__main__":
+    main()
