@@ -795,10 +795,13 @@ int flush_batch(Batch& b) {
     }
     // ---- outputs: the small arrays first, then the PCM in chunks -- the host hands chunk k to the callers' buffers while
     //      chunk k + 1 is still crossing PCIe (the scatter is as long as the copy: 5 MB per 16,384 frames each) ----
-    constexpr int kChunks = 4;
+    constexpr int kMaxChunks = 4;
+    // small flushes (many host threads, each with a share of the channels) go out as one piece: every extra copy and event is a
+    // trip through the HIP runtime's per-device lock, which is what bounds the rate when sixteen threads flush at once
+    const int kChunks = rows >= 8192 ? kMaxChunks : 1;
     if (!s.chunk_done[0]) {
         HIP_OK(hipEventCreateWithFlags(&s.chunk_done[0], hipEventDisableTiming | hipEventBlockingSync));   // the long wait sleeps
-        for (int k = 1; k <= kChunks; ++k) {
+        for (int k = 1; k <= kMaxChunks; ++k) {
             HIP_OK(hipEventCreateWithFlags(&s.chunk_done[k], hipEventDisableTiming));
         }
     }
