@@ -104,6 +104,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float lane_get(float v, int src) { return __shfl(v, src, kWave); }
 __device__ __forceinline__ int lane_get(int v, int src) { return __shfl(v, src, kWave); }
 
+// the value of lane `src` for a WAVE-UNIFORM src: one v_readlane_b32 (the result is a scalar), no LDS round trip
+__device__ __forceinline__ float lane_read(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src) & 63));
+}
+
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
 
 // base-4 digit reversal of an 8-bit index (radix-4 FFT ordering)

@@ -224,7 +224,7 @@ struct WaveScratchT {
         } x;
         struct {                       // unvoiced path (the coefficients are dead by then)
             float2 fft[256];           //   in-place radix-4 FFT
-            float  bins[132];          //   |X(k)|^2, k = 0..128, then the per-bin scale in the same place
+            float  bins[144];          //   |X(k)|^2, k = 0..128, then the per-bin scale in the same place (+ slack: see the band sums)
         };
     };
     // per-lane values that only cross the unvoiced transform pair (see synth_core); none in the LDS-resident kernel
@@ -467,12 +467,12 @@ __device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev
     const int cur_L = L;   // 9..56
     const int prev_L = prev.L < 1 ? 1 : (prev.L > 56 ? 56 : prev.L);
     {
-        const float padM = lane_get(prev.Ml, prev_L), padL = lane_get(prev.log2Ml, prev_L);
+        const float padM = lane_read(prev.Ml, prev_L), padL = lane_read(prev.log2Ml, prev_L);   // wave-uniform index: v_readlane, no LDS trip
         if (lane > prev_L && lane <= cur_L) {
             prev.Ml = padM;
             prev.log2Ml = padL;
         }
-        const float m1 = lane_get(prev.Ml, 1), l1 = lane_get(prev.log2Ml, 1);
+        const float m1 = lane_read(prev.Ml, 1), l1 = lane_read(prev.log2Ml, 1);
         if (lane == 0) {
             prev.Ml = m1;
             prev.log2Ml = l1;
@@ -678,6 +678,19 @@ __device__ __forceinline__ float local_energy(float prev_le, float RM0) {
     return le;
 }
 
+// The same threshold from hardware sqrt / exp / rcp (1-2 ulp each, relative error of the result < 3e-6): three IEEE square
+// roots, an expf and a division are ~80 VALU instructions for ONE wave-uniform number, every frame.  It only has to say
+// whether any amplitude is NEAR the threshold (2e-5, an order of magnitude wider than its own error); frames where one is
+// are decided with the exact value (and the exact replay), all others compare against a threshold none of their amplitudes
+// is close to -- the decision is the reference's either way.
+__device__ __forceinline__ float smoothing_threshold_fast(float le, float er, int e4) {
+    const float x8 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(le)));
+    const float energy = x8 * x8 * x8;
+    return (er <= 0.0125f && e4 == 0)
+               ? ((45.255f * energy) * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f((277.26f * 1.4426950408889634f) * er)))
+               : (1.414f * energy);
+}
+
 __device__ __forceinline__ void smooth(Parms& cur, const Parms& prev, float RM0, int lane, const float* pre_ml, float* tmp) {
     const int L = cur.L;
     const float er = cur.errorRate;
@@ -686,21 +699,27 @@ __device__ __forceinline__ void smooth(Parms& cur, const Parms& prev, float RM0,
     const bool in = lane >= 1 && lane <= L;
     bool force = false;
     if (!(er <= 0.005f && et <= 4)) {   // otherwise VM = FLT_MAX and nothing can exceed it
-        float VM = smoothing_threshold(le, er, e4);
-        force = in && cur.Ml > VM;
-        const bool near = in && fabsf(cur.Ml - VM) <= 2e-5f * VM;
-        if (__ballot(near) != 0ULL && cur.w0 >= 0.0f && cur.w0 < 1.0f) {   // rare: decide again with the reference's own arithmetic
-            float rm0e;
-            if (pre_ml) {
-                __threadfence_block();   // the snapshot was stored by this wave
-                const float pre = (lane < MBX_BAND_SLOTS) ? pre_ml[lane] : 0.0f;
-                cur.Ml = enhance_exact(pre, cur.w0, L, tmp, lane, rm0e);
-            } else {
-                rm0e = RM0;   // the caller's sequential sum already
-            }
-            le = local_energy(prev.localEnergy, rm0e);
-            VM = smoothing_threshold(le, er, e4);
+        const float VMf = smoothing_threshold_fast(le, er, e4);
+        force = in && cur.Ml > VMf;
+        // (a NaN / infinite threshold compares false here: such states take the exact path below)
+        const bool near_fast = in && !(fabsf(cur.Ml - VMf) > 4e-5f * VMf);
+        if (__ballot(near_fast) != 0ULL) {
+            float VM = smoothing_threshold(le, er, e4);
             force = in && cur.Ml > VM;
+            const bool near = in && fabsf(cur.Ml - VM) <= 2e-5f * VM;
+            if (__ballot(near) != 0ULL && cur.w0 >= 0.0f && cur.w0 < 1.0f) {   // rare: decide again with the reference's own arithmetic
+                float rm0e;
+                if (pre_ml) {
+                    __threadfence_block();   // the snapshot was stored by this wave
+                    const float pre = (lane < MBX_BAND_SLOTS) ? pre_ml[lane] : 0.0f;
+                    cur.Ml = enhance_exact(pre, cur.w0, L, tmp, lane, rm0e);
+                } else {
+                    rm0e = RM0;   // the caller's sequential sum already
+                }
+                le = local_energy(prev.localEnergy, rm0e);
+                VM = smoothing_threshold(le, er, e4);
+                force = in && cur.Ml > VM;
+            }
         }
     } else {
         force = in && cur.Ml > __FLT_MAX__;   // +inf amplitude still compares greater than FLT_MAX
@@ -756,6 +775,38 @@ __device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
         out[j] = u * gain;
     }
     rng.cn_seed48 = java_lcg_jump(rng.cn_seed48, 160);
+}
+
+// fmodf(x, 2 pi) brought into [0, 2 pi) -- the reference's `wrapped = fmodf(PSIl, 2 pi); if (wrapped < 0) wrapped += 2 pi`
+// (src/core/mbelib.c:901-912), bit for bit: fmodf is exact, and so is this for 0 <= x < 4e6.  n is the truncated
+// quotient or one more (the product is biased upwards by 1e-6, five times its own rounding error), x - n y is then a
+// multiple of ulp(2 pi) of magnitude below 2 pi, i.e. a float: the FMA returns it unrounded, and adding 2 pi to a negative
+// one gives the true remainder, again a float.  OCML's fmodf is ~36 VALU instructions with a loop; anything outside the
+// range (negative, huge, NaN: caller-made states) still goes through it, for the whole wave.
+__device__ __forceinline__ float wrap_two_pi(float x, bool active) {
+    const float y = 2.0f * (float)M_PI;
+    if (__ballot(active && !(x >= 0.0f && x < 4.0e6f)) != 0ULL) {
+        float w = fmodf(x, y);
+        if (w < 0.0f) {
+            w += y;
+        }
+        return w;
+    }
+    const float n = truncf(x * (0.15915494f * 1.000001f));
+    float r = fmaf(-n, y, x);
+    if (r < 0.0f) {
+        r += y;
+    }
+    return r;
+}
+
+// a / b, correctly rounded, for a wave-uniform divisor whose correctly rounded reciprocal is at hand (Markstein: with
+// y = RN(1 / b), q = RN(a y) and the exact residual r = a - b q, RN(q + r y) = RN(a / b)): three instructions instead of the
+// ~12 of an IEEE division.  |a| is either 0 or far from the overflow / underflow ends where the theorem needs care.
+__device__ __forceinline__ float div_by_uniform(float a, float b, float rcp_b) {
+    const float q = a * rcp_b;
+    const float r = fmaf(-q, b, a);
+    return fmaf(r, rcp_b, q);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -863,19 +914,16 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     // ---- phases ----------------------------------------------------------------------------
     const int numUv = popc64(__ballot(lane <= cur.L && cur.Vl == 0));
     const float cw0 = cur.w0, pw0 = prev.w0;
-    const float TWO_PI = 2.0f * (float)M_PI;
+    const float inv_L = ((ConstDerived)tabs.d)->l_ratio[1][cur.L];   // (float)1 / (float)L from the host (scalar load)
     if (lane >= 1 && lane <= 56 && !MBX_ABL(tabs, 64)) {
-        float wrapped = fmodf(prev.PSIl, TWO_PI);
-        if (wrapped < 0.0f) {
-            wrapped += TWO_PI;
-        }
+        float wrapped = wrap_two_pi(prev.PSIl, lane >= 1 && lane <= 56);
         prev.PSIl = wrapped;
         cur.PSIl = wrapped + ((pw0 + cw0) * ((float)(lane * N) / 2.0f));
         if (lane <= (cur.L / 4)) {
             cur.PHIl = cur.PSIl;
         } else {
             const float pl = ((2.0f * (float)M_PI / 53125.0f) * nz[0]) - (float)M_PI;
-            cur.PHIl = cur.PSIl + (((float)numUv * pl) / (float)cur.L);
+            cur.PHIl = cur.PSIl + div_by_uniform((float)numUv * pl, (float)cur.L, inv_L);
         }
     }
 
@@ -1207,25 +1255,30 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
         float band_sc = 0.0f;
         int band_a = 0, band_b = 0;
+        const float mult = (256.0f / (2.0f * 3.14159265358979323846f)) * cur.w0;
+        // b - a = ceil((l + .5) mult) - ceil((l - .5) mult) <= floor(mult) + 1: the widest band of the frame (wave-uniform)
+        const int span = uni((mult >= 0.0f && mult < 13.0f) ? ((int)mult + 1) : 14);
         if (lane >= 1 && lane <= cur.L && band_unvoiced) {
-            const float mult = (256.0f / (2.0f * 3.14159265358979323846f)) * cur.w0;
             int a = (int)ceilf(((float)lane - 0.5f) * mult);
             int b = (int)ceilf(((float)lane + 0.5f) * mult);
             a = a < 0 ? 0 : a;
             b = b > 128 ? 128 : b;
             float num = 0.0f;
+            const int count = b - a;
+            const float* const bp = &S.bins[a];   // one address, the bin index is the instruction's offset (bins is padded past 128 + 13)
 #pragma unroll
             for (int c = 0; c < 14; ++c) {
-                const int k = a + c;
-                const float m2 = S.bins[k < 128 ? k : 128];
-                if (k < b) {
+                if (c >= span) {   // wave-uniform: no band is wider (a random-bit frame averages four bins per band, not fourteen)
+                    break;
+                }
+                const float m2 = bp[c];
+                if (c < count) {
                     num += m2;
                 }
             }
             for (int k = a + 14; k < b; ++k) {   // not reached for valid w0; keeps odd states exact
                 num += S.bins[k];
             }
-            const int count = b - a;
             if (count > 0 && num > 1e-10f) {
                 // v_rcp / v_rsq (1 ulp each): the bin energies come from a float FFT that differs from the reference's by more
                 band_sc = (146.17696f * band_M) * __builtin_amdgcn_rsqf(num * __builtin_amdgcn_rcpf((float)count));
@@ -1776,12 +1829,12 @@ __device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev
     const int prev_L = prev.L < 1 ? 1 : (prev.L > 56 ? 56 : prev.L);
     const int cur_L = L;
     {
-        const float padM = lane_get(prev.Ml, prev_L), padL = lane_get(prev.log2Ml, prev_L);
+        const float padM = lane_read(prev.Ml, prev_L), padL = lane_read(prev.log2Ml, prev_L);   // wave-uniform index: v_readlane, no LDS trip
         if (lane > prev_L && lane <= cur_L) {
             prev.Ml = padM;
             prev.log2Ml = padL;
         }
-        const float m1 = lane_get(prev.Ml, 1), l1 = lane_get(prev.log2Ml, 1);
+        const float m1 = lane_read(prev.Ml, 1), l1 = lane_read(prev.log2Ml, 1);
         if (lane == 0) {
             prev.Ml = m1;
             prev.log2Ml = l1;
@@ -1792,7 +1845,7 @@ __device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev
     int lo = (int)pos;
     lo = lo > 56 ? 56 : lo;
     const float frac = pos - (float)lo;
-    const float phi0 = lane_get(prev.PHIl, 0);   // the reference's log2Ml[57] aliases PHIl[0]
+    const float phi0 = lane_read(prev.PHIl, 0);   // the reference's log2Ml[57] aliases PHIl[0]
     const float a = lane_get(prev.log2Ml, lo);
     const float bnext = lane_get(prev.log2Ml, (lo + 1) & 63);
     const float b = (lo + 1 > 56) ? phi0 : bnext;
