@@ -777,6 +777,41 @@ __device__ void comfort_noise(float out[3], StreamRng& rng, int lane) {
     rng.cn_seed48 = java_lcg_jump(rng.cn_seed48, 160);
 }
 
+// Packed complex arithmetic with the swaps and signs as OPERAND MODIFIERS (op_sel / neg of the VOP3P encoding).  Written as
+// inline assembly because the compiler materialises a shuffled operand such as (-w.y, w.x) with a v_xor and a v_mov before
+// every use: a complex product came out as four VALU instructions, a multiplication by -+i as two.  The arithmetic is the
+// same as the vector-builtin formulation bit for bit (one packed multiply, one packed FMA).
+//   cmul_pk(u, w)  = u w          cmul_cw(u, w) = u conj(w)          cmul_cu(u, w) = conj(u) w
+//   add_mi(a, b)   = a - i b      sub_mi(a, b)  = a + i b
+__device__ __forceinline__ v2f cmul_pk(v2f u, v2f w) {
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(u), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(u), "v"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f cmul_cw(v2f u, v2f w) {
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(u), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(u), "v"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f cmul_cu(v2f u, v2f w) {
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(u), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(u), "v"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f add_mi(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f sub_mi(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // fmodf(x, 2 pi) brought into [0, 2 pi) -- the reference's `wrapped = fmodf(PSIl, 2 pi); if (wrapped < 0) wrapped += 2 pi`
 // (src/core/mbelib.c:901-912), bit for bit: fmodf is exact, and so is this for 0 <= x < 4e6.  n is the truncated
 // quotient or one more (the product is biased upwards by 1e-6, five times its own rounding error), x - n y is then a
@@ -868,7 +903,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     const uint32_t x0 = cold ? 0u : (((uint32_t)cur.noiseSeed) % 53125u);
     auto at = [&](int k) -> float {   // k-th value of the LCG started at x0
         k = k < 0 ? 0 : k;
-        return (float)((D->lcg_mul[k] * x0 + D->lcg_add[k]) % 53125u);
+        return (float)((__umul24(D->lcg_mul[k], x0) + D->lcg_add[k]) % 53125u);   // both factors are below 53,125: a 24-bit multiply is exact
     };
     if (cold) {
         nz[0] = nz[1] = nz[2] = nz[3] = 0.0f;
@@ -1067,6 +1102,22 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             v2f Qc = Ec, Qs = Es;   // harmonic 1
             v2f even = {0.0f, 0.0f}, odd = {0.0f, 0.0f}, even_d = {0.0f, 0.0f}, odd_d = {0.0f, 0.0f};
             const int last = uni(maxl);
+#ifdef MBX_BANK_SKIP
+            const unsigned long long live = __ballot(wv_p || wv_c);   // harmonics with a coefficient in either model
+#pragma unroll 2
+            for (int l = 1; l <= last; ++l) {
+                if ((live >> l) & 1ULL) {
+                    const float4 a = S.coef_amp[l], b = S.coef_drift[l];   // wave-uniform address: LDS broadcasts
+                    even = __builtin_elementwise_fma(Qc, v2f{a.x, a.y}, even);
+                    odd = __builtin_elementwise_fma(Qs, v2f{a.z, a.w}, odd);
+                    even_d = __builtin_elementwise_fma(Qc, v2f{b.x, b.y}, even_d);
+                    odd_d = __builtin_elementwise_fma(Qs, v2f{b.z, b.w}, odd_d);
+                }
+                const v2f nq = __builtin_elementwise_fma(Qc, Ec, -(Qs * Es));
+                Qs = __builtin_elementwise_fma(Qs, Ec, Qc * Es);
+                Qc = nq;
+            }
+#else
 #pragma unroll 2
             for (int l = 1; l <= last; ++l) {
                 const float4 a = S.coef_amp[l], b = S.coef_drift[l];   // wave-uniform address: LDS broadcasts
@@ -1078,6 +1129,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 Qs = __builtin_elementwise_fma(Qs, Ec, Qc * Es);
                 Qc = nq;
             }
+#endif
             // sample centre + k: even - odd - k (even_d + odd_d); centre - k: even + odd + k (even_d - odd_d)
             const v2f kf = splat((float)lane);
             const v2f v_plus = ((even - odd) - (kf * (even_d + odd_d))) * w_plus;
@@ -1180,18 +1232,14 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         constexpr auto fsw = [](int e) constexpr -> int { return kSwz ? (e ^ ((e >> 2) & 3) ^ (((e >> 4) & 7) << 2)) : e; };
         constexpr auto elem = [fsw](int base_sw, int c) constexpr -> int { return kSwz ? (base_sw ^ fsw(c)) : (base_sw + c); };   // element base + c
         const int lane_sw = fsw(lane);   // lane + 64 r  ->  elem(lane_sw, 64 r)
-        auto mul_mi = [](v2f a) -> v2f { return v2f{a.y, -a.x}; };   // -i a
-        auto cmul = [](v2f u, v2f w) -> v2f {                         // u w
-            return __builtin_elementwise_fma(v2f{u.y, u.y}, v2f{-w.y, w.x}, v2f{u.x, u.x} * w);
-        };
         // w^1, w^2, w^3 of one stage: one hardware evaluation, two complex products (each 2-3 ulp, like the butterflies);
         // the inverse transform asks for the conjugates directly
         auto twiddles = [&](int m, bool conj, v2f& w1, v2f& w2, v2f& w3) {
             const float rev = (float)(m & 255) * (1.0f / 256.0f);
             const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
             w1 = conj ? v2f{c, sn} : v2f{c, -sn};
-            w2 = cmul(w1, w1);
-            w3 = cmul(w1, w2);
+            w2 = cmul_pk(w1, w1);
+            w3 = cmul_pk(w1, w2);
         };
         float win[4];
 #pragma unroll
@@ -1203,10 +1251,11 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const float s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
             v2f w1, w2, w3;
             twiddles(lane, false, w1, w2, w3);
+            const v2f dd = {d02, d13};
             F[lane_sw] = v2f{s02 + s13, 0.0f};
-            F[elem(lane_sw, 64)] = cmul(v2f{d02, -d13}, w1);
+            F[elem(lane_sw, 64)] = cmul_cu(dd, w1);    // (d02 - i d13) w
             F[elem(lane_sw, 128)] = splat(s02 - s13) * w2;
-            F[elem(lane_sw, 192)] = cmul(v2f{d02, d13}, w3);
+            F[elem(lane_sw, 192)] = cmul_pk(dd, w3);   // (d02 + i d13) w^3
         }
         wave_lds_sync();
 #pragma unroll
@@ -1216,31 +1265,37 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const int i1 = elem(base, q), i2 = elem(base, 2 * q), i3 = elem(base, 3 * q);
             const int tstep = 64 / q;   // 256 / (4q)
             const v2f a0 = F[base], a1 = F[i1], a2 = F[i2], a3 = F[i3];
-            const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, md13 = mul_mi(a1 - a3);
+            const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
             wave_lds_sync();
             F[base] = s02 + s13;
             if (q == 1) {   // last forward stage: all twiddles are 1
-                F[i1] = d02 + md13;   // d02 - i*d13
+                F[i1] = add_mi(d02, d13);   // d02 - i*d13
                 F[i2] = s02 - s13;
-                F[i3] = d02 - md13;   // d02 + i*d13
+                F[i3] = sub_mi(d02, d13);   // d02 + i*d13
             } else {
                 v2f w1, w2, w3;
                 twiddles(jj * tstep, false, w1, w2, w3);
-                F[i1] = cmul(d02 + md13, w1);
-                F[i2] = cmul(s02 - s13, w2);
-                F[i3] = cmul(d02 - md13, w3);
+                F[i1] = cmul_pk(add_mi(d02, d13), w1);
+                F[i2] = cmul_pk(s02 - s13, w2);
+                F[i3] = cmul_pk(sub_mi(d02, d13), w3);
             }
             wave_lds_sync();
         }
         // |X(k)|^2 for k = 0..128 in natural order (position p holds bin rev4(p); rev4(lane + 64 r) = rev4(lane) + r)
         const int kbase = rev4(lane & 63);
+        {   // all four reads first: a branch around each read-modify-write made four LDS round trips in series
+            float m2[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pidx = elem(lane_sw, 64 * r);
-            const int k = kbase + r;
-            if (k <= 128) {
-                const v2f X = F[pidx];
-                S.bins[k] = (k == 0) ? (X.x * X.x) : ((X.x * X.x) + (X.y * X.y));
+            for (int r = 0; r < 4; ++r) {
+                const v2f X = F[elem(lane_sw, 64 * r)];
+                const v2f sq = X * X;
+                m2[r] = (kbase + r == 0) ? sq.x : (sq.x + sq.y);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kbase + r <= 128) {
+                    S.bins[kbase + r] = m2[r];
+                }
             }
         }
         wave_lds_sync();
@@ -1317,25 +1372,25 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             if (q != 1) {   // multiply by the conjugate twiddles
                 v2f w1, w2, w3;
                 twiddles(jj * tstep, true, w1, w2, w3);
-                z1 = cmul(z1, w1);
-                z2 = cmul(z2, w2);
-                z3 = cmul(z3, w3);
+                z1 = cmul_pk(z1, w1);
+                z2 = cmul_pk(z2, w2);
+                z3 = cmul_pk(z3, w3);
             }
-            const v2f s02 = x0 + z2, d02 = x0 - z2, s13 = z1 + z3, md13 = mul_mi(z1 - z3);
+            const v2f s02 = x0 + z2, d02 = x0 - z2, s13 = z1 + z3, d13 = z1 - z3;
             wave_lds_sync();
             F[base] = s02 + s13;
-            F[i1] = d02 - md13;       // d02 + i*d13
+            F[i1] = sub_mi(d02, d13);   // d02 + i*d13
             F[i2] = s02 - s13;
-            F[i3] = d02 + md13;   // d02 - i*d13
+            F[i3] = add_mi(d02, d13);   // d02 - i*d13
             wave_lds_sync();
         }
         {   // last inverse stage (span 64): only the real parts are needed, results stay in registers
             v2f w1, w2, w3;
             twiddles(lane, true, w1, w2, w3);
             const v2f x0 = F[lane_sw];
-            const v2f z1 = cmul(F[elem(lane_sw, 64)], w1);
-            const v2f z2 = cmul(F[elem(lane_sw, 128)], w2);
-            const v2f z3 = cmul(F[elem(lane_sw, 192)], w3);
+            const v2f z1 = cmul_pk(F[elem(lane_sw, 64)], w1);
+            const v2f z2 = cmul_pk(F[elem(lane_sw, 128)], w2);
+            const v2f z3 = cmul_pk(F[elem(lane_sw, 192)], w3);
             const float s02 = x0.x + z2.x, d02 = x0.x - z2.x, s13 = z1.x + z3.x, d13y = z1.y - z3.y;
             cur.uw[0] = (s02 + s13) * (1.0f / 256.0f);
             cur.uw[1] = (d02 - d13y) * (1.0f / 256.0f);   // Re(d02 + i*d13)
