@@ -295,6 +295,18 @@ typedef const MBX_GLOBAL DerivedTables* GlobalDerived;
 typedef const MBX_GLOBAL float* GlobalFloats;
 __device__ __forceinline__ uint32_t low_bits(uint32_t v, int n) { return v & ((1u << n) - 1u); }
 
+// One table entry at (wave-uniform byte address) + (per-lane 32-bit byte offset): written this way the load is a
+// global_load with an SGPR base and a 32-bit VGPR offset.  Indexing a multi-dimensional table member with a uniform row and a
+// per-lane column made the compiler form 64-bit per-lane addresses instead (v_lshl_add_u64, v_add_co / v_addc, v_mad_i64_i32:
+// ~30 VALU instructions a frame in the IMBE expansion alone, several of them double-rate ones).
+template <class T>
+__device__ __forceinline__ T tab_at(const void* uniform_base, size_t uniform_bytes, uint32_t lane_bytes) {
+    const MBX_GLOBAL char* p = (const MBX_GLOBAL char*)uniform_base + uniform_bytes;
+    asm("" : "+s"(p));   // the uniform sum stays ONE scalar value: otherwise a member offset too large for the instruction's
+                         // immediate field is added to the per-lane part again, in 64-bit vector arithmetic
+    return *(const MBX_GLOBAL T*)(p + lane_bytes);
+}
+
 // a frame's parameter record by SCALAR loads (wave-uniform address)
 __device__ __forceinline__ uint4 load_record_scalar(const mbx_param_record* rp) {
     const __attribute__((address_space(4))) uint32_t* rq = (const __attribute__((address_space(4))) uint32_t*)rp;
@@ -304,8 +316,6 @@ __device__ __forceinline__ uint4 load_record_scalar(const mbx_param_record* rp) 
 template <class Scratch>
 __device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane) {
     ConstTables T = (ConstTables)Tgen;
-    GlobalTables Tg = (GlobalTables)Tgen;
-    GlobalDerived Dg = (GlobalDerived)Dgen;
     int b0 = (int)(rec.x >> 26);
     b0 = (b0 << 2) | (int)((rec.z >> 9) & 3u);   // payload bits 85, 86
     int bad = 1, L = 0, K = 0;
@@ -325,30 +335,35 @@ __device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* 
     if (!bad) {
         const int L9 = L - 9;
         // ---- every per-lane table value is requested here ----
-        const MBX_GLOBAL uint16_t* bo = (const MBX_GLOBAL uint16_t*)(&Tg->imbe_bo[L9][0][0]);
-        const uint32_t e0 = bo[lane], e1 = bo[lane < 15 ? lane + 64 : 78];
-        const int g = (lane >= 2 && lane <= 6) ? lane - 2 : 0;
-        const float nb = Tg->imbe_ba[L9][g][0], step = Tg->imbe_ba[L9][g][1];
-        const float b2 = Tg->imbe_B2[lane];
-        const float qs = Tg->imbe_quantstep[lane < 11 ? lane : 0];
+        const uint32_t ul = (uint32_t)lane;
+        const size_t uL9 = (size_t)(uint32_t)L9;
+        const uint32_t e0 = tab_at<uint16_t>(Tgen, offsetof(mbx_tables, imbe_bo) + uL9 * sizeof(Tgen->imbe_bo[0]), 2u * ul);
+        const uint32_t e1 = tab_at<uint16_t>(Tgen, offsetof(mbx_tables, imbe_bo) + uL9 * sizeof(Tgen->imbe_bo[0]), 2u * (lane < 15 ? ul + 64u : 78u));
+        const uint32_t g = (lane >= 2 && lane <= 6) ? ul - 2u : 0u;
+        const v2f bas = tab_at<v2f>(Tgen, offsetof(mbx_tables, imbe_ba) + uL9 * sizeof(Tgen->imbe_ba[0]), 8u * g);
+        const float nb = bas.x, step = bas.y;
+        const float b2 = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_B2), 4u * ul);
+        const float qs = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_quantstep), 4u * (lane < 11 ? ul : 0u));
         // which higher-order coefficient / harmonic a lane owns depends on L only: host-made tables (mbx_init)
-        const uint32_t own = Dg->imbe_lane_map[L9][lane];
+        const uint32_t own = tab_at<uint32_t>(Dgen, offsetof(DerivedTables, imbe_lane_map) + uL9 * sizeof(Dgen->imbe_lane_map[0]), 4u * ul);
         const int hblk = (int)(own & 7u), hk = (int)((own >> 3) & 15u);
         const int iblk = (int)((own >> 7) & 7u);
-        const int Bm = Tg->imbe_hoba[L9][lane < 50 ? lane : 0];
-        const float sd = Dg->imbe_hoc_sd[L9][lane];
+        const int Bm = tab_at<uint8_t>(Tgen, offsetof(mbx_tables, imbe_hoba) + uL9 * sizeof(Tgen->imbe_hoba[0]), lane < 50 ? ul : 0u);
+        const float sd = tab_at<float>(Dgen, offsetof(DerivedTables, imbe_hoc_sd) + uL9 * sizeof(Dgen->imbe_hoc_sd[0]), 4u * ul);
         const bool harm = lane >= 1 && lane <= L;
         float cosr[11], ric[7];   // fetched now: loads cannot move up across the LDS fences below
         {
-            GlobalFloats row = &Dg->imbe_idct_rows[L9][lane][0];
-#pragma unroll
-            for (int k = 1; k <= 10; ++k) {
-                cosr[k] = row[k - 1];
-            }
-            GlobalFloats col = &Tg->imbe_ri_cos[0][(lane >= 1 && lane <= 6) ? lane : 0];
+            const size_t rows = offsetof(DerivedTables, imbe_idct_rows) + uL9 * sizeof(Dgen->imbe_idct_rows[0]);
+            typedef float v4f_u __attribute__((ext_vector_type(4), aligned(8)));   // a row is 40 bytes: 8-byte aligned
+            const v4f_u r0 = tab_at<v4f_u>(Dgen, rows, 40u * ul), r1 = tab_at<v4f_u>(Dgen, rows + 16u, 40u * ul);
+            const v2f r2 = tab_at<v2f>(Dgen, rows + 32u, 40u * ul);
+            cosr[1] = r0.x, cosr[2] = r0.y, cosr[3] = r0.z, cosr[4] = r0.w;
+            cosr[5] = r1.x, cosr[6] = r1.y, cosr[7] = r1.z, cosr[8] = r1.w;
+            cosr[9] = r2.x, cosr[10] = r2.y;
+            const uint32_t col = 4u * ((lane >= 1 && lane <= 6) ? ul : 0u);
 #pragma unroll
             for (int m = 1; m <= 6; ++m) {
-                ric[m] = col[7 * m];
+                ric[m] = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_ri_cos) + 28u * (size_t)m, col);
             }
         }
 
@@ -874,7 +889,6 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             return ((GlobalFloats)snap)[dword];
         }
     };
-    GlobalTables T = (GlobalTables)tabs.t;
     GlobalDerived D = (GlobalDerived)tabs.d;
     constexpr int N = 160;
     out[0] = out[1] = out[2] = 0.0f;
@@ -903,7 +917,9 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     const uint32_t x0 = cold ? 0u : (((uint32_t)cur.noiseSeed) % 53125u);
     auto at = [&](int k) -> float {   // k-th value of the LCG started at x0
         k = k < 0 ? 0 : k;
-        return (float)((__umul24(D->lcg_mul[k], x0) + D->lcg_add[k]) % 53125u);   // both factors are below 53,125: a 24-bit multiply is exact
+        const uint32_t mul = tab_at<uint32_t>(tabs.d, offsetof(DerivedTables, lcg_mul), 4u * (uint32_t)k);
+        const uint32_t add = tab_at<uint32_t>(tabs.d, offsetof(DerivedTables, lcg_add), 4u * (uint32_t)k);
+        return (float)((__umul24(mul, x0) + add) % 53125u);   // both factors are below 53,125: a 24-bit multiply is exact
     };
     if (cold) {
         nz[0] = nz[1] = nz[2] = nz[3] = 0.0f;
@@ -1094,10 +1110,10 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 Ec.y = c;
                 Es.y = d;
             }
-            GlobalFloats Ws = T->ws;
             const int kk = lane <= kMidPrev ? lane : kMidPrev;   // lanes 53..63 idle along
-            const v2f w_plus = {Ws[N + kMidPrev + kk], Ws[kMidCur + (kk < 52 ? kk : 51)]};
-            const v2f w_minus = {Ws[N + kMidPrev - kk], Ws[kMidCur - kk]};
+            auto Ws = [&](int i) -> float { return tab_at<float>(tabs.t, offsetof(mbx_tables, ws), 4u * (uint32_t)i); };
+            const v2f w_plus = {Ws(N + kMidPrev + kk), Ws(kMidCur + (kk < 52 ? kk : 51))};
+            const v2f w_minus = {Ws(N + kMidPrev - kk), Ws(kMidCur - kk)};
             wave_lds_sync();
             v2f Qc = Ec, Qs = Es;   // harmonic 1
             v2f even = {0.0f, 0.0f}, odd = {0.0f, 0.0f}, even_d = {0.0f, 0.0f}, odd_d = {0.0f, 0.0f};
@@ -1226,9 +1242,9 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         // linear, fsw(base + r q) = fsw(base) ^ fsw(r q) whenever base has no bit in r q's digit: one swizzle per stage
         // and three XORs with literals.  (tools/fft_swizzle.py searches the family and prints the conflict counts.)
         v2f* const F = reinterpret_cast<v2f*>(S.fft);
-        // Only in the LDS-resident instances: three more address registers across a butterfly are a spill under the 72 / 80
-        // register caps of the HBM-slot instances, which run one to three frames per stream and are not bound by the LDS pipe.
-        constexpr bool kSwz = kPark;
+        // (Round 3 kept plain indices in the HBM-slot instances: three more address registers across a butterfly were a spill under
+        // their 72 / 80-register caps.  With the products and rotations in two / one instruction the registers are there.)
+        constexpr bool kSwz = true;
         constexpr auto fsw = [](int e) constexpr -> int { return kSwz ? (e ^ ((e >> 2) & 3) ^ (((e >> 4) & 7) << 2)) : e; };
         constexpr auto elem = [fsw](int base_sw, int c) constexpr -> int { return kSwz ? (base_sw ^ fsw(c)) : (base_sw + c); };   // element base + c
         const int lane_sw = fsw(lane);   // lane + 64 r  ->  elem(lane_sw, 64 r)
@@ -1244,7 +1260,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         float win[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            win[r] = T->uv_window[lane + 64 * r];
+            win[r] = tab_at<float>(tabs.t, offsetof(mbx_tables, uv_window) + 256u * (size_t)r, 4u * (uint32_t)lane);
         }
         {   // forward stage 1 (span 64): real inputs straight from registers
             const float a0 = nz[0] * win[0], a1 = nz[1] * win[1], a2 = nz[2] * win[2], a3 = nz[3] * win[3];
@@ -1428,10 +1444,14 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
         // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
         // the division by w(n)^2 + w(n-160)^2 is a multiplication by its rounded reciprocal (<= 1 ulp of the unvoiced part)
-        const float wprev[2] = {T->wola_w_prev[lane], T->wola_w_prev[lane + 64]};   // w(n) is 0 from n = 106 on
+        const uint32_t lb = 4u * (uint32_t)lane;
+        const float wprev[2] = {tab_at<float>(tabs.t, offsetof(mbx_tables, wola_w_prev), lb),
+                                tab_at<float>(tabs.t, offsetof(mbx_tables, wola_w_prev) + 256u, lb)};   // w(n) is 0 from n = 106 on
         if (any_unvoiced) {
-            const float winv[3] = {D->wola_inv[lane], D->wola_inv[lane + 64], (lane < 32) ? D->wola_inv[lane + 128] : 0.0f};
-            const float wcurr[3] = {T->wola_w_curr[lane], T->wola_w_curr[lane + 64], (lane < 32) ? T->wola_w_curr[lane + 128] : 0.0f};
+            const float winv[3] = {tab_at<float>(tabs.d, offsetof(DerivedTables, wola_inv), lb), tab_at<float>(tabs.d, offsetof(DerivedTables, wola_inv) + 256u, lb),
+                                   (lane < 32) ? tab_at<float>(tabs.d, offsetof(DerivedTables, wola_inv) + 512u, lb) : 0.0f};
+            const float wcurr[3] = {tab_at<float>(tabs.t, offsetof(mbx_tables, wola_w_curr), lb), tab_at<float>(tabs.t, offsetof(mbx_tables, wola_w_curr) + 256u, lb),
+                                    (lane < 32) ? tab_at<float>(tabs.t, offsetof(mbx_tables, wola_w_curr) + 512u, lb) : 0.0f};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const float give = (lane < 32) ? cur.uw[j] : ((j == 0) ? 0.0f : cur.uw[j - 1]);
@@ -1443,8 +1463,8 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 }
             }
         } else {   // this frame's Uw is all zeros: only the previous frame's half of the overlap remains
-            acc[0] += (wprev[0] * prev.uw[2]) * D->wola_inv[lane];
-            acc[1] += (wprev[1] * prev.uw[3]) * D->wola_inv[lane + 64];
+            acc[0] += (wprev[0] * prev.uw[2]) * tab_at<float>(tabs.d, offsetof(DerivedTables, wola_inv), lb);
+            acc[1] += (wprev[1] * prev.uw[3]) * tab_at<float>(tabs.d, offsetof(DerivedTables, wola_inv) + 256u, lb);
         }
         wave_lds_sync();
     }
