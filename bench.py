@@ -45,6 +45,9 @@ VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 (non-MFMA) peak
 WORKLOADS = {
     # name: (codec, streams per GPU, T, description)
     "imbe_voiced": (0, 65536, 1, "BASELINE configs[1]: 65,536 IMBE 7200x4400 streams x T=1, clean all-voiced frames, warm state"),
+    # the same workload on RESIDENT state (mbx_process_batch_resident: what sessions and the queue mode's pool use) -- reported
+    # beside the headline with its own algorithmic bytes, never as it: the drop-in batch call keeps the ABI triplets whole
+    "imbe_voiced_resident": (0, 65536, 1, "65,536 IMBE 7200x4400 streams x T=1, clean all-voiced frames, warm RESIDENT state (prev_mp_enhanced elided, prev_mp lazy)"),
     "imbe_mixed": (0, 65536, 16, "BASELINE configs[3]: 65,536 IMBE streams x T=16 random-bit frames (mixed voiced/unvoiced)"),
     "ambe_fec": (1, 65536, 1, "BASELINE configs[2]: 65,536 AMBE+2 streams x T=1, clean voice frames + 1% bit flips"),
     "ambe_stream": (1, 8192, 128, "BASELINE configs[4] per-GPU shard: 8,192 AMBE+2 streams x T=128 random-bit frames, int16 out"),
@@ -65,7 +68,7 @@ def make_frames(name, codec, S, T, rank):
     from mbelib_neo_amd import framegen
 
     rng = framegen.rng_for(0xBE0000 + 97 * rank + codec)
-    if name == "imbe_voiced":
+    if name in ("imbe_voiced", "imbe_voiced_resident"):
         return framegen.imbe_clean_voiced_frames(S * T, rng)
     if name == "ambe_fec":
         return framegen.ambe_noisy_voice_frames(S * T, rng, ber=0.01)
@@ -86,10 +89,15 @@ def nominal_flops_per_frame(workload):
     return 36000 + 12000 + 4000, "survey's random-bit mix: 36k voiced bank + 12k unvoiced FFT path + 4k"
 
 
-def algorithmic_bytes_per_launch(codec, S, T):
+def algorithmic_bytes_per_launch(codec, S, T, resident=False):
     """B_io = packed channel bits in + int16 PCM out per frame; B_state = load +
-    store of the three-struct state per stream per launch."""
+    store of the three-struct state per stream per launch.
+    resident: what the resident form has to move per stream and launch -- cur_mp in and out (2 x 2604), prev_mp out
+    (2604: the snapshot), and of prev_mp in only what the decode reads (Ml, log2Ml, PHIl: 3 x 57 floats, + 5 scalars =
+    704 B); prev_mp_enhanced not at all."""
     b_io = (18 if codec in (0, 2) else 9) + 320
+    if resident:
+        return S * T * b_io + S * (3 * 2604 + 704)
     return S * T * b_io + S * 2 * 3 * 2604
 
 
@@ -359,8 +367,10 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     from mbelib_neo_amd import _native, decoder
 
     codec = WORKLOADS[name][0]
+    resident = name.endswith("_resident")
     frames = make_frames(name, codec, S, T, rank)
-    dec = decoder.BatchDecoder(codec, S, device=local_rank, seeds=np.arange(first_stream, first_stream + S) + 1234, tables_blob=blob)
+    dec = decoder.BatchDecoder(codec, S, device=local_rank, seeds=np.arange(first_stream, first_stream + S) + 1234, tables_blob=blob,
+                               resident=resident)
     d_frames = dec.to_device(frames)
     out = dec.make_outputs(T, want_pcm16=True, want_float=False, want_results=True)
     L = _native.lib()
@@ -393,11 +403,19 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
             run = L.mbx_stream_expanded
         if ev is not None and not soft:
             ev[0].record()
-        _native.check(
-            run(stream_codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
-                out["pcm16"].data_ptr(), None, out["results"].data_ptr(), stream),
-            "stream",
-        )
+        if resident:
+            assert split, "the resident bench workloads are the T = 1 ones (expand launch + stream launch)"
+            _native.check(
+                L.mbx_stream_expanded_resident(stream_codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.resident.data_ptr(),
+                                               dec.rng.data_ptr(), out["pcm16"].data_ptr(), None, out["results"].data_ptr(), stream),
+                "stream (resident)",
+            )
+        else:
+            _native.check(
+                run(stream_codec, S, T, out["records"].data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
+                    out["pcm16"].data_ptr(), None, out["results"].data_ptr(), stream),
+                "stream",
+            )
         if ev is not None and not soft:
             ev[1].record()
 
@@ -447,8 +465,8 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
                   3: "fec_ambe3600x2450_soft_kernel"}[codec]
         alg_bytes = soft_fec_bytes_per_launch(codec, n)
     else:
-        kernel = L.mbx_stream_kernel_name(codec, T).decode()
-        alg_bytes = algorithmic_bytes_per_launch(codec, S, T)
+        kernel = L.mbx_stream_kernel_name(codec, -1 if resident else T).decode()   # (T < 0: the instances of the resident launches)
+        alg_bytes = algorithmic_bytes_per_launch(codec, S, T, resident)
     del dec, d_frames, out
     torch.cuda.empty_cache()
     return {
@@ -658,7 +676,7 @@ def main():
     if extras and args.workload == "imbe_voiced":
         # the other three GPU configs of BASELINE.json, driver-timed in the same line (10 steps each)
         line["other_configs"] = {}
-        for other in ("ambe_fec", "imbe_mixed", "ambe_stream"):
+        for other in ("imbe_voiced_resident", "ambe_fec", "imbe_mixed", "ambe_stream"):
             oc, oS, oT, odesc = WORKLOADS[other]
             om = run_workload(other, oS, oT, 10, 2, rank, 0, local_rank, blob, 1, dist, args)
             orf = roofline_of(other, oS, oT, om)

@@ -263,6 +263,24 @@ int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_i
                               mbe_parms* d_state_pool, mbx_stream_rng* d_rng_pool, int16_t* d_pcm16, float* d_pcmf,
                               mbe_process_result* d_results, mbx_param_record* d_records, void* stream);
 
+/* Resident state -- for a caller that OWNS the state of its streams between launches (sessions; the queue mode's device
+ * pool).  d_state_pool is the same [slots][3] array of ABI structs, d_resident one word per slot (zero-initialised by the
+ * caller).  After every ordinary frame the reference leaves prev_mp_enhanced a field-for-field copy of cur_mp
+ * (ref src/imbe/imbe7200x4400.c:842-856, src/ambe/ambe3600x2450.c:790-800); while d_resident[slot] != 0 that struct is
+ * ELIDED: the kernels neither write nor read it, and of prev_mp they fetch only what the decode reads (the rest on demand:
+ * repeats, erasures).  PCM, results and every later frame are bit-identical to mbx_process_batch_indexed on the same
+ * inputs; the three structs are in their ABI form again after mbx_resident_materialize() (which clears the words).
+ * d_stream_index may be NULL (row s = slot s).  ref (what the state is): include/mbelib-neo/mbelib.h:88-139. */
+int mbx_process_batch_resident(int codec, int S, int T, const int32_t* d_stream_index, const uint8_t* d_frames,
+                               mbe_parms* d_state_pool, uint32_t* d_resident, mbx_stream_rng* d_rng_pool, int16_t* d_pcm16,
+                               float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records, void* stream);
+/* the stream stage alone on resident state, after mbx_expand_records() on the same stream (cf. mbx_stream_expanded) */
+int mbx_stream_expanded_resident(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state, uint32_t* d_resident,
+                                 mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                                 void* stream);
+/* prev_mp_enhanced := cur_mp for the n listed slots (d_stream_index NULL: slots 0..n-1) whose struct is elided */
+int mbx_resident_materialize(int n, const int32_t* d_stream_index, mbe_parms* d_state_pool, uint32_t* d_resident, void* stream);
+
 /* ref: mbe_synthesizeSpeechf  include/mbelib-neo/mbelib.h:652, src/core/mbelib.c:1112-1115.
  * One frame for each of S (cur, prev) pairs; both structs are updated like the reference does. */
 int mbx_synthesize_speech(int S, mbe_parms* d_cur, mbe_parms* d_prev, mbx_stream_rng* d_rng, float* d_pcmf,
@@ -346,7 +364,8 @@ void mbx_rng_default(mbx_stream_rng* rng);
 void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed);
 
 /* name of the stream kernel a launch with T frames per stream takes (for the bench / profile summaries): with T >= 4 the
- * instance that keeps prev_mp / prev_mp_enhanced in LDS for the whole launch (*_lds), otherwise the HBM-slot one */
+ * instance that keeps prev_mp / prev_mp_enhanced in LDS for the whole launch (*_lds), otherwise the HBM-slot one; T < 0:
+ * the instance of the resident launches (*_res, mbx_process_batch_resident) */
 const char* mbx_stream_kernel_name(int codec, int T);
 
 #ifdef __cplusplus

@@ -52,6 +52,9 @@ _SIGNATURES = {
     "mbx_stage_in": (C.c_int, [_vp, _vp, _sz, _vp]),
     "mbx_process_frame": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp]),
     "mbx_process_batch_indexed": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_process_batch_resident": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_resident_materialize": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),
+    "mbx_stream_expanded_resident": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_fec_stage": (C.c_int, [C.c_int, C.c_int, _vp, _sz, _vp, _vp, _vp]),
     "mbx_decode_parms": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mbx_synthesize_speech": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -120,6 +123,8 @@ def lib():
             try:
                 fn = getattr(handle, name)
             except AttributeError as e:
+                if os.environ.get("MBX_HIP_LIBRARY_ALLOW_OLDER") == "1":   # tools/abx.sh: A/B against a library of an earlier commit
+                    continue
                 raise NativeLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args

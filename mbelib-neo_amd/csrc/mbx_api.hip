@@ -27,6 +27,12 @@ __global__ void expand_ambe_kernel(const mbx_param_record*, size_t, FrameParams*
 __global__ void expand_ambe2400_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void imbe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                       int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                       int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe2400_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                           int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_lds(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                        int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel_lds(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
@@ -763,13 +769,29 @@ static int launch_expand(Context* c, int codec, const mbx_param_record* d_record
 // and per session -- whoever re-walks the same state -- not process-wide.
 static int launch_stream(Context* c, bool reverse, int codec, int S, int T, const mbx_param_record* d_records,
                          const mbx::FrameParams* params, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
-                         float* d_pcmf, mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr) {
+                         float* d_pcmf, mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr,
+                         uint32_t* d_resident = nullptr) {
     mbx::DeviceTables tabs = c->tabs;
     tabs.reverse = (reverse && reverse_enabled()) ? 1 : 0;
     tabs.stream_map = d_stream_index;
+    tabs.resident = d_resident;
     // With several frames per stream prev_mp / prev_mp_enhanced stay in LDS for the whole launch (the *_lds instances,
     // four waves per SIMD) instead of being parked in their HBM slots every frame: mbx_stream.hip, ParkedState.
+    // Resident state (d_resident) is understood by those instances only, whatever T is.
     const bool lds_resident = T >= kLdsResidentMinFrames && lds_resident_enabled();
+    if (d_resident) {
+        if (codec == MBX_CODEC_IMBE7200X4400) {
+            hipLaunchKernelGGL(mbx::imbe_stream_kernel_res, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                               params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+        } else if (codec == MBX_CODEC_AMBE3600X2400) {
+            hipLaunchKernelGGL(mbx::ambe2400_stream_kernel_res, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                               params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+        } else {
+            hipLaunchKernelGGL(mbx::ambe_stream_kernel_res, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                               params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+        }
+        return check_launch("stream_kernel_res");
+    }
     if (codec == MBX_CODEC_IMBE7200X4400) {
         if (lds_resident) {
             hipLaunchKernelGGL(mbx::imbe_stream_kernel_lds, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
@@ -830,7 +852,8 @@ extern "C" int mbx_uses_expand_launch(int codec, int S, int T) { return needs_wo
 // counter that decides the walking direction
 static int run_stream_stage(Context* c, unsigned order, int codec, int S, int T, const mbx_param_record* d_records,
                             mbx::FrameParams* ws, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
-                            mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr) {
+                            mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr,
+                            uint32_t* d_resident = nullptr) {
     if (needs_workspace(codec, S, T)) {
         int rc = launch_expand(c, codec, d_records, (size_t)S * (size_t)T, ws, stream);
         if (rc < 0) {
@@ -840,7 +863,7 @@ static int run_stream_stage(Context* c, unsigned order, int codec, int S, int T,
         ws = nullptr;
     }
     return launch_stream(c, (order & 1u) != 0u, codec, S, T, d_records, ws, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
-                         d_stream_index);
+                         d_stream_index, d_resident);
 }
 
 int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream) {
@@ -864,9 +887,27 @@ int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, v
     return rc;
 }
 
+static int stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state, uint32_t* d_resident,
+                           mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, void* stream);
+
 int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream) {
+    return stream_expanded(codec, S, T, d_records, d_state, nullptr, d_rng, d_pcm16, d_pcmf, d_results, stream);
+}
+
+// the same on resident state (mbx_process_batch_resident): bench.py brackets the stream kernel alone with it
+int mbx_stream_expanded_resident(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state, uint32_t* d_resident,
+                                 mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                                 void* stream) {
+    if (!d_resident) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    return stream_expanded(codec, S, T, d_records, d_state, d_resident, d_rng, d_pcm16, d_pcmf, d_results, stream);
+}
+
+static int stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state, uint32_t* d_resident,
+                           mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, void* stream) {
     REQUIRE_CTX(c);
     if (!stream_args_ok(codec, S, T, d_records, d_state, d_rng)) {
         return MBE_STATUS_INVALID_ARGUMENT;
@@ -881,7 +922,7 @@ int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_recor
                     "mbx_stream_expanded: the last mbx_expand_records() on this stream was not for this codec / batch / record array");
     }
     return launch_stream(c, (slot.launches++ & 1u) != 0u, codec, S, T, d_records, slot.workspace, d_state, d_rng, d_pcm16, d_pcmf,
-                         d_results, stream);
+                         d_results, stream, nullptr, d_resident);
 }
 
 int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
@@ -987,6 +1028,7 @@ int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx
     mbx::DeviceTables tabs = c->tabs;
     tabs.reverse = 0;
     tabs.stream_map = nullptr;
+    tabs.resident = nullptr;
     if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {
         hipLaunchKernelGGL(mbx::imbe_frame_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, codec, d_frame, d_record, d_state, d_rng,
                            d_pcm16, d_pcmf, d_result, d_done, token, tabs);
@@ -1041,6 +1083,79 @@ int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_i
     }
     return run_stream_stage(c, slot.launches++, stream_codec, S, T, d_records, slot.workspace, d_state_pool, d_rng_pool, d_pcm16,
                             d_pcmf, d_results, stream, d_stream_index);
+}
+
+// ---- resident state (sessions, queue mode) ------------------------------------------------------------------------------
+// The drop-in batch calls above keep the reference's three structs per stream whole after every launch: a caller may read
+// them at any time.  A caller that OWNS the state for a while (a session; the queue mode's device pool) does not need that:
+// after every ordinary frame prev_mp_enhanced is a field-for-field copy of cur_mp (ref src/imbe/imbe7200x4400.c:842-856,
+// src/ambe/ambe3600x2450.c:790-800), so d_resident[slot] != 0 says "elided" and the kernels neither write nor read that struct;
+// and of prev_mp a launch fetches only what the decode reads.  At T = 1 that is 8.9 KB of state traffic per frame instead of
+// 14.1 KB.  mbx_resident_materialize() brings the triplets back to the ABI form (bit-identical to what mbx_process_batch
+// would have left), after which d_resident is zero again.
+int mbx_process_batch_resident(int codec, int S, int T, const int32_t* d_stream_index, const uint8_t* d_frames,
+                               mbe_parms* d_state_pool, uint32_t* d_resident, mbx_stream_rng* d_rng_pool, int16_t* d_pcm16,
+                               float* d_pcmf, mbe_process_result* d_results, mbx_param_record* d_records, void* stream) {
+    REQUIRE_CTX(c);
+    if (!d_frames || !d_records || !d_state_pool || !d_resident || !d_rng_pool || S < 0 || T < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0 || T == 0) {
+        return 0;
+    }
+    int stream_codec;
+    int rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
+    if (rc < 0) {
+        return rc;
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    StreamSlot& slot = c->slots[stream];
+    if (needs_workspace(stream_codec, S, T)) {
+        rc = ensure_workspace(c, slot, (size_t)S * (size_t)T, stream);
+        if (rc < 0) {
+            return rc;
+        }
+        slot.exp_codec = -1;
+    }
+    return run_stream_stage(c, slot.launches++, stream_codec, S, T, d_records, slot.workspace, d_state_pool, d_rng_pool, d_pcm16,
+                            d_pcmf, d_results, stream, d_stream_index, d_resident);
+}
+
+namespace mbx {
+// prev_mp_enhanced := cur_mp for every listed slot whose struct is elided; one wavefront per slot
+__global__ void __launch_bounds__(64)
+resident_materialize_kernel(int n, const int32_t* __restrict__ index, mbe_parms* __restrict__ state, uint32_t* __restrict__ resident) {
+    const int i = blockIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const size_t slot = index ? (size_t)index[i] : (size_t)i;
+    if (resident[slot] == 0u) {
+        return;
+    }
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&state[3 * slot + 0]);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&state[3 * slot + 2]);
+    for (int k = threadIdx.x; k < (int)(sizeof(mbe_parms) / 4); k += 64) {
+        dst[k] = src[k];
+    }
+    if (threadIdx.x == 0) {
+        resident[slot] = 0u;
+    }
+}
+}  // namespace mbx
+
+int mbx_resident_materialize(int n, const int32_t* d_stream_index, mbe_parms* d_state_pool, uint32_t* d_resident, void* stream) {
+    REQUIRE_CTX(c);
+    (void)c;
+    if (!d_state_pool || !d_resident || n < 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    hipLaunchKernelGGL(mbx::resident_materialize_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, n, d_stream_index,
+                       d_state_pool, d_resident);
+    return check_launch("resident_materialize_kernel");
 }
 
 int mbx_process_batch_soft(int codec, int S, int T, const mbe_soft_bit* d_soft, mbe_parms* d_state, mbx_stream_rng* d_rng,
@@ -1228,6 +1343,11 @@ int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe
 }
 
 const char* mbx_stream_kernel_name(int codec, int T) {
+    if (T < 0) {   // the instances of the resident launches (mbx_process_batch_resident), whatever T is
+        return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? "imbe_stream_kernel_res"
+               : (codec == MBX_CODEC_AMBE3600X2400)                                    ? "ambe2400_stream_kernel_res"
+                                                                                        : "ambe_stream_kernel_res";
+    }
     const bool lds = T >= kLdsResidentMinFrames && lds_resident_enabled();
     if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {
         return lds ? "imbe_stream_kernel_lds" : "imbe_stream_kernel";

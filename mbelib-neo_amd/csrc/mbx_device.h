@@ -55,6 +55,12 @@ struct DeviceTables {
     int                  ablate;   // timing-only stage mask; read only by the -DMBX_ABLATE development build (tools/)
     int                  reverse;  // stream kernels: workgroup b takes stream S - 1 - b (see launch_stream, mbx_api.hip)
     const int32_t*       stream_map;   // stream kernels: batch row s works on state / rng slot stream_map[s] (nullptr: slot s)
+    // Resident state (sessions, queue mode; nullptr: the ABI triplet is kept whole, what every mbx_process_* entry point does).
+    // resident[slot] != 0 says "prev_mp_enhanced of this stream is elided: it equals cur_mp field for field" -- true after every
+    // frame that ends with prev_mp_enhanced := cur_mp (all IMBE frames, AMBE voice / erasure / re-initialisation frames).  The
+    // LDS-resident stream kernels then neither read nor write that struct, and they fetch from prev_mp only what the decode
+    // reads (the rest on demand: repeats, erasures).  mbx_resident_materialize() writes the elided structs out.
+    uint32_t*            resident;
 };
 
 // Stage masks for timing experiments exist only in the development build (make ablate -> libmbx_hip_ablate.so, used by

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -94,6 +95,7 @@ struct mbx_session {
     size_t   frame_bytes = 0;
     mbe_parms*      d_state = nullptr;   // [streams][3]
     mbx_stream_rng* d_rng = nullptr;     // [streams]
+    uint32_t*       d_resident = nullptr;   // [streams]: prev_mp_enhanced of the stream is elided (mbx_process_batch_resident, include/mbx.h)
     hipStream_t s_comp = nullptr, s_out = nullptr;
     Slot     slot[kDepth];
     unsigned long long submitted = 0;
@@ -254,7 +256,10 @@ int enqueue(mbx_session* s, Slot& sl, int n, int T, const int32_t* index, const 
     int16_t* d16 = pcm16 ? sl.d_pcm16 : nullptr;
     float*   dfl = pcmf ? sl.d_pcmf : nullptr;
     mbe_process_result* dres = results ? sl.d_results : nullptr;
-    if (index) {
+    if (s->d_resident) {   // the session owns the state between submits: the resident form (no prev_mp_enhanced traffic, lazy prev_mp)
+        rc = mbx_process_batch_resident(s->codec, n, T, index ? sl.d_index : nullptr, sl.d_frames, s->d_state, s->d_resident, s->d_rng,
+                                        d16, dfl, dres, sl.d_records, s->s_comp);
+    } else if (index) {
         rc = mbx_process_batch_indexed(s->codec, n, T, sl.d_index, sl.d_frames, s->d_state, s->d_rng, d16, dfl, dres, sl.d_records,
                                        s->s_comp);
     } else {
@@ -344,6 +349,10 @@ int mbx_session_create(mbx_session** out, int codec, int streams, size_t max_fra
     } while (0)
     C_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_state), (size_t)streams * 3 * sizeof(mbe_parms)));
     C_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_rng), (size_t)streams * sizeof(mbx_stream_rng)));
+    if (!getenv("MBX_SESSION_ABI_STATE")) {   // (development switch: keep the ABI triplets whole after every submit, for A/B timing)
+        C_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_resident), (size_t)streams * sizeof(uint32_t)));
+        C_TRY(hipMemset(s->d_resident, 0, (size_t)streams * sizeof(uint32_t)));
+    }
     C_TRY(hipStreamCreateWithFlags(&s->s_comp, hipStreamNonBlocking));
     C_TRY(hipStreamCreateWithFlags(&s->s_out, hipStreamNonBlocking));
     const size_t mf = s->max_frames;
@@ -410,6 +419,7 @@ int mbx_session_destroy(mbx_session* s) {
         }
     }
     (void)hipFree(s->d_state);
+    (void)hipFree(s->d_resident);
     (void)hipFree(s->d_rng);
     if (s->s_comp) {
         (void)hipStreamDestroy(s->s_comp);
@@ -450,6 +460,9 @@ int mbx_session_set_state(mbx_session* s, int first, int count, const mbe_parms*
     S_TRY(hipStreamSynchronize(s->s_comp));   // (a submit that failed halfway leaves no busy slot to wait on)
     if (state) {
         S_TRY(hipMemcpy(s->d_state + 3 * (size_t)first, state, (size_t)count * 3 * sizeof(mbe_parms), hipMemcpyHostToDevice));
+        if (s->d_resident) {   // the caller's triplets are whole: nothing is elided any more
+            S_TRY(hipMemset(s->d_resident + first, 0, (size_t)count * sizeof(uint32_t)));
+        }
     }
     if (rng) {
         S_TRY(hipMemcpy(s->d_rng + first, rng, (size_t)count * sizeof(mbx_stream_rng), hipMemcpyHostToDevice));
@@ -468,6 +481,13 @@ int mbx_session_get_state(mbx_session* s, int first, int count, mbe_parms* state
     DeviceGuard guard(s->device);
     S_TRY(hipStreamSynchronize(s->s_comp));
     if (state) {
+        if (s->d_resident) {   // write the elided prev_mp_enhanced structs out: the triplets leave in their ABI form
+            rc = mbx_resident_materialize(count, nullptr, s->d_state + 3 * (size_t)first, s->d_resident + first, s->s_comp);
+            if (rc < 0) {
+                return rc;
+            }
+            S_TRY(hipStreamSynchronize(s->s_comp));
+        }
         S_TRY(hipMemcpy(state, s->d_state + 3 * (size_t)first, (size_t)count * 3 * sizeof(mbe_parms), hipMemcpyDeviceToHost));
     }
     if (rng) {

@@ -1564,6 +1564,26 @@ __device__ __forceinline__ float slot_read(const float* f, int dword) {   // one
     }
 }
 
+// what load_prev_view reads, and nothing else: resident launches bring only this much of prev_mp into LDS at their start
+// (0.7 KB instead of 2.6 KB); a frame that needs the rest (a repeat copies prev_mp whole, an AMBE erasure takes its phases and
+// noise state) completes the copy first -- see `prev_partial` in the stream bodies.
+__device__ __forceinline__ void copy_prev_view(mbe_parms* dst, const mbe_parms* src, int lane) {
+    const float* f = reinterpret_cast<const float*>(src);
+    float* g = reinterpret_cast<float*>(dst);
+    const bool band = lane < MBX_BAND_SLOTS;
+    const float ml = band ? f[O_ML + lane] : 0.0f, l2 = band ? f[O_LOG2ML + lane] : 0.0f, ph = band ? f[O_PHI + lane] : 0.0f;
+    const int sc = (lane == 0) ? O_L : ((lane == 1) ? O_GAMMA : ((lane == 2) ? O_ERRORRATE : ((lane == 3) ? O_REPEAT : O_MUTETHR)));
+    const float sv = (lane < 5) ? f[sc] : 0.0f;
+    if (band) {
+        g[O_ML + lane] = ml;
+        g[O_LOG2ML + lane] = l2;
+        g[O_PHI + lane] = ph;
+    }
+    if (lane < 5) {
+        g[sc] = sv;
+    }
+}
+
 __device__ __forceinline__ void copy_parms(mbe_parms* dst, const mbe_parms* src, int lane) {
     Parms t;
     load_parms(t, src, lane);
@@ -1600,7 +1620,7 @@ __device__ __forceinline__ uint4 frame_record(int fec_codec, const uint8_t* fram
 
 // kFrame: the single-frame kernels behind the synchronous per-frame API (S = T = 1): the record comes in registers from
 // the FEC the same wave has just run (rec_in), not from memory.
-template <bool kPark, bool kFrame = false>
+template <bool kPark, bool kFrame = false, bool kRes = false>
 __device__ __forceinline__ void
 imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
@@ -1629,18 +1649,29 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     Parms enh_keep;   // kPark: the fields of prev_mp_enhanced that synthesis reads, carried from frame to frame in registers
     Parms cur;
     StreamRng rng;
+    // resident launches (DeviceTables::resident): prev_mp_enhanced elided while it equals cur_mp, prev_mp fetched lazily
+    uint32_t* const res = (kPark && kRes) ? tabs_in.resident : nullptr;   // (kRes: own kernel instances, the others carry none of this)
+    bool prev_partial = false;   // wave-uniform: the LDS copy of prev_mp holds only the decode's view of it
     if constexpr (kPark) {
         slot_prev = &park.prev;
         slot_enh = nullptr;
-        load_enh_view(enh_keep, home_enh, lane_in);
-        Parms home;
-        load_parms(home, home_prev, lane_in);
-        load_parms(cur, slot_cur, lane_in);
-        load_rng(rng, &rngs[slot]);
-        if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
-            rec_in = frame_record(fec_codec, frame_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+        const bool elided = res && (uni(res[slot]) != 0u);
+        load_enh_view(enh_keep, elided ? slot_cur : home_enh, lane_in);
+        if (res) {
+            copy_prev_view(slot_prev, home_prev, lane_in);
+            prev_partial = true;
+            load_parms(cur, slot_cur, lane_in);
+            load_rng(rng, &rngs[slot]);
+        } else {
+            Parms home;
+            load_parms(home, home_prev, lane_in);
+            load_parms(cur, slot_cur, lane_in);
+            load_rng(rng, &rngs[slot]);
+            if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
+                rec_in = frame_record(fec_codec, frame_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+            }
+            store_parms(home, slot_prev, lane_in);
         }
-        store_parms(home, slot_prev, lane_in);
         wave_lds_sync();
     } else {
         slot_prev = home_prev;
@@ -1711,6 +1742,10 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 } else {
                     // cur_mp := prev_mp.  Only the prediction memory was loaded (and padded by the
                     // decode); everything else is fetched from the slot now.
+                    if (prev_partial) {   // resident launch: the rest of prev_mp has not been brought in yet
+                        copy_parms(slot_prev, home_prev, lane);
+                        slot_fence<kPark>();
+                    }
                     load_parms(cur, slot_prev, lane);
                     cur.Ml = prev.Ml;
                     cur.log2Ml = prev.log2Ml;
@@ -1723,6 +1758,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         // prev_mp := cur_mp (snapshot before enhancement).  The scheduling barriers keep the 14 stores in one piece: mixed
         // into the decode before them or the enhancement after them they stretch live ranges past the 72-register budget.
         if (!MBX_ABL(tabs, 256)) store_parms(cur, slot_prev, lane);
+        prev_partial = false;
         // Register diet for the synthesiser: what the snapshot holds and the synthesiser does not change (log2Ml) or
         // replaces only at its end (previousUw, the noise overlap) is dropped here and read back from the snapshot
         // afterwards -- seven VGPRs less across the voiced bank.
@@ -1791,9 +1827,17 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     if (!MBX_ABL(tabs_in, 1024)) store_parms(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
     if constexpr (kPark) {   // prev_mp goes home from LDS; prev_mp_enhanced IS cur_mp after the last frame
-        store_parms(cur, home_enh, lane_in);
+        if (res) {
+            if (Tn > 0 && lane_in == 0) {
+                res[slot] = 1u;   // ... and is not written at all by a resident launch
+            }
+        } else {
+            store_parms(cur, home_enh, lane_in);
+        }
         wave_lds_sync();
-        copy_parms(home_prev, slot_prev, lane_in);
+        if (!prev_partial) {
+            copy_parms(home_prev, slot_prev, lane_in);
+        }
     }
 }
 
@@ -2051,7 +2095,7 @@ __device__ void tone_dstar_frame(float out[3], int id1, Parms& cur, int lane) {
 
 // k2400: AMBE 3600x2400 (D-STAR) frame policy, ref src/ambe/ambe3600x2400.c:629-763 -- no erasure class, D-STAR
 // tones, repeats decided by the total error count alone.  The prediction (decode_ambe) is common.
-template <bool k2400, bool kPark, bool kFrame = false>
+template <bool k2400, bool kPark, bool kFrame = false, bool kRes = false>
 __device__ __forceinline__ void
 ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
@@ -2090,17 +2134,29 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     bool synced = false;
     Parms cur;
     StreamRng rng;
+    // resident launches (DeviceTables::resident): `synced` is carried from launch to launch in resident[slot], the struct of
+    // prev_mp_enhanced is neither read nor written while it holds, and prev_mp comes into LDS lazily (see the IMBE kernel)
+    uint32_t* const res = (kPark && kRes) ? tabs_in.resident : nullptr;
+    bool prev_partial = false;
     if constexpr (kPark) {
         slot_prev = &park.prev;
-        load_enh_view(enh_keep, home_enh, lane_in);
-        Parms home;
-        load_parms(home, home_prev, lane_in);
-        load_parms(cur, slot_cur, lane_in);
-        load_rng(rng, &rngs[slot]);
-        if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
-            rec_in = frame_record(MBX_CODEC_AMBE3600X2450, frame_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+        synced = res && (uni(res[slot]) != 0u);
+        load_enh_view(enh_keep, synced ? slot_cur : home_enh, lane_in);
+        if (res) {
+            copy_prev_view(slot_prev, home_prev, lane_in);
+            prev_partial = true;
+            load_parms(cur, slot_cur, lane_in);
+            load_rng(rng, &rngs[slot]);
+        } else {
+            Parms home;
+            load_parms(home, home_prev, lane_in);
+            load_parms(cur, slot_cur, lane_in);
+            load_rng(rng, &rngs[slot]);
+            if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
+                rec_in = frame_record(MBX_CODEC_AMBE3600X2450, frame_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+            }
+            store_parms(home, slot_prev, lane_in);
         }
-        store_parms(home, slot_prev, lane_in);
         wave_lds_sync();
     } else {
         slot_prev = home_prev;
@@ -2119,6 +2175,13 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         enh_keep.amplitudeThreshold = from.amplitudeThreshold;
         enh_keep.uw[2] = from.uw[2];
         enh_keep.uw[3] = from.uw[3];
+    };
+    auto complete_prev = [&](int lane) {   // resident launch: a frame is about to read more of prev_mp than the decode's view
+        if (prev_partial) {
+            copy_parms(slot_prev, home_prev, lane);
+            slot_fence<kPark>();
+            prev_partial = false;
+        }
     };
     float row_now = 0.0f;
     if constexpr (kPark) {
@@ -2199,6 +2262,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 init_ambe_parms(prev, lane);
                 cur = prev;
                 store_parms(prev, slot_prev, lane);
+                prev_partial = false;
                 if constexpr (kPark) {
                     keep_enh_view(prev);
                     enh = enh_keep;
@@ -2236,6 +2300,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     cur.repeatCount = 0;
                 } else if (valid_tone) {
                 } else if (total > 3) {
+                    complete_prev(lane);
                     load_parms(cur, slot_prev, lane);   // cur_mp := prev_mp
                     if (bad == 0) {                     // (the decode padded the prediction memory in registers)
                         cur.Ml = prev.Ml;
@@ -2249,12 +2314,14 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             } else if (bad == 2) {
                 flags |= MBE_PROCESS_FLAG_ERASURE;
                 cur.repeatCount = 0;
+                complete_prev(lane);
                 load_continuity(prev, slot_prev, lane);   // phases, overlap-add and noise state of prev_mp
                 set_ambe_erasure_parms(cur, prev, lane);
             } else if (bad == 7) {
                 flags |= MBE_PROCESS_FLAG_TONE;
                 cur.repeatCount = 0;
             } else if (((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? ((c0 >= 4) || ((c0 >= 2) && (total >= 6))) : (total > 3)) {
+                complete_prev(lane);
                 load_parms(cur, slot_prev, lane);   // cur_mp := prev_mp (see the IMBE kernel)
                 cur.Ml = prev.Ml;
                 cur.log2Ml = prev.log2Ml;
@@ -2292,6 +2359,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         float rm0 = 0.0f;
         if (action == kVoice) {
             store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
+            prev_partial = false;
             cur.log2Ml = 0.0f;                   // read back from the snapshot after the synthesiser (see the IMBE kernel)
             cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
             rm0 = enhance(cur, lane, scratch.x.C);
@@ -2303,7 +2371,9 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 // The copy takes the LDS home of prev_mp for the duration (it is the synthesiser's snapshot), prev_mp waits in
                 // its HBM home.  prev_mp_enhanced is current in ITS home: this is a tone-class frame (see `synced`).
                 wave_lds_sync();
-                copy_parms(home_prev, slot_prev, lane);
+                if (!prev_partial) {   // (a resident launch that has only the view in LDS: the home is current as it is)
+                    copy_parms(home_prev, slot_prev, lane);
+                }
                 __threadfence_block();
                 copy_parms(slot_prev, home_enh, lane);
                 slot_fence<kPark>();
@@ -2346,6 +2416,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     wave_lds_sync();
                     __threadfence_block();
                     copy_parms(slot_prev, home_prev, lane);   // prev_mp returns to LDS
+                    prev_partial = false;
                 }
             } else {
                 store_parms(cur, slot_enh, lane);
@@ -2359,12 +2430,14 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         } else if (action == kToneDstar) {
             tone_dstar_frame(out, bad, cur, lane);
             store_parms(cur, slot_prev, lane);   // mbe_moveMbeParms(cur_mp, prev_mp)
+            prev_partial = false;
         } else {
             comfort_noise(out, rng, lane);
             if (action == kNoiseReinit) {   // mbe_initAmbeParms_common(cur, prev, prev_enhanced)
                 init_ambe_parms(cur, lane);
             }
             store_parms(cur, slot_prev, lane);
+            prev_partial = false;
             if constexpr (kPark) {
                 keep_enh_view(cur);
                 synced = true;
@@ -2391,11 +2464,17 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     store_parms(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
     if constexpr (kPark) {   // prev_mp goes home from LDS; prev_mp_enhanced from `cur` unless its home is already current
-        if (synced) {
+        if (res) {
+            if (lane_in == 0) {
+                res[slot] = synced ? 1u : 0u;   // a resident launch leaves the struct elided while it equals cur_mp
+            }
+        } else if (synced) {
             store_parms(cur, home_enh, lane_in);
         }
         wave_lds_sync();
-        copy_parms(home_prev, slot_prev, lane_in);
+        if (!prev_partial) {
+            copy_parms(home_prev, slot_prev, lane_in);
+        }
     }
 }
 
@@ -2473,6 +2552,29 @@ ambe2400_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ r
                            mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                            float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     ambe_stream_body<true, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// Resident state (DeviceTables::resident, mbx_process_batch_resident): the LDS-resident bodies with prev_mp_enhanced elided
+// while it equals cur_mp and prev_mp fetched lazily -- at every T, T = 1 included (sessions, queue mode).
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_IMBE_LDS_WAVES_PER_SIMD)
+imbe_stream_kernel_res(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                       mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                       float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<true, false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
+ambe_stream_kernel_res(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                       mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                       float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<false, true, false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
+ambe2400_stream_kernel_res(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                           mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                           float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<true, true, false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 __global__ void __launch_bounds__(64)

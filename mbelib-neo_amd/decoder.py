@@ -50,7 +50,11 @@ def _torch():
 
 
 class BatchDecoder:
-    def __init__(self, codec, streams, device=0, seeds=None, tables_blob=None):
+    """resident=True: the decoder owns the state between launches and uses the resident form (mbx_process_batch_resident,
+    include/mbx.h): prev_mp_enhanced elided while it equals cur_mp, prev_mp fetched lazily; state_numpy() materialises the
+    ABI triplets first.  PCM, results and state are bit-identical to the default."""
+
+    def __init__(self, codec, streams, device=0, seeds=None, tables_blob=None, resident=False):
         torch = _torch()
         self.codec = int(codec)
         self.streams = int(streams)
@@ -61,9 +65,19 @@ class BatchDecoder:
         rg = rng_default(self.streams) if seeds is None else rng_seeded(seeds)
         self.state = torch.from_numpy(st.view(np.uint8).reshape(-1)).to(self.device)
         self.rng = torch.from_numpy(rg.view(np.uint8).reshape(-1)).to(self.device)
+        self.resident = torch.zeros(self.streams, dtype=torch.int32, device=self.device) if resident else None
 
     # -- state access (host copies) --------------------------------------------------------
+    def materialize(self):
+        """resident decoders: write the elided prev_mp_enhanced structs out (no-op otherwise)"""
+        if self.resident is not None:
+            torch = _torch()
+            with torch.cuda.device(self.device):
+                _native.check(_native.lib().mbx_resident_materialize(self.streams, None, self.state.data_ptr(), self.resident.data_ptr(),
+                                                                     torch.cuda.current_stream().cuda_stream), "mbx_resident_materialize")
+
     def state_numpy(self):
+        self.materialize()
         return self.state.cpu().numpy().view(PARMS_DTYPE).reshape(self.streams, 3)
 
     def rng_numpy(self):
@@ -72,6 +86,8 @@ class BatchDecoder:
     def set_state(self, state, rng=None):
         torch = _torch()
         self.state.copy_(torch.from_numpy(np.ascontiguousarray(state).view(np.uint8).reshape(-1)))
+        if self.resident is not None:
+            self.resident.zero_()
         if rng is not None:
             self.rng.copy_(torch.from_numpy(np.ascontiguousarray(rng).view(np.uint8).reshape(-1)))
 
@@ -119,11 +135,18 @@ class BatchDecoder:
             return t.data_ptr() if t is not None else None
 
         with torch.cuda.device(self.device):   # the launcher works on the current device's context
-            rc = _native.lib().mbx_process_batch(
-                self.codec, self.streams, int(T), d_frames.data_ptr(), self.state.data_ptr(), self.rng.data_ptr(),
-                ptr(out["pcm16"]), ptr(out["pcmf"]), ptr(out["results"]), out["records"].data_ptr(),
-                torch.cuda.current_stream().cuda_stream,
-            )
+            if self.resident is not None:
+                rc = _native.lib().mbx_process_batch_resident(
+                    self.codec, self.streams, int(T), None, d_frames.data_ptr(), self.state.data_ptr(), self.resident.data_ptr(),
+                    self.rng.data_ptr(), ptr(out["pcm16"]), ptr(out["pcmf"]), ptr(out["results"]), out["records"].data_ptr(),
+                    torch.cuda.current_stream().cuda_stream,
+                )
+            else:
+                rc = _native.lib().mbx_process_batch(
+                    self.codec, self.streams, int(T), d_frames.data_ptr(), self.state.data_ptr(), self.rng.data_ptr(),
+                    ptr(out["pcm16"]), ptr(out["pcmf"]), ptr(out["results"]), out["records"].data_ptr(),
+                    torch.cuda.current_stream().cuda_stream,
+                )
         _native.check(rc, "mbx_process_batch")
         return out
 

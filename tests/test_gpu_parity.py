@@ -1107,6 +1107,49 @@ def test_ambe_tone_and_erasure_classes_in_lds_resident_launches(mbx, oracle):
     assert np.array_equal(np.asarray(state).view(np.uint8), np.asarray(got["state"]).view(np.uint8))
 
 
+@pytest.mark.parametrize("codec", [0, 1, 2, 3])
+def test_resident_state_is_bit_identical_to_the_abi_triplets(mbx, oracle, codec):
+    """Resident launches (mbx_process_batch_resident: prev_mp_enhanced elided while it equals cur_mp, prev_mp fetched lazily;
+    what sessions and the queue mode's device pool use) against the drop-in launcher on the same frames: launches of
+    T = 1, 1, 2, 4, 1, 3, 16, 1 frames per stream in a row -- random channel bits (repeats, mutes, headroom resets; AMBE: erasures
+    and tone classes by chance) and, for AMBE+2, scripted tone / invalid-tone / erasure sequences.  PCM and results must be
+    bit-identical launch by launch, and the materialised triplets bit-identical to the ones mbx_process_batch leaves -- after
+    every launch, i.e. from every mix of elided / whole structs.  ref include/mbelib-neo/mbelib.h:88-139 (the three structs)."""
+    import torch
+    from mbelib_neo_amd import decoder, framegen
+    from mbelib_neo_amd.layout import FRAME_BYTES
+
+    S = 768
+    fb = FRAME_BYTES[codec]
+    plan = [1, 1, 2, 4, 1, 3, 16, 1]
+    total = sum(plan)
+    rng = framegen.rng_for(900 + codec)
+    frames = framegen.random_frames(codec, S * total, rng).reshape(S, total, fb)
+    if codec == 1:   # scripted classes on the first 256 streams: every tone / erasure transition around launch boundaries
+        for s_ in range(256):
+            frames[s_] = _ambe_class_frames("".join(rng.choice(list("vvvtie"), size=total)), rng)
+    seeds = np.arange(S) + 31
+    a = decoder.BatchDecoder(codec, S, seeds=seeds)
+    b = decoder.BatchDecoder(codec, S, seeds=seeds, resident=True)
+    t0 = 0
+    for k, T in enumerate(plan):
+        chunk = np.ascontiguousarray(frames[:, t0:t0 + T]).reshape(-1, fb)
+        oa = a.decode(chunk, T, want_float=True)
+        ob = b.decode(chunk, T, want_float=True)
+        torch.cuda.synchronize()
+        assert torch.equal(oa["pcm16"], ob["pcm16"]), f"launch {k} (T={T}): int16 PCM differs"
+        assert oa["pcmf"].cpu().numpy().tobytes() == ob["pcmf"].cpu().numpy().tobytes(), f"launch {k} (T={T}): float PCM differs"
+        assert torch.equal(oa["results"], ob["results"]), f"launch {k} (T={T}): results differ"
+        if k % 2 == 1 or k == len(plan) - 1:   # materialise only now and then: the elided form must survive several launches
+            elided = int((b.resident != 0).sum().item())
+            sa, sb = a.state_numpy(), b.state_numpy()
+            assert int((b.resident != 0).sum().item()) == 0
+            assert sa.tobytes() == sb.tobytes(), f"after launch {k}: state triplets differ ({elided} streams were elided)"
+            assert a.rng_numpy().tobytes() == b.rng_numpy().tobytes()
+        t0 += T
+    assert elided > S // 2, "the resident form was hardly exercised"
+
+
 # ---- multi-GPU readiness (SURVEY.md §8(e)) -----------------------------------------------------------------------------
 def test_c_abi_rccl_table_broadcast_one_rank(mbx):
     """The C library's own collective (mbx_comm_* / mbx_init_broadcast: ncclBroadcast of the table blob + min/max all-reduce

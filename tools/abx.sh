@@ -14,6 +14,7 @@ for r in range(rounds):
             env = dict(os.environ)
             if n != "product":
                 env["MBX_HIP_LIBRARY"] = os.path.join(os.getcwd(), "mbelib-neo_amd", "variants", f"libmbx_hip_{n}.so")
+                env["MBX_HIP_LIBRARY_ALLOW_OLDER"] = "1"
             out = subprocess.run([sys.executable, "bench.py", "--workload", w, "--steps", "10", "--no-cpu-baseline", "--no-extras"],
                                  env=env, capture_output=True, text=True)
             try:

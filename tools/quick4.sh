@@ -2,7 +2,7 @@
 # quick4.sh [label] -- GPU box: kernel time of the four BASELINE workloads with the library in the tree (development aid)
 cd "$(dirname "$0")/.."
 L=${1:-q}
-for w in imbe_voiced imbe_mixed ambe_fec ambe_stream; do
+for w in imbe_voiced imbe_voiced_resident imbe_mixed ambe_fec ambe_stream; do
   python bench.py --workload $w --steps 10 --no-cpu-baseline --no-extras > gpurun_out/${L}_$w.log 2> gpurun_out/${L}_$w.err || { tail -5 gpurun_out/${L}_$w.err; exit 1; }
   python - "$w" "gpurun_out/${L}_$w.log" <<'PY'
 import json, sys
