@@ -558,6 +558,7 @@ struct Batch {
     std::unordered_map<const mbe_parms*, int> aux;        // prev_mp / prev_mp_enhanced -> channel (direct use of either struct)
     DevArr<mbe_parms>      d_state;                       // [channels][3]
     DevArr<mbx_stream_rng> d_rng;
+    DevArr<uint32_t>       d_elided;                      // resident mode: prev_mp_enhanced of the slot is elided (mbx_process_batch_resident)
     size_t                 resident = 0;                  // channels [0, resident) hold their state on the device
     DevArr<uint8_t>            d_frames;
     DevArr<mbx_param_record>   d_records;
@@ -600,21 +601,28 @@ void pool_reserve(Batch& b, Slot& s, size_t n) {
     const size_t cap = n + n / 2 + 64;
     mbe_parms* ns = nullptr;
     mbx_stream_rng* nr = nullptr;
+    uint32_t* ne = nullptr;
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&ns), cap * 3 * sizeof(mbe_parms)));
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&nr), cap * sizeof(mbx_stream_rng)));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&ne), cap * sizeof(uint32_t)));
+    HIP_OK(hipMemsetAsync(ne, 0, cap * sizeof(uint32_t), s.stream));
     if (b.resident) {
         HIP_OK(hipMemcpyAsync(ns, b.d_state.p, b.resident * 3 * sizeof(mbe_parms), hipMemcpyDeviceToDevice, s.stream));
         HIP_OK(hipMemcpyAsync(nr, b.d_rng.p, b.resident * sizeof(mbx_stream_rng), hipMemcpyDeviceToDevice, s.stream));
-        s.sync();
+        HIP_OK(hipMemcpyAsync(ne, b.d_elided.p, b.resident * sizeof(uint32_t), hipMemcpyDeviceToDevice, s.stream));
     }
+    s.sync();
     if (b.d_state.p) {
         HIP_OK(hipFree(b.d_state.p));
         HIP_OK(hipFree(b.d_rng.p));
+        HIP_OK(hipFree(b.d_elided.p));
     }
     b.d_state.p = ns;
     b.d_state.cap = cap * 3;
     b.d_rng.p = nr;
     b.d_rng.cap = cap;
+    b.d_elided.p = ne;
+    b.d_elided.cap = cap;
 }
 
 // bring the state held in pool slots [first, first + count) back into the host structs of the channels that own them
@@ -625,6 +633,11 @@ void pool_download(Batch& b, Slot& s, size_t first, const std::vector<int>& owne
         return;
     }
     b.h_state.need(count * 3);
+    // resident mode launches through mbx_process_batch_resident: the elided prev_mp_enhanced structs are written out first, so
+    // that what goes home is the ABI triplet (bit-identical to what the synchronous calls would have left)
+    if (b.mode == MBE_BATCH_STATE_RESIDENT) {
+        must(mbx_resident_materialize((int)count, nullptr, b.d_state.p + 3 * first, b.d_elided.p + first, s.stream), "mbx_resident_materialize");
+    }
     s.down(b.h_state.p, b.d_state.p + 3 * first, count * 3 * sizeof(mbe_parms));
     if (with_rng) {
         b.h_rng.need(count);
@@ -707,6 +720,7 @@ int flush_batch(Batch& b) {
         }
         s.up(b.d_state.p + 3 * first_slot, b.h_state.p, upload.size() * 3 * sizeof(mbe_parms));
         s.up(b.d_rng.p + first_slot, b.h_rng.p, upload.size() * sizeof(mbx_stream_rng));
+        HIP_OK(hipMemsetAsync(b.d_elided.p + first_slot, 0, upload.size() * sizeof(uint32_t), s.stream));   // whole triplets came up
         b.resident = first_slot + upload.size();
     }
     // ---- groups of channels with the same codec and the same number of pending frames ----
@@ -787,11 +801,19 @@ int flush_batch(Batch& b) {
     s.up(b.d_index.p, b.h_index.p, idx0 * sizeof(int32_t));
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Group& g = groups[gi];
-        must(mbx_process_batch_indexed(g.codec, (int)g.nch, g.T, b.d_index.p + index_off[gi], b.d_frames.p + g.byte0, b.d_state.p,
-                                       b.d_rng.p, any_short ? b.d_pcm16.p + g.row0 * 160 : nullptr,
-                                       any_float ? b.d_pcmf.p + g.row0 * 160 : nullptr, b.d_results.p + g.row0,
-                                       b.d_records.p + g.row0, s.stream),
-             "mbx_process_batch_indexed");
+        if (b.mode == MBE_BATCH_STATE_RESIDENT) {   // the pool owns the state between flushes: no prev_mp_enhanced traffic, lazy prev_mp
+            must(mbx_process_batch_resident(g.codec, (int)g.nch, g.T, b.d_index.p + index_off[gi], b.d_frames.p + g.byte0, b.d_state.p,
+                                            b.d_elided.p, b.d_rng.p, any_short ? b.d_pcm16.p + g.row0 * 160 : nullptr,
+                                            any_float ? b.d_pcmf.p + g.row0 * 160 : nullptr, b.d_results.p + g.row0,
+                                            b.d_records.p + g.row0, s.stream),
+                 "mbx_process_batch_resident");
+        } else {
+            must(mbx_process_batch_indexed(g.codec, (int)g.nch, g.T, b.d_index.p + index_off[gi], b.d_frames.p + g.byte0, b.d_state.p,
+                                           b.d_rng.p, any_short ? b.d_pcm16.p + g.row0 * 160 : nullptr,
+                                           any_float ? b.d_pcmf.p + g.row0 * 160 : nullptr, b.d_results.p + g.row0,
+                                           b.d_records.p + g.row0, s.stream),
+                 "mbx_process_batch_indexed");
+        }
     }
     // ---- outputs: the small arrays first, then the PCM in chunks -- the host hands chunk k to the callers' buffers while
     //      chunk k + 1 is still crossing PCIe (the scatter is as long as the copy: 5 MB per 16,384 frames each) ----
@@ -880,6 +902,7 @@ void release_channel(Batch& b, int c) {
             HIP_OK(hipMemcpyAsync(b.d_state.p + 3 * (size_t)c, b.d_state.p + 3 * last, 3 * sizeof(mbe_parms), hipMemcpyDeviceToDevice,
                                   s.stream));
             HIP_OK(hipMemcpyAsync(b.d_rng.p + c, b.d_rng.p + last, sizeof(mbx_stream_rng), hipMemcpyDeviceToDevice, s.stream));
+            HIP_OK(hipMemcpyAsync(b.d_elided.p + c, b.d_elided.p + last, sizeof(uint32_t), hipMemcpyDeviceToDevice, s.stream));
             s.sync();
         }
         b.resident = last;
