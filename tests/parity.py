@@ -5,7 +5,15 @@ flags, return codes, L/K/Vl, repeat counters, thresholds, the LCG noise state); 
 relative RMS <= 1e-4 per batch and <= 1e-3 for the worst single frame; int16 PCM within
 1 LSB on >= 99.9 % of samples and never more than 3 LSB -- except in frames that are driven INTO THE SOFT CLIP
 (a float sample of the reference at +-4446.95, i.e. harmonic amplitudes beyond the output range: random channel bits
-decode to 60,000-80,000 against +-4,447), where the bound is 6 LSB.
+decode to 60,000-80,000 against +-4,447), where the bound is 4 LSB: the worst difference observed in 94 M samples, pinned
+by the fixture below (SURVEY.md section 8(c) says 3 everywhere; this is the one stated deviation from it).  check_pcm also
+fails when more than 35 % of a workload's frames fall under the clipped bound (random channel bits: 20 %), so a workload
+cannot drift under the looser bound unnoticed.
+
+WHICH CHECKER: `ref_*` arguments come either from the ORACLE (oracle/mbx_oracle.c: the CPU restatement, whose unvoiced FFT
+is double precision -- 6e-8 relative away from the reference's float PFFFT; every integer and every decision identical to
+the real reference on 131,072 random frames per codec, oracle/_ref/cmp_ref) or from a GOLDEN FIXTURE written by the real
+reference (tests/golden/*.bin via oracle/_ref: float PFFFT).  Each test says in its docstring which of the two it uses.
 
 Why the clipped frames have their own bound (tests/golden/tail_cases.npz, test_tail_cases_*): the samples that are NOT
 clipped in such a frame are where a sum of amplitude ~1e5 happens to cross the output range, so an error of 5e-6 of the
@@ -23,7 +31,8 @@ PCM_REL_RMS = 1e-4
 PCM_WORST_FRAME = 1e-3
 STATE_REL_RMS = 1e-4
 INT16_MAX_LSB = 3            # frames below the clip
-INT16_MAX_LSB_CLIPPED = 6    # frames with a sample at the soft-clip level (see the module docstring)
+INT16_MAX_LSB_CLIPPED = 4    # frames with a sample at the soft-clip level: the observed worst case (see the module docstring)
+MAX_CLIPPED_SHARE = 0.35     # of a workload's frames (random channel bits drive 20 % of the frames into the clip)
 CLIP_LEVEL = 32767.0 * 0.95 / 7.0   # ref src/core/mbelib.c:1148-1177 soft clip of the float PCM
 
 
@@ -63,6 +72,7 @@ def check_pcm(ref_f, got_f, ref_s=None, got_s=None, rel=PCM_REL_RMS, worst=PCM_W
         assert below <= INT16_MAX_LSB, f"{what}: int16 differs by {below} LSB in a frame below the clip"
         assert inside <= INT16_MAX_LSB_CLIPPED, f"{what}: int16 differs by {inside} LSB in a clipped frame"
         assert frac >= 0.999, f"{what}: only {frac:.5f} of int16 samples within 1 LSB"
+        assert float(np.mean(clip)) <= MAX_CLIPPED_SHARE, f"{what}: {np.mean(clip):.2f} of the frames reach the soft clip -- too many for the clipped-frame bound to govern"
         out["int16_exact"] = float(np.mean(d == 0))
         out["int16_max"] = int(d.max())
         out["int16_max_below_clip"] = below

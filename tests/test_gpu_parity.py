@@ -361,6 +361,88 @@ def test_ambe_long_streams_config5_shape(mbx, oracle):
     assert a[0].tobytes() == c[0].tobytes() and a[1].tobytes() == c[1].tobytes()
 
 
+def _full_shape_run(codec, S, splits, frames, seeds, d_pick, resident=False):
+    """decode S streams in launches of `splits` frames each; returns (pcm16, pcmf, results) of the picked streams, the final
+    state / rng, and a digest over every int16 sample of every stream"""
+    import torch
+    from mbelib_neo_amd import decoder
+    from mbelib_neo_amd.layout import FRAME_BYTES
+
+    fb = FRAME_BYTES[codec]
+    dec = decoder.BatchDecoder(codec, S, seeds=seeds, resident=resident)
+    pcs, pfs, res, digest = [], [], [], 0
+    t0 = 0
+    for t in splits:
+        out = dec.decode(np.ascontiguousarray(frames[:, t0:t0 + t]).reshape(-1, fb), t, want_float=True)
+        pcs.append(out["pcm16"].reshape(S, t, 160)[d_pick])
+        pfs.append(out["pcmf"].reshape(S, t, 160)[d_pick])
+        res.append(out["results"].reshape(S, t, 5)[d_pick])
+        digest += out["pcm16"].to(torch.int64).sum().item() * (t0 + 1)
+        t0 += t
+        del out
+    torch.cuda.synchronize()
+    return (torch.cat(pcs, dim=1).cpu().numpy(), torch.cat(pfs, dim=1).cpu().numpy(), torch.cat(res, dim=1).cpu().numpy(),
+            dec.state_numpy(), dec.rng_numpy(), digest)
+
+
+def test_ambe_fec_config3_full_shape(mbx, oracle):
+    """BASELINE configs[2] at its full shape through the kernel bench.py times for it: 65,536 AMBE+2 streams x T = 1 per launch
+    (`ambe_stream_kernel`, the HBM-slot instance), clean voice frames with 1 % bit flips, four ticks in a row so that the
+    state is warm.  HIP vs ORACLE (the CPU restatement, double-precision FFT) on a strided sample of 264 streams: results
+    exact, PCM / state in tolerance; every other stream through determinism (a second run is bit-identical in every int16
+    sample, state and RNG) and through the resident form (bit-identical again)."""
+    import torch
+    from mbelib_neo_amd import framegen
+    from mbelib_neo_amd.layout import RESULT_DTYPE
+
+    S, T = 65536, 4
+    frames = framegen.ambe_noisy_voice_frames(S * T, framegen.rng_for(203), ber=0.01).reshape(S, T, 9)
+    seeds = np.arange(S) + 4321
+    pick = np.arange(5, S, 249)
+    assert len(pick) >= 256
+    d_pick = torch.from_numpy(pick).cuda()
+    a = _full_shape_run(1, S, [1, 1, 1, 1], frames, seeds, d_pick)
+    assert mbx.lib().mbx_stream_kernel_name(1, 1) == b"ambe_stream_kernel"
+    ref = oracle.process_batch(1, len(pick), T, frames[pick].reshape(-1, 9), oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
+    parity.check_results(ref["results"], np.ascontiguousarray(a[2]).view(RESULT_DTYPE).reshape(-1))
+    m = parity.check_pcm(ref["pcmf"], a[1].reshape(-1, 160), ref["pcm16"], a[0].reshape(-1, 160))
+    print("AMBE+2 65,536 x 1 x 4 ticks:", m)
+    parity.check_state(ref["state"], a[3][pick])
+    b = _full_shape_run(1, S, [1, 1, 1, 1], frames, seeds, d_pick)
+    assert a[5] == b[5] and a[3].tobytes() == b[3].tobytes() and a[4].tobytes() == b[4].tobytes() and a[0].tobytes() == b[0].tobytes()
+    c = _full_shape_run(1, S, [1, 1, 1, 1], frames, seeds, d_pick, resident=True)
+    assert a[5] == c[5] and a[3].tobytes() == c[3].tobytes() and a[1].tobytes() == c[1].tobytes()
+
+
+def test_imbe_mixed_config4_full_shape(mbx, oracle):
+    """BASELINE configs[3] at the shape bench.py runs it: 65,536 IMBE streams x T = 16 random-bit frames (mixed voiced /
+    unvoiced, repeats, mutes) in ONE launch of `imbe_stream_kernel_lds`.  HIP vs ORACLE on a strided sample of 260 streams
+    over all 16 frames; every other stream through determinism and through the 8 + 8 split (state through HBM in between)."""
+    import torch
+    from mbelib_neo_amd import framegen
+    from mbelib_neo_amd.layout import RESULT_DTYPE
+
+    S, T = 65536, 16
+    frames = framegen.random_frames(0, S * T, framegen.rng_for(204)).reshape(S, T, 18)
+    seeds = np.arange(S) + 99
+    pick = np.arange(11, S, 253)
+    assert len(pick) >= 256
+    d_pick = torch.from_numpy(pick).cuda()
+    a = _full_shape_run(0, S, [16], frames, seeds, d_pick)
+    assert mbx.lib().mbx_stream_kernel_name(0, 16) == b"imbe_stream_kernel_lds"
+    ref = oracle.process_batch(0, len(pick), T, frames[pick].reshape(-1, 18), oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
+    parity.check_results(ref["results"], np.ascontiguousarray(a[2]).view(RESULT_DTYPE).reshape(-1))
+    m = parity.check_pcm(ref["pcmf"], a[1].reshape(-1, 160), ref["pcm16"], a[0].reshape(-1, 160))
+    print("IMBE 65,536 x 16:", m)
+    parity.check_state(ref["state"], a[3][pick])
+    flags = ref["results"]["flags"]
+    assert (flags & 0x40).any() and (flags & 0x80).any()   # repeats and mutes are in the sample
+    b = _full_shape_run(0, S, [16], frames, seeds, d_pick)
+    assert a[5] == b[5] and a[3].tobytes() == b[3].tobytes() and a[4].tobytes() == b[4].tobytes() and a[0].tobytes() == b[0].tobytes()
+    c = _full_shape_run(0, S, [8, 8], frames, seeds, d_pick)
+    assert a[3].tobytes() == c[3].tobytes() and a[4].tobytes() == c[4].tobytes() and a[0].tobytes() == c[0].tobytes() and a[1].tobytes() == c[1].tobytes()
+
+
 @pytest.mark.parametrize("codec", [0, 1, 2, 3])
 def test_lds_resident_and_hbm_slot_kernel_instances_are_identical(mbx, oracle, codec):
     """Launches with T >= 4 frames per stream take the stream-kernel instance that keeps prev_mp / prev_mp_enhanced in LDS
