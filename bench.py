@@ -658,10 +658,12 @@ def main():
         "basis": fpf_basis,
     }
     issue = line["roofline"].get("issue") or {}
-    # measured, not modelled: VALU issue utilisation of the dominant kernel from the SQ counters of this build (instruction counts
+    # MODELLED from measured counts: VALU issue utilisation of the dominant kernel from the SQ counters of this build (instruction counts
     # priced with the per-instruction costs tools/valu_issue.hip measured), None without a matching summary
-    line["valu"]["measured_busy"] = issue.get("valu_issue_utilisation")
-    line["valu"]["measured_busy_source"] = issue.get("source") or issue.get("stale")
+    line["valu"]["modelled_valu_issue_utilisation"] = issue.get("valu_issue_utilisation")               # every instruction at the cost of the expensive class
+    line["valu"]["modelled_valu_issue_utilisation_lower_bound"] = issue.get("valu_issue_utilisation_lower_bound")
+    line["valu"]["cost_model"] = issue.get("valu_cost_model")   # per-instruction costs from tools/valu_issue.hip at FOUR waves per SIMD; the kernels run at 3.8-7
+    line["valu"]["modelled_source"] = issue.get("source") or issue.get("stale")
     extras = world == 1 and not args.no_extras and not args.ablate and not args.streams
     if extras:
         # the library's default order for back-to-back launches over the same state: a launch walks the streams in the

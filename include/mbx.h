@@ -98,6 +98,10 @@ size_t mbx_workspace_bytes(size_t max_frames);
  *       same size that RECEIVES it.  One ncclBroadcast moves the bytes GPU to GPU, every rank then runs
  *       mbx_init(device, blob, bytes) on its copy, and an ncclAllReduce (min, max) of the per-rank mbx_table_checksum()
  *       must coincide -- MBX_EBADTABLE otherwise.  minmax (may be NULL) receives {min, max}.
+ *       A rank whose copy fails that validation still takes part in the agreement (with a pair that cannot agree), so every
+ *       rank returns -- the failed one with its own error, the others with MBX_EBADTABLE -- instead of waiting for ever.
+ *   mbx_comm_agree(comm, value, minmax, stream)
+ *       the agreement step alone: 0 when every rank passed the same 32-bit value, MBX_EBADTABLE on every rank otherwise.
  *   mbx_comm_unique_id(id)  rank 0 makes the 128-byte id and hands it to the other ranks by whatever channel the host has
  *   mbx_comm_init(&comm, nranks, id, rank, device) / mbx_comm_destroy(comm)
  *       ncclCommInitRank / ncclCommDestroy for hosts that do not want the RCCL headers; one rank per GPU. */
@@ -105,6 +109,7 @@ size_t mbx_workspace_bytes(size_t max_frames);
 int mbx_comm_unique_id(void* id128);
 int mbx_comm_init(void** comm, int nranks, const void* id128, int rank, int device);
 int mbx_comm_destroy(void* comm);
+int mbx_comm_agree(void* comm, uint32_t value, uint32_t* min_max, void* stream);
 int mbx_init_broadcast(void* comm, int root, int device, void* table_blob, size_t table_bytes, uint32_t* checksums_min_max,
                        void* stream);
 

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "mbx_comm_unique_id": (C.c_int, [_vp]),
     "mbx_comm_init": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
     "mbx_comm_destroy": (C.c_int, [_vp]),
+    "mbx_comm_agree": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "mbx_init_broadcast": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
     "mbx_pack_imbe7200x4400": (C.c_int, [_vp, _sz, _vp]),
     "mbx_pack_ambe3600x2450": (C.c_int, [_vp, _sz, _vp]),

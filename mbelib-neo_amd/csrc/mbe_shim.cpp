@@ -204,6 +204,11 @@ struct SlotHolder {
     Slot* p = nullptr;
     ~SlotHolder() {
         if (p) {
+            // the stream's workspace slot lives in the context of g_device: a host that has switched devices on this thread must
+            // not have the release resolved against another device's context (the slot would leak, keyed by a dead hipStream_t)
+            int before = -1;
+            (void)hipGetDevice(&before);
+            (void)hipSetDevice(g_device);
             (void)hipStreamSynchronize(p->stream);
             (void)mbx_release_stream(p->stream);
             if (p->batch_done) {
@@ -216,6 +221,9 @@ struct SlotHolder {
             }
             (void)hipStreamDestroy(p->stream);
             (void)hipHostFree(p->block);
+            if (before >= 0 && before != g_device) {
+                (void)hipSetDevice(before);
+            }
             (void)hipGetLastError();
             delete p;
         }

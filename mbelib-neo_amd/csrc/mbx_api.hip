@@ -157,7 +157,11 @@ void free_context(Context& c) {   // caller holds g_init_mu and c.mu
 }
 
 int lds_min_frames() {   // frames per stream from which the LDS-resident instances are used (MBX_LDS_MIN_FRAMES: A/B timing)
-    static const int v = getenv("MBX_LDS_MIN_FRAMES") ? atoi(getenv("MBX_LDS_MIN_FRAMES")) : 4;
+    static const int v = [] {
+        const char* e = getenv("MBX_LDS_MIN_FRAMES");
+        const int n = e ? atoi(e) : 4;
+        return (n >= 1 && n <= 1 << 20) ? n : 4;   // anything else (0, negative, not a number) is ignored
+    }();
     return v;
 }
 #define kLdsResidentMinFrames lds_min_frames()

@@ -100,6 +100,18 @@ struct DevBytes {
     }
 };
 
+// min and max over the ranks of one 32-bit value (two all-reduces of one word each); `failed`: this rank contributes
+// (0, 0xffffffff) instead, which no set of honest values can equal.  0 when every rank passed the same value.
+int agree(const Rccl* R, ncclComm_t c, uint32_t value, bool failed, uint32_t* d /* 4 words of device memory */, uint32_t out[2], hipStream_t st) {
+    const uint32_t in[2] = {failed ? 0u : value, failed ? 0xffffffffu : value};
+    H_TRY(hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, st));
+    N_TRY(R, R->AllReduce(d, d + 2, 1, ncclUint32, ncclMin, c, st));
+    N_TRY(R, R->AllReduce(d + 1, d + 3, 1, ncclUint32, ncclMax, c, st));
+    H_TRY(hipMemcpyAsync(out, d + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    H_TRY(hipStreamSynchronize(st));
+    return (out[0] == out[1] && !failed) ? 0 : MBX_EBADTABLE;
+}
+
 }  // namespace
 
 extern "C" {
@@ -175,29 +187,49 @@ int mbx_init_broadcast(void* comm, int root, int device, void* table_blob, size_
     if (rank != root) {
         H_TRY(hipMemcpyAsync(table_blob, blob.p, table_bytes, hipMemcpyDeviceToHost, st));
     }
-    H_TRY(hipStreamSynchronize(st));
-    int rc = mbx_init(device, table_blob, table_bytes);   // validates magic / version / checksum of what arrived
-    if (rc < 0) {
-        return rc;
+    // From here on every rank takes part in the agreement below WHATEVER happened to it locally: a rank that returned early
+    // (a blob that fails mbx_init's magic / checksum test is exactly the case this function exists to catch) would leave the
+    // others blocked in the all-reduce for ever.  A failed rank contributes a pair that cannot agree and reports its own error.
+    int local_rc = 0;
+    if (hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError();
+        local_rc = cfail(MBX_ENODEVICE, "mbx_init_broadcast: the broadcast did not complete on this rank");
     }
-    // every rank decodes with the same tables: min and max of the per-rank checksums must coincide
-    const uint32_t mine = mbx_table_checksum();
-    const uint32_t in[2] = {mine, mine};
+    if (local_rc == 0) {
+        local_rc = mbx_init(device, table_blob, table_bytes);   // validates magic / version / checksum of what arrived
+    }
     uint32_t out[2] = {0u, 0u};
-    uint32_t* d = static_cast<uint32_t*>(sums.p);
-    H_TRY(hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, st));
-    N_TRY(R, R->AllReduce(d, d + 2, 1, ncclUint32, ncclMin, c, st));
-    N_TRY(R, R->AllReduce(d + 1, d + 3, 1, ncclUint32, ncclMax, c, st));
-    H_TRY(hipMemcpyAsync(out, d + 2, sizeof(out), hipMemcpyDeviceToHost, st));
-    H_TRY(hipStreamSynchronize(st));
+    const int arc = agree(R, c, local_rc == 0 ? mbx_table_checksum() : 0u, local_rc != 0, static_cast<uint32_t*>(sums.p), out, st);
     if (checksums_min_max) {
         checksums_min_max[0] = out[0];
         checksums_min_max[1] = out[1];
     }
-    if (out[0] != out[1] || out[0] != mine) {
-        return cfail(MBX_EBADTABLE, "mbx_init_broadcast: the table checksums differ between ranks");
+    if (local_rc < 0) {
+        return local_rc;
     }
-    return 0;
+    if (arc == MBX_EBADTABLE) {
+        return cfail(MBX_EBADTABLE, "mbx_init_broadcast: the table checksums differ between ranks (or a rank failed to initialise)");
+    }
+    return arc;
+}
+
+int mbx_comm_agree(void* comm, uint32_t value, uint32_t* min_max, void* stream) {
+    const Rccl* R = rccl();
+    if (!R) {
+        return MBX_ENODEVICE;
+    }
+    if (!comm) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    DevBytes sums;
+    H_TRY(hipMalloc(&sums.p, 4 * sizeof(uint32_t)));
+    uint32_t out[2] = {0u, 0u};
+    const int rc = agree(R, static_cast<ncclComm_t>(comm), value, false, static_cast<uint32_t*>(sums.p), out, static_cast<hipStream_t>(stream));
+    if (min_max) {
+        min_max[0] = out[0];
+        min_max[1] = out[1];
+    }
+    return rc == MBX_EBADTABLE ? cfail(MBX_EBADTABLE, "mbx_comm_agree: the ranks passed different values") : rc;
 }
 
 }  // extern "C"

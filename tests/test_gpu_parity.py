@@ -1233,30 +1233,79 @@ def test_resident_state_is_bit_identical_to_the_abi_triplets(mbx, oracle, codec)
 
 
 # ---- multi-GPU readiness -----------------------------------------------------------------------------
-def test_c_abi_rccl_table_broadcast_one_rank(mbx):
-    """The C library's own collective (mbx_comm_* / mbx_init_broadcast: ncclBroadcast of the table blob + min/max all-reduce
-    of the per-rank checksums), with the one rank a one-GPU box has: communicator from a unique id, broadcast, upload,
-    checksum agreement.  RCCL is bound at run time; libmbx_hip.so must not carry a link-time dependency on it."""
+def test_c_abi_rccl_table_broadcast_every_visible_device(mbx):
+    """The C library's own collective (mbx_comm_* / mbx_init_broadcast / mbx_comm_agree: ncclBroadcast of the table blob + min/max
+    all-reduce of the per-rank checksums) with ONE RANK PER VISIBLE DEVICE, one host thread each, in this process: rank 0 passes
+    the blob, every other rank an empty buffer that must come back filled with it; every rank ends initialised with the same
+    checksum.  Then the failure paths, which must RETURN on every rank instead of hanging: a rank that passes a different value to
+    mbx_comm_agree (needs >= 2 devices), and a root whose blob is corrupt (mbx_init refuses it on every rank: the ranks still meet
+    in the agreement).  On a one-GPU box this is the one-rank case; on the first multi-GPU box it runs the non-root and mismatch
+    branches without anyone editing it.  RCCL is bound at run time; libmbx_hip.so must not carry a link-time dependency on it."""
     import ctypes as C
     import subprocess
+    import threading
 
+    import torch
     from mbelib_neo_amd import _native
+    MBX_EBADTABLE = -102   # include/mbx.h
 
     L = _native.lib()
     needed = subprocess.run(["objdump", "-p", _native.library_path()], capture_output=True, text=True).stdout
     assert "librccl" not in needed
-    blob = mbx.load_tables_blob()
+    blob = bytes(mbx.load_tables_blob())
+    N = torch.cuda.device_count()
     ident = C.create_string_buffer(128)
     _native.check(L.mbx_comm_unique_id(ident), "mbx_comm_unique_id")
-    comm = C.c_void_p()
-    _native.check(L.mbx_comm_init(C.byref(comm), 1, ident, 0, 0), "mbx_comm_init")
-    buf = C.create_string_buffer(bytes(blob), len(blob))
-    minmax = (C.c_uint32 * 2)()
-    _native.check(L.mbx_init_broadcast(comm, 0, 0, buf, len(blob), minmax, None), "mbx_init_broadcast")
-    assert minmax[0] == minmax[1] == L.mbx_table_checksum() != 0
-    assert L.mbx_init_broadcast(comm, 1, 0, buf, len(blob), minmax, None) < 0      # root outside the communicator
-    assert L.mbx_init_broadcast(comm, 0, 0, buf, len(blob) - 4, minmax, None) < 0  # not a table blob
-    _native.check(L.mbx_comm_destroy(comm), "mbx_comm_destroy")
+    out = [dict() for _ in range(N)]
+
+    def rank_main(r):
+        o = out[r]
+        try:
+            comm = C.c_void_p()
+            o["init"] = L.mbx_comm_init(C.byref(comm), N, ident, r, r)
+            if o["init"] < 0:
+                return
+            buf = C.create_string_buffer(blob if r == 0 else bytes(len(blob)), len(blob))
+            minmax = (C.c_uint32 * 2)()
+            o["bcast"] = L.mbx_init_broadcast(comm, 0, r, buf, len(blob), minmax, None)
+            o["blob_ok"] = buf.raw == blob
+            o["minmax"] = (minmax[0], minmax[1])
+            o["checksum"] = L.mbx_table_checksum()   # (of the calling thread's current device: set by mbx_init_broadcast)
+            o["agree_same"] = L.mbx_comm_agree(comm, 7, minmax, None)
+            o["agree_diff"] = L.mbx_comm_agree(comm, 7 if r + 1 < N or N == 1 else 8, minmax, None)
+            o["agree_diff_minmax"] = (minmax[0], minmax[1])
+            bad = bytearray(blob if r == 0 else bytes(len(blob)))
+            if r == 0:
+                bad[len(bad) // 2] ^= 0x40   # the root's copy is corrupt: what arrives fails mbx_init's checksum test on every rank
+            buf2 = C.create_string_buffer(bytes(bad), len(bad))
+            o["bcast_bad"] = L.mbx_init_broadcast(comm, 0, r, buf2, len(blob), minmax, None)
+            o["bad_args"] = (L.mbx_init_broadcast(comm, N, r, buf, len(blob), minmax, None),       # root outside the communicator
+                             L.mbx_init_broadcast(comm, 0, r, buf, len(blob) - 4, minmax, None))   # not a table blob
+            o["destroy"] = L.mbx_comm_destroy(comm)
+        except Exception as e:   # noqa: BLE001
+            o["exception"] = repr(e)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), f"a rank is stuck in a collective: {out}"
+    sums = {o.get("checksum") for o in out}
+    for r, o in enumerate(out):
+        assert "exception" not in o, (r, o)
+        assert o["init"] == 0 and o["bcast"] == 0 and o["blob_ok"], (r, o)
+        assert o["minmax"][0] == o["minmax"][1] == o["checksum"] != 0, (r, o)
+        assert o["agree_same"] == 0, (r, o)
+        if N > 1:
+            assert o["agree_diff"] == MBX_EBADTABLE and o["agree_diff_minmax"] == (7, 8), (r, o)   # on EVERY rank
+        else:
+            assert o["agree_diff"] == 0
+        assert o["bcast_bad"] < 0, (r, o)                                   # every rank returns, none hangs
+        assert o["bad_args"][0] < 0 and o["bad_args"][1] < 0 and o["destroy"] == 0, (r, o)
+    assert len(sums) == 1
+    torch.cuda.set_device(0)   # (mbx_init refuses a corrupt blob before it touches the device's context: the good tables are still there)
+    assert L.mbx_table_checksum() == out[0]["checksum"]
 
 
 def test_every_visible_device_decodes(mbx, oracle):

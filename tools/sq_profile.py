@@ -118,7 +118,7 @@ def issue_model(c, kernel_ns, frames):
                        "issuing": g("SQ_ACTIVE_INST_ANY", 0.0) / wave_q} if wave_q else None),
     }
     m["per_frame"]["valu_f64"] = (g("SQ_INSTS_VALU_FMA_F64", 0.0) + g("SQ_INSTS_VALU_MUL_F64", 0.0) + g("SQ_INSTS_VALU_ADD_F64", 0.0)) / frames
-    m["measured_busy"] = m["valu_issue_utilisation"]
+    m["modelled_valu_issue_utilisation"] = m["valu_issue_utilisation"]   # SQ instruction COUNTS priced with the microbenchmark's per-instruction costs: a model
     return m
 
 
