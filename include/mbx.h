@@ -228,6 +228,24 @@ int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_recor
  * frames of a batch instead of a DMA copy, which would queue behind the previous batch's PCM on the copy engine */
 int mbx_stage_in(void* d_dst, const void* pinned_src, size_t bytes, void* stream);
 
+/* A FRAME SERVER: one wavefront that stays on the device and serves mbx_process_frame requests from a mailbox in pinned,
+ * coherent host memory (hipHostMalloc(..., hipHostMallocCoherent), 64-byte aligned) -- the path of a host that calls the
+ * synchronous mbe_process*Frame[f] back to back.  A launch per call costs the launch itself (~5 us) and an instruction cache
+ * that every dispatch starts cold (~3 us of a 16 us kernel); a served request costs neither.
+ *   the buffers (state triplet, rng, PCM, result, record: the arguments of mbx_process_frame, device-accessible) are fixed when
+ *   the server starts; a request names the codec, the outputs wanted and carries the wire frame.
+ *   host, per request:  write codec / want / frame into the mailbox, then store ++seq_in with release order (everything in
+ *                       ONE 64-byte line: the server reads it with one load); complete when seq_out == seq_in (acquire load).
+ *   server:             polls that line; exits -- after storing alive = 0, touching nothing afterwards -- when quit != 0, when
+ *                       no request has arrived for idle_us microseconds, or after 2 s (it cannot outlive its host by more, and
+ *                       a device-wide synchronisation elsewhere in the process is held up by idle_us at most).  A request that
+ *                       arrives while alive == 0 is NOT served: the host sets alive = 1 and starts a server again (same
+ *                       mailbox, same stream: it queues behind the one that is leaving), which finds seq_in != seq_out.
+ * mbx_frame_server_start launches the wavefront on `stream` (a stream of its own: it occupies the stream while it lives).
+ * (struct mbx_frame_mailbox: include/mbx_types.h) */
+int mbx_frame_server_start(mbx_frame_mailbox* mailbox, unsigned idle_us, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
+                           float* d_pcmf, mbe_process_result* d_result, mbx_param_record* d_record, void* stream);
+
 /* ONE frame of ONE stream as one launch of one wavefront (FEC + parameter decode + policy + synthesis + float->int16):
  * what the synchronous mbe_process*Frame[f] of libmbe_neo_amd.so issue.
  *   ref: mbe_processImbe7200x4400Frame[f]  include/mbelib-neo/mbelib.h:429-441, mbe_processAmbe3600x2450Frame[f] :505-517,

@@ -146,4 +146,17 @@ MBX_STATIC_ASSERT(sizeof(mbe_process_result) == 20, "mbe_process_result");
 MBX_STATIC_ASSERT(sizeof(mbx_stream_rng) == 24, "mbx_stream_rng");
 MBX_STATIC_ASSERT(sizeof(mbx_param_record) == 16, "mbx_param_record");
 
+/* request mailbox of a frame server (include/mbx.h, mbx_frame_server_start): pinned, coherent host memory */
+typedef struct mbx_frame_mailbox {
+    /* the REQUEST: one 64-byte line, written by the host -- fields first, seq_in last -- and read by the server with ONE load,
+     * so a snapshot that shows the new seq_in shows the whole request */
+    uint32_t seq_in, quit;
+    int32_t  codec;
+    uint32_t want;                                   /* bit 0: int16 PCM, bit 1: float PCM */
+    uint8_t  frame[24];                              /* the wire frame (18 | 9 bytes) */
+    uint32_t pad0[6];
+    uint32_t seq_out, alive, served, pad1[13];       /* written by the server (its own line); served: requests since its start */
+} mbx_frame_mailbox;
+MBX_STATIC_ASSERT(offsetof(mbx_frame_mailbox, seq_out) == 64 && offsetof(mbx_frame_mailbox, frame) == 16 && sizeof(mbx_frame_mailbox) == 128, "mbx_frame_mailbox");
+
 #endif /* MBX_TYPES_H */

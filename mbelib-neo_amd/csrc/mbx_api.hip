@@ -27,6 +27,8 @@ __global__ void expand_ambe_kernel(const mbx_param_record*, size_t, FrameParams*
 __global__ void expand_ambe2400_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void frame_server_kernel(mbx_frame_mailbox*, unsigned, mbe_parms*, mbx_stream_rng*, int16_t*, float*, mbe_process_result*,
+                                    mbx_param_record*, DeviceTables);
 __global__ void imbe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                        int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
@@ -1044,6 +1046,21 @@ int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx
                            d_pcmf, d_result, d_done, token, tabs);
     }
     return check_launch("frame_kernel");
+}
+
+int mbx_frame_server_start(mbx_frame_mailbox* mailbox, unsigned idle_us, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
+                           float* d_pcmf, mbe_process_result* d_result, mbx_param_record* d_record, void* stream) {
+    REQUIRE_CTX(c);
+    if (!mailbox || (reinterpret_cast<uintptr_t>(mailbox) & 63u) || idle_us == 0 || idle_us > 1000000u || !d_state || !d_rng || !d_record) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbx::DeviceTables tabs = c->tabs;
+    tabs.reverse = 0;
+    tabs.stream_map = nullptr;
+    tabs.resident = nullptr;
+    hipLaunchKernelGGL(mbx::frame_server_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mailbox, idle_us * 100u, d_state, d_rng,
+                       d_pcm16, d_pcmf, d_result, d_record, tabs);
+    return check_launch("frame_server_kernel");
 }
 
 int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_parms* d_state, mbx_stream_rng* d_rng,

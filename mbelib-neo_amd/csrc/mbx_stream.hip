@@ -2520,6 +2520,73 @@ ambe2400_frame_kernel(const uint8_t* __restrict__ frame, mbx_param_record* __res
     ambe_frame_body<true>(frame, record, state, rng, pcm16, pcmf, result, done, token, tabs);
 }
 
+// ------------------------------------------------------------------------------------------
+// Frame server (include/mbx.h, mbx_frame_mailbox): the single-frame kernels as ONE wavefront that stays on the device and takes
+// its requests from pinned host memory.  What a request saves against a launch of its own: the launch (~5 us of host + command
+// processor) and the instruction fetch of a kernel whose instruction cache starts cold at every dispatch.
+// Exits: quit flag, idle time-out, a hard life-time cap, and -- should the clock ever misbehave -- a poll count; after storing
+// alive = 0 it touches nothing, so the host may start a successor at once.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+frame_server_kernel(mbx_frame_mailbox* mb, unsigned idle_ticks /* of the 100 MHz wall clock */, mbe_parms* state, mbx_stream_rng* rng,
+                    int16_t* pcm16, float* pcmf, mbe_process_result* result, mbx_param_record* record, DeviceTables tabs) {
+    __shared__ uint32_t frame_words[8];
+    const int lane = lane_id();
+    const uint32_t* const line = reinterpret_cast<const uint32_t*>(mb);   // the request line: dword `lane` of it, lanes 0..15
+    auto poll = [&]() -> uint32_t {   // ONE 64-byte read of host memory, system-coherent, never from the scalar cache
+        return (lane < 16) ? __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+    };
+    uint32_t last = uni(__hip_atomic_load(&mb->seq_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    uint32_t served = 0u;
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long t_last = t_start;
+    unsigned polls = 0u;
+    constexpr unsigned long long kMaxLifeTicks = 200000000ULL;   // 2 s
+    constexpr unsigned kMaxIdlePolls = 1u << 24;                 // (backstop should the clock misbehave)
+    for (;;) {
+        const uint32_t v = poll();
+        const uint32_t in = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+        if (in != last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // the caller's structs: not from stale cache lines
+            __builtin_amdgcn_s_dcache_inv();                //   (the scalar cache is not covered by the fence)
+            const int codec = __builtin_amdgcn_readlane((int)v, 2);
+            const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)v, 3);
+            if (lane >= 4 && lane < 10) {
+                frame_words[lane - 4] = v;   // the wire frame came with the request: the FEC starts without another trip to the host
+            }
+            wave_lds_sync();
+            const uint8_t* frame = reinterpret_cast<const uint8_t*>(frame_words);
+            int16_t* const o16 = (want & 1u) ? pcm16 : nullptr;
+            float* const of = (want & 2u) ? pcmf : nullptr;
+            if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {
+                imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame, codec);
+            } else if (codec == MBX_CODEC_AMBE3600X2400) {
+                ambe_stream_body<true, true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame);
+            } else {
+                ambe_stream_body<false, true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame);
+            }
+            last = in;
+            ++served;
+            if (lane == 0) {
+                __hip_atomic_store(&mb->served, served, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            frame_done(&mb->seq_out, in, lane);   // system-scope fence, then the completion word
+            t_last = wall_clock64();
+            polls = 0u;
+            continue;
+        }
+        const unsigned long long now = wall_clock64();
+        const bool quit = __builtin_amdgcn_readlane((int)v, 1) != 0;
+        if (quit || (now - t_last) > (unsigned long long)idle_ticks || (now - t_start) > kMaxLifeTicks || ++polls > kMaxIdlePolls) {
+            if (lane == 0) {
+                __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // mbe_synthesizeSpeechf for S independent (cur, prev) pairs.
 
 __global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)

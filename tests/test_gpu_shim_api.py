@@ -3,6 +3,7 @@ own CTest programs (tests/test_frame_paths.c, test_input_validation.c, test_floa
 test_golden_pcm.c, test_ecc.c, test_params.c) -- same scenarios, same assertions -- with the
 library under test swapped for the MI355X one."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -385,6 +386,21 @@ def test_streams_frame_by_frame_match_reference_goldens(mbe):
 
 
 # ---- soft-decision entry points (reference tests/test_soft_decision.c style: per-frame API) -------
+def test_streams_frame_by_frame_through_the_frame_server():
+    """The same golden streams with MBE_NEO_FRAME_SERVER=1 (opt-in): synchronous calls served by a resident wavefront from a
+    mailbox in pinned memory (mbx_frame_server_start) instead of a launch each -- back-to-back requests, server restarts after
+    its idle time-out (a pause between the two codecs), thread-exit shutdown.  Own process: the switch is read once, at load."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MBE_NEO_FRAME_SERVER="1")
+    code = ("import time, pytest, sys; sys.path.insert(0, %r); import test_gpu_shim_api as t, shim_lib; m = shim_lib.load(); "
+            "t.test_streams_frame_by_frame_match_reference_goldens(m); time.sleep(0.01); t.test_golden_pcm(m); "
+            "t.test_ambe2400_entry_points_match_reference_fixture(m); print('served ok')" % os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "served ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_soft_entry_points_match_reference_fixture(mbe):
     kat = golden_io.soft_kat()
     for row in kat["golay"][:60]:
