@@ -2108,7 +2108,10 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     // itself, eight lanes per frame exactly like the expand kernels (mbx_expand_ambe.h), into eight LDS rows -- no
     // expand launch, no 256-byte row per frame through HBM.  (One frame at a time fills 8 of 64 lanes: round 2 measured
     // that slower than the separate launch.)  Row stride 65 dwords: the eight frames write the same columns at once.
-    constexpr int kXRows = 8, kXStride = 65;
+#ifndef MBX_AMBE_XROWS
+#define MBX_AMBE_XROWS 8
+#endif
+    constexpr int kXRows = MBX_AMBE_XROWS, kXStride = 65;
     __shared__ float xrows[kPark ? kXRows : 1][kPark ? kXStride : 1];
     if ((int)blockIdx.x >= S) {
         return;
@@ -2221,10 +2224,12 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     const int q = lane >> 3;
                     const bool have = (t + q) < Tn;
                     wave_lds_sync();   // the previous eight rows have been read
-                    if constexpr (kFrame) {
-                        xp::expand_ambe_frame_rec<k2400>(q == 0, xp::u32x4{rec_in.x, rec_in.y, rec_in.z, rec_in.w}, xrows[q], lane & 7, tabs);
-                    } else {
-                        xp::expand_ambe_frame<k2400>(have, &records[have ? f + (size_t)q : f], xrows[q], lane & 7, tabs);
+                    if (kXRows == 8 || q < kXRows) {   // (fewer rows than frame slots in the wave: the upper lanes sit the pass out)
+                        if constexpr (kFrame) {
+                            xp::expand_ambe_frame_rec<k2400>(q == 0, xp::u32x4{rec_in.x, rec_in.y, rec_in.z, rec_in.w}, xrows[q], lane & 7, tabs);
+                        } else {
+                            xp::expand_ambe_frame<k2400>(have, &records[have ? f + (size_t)q : f], xrows[q], lane & 7, tabs);
+                        }
                     }
                     wave_lds_sync();
                 }
