@@ -2062,10 +2062,10 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
 }
 
 #ifndef MBX_AMBE_WAVES_PER_SIMD
-#define MBX_AMBE_WAVES_PER_SIMD 6       // AMBE+2 3600x2450: 79 VGPRs, spill-free
+#define MBX_AMBE_WAVES_PER_SIMD 6       // AMBE+2 3600x2450: 80 VGPRs and 12 bytes of scratch (tools/kres.sh); five waves without the spill are 8 % slower
 #endif
 #ifndef MBX_AMBE2400_WAVES_PER_SIMD
-#define MBX_AMBE2400_WAVES_PER_SIMD 6   // AMBE 3600x2400: 79 VGPRs, spill-free
+#define MBX_AMBE2400_WAVES_PER_SIMD 6   // AMBE 3600x2400: 77 VGPRs, no scratch
 #endif
 // D-STAR single tone (ref src/core/mbelib.c:813-856 + :708-736): 156.25 Hz (index 5), 187.5 Hz (6) or 31.25 Hz x index
 // (7..122) at the fixed amplitude 103
