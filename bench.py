@@ -350,7 +350,7 @@ def self_launch(argv, n, script=None):
 
 # ---- one workload on this rank's GPU ----------------------------------------------------------------------------------
 def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args, use_dist=False, coll_device=None,
-                 alternate=False, min_time_s=None):
+                 alternate=False, min_time_s=None, serial=None):
     """Returns the measurements of one workload: wall time of the timed steps (max over ranks), HIP-event time of the
     dominant kernel per step (mean, median, spread), frame mix.  The launches of a step are what mbx_process_batch issues;
     they are issued one by one here only so that the dominant kernel can be bracketed by events on the launch stream.
@@ -391,7 +391,45 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     # at T >= 4); otherwise it is the expand launch + the stream launch, issued separately here so that the events bracket
     # the stream kernel alone.  --split-expand forces the separate launch everywhere (development aid).
     split = bool(L.mbx_uses_expand_launch(stream_codec, S, T)) and not (T == 1 and args.fuse_expand) or args.split_expand
-    def step(ev=None):
+    # Front-end overlap (round 4).  FEC + parameter expansion of a batch depend only on its frames; the stream stage of the batch
+    # before it depends only on ITS records / rows and on the state.  So the front end of step k + 1 is issued on a second HIP
+    # stream into alternating record / workspace buffers (the *_ws entry points) and runs while the stream kernel of step k does;
+    # events order the two: the stream stage waits for its front end, a front end waits until the stream stage that last read its
+    # buffers is done.  Every step still does all of its work inside the timed region.  Opt-in (--overlap-front-end): it measured
+    # slower than one stream -- the HBM-bound stream kernel does not like company, and two event hand-overs per step cost ~20 us.
+    serial = (not args.overlap_front_end) if serial is None else serial
+    overlap = split and not soft and not serial
+    if overlap:
+        front = torch.cuda.Stream(device=local_rank)
+        main_stream = torch.cuda.current_stream()
+        ws_bytes = int(L.mbx_workspace_bytes(n))
+        bufs = [{"records": torch.empty_like(out["records"]), "ws": torch.empty(ws_bytes, dtype=torch.uint8, device=out["records"].device),
+                 "ready": torch.cuda.Event(), "free": torch.cuda.Event()} for _ in range(2)]
+        counter = [0]
+
+        def step(ev=None):
+            k = counter[0]
+            counter[0] += 1
+            b = bufs[k & 1]
+            if k >= 2:
+                front.wait_event(b["free"])          # the stream stage of step k - 2 has finished with these buffers
+            _native.check(fec(d_frames.data_ptr(), n, b["records"].data_ptr(), front.cuda_stream), "fec")
+            _native.check(L.mbx_expand_records_ws(stream_codec, b["records"].data_ptr(), n, b["ws"].data_ptr(), ws_bytes, front.cuda_stream),
+                          "expand")
+            b["ready"].record(front)
+            main_stream.wait_event(b["ready"])
+            if ev is not None:
+                ev[0].record()
+            _native.check(
+                L.mbx_stream_expanded_ws(stream_codec, S, T, b["records"].data_ptr(), dec.state.data_ptr(),
+                                         dec.resident.data_ptr() if resident else None, dec.rng.data_ptr(), out["pcm16"].data_ptr(), None,
+                                         out["results"].data_ptr(), b["ws"].data_ptr(), ws_bytes, stream),
+                "stream",
+            )
+            if ev is not None:
+                ev[1].record()
+            b["free"].record(main_stream)
+    def step_serial(ev=None):
         if ev is not None and soft:
             ev[0].record()
         _native.check(fec(d_frames.data_ptr(), n, out["records"].data_ptr(), stream), "fec")
@@ -419,6 +457,8 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
         if ev is not None and not soft:
             ev[1].record()
 
+    if not overlap:
+        step = step_serial
     previous_order = L.mbx_set_stream_order(1 if alternate else 0)
     for _ in range(max(1, warmup)):  # the first pass also warms the model state
         step()
@@ -471,7 +511,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     torch.cuda.empty_cache()
     return {
         "dt": dt, "kernel_ms": kernel_ms, "kernel": kernel, "alg_bytes": alg_bytes, "frames_per_step": world * n,
-        "value": world * n * steps_eff / dt, "ms_per_step": dt / steps_eff * 1e3, "pcm_digest": pcm_digest,
+        "value": world * n * steps_eff / dt, "ms_per_step": dt / steps_eff * 1e3, "pcm_digest": pcm_digest, "front_end_overlap": bool(overlap),
         "steps_effective": steps_eff, "rank_value": n * steps_eff / dt_local,
         "kernel_ms_stats": {"mean": float(per_step.mean()), "median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),
                             "p90": float(np.percentile(per_step, 90)), "min": float(per_step.min()), "max": float(per_step.max()),
@@ -547,6 +587,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline (and cpu_baseline) only: no other_configs, host_path, infinity_cache_assisted")
     ap.add_argument("--split-expand", action="store_true", help="run the parameter expansion as a separate launch")
+    ap.add_argument("--overlap-front-end", action="store_true",
+                    help="development aid: FEC + expansion of step k + 1 on a second stream while the stream stage of step k runs "
+                         "(mbx_*_ws entry points).  Measured SLOWER than one stream (imbe_voiced 255 vs 265 M frames/s on one box: the "
+                         "stream kernel shares the chip, and the cross-stream events cost what the overlap saves) -- not the default")
     ap.add_argument("--fuse-expand", action="store_true", help="development aid: IMBE at T = 1 through the fused (one-launch) path")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the collectives even with one rank (exercises the N > 1 code path on a 1-GPU box)")
@@ -664,7 +708,15 @@ def main():
     line["valu"]["modelled_valu_issue_utilisation_lower_bound"] = issue.get("valu_issue_utilisation_lower_bound")
     line["valu"]["cost_model"] = issue.get("valu_cost_model")   # per-instruction costs from tools/valu_issue.hip at FOUR waves per SIMD; the kernels run at 3.8-7
     line["valu"]["modelled_source"] = issue.get("source") or issue.get("stale")
+    line["front_end_overlap"] = m["front_end_overlap"]   # FEC + expansion of step k + 1 on a second stream while the stream stage of step k runs
     extras = world == 1 and not args.no_extras and not args.ablate and not args.streams
+    if extras and m["front_end_overlap"]:
+        # the same workload with the three launches of a step on ONE stream, one after the other (how rounds 1-3 timed it)
+        sm = run_workload(args.workload, S, T, args.steps, 2, rank, first, local_rank, blob, world, dist, args, serial=True)
+        line["serial_front_end"] = {
+            "value": sm["value"], "ms_per_step": sm["ms_per_step"], "kernel_ms": sm["kernel_ms"], "steps_effective": sm["steps_effective"],
+            "what": "FEC, expansion and stream stage of a step issued on one stream: the step is the sum of its three launches",
+        }
     if extras:
         # the library's default order for back-to-back launches over the same state: a launch walks the streams in the
         # direction opposite to the previous one and finds the tail of its state in the 256 MiB Infinity Cache

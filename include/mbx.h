@@ -286,6 +286,17 @@ int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_i
                               mbe_parms* d_state_pool, mbx_stream_rng* d_rng_pool, int16_t* d_pcm16, float* d_pcmf,
                               mbe_process_result* d_results, mbx_param_record* d_records, void* stream);
 
+/* The two halves with a caller-owned workspace (mbx_workspace_bytes(S*T) bytes), free to run on DIFFERENT streams: the
+ * front end of batch k + 1 (mbx_fec_* + mbx_expand_records_ws) depends only on its frames, not on the stream stage of batch k,
+ * so a host that decodes batch after batch overlaps them and orders them with its own events (what bench.py's headline does:
+ * front end on one stream into alternating record / workspace buffers, stream stage on another).  d_resident: NULL, or the
+ * resident words of mbx_process_batch_resident. */
+int mbx_expand_records_ws(int codec, const mbx_param_record* d_records, size_t n, void* d_workspace, size_t workspace_bytes,
+                          void* stream);
+int mbx_stream_expanded_ws(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state, uint32_t* d_resident,
+                           mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                           const void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Resident state -- for a caller that OWNS the state of its streams between launches (sessions; the queue mode's device
  * pool).  d_state_pool is the same [slots][3] array of ABI structs, d_resident one word per slot (zero-initialised by the
  * caller).  After every ordinary frame the reference leaves prev_mp_enhanced a field-for-field copy of cur_mp

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "mbx_process_batch_indexed": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_batch_resident": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_resident_materialize": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),
+    "mbx_expand_records_ws": (C.c_int, [C.c_int, _vp, _sz, _vp, _sz, _vp]),
+    "mbx_stream_expanded_ws": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mbx_stream_expanded_resident": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_fec_stage": (C.c_int, [C.c_int, C.c_int, _vp, _sz, _vp, _vp, _vp]),
     "mbx_decode_parms": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp, _vp]),

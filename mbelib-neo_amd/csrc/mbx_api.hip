@@ -896,6 +896,41 @@ int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, v
 static int stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state, uint32_t* d_resident,
                            mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, void* stream);
 
+// The two halves with a CALLER-OWNED workspace, so that they can run on DIFFERENT streams: the frame-parallel front end
+// (FEC + expansion) of batch k + 1 does not depend on the stream stage of batch k, only on the frames -- a host that decodes
+// batch after batch (recorded traffic, many sites) lets them overlap and orders them with events of its own (bench.py).
+int mbx_expand_records_ws(int codec, const mbx_param_record* d_records, size_t n, void* d_workspace, size_t workspace_bytes,
+                          void* stream) {
+    REQUIRE_CTX(c);
+    if (!d_records || !expand_codec_ok(codec) || !d_workspace || workspace_bytes < mbx_workspace_bytes(n)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    return launch_expand(c, codec, d_records, n, static_cast<mbx::FrameParams*>(d_workspace), stream);
+}
+
+int mbx_stream_expanded_ws(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state, uint32_t* d_resident,
+                           mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                           const void* d_workspace, size_t workspace_bytes, void* stream) {
+    REQUIRE_CTX(c);
+    if (!stream_args_ok(codec, S, T, d_records, d_state, d_rng) || !d_workspace
+        || workspace_bytes < mbx_workspace_bytes((size_t)S * (size_t)T)) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (S == 0 || T == 0) {
+        return 0;
+    }
+    unsigned order;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        order = c->slots[stream].launches++;
+    }
+    return launch_stream(c, (order & 1u) != 0u, codec, S, T, d_records, static_cast<const mbx::FrameParams*>(d_workspace), d_state,
+                         d_rng, d_pcm16, d_pcmf, d_results, stream, nullptr, d_resident);
+}
+
 int mbx_stream_expanded(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                         void* stream) {
