@@ -505,7 +505,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
                   3: "fec_ambe3600x2450_soft_kernel"}[codec]
         alg_bytes = soft_fec_bytes_per_launch(codec, n)
     else:
-        kernel = L.mbx_stream_kernel_name(codec, -1 if resident else T).decode()   # (T < 0: the instances of the resident launches)
+        kernel = L.mbx_stream_kernel_name(codec, -T if resident else T).decode()   # (T < 0: the instances of the resident launches)
         alg_bytes = algorithmic_bytes_per_launch(codec, S, T, resident)
     del dec, d_frames, out
     torch.cuda.empty_cache()

@@ -399,7 +399,7 @@ void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed);
 
 /* name of the stream kernel a launch with T frames per stream takes (for the bench / profile summaries): with T >= 4 the
  * instance that keeps prev_mp / prev_mp_enhanced in LDS for the whole launch (*_lds), otherwise the HBM-slot one; T < 0:
- * the instance of the resident launches (*_res, mbx_process_batch_resident) */
+ * the instance a resident launch (mbx_process_batch_resident) with -T frames per stream takes (*_res, *_res1) */
 const char* mbx_stream_kernel_name(int codec, int T);
 
 #ifdef __cplusplus

@@ -29,6 +29,8 @@ __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const Fram
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void frame_server_kernel(mbx_frame_mailbox*, unsigned, mbe_parms*, mbx_stream_rng*, int16_t*, float*, mbe_process_result*,
                                     mbx_param_record*, DeviceTables);
+__global__ void imbe_stream_kernel_res1(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                        int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                        int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
@@ -786,7 +788,10 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
     // Resident state (d_resident) is understood by those instances only, whatever T is.
     const bool lds_resident = T >= kLdsResidentMinFrames && lds_resident_enabled();
     if (d_resident) {
-        if (codec == MBX_CODEC_IMBE7200X4400) {
+        if (codec == MBX_CODEC_IMBE7200X4400 && T == 1 && !getenv("MBX_NO_RES1")) {
+            hipLaunchKernelGGL(mbx::imbe_stream_kernel_res1, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                               params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+        } else if (codec == MBX_CODEC_IMBE7200X4400) {
             hipLaunchKernelGGL(mbx::imbe_stream_kernel_res, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                                params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         } else if (codec == MBX_CODEC_AMBE3600X2400) {
@@ -1399,8 +1404,8 @@ int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe
 }
 
 const char* mbx_stream_kernel_name(int codec, int T) {
-    if (T < 0) {   // the instances of the resident launches (mbx_process_batch_resident), whatever T is
-        return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? "imbe_stream_kernel_res"
+    if (T < 0) {   // the instances of the resident launches (mbx_process_batch_resident) with -T frames per stream
+        return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? ((T == -1 && !getenv("MBX_NO_RES1")) ? "imbe_stream_kernel_res1" : "imbe_stream_kernel_res")
                : (codec == MBX_CODEC_AMBE3600X2400)                                    ? "ambe2400_stream_kernel_res"
                                                                                         : "ambe_stream_kernel_res";
     }

@@ -1651,6 +1651,12 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     StreamRng rng;
     // resident launches (DeviceTables::resident): prev_mp_enhanced elided while it equals cur_mp, prev_mp fetched lazily
     uint32_t* const res = (kPark && kRes) ? tabs_in.resident : nullptr;   // (kRes: own kernel instances, the others carry none of this)
+    // kRes without kPark: the HBM-slot instance for resident launches of ONE frame per stream.  It reads of prev_mp only the
+    // decode's view anyway (load_prev_view) and writes the snapshot straight to its home; what it adds is the elision: the
+    // enhanced model's view comes from cur_mp's struct when elided, and prev_mp_enhanced is not written.  (One frame only: with
+    // more, the next frame would look for the view in a struct this launch has not written.)
+    uint32_t* const res1 = (!kPark && kRes) ? tabs_in.resident : nullptr;
+    const bool elided1 = res1 && (uni(res1[slot]) != 0u);
     bool prev_partial = false;   // wave-uniform: the LDS copy of prev_mp holds only the decode's view of it
     if constexpr (kPark) {
         slot_prev = &park.prev;
@@ -1705,7 +1711,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         if constexpr (kPark) {
             enh = enh_keep;
         } else {
-            load_enh_view(enh, slot_enh, lane);
+            load_enh_view(enh, elided1 ? slot_cur : slot_enh, lane);
         }
         Parms prev;
         load_prev_view(prev, slot_prev, lane);
@@ -1805,6 +1811,10 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             enh_keep.amplitudeThreshold = cur.amplitudeThreshold;
             enh_keep.uw[2] = cur.uw[2];
             enh_keep.uw[3] = cur.uw[3];
+        } else if (res1) {
+            if (lane == 0) {
+                res1[slot] = 1u;   // prev_mp_enhanced := cur_mp, elided
+            }
         } else {
             if (!MBX_ABL(tabs, 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
         }
@@ -2633,6 +2643,14 @@ imbe_stream_kernel_res(int S, int Tn, const mbx_param_record* __restrict__ recor
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     imbe_stream_body<true, false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// one frame per stream on resident state: the HBM-slot body (seven waves per SIMD, no LDS copy of prev_mp)
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe_stream_kernel_res1(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<false, false, true>(S, Tn > 1 ? 1 : Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 __global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)

@@ -304,3 +304,45 @@ def test_fft_swizzle_of_the_kernel_is_conflict_free_in_the_bank_model():
             assert fs.kernel_map(a ^ b) == fs.kernel_map(a) ^ fs.kernel_map(b)
     src = open(os.path.join(ROOT, "mbelib-neo_amd", "csrc", "mbx_stream.hip")).read()
     assert "(e ^ ((e >> 2) & 3) ^ (((e >> 4) & 7) << 2))" in src   # the kernel's map is the one checked here
+
+
+def test_exact_shortcuts_of_the_stream_kernel_are_exact():
+    """Two float shortcuts of mbx_stream.hip claim to be BIT-identical to what the reference computes (round 4; each replaces a
+    12-36-instruction IEEE expansion executed once per frame).  Their arithmetic is restated here in numpy -- float32 values,
+    the FMA's single rounding emulated in float64, which is exact for these operand widths -- and checked against the plain
+    expressions on millions of values:
+      wrap_two_pi(x)            = fmodf(x, 2 pi)              for 0 <= x < 4e6   (ref src/core/mbelib.c:901-912)
+      div_by_uniform(a, L, 1/L) = a / L  correctly rounded    for L = 1..56       (ref src/core/mbelib.c:925-940, the phase offset)"""
+    rng = np.random.default_rng(20240404)
+    y = np.float32(2.0) * np.float32(np.pi)
+    c = np.float32(np.float32(0.15915494) * np.float32(1.000001))
+
+    def wrap(x):
+        n = np.trunc(x * c).astype(np.float32)
+        r = x.astype(np.float64) - n.astype(np.float64) * np.float64(y)     # the FMA: exact product, one rounding ...
+        r32 = r.astype(np.float32)
+        assert np.all(r32.astype(np.float64) == r)                          # ... which never rounds: the value is a float
+        r2 = np.where(r32 < 0, r32.astype(np.float64) + np.float64(y), r32.astype(np.float64))
+        out = r2.astype(np.float32)
+        assert np.all(out.astype(np.float64) == r2)
+        return out
+
+    for scale in (7.0, 100.0, 5000.0, 1e5, 3.9e6):
+        x = (rng.random(1_000_000) * scale).astype(np.float32)
+        assert np.array_equal(np.fmod(x, y).view(np.uint32), wrap(x).view(np.uint32)), scale
+    k = np.arange(0, 600000, dtype=np.float64)
+    edge = (k * np.float64(y)).astype(np.float32)
+    for x in (edge, np.nextafter(edge, np.float32(np.inf)), np.nextafter(edge, np.float32(0))):
+        x = np.abs(x)
+        assert np.array_equal(np.fmod(x, y).view(np.uint32), wrap(x).view(np.uint32))
+    for L in range(1, 57):
+        b = np.float32(L)
+        rcp = np.float32(1) / b
+        a = ((rng.random(100_000) * 2 - 1) * np.float32(np.pi) * rng.integers(1, 57, 100_000)).astype(np.float32)
+        q = (a * rcp).astype(np.float32)
+        r = a.astype(np.float64) - q.astype(np.float64) * np.float64(b)
+        got = (r * np.float64(rcp) + q.astype(np.float64)).astype(np.float32)
+        ref = (a.astype(np.float64) / np.float64(b)).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), L
+    src = open(os.path.join(ROOT, "mbelib-neo_amd", "csrc", "mbx_stream.hip")).read()
+    assert "truncf(x * (0.15915494f * 1.000001f))" in src and "return fmaf(r, rcp_b, q);" in src   # the kernel's expressions are these

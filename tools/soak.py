@@ -41,7 +41,7 @@ def main():
                     for _ in range(2):
                         frames &= framegen.random_frames(codec, S * T, rng)
                     ref = o.process_batch(codec, S, T, frames, o.init_state(S), o.rng_seeded(seeds))
-                    dec = decoder.BatchDecoder(codec, S, seeds=np.asarray(seeds))
+                    dec = decoder.BatchDecoder(codec, S, seeds=np.asarray(seeds), resident=(r % 2 == 1))   # odd rounds: the resident kernel instances
                     fr3 = frames.reshape(S, T, -1)
                     parts = [dec.decode(np.ascontiguousarray(fr3[:, t]), 1, want_float=True) for t in range(T)]
                     torch.cuda.synchronize()
@@ -97,7 +97,7 @@ def main():
                "libmbx_hip_sha256_16": hashlib.sha256(open(_native.library_path(), "rb").read()).hexdigest()[:16],
                "worst": {f"codec{c}_{k}": v for (c, k), v in worst.items()}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(summary, open(os.path.join(ROOT, "gpurun_out", f"soak_r03_{first}.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(ROOT, "gpurun_out", f"soak_{os.environ.get('MBX_ROUND', 'r04')}_{first}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
