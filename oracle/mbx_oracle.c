@@ -5,8 +5,10 @@
  * table blob, explicit per-stream RNG state), what the reference computes on the hot path.
  * Every function names the reference location it follows; `ref:` paths are relative to
  * /root/reference.  Float expressions keep the reference's operand order and types so the
- * results are bit-identical under an IEEE build (-ffp-contract=off, no fast-math); the one
- * deliberate difference is the 256-point FFT (double precision here, PFFFT there).
+ * results are bit-identical under an IEEE build (-ffp-contract=off, no fast-math).  The 256-point FFT of the unvoiced
+ * path comes in two forms: a double-precision one (the default: what the HIP path is compared with, a precision ABOVE both
+ * float implementations) and, after mbxo_set_fft_float(1), FFTPACK's float real transform as the reference's PFFFT runs it --
+ * with that one the float PCM is the reference's bit for bit (its float golden hash is reproduced).
  */
 #define _GNU_SOURCE 1 /* sincosf */
 #include "mbx_oracle.h"
@@ -1953,6 +1955,218 @@ fft256(double* re, double* im, int inverse) {
 }
 
 /* =====================================================================================
+ * The reference's OWN 256-point real transform, restated in float: mbxo_set_fft_float(1).
+ *
+ * The reference calls PFFFT (ref src/core/mbe_unvoiced_fft.c:738,751: pffft_transform_ordered), a third-party library
+ * vendored under src/external/pffft; its scalar build (what oracle/_ref compiles, PFFFT_SIMD_DISABLE) is FFTPACK's real
+ * transform -- P. N. Swarztrauber's published algorithm (rfftf / rfftb with the radix-4 passes radf4 / radb4) -- followed by
+ * a re-ordering of the half-complex result.  256 = 4^4, so four radix-4 passes each way and nothing else.  The arithmetic
+ * below follows that algorithm operation for operation (every product and sum rounded to float in the same order, no
+ * contraction), which is what makes the oracle's float PCM equal to the reference's to the last bit
+ * (tests/test_oracle_golden.py: FNV hash 0x59741032 of ref tests/test_golden_pcm.c:78).  Structure and names are this
+ * file's: x(i, k, j) / y(i, j, k) are the three-index views FFTPACK describes as cc(ido, l1, 4) / ch(ido, 4, l1).
+ *   ref: src/external/pffft/pffft.c:749-833 (forward pass), :837-924 (backward pass), :1109-1199 (pass schedules),
+ *        :1230-1262 (twiddles), :2018-2040 (ordering)
+ * ===================================================================================== */
+static int g_fft_float = 0;
+
+void
+mbxo_set_fft_float(int on) {
+    g_fft_float = on ? 1 : 0;
+}
+
+static float g_rtw[256]; /* FFTPACK's real-transform twiddles for n = 256 */
+static int g_rtw_ready = 0;
+
+static void
+real_twiddles_256(void) {
+    const int n = 256;
+    const float argh = (float)((2 * M_PI) / n);
+    int is = 0, l1 = 1;
+    for (int pass = 0; pass < 3; ++pass) { /* all factors but the last */
+        const int l2 = l1 * 4, ido = n / l2;
+        int ld = 0;
+        for (int j = 1; j <= 3; ++j) {
+            ld += l1;
+            const float argld = (float)ld * argh;
+            int i = is;
+            for (int fi = 1; 2 * fi + 1 <= ido; ++fi) {
+                i += 2;
+                g_rtw[i - 2] = (float)cos((double)((float)fi * argld));
+                g_rtw[i - 1] = (float)sin((double)((float)fi * argld));
+            }
+            is += ido;
+        }
+        l1 = l2;
+    }
+    g_rtw_ready = 1;
+}
+
+/* (ar + i ai) (wr - i wi) and (ar + i ai) (wr + i wi), in the library's operation order */
+#define CMUL_CONJ(ar, ai, wr, wi)            \
+    do {                                     \
+        const float t_ = (ar) * (wi);        \
+        (ar) = (ar) * (wr);                  \
+        (ar) = (ar) + ((ai) * (wi));         \
+        (ai) = (ai) * (wr);                  \
+        (ai) = (ai) - t_;                    \
+    } while (0)
+#define CMUL_FWD(ar, ai, wr, wi)             \
+    do {                                     \
+        const float t_ = (ar) * (wi);        \
+        (ar) = (ar) * (wr);                  \
+        (ar) = (ar) - ((ai) * (wi));         \
+        (ai) = (ai) * (wr);                  \
+        (ai) = (ai) + t_;                    \
+    } while (0)
+
+/* one forward radix-4 pass: x(i, k, j), i < ido, k < l1, j < 4  ->  y(i, j, k) */
+static void
+real_pass4_forward(int ido, int l1, const float* x, float* y, const float* w1, const float* w2, const float* w3) {
+#define X_(i, k, j) x[(i) + ido * ((k) + l1 * (j))]
+#define Y_(i, j, k) y[(i) + ido * ((j) + 4 * (k))]
+    const float minus_half_sqrt2 = (float)-0.7071067811865475;
+    for (int k = 0; k < l1; ++k) {
+        const float a0 = X_(0, k, 0), a1 = X_(0, k, 1), a2 = X_(0, k, 2), a3 = X_(0, k, 3);
+        const float s13 = a1 + a3, s02 = a0 + a2;
+        Y_(ido - 1, 1, k) = a0 - a2;
+        Y_(0, 2, k) = a3 - a1;
+        Y_(0, 0, k) = s13 + s02;
+        Y_(ido - 1, 3, k) = s02 - s13;
+    }
+    if (ido < 2) {
+        return;
+    }
+    if (ido != 2) {
+        for (int k = 0; k < l1; ++k) {
+            for (int i = 2; i < ido; i += 2) {
+                const int ic = ido - i;
+                float r2 = X_(i - 1, k, 1), q2 = X_(i, k, 1);
+                CMUL_CONJ(r2, q2, w1[i - 2], w1[i - 1]);
+                float r3 = X_(i - 1, k, 2), q3 = X_(i, k, 2);
+                CMUL_CONJ(r3, q3, w2[i - 2], w2[i - 1]);
+                float r4 = X_(i - 1, k, 3), q4 = X_(i, k, 3);
+                CMUL_CONJ(r4, q4, w3[i - 2], w3[i - 1]);
+                const float tr1 = r2 + r4, tr4 = r4 - r2;
+                const float tr2 = X_(i - 1, k, 0) + r3, tr3 = X_(i - 1, k, 0) - r3;
+                Y_(i - 1, 0, k) = tr1 + tr2;
+                Y_(ic - 1, 3, k) = tr2 - tr1;
+                const float ti1 = q2 + q4, ti4 = q2 - q4;
+                Y_(i - 1, 2, k) = ti4 + tr3;
+                Y_(ic - 1, 1, k) = tr3 - ti4;
+                const float ti2 = X_(i, k, 0) + q3, ti3 = X_(i, k, 0) - q3;
+                Y_(i, 0, k) = ti1 + ti2;
+                Y_(ic, 3, k) = ti1 - ti2;
+                Y_(i, 2, k) = tr4 + ti3;
+                Y_(ic, 1, k) = tr4 - ti3;
+            }
+        }
+    }
+    for (int k = 0; k < l1; ++k) { /* ido is even: the middle column */
+        const float a = X_(ido - 1, k, 1), b = X_(ido - 1, k, 3), c = X_(ido - 1, k, 0), d = X_(ido - 1, k, 2);
+        const float ti1 = minus_half_sqrt2 * (a + b), tr1 = minus_half_sqrt2 * (b - a);
+        Y_(ido - 1, 0, k) = tr1 + c;
+        Y_(ido - 1, 2, k) = c - tr1;
+        Y_(0, 1, k) = ti1 - d;
+        Y_(0, 3, k) = ti1 + d;
+    }
+#undef X_
+#undef Y_
+}
+
+/* one backward radix-4 pass: c(i, j, k), j < 4  ->  h(i, k, j) */
+static void
+real_pass4_backward(int ido, int l1, const float* c, float* h, const float* w1, const float* w2, const float* w3) {
+#define C_(i, j, k) c[(i) + ido * ((j) + 4 * (k))]
+#define H_(i, k, j) h[(i) + ido * ((k) + l1 * (j))]
+    const float minus_sqrt2 = (float)-1.414213562373095;
+    const float two = 2.f;
+    for (int k = 0; k < l1; ++k) {
+        const float a = C_(0, 0, k), b = C_(ido - 1, 3, k), cc = C_(0, 2, k), d = C_(ido - 1, 1, k);
+        const float tr3 = two * d, tr2 = a + b, tr1 = a - b, tr4 = two * cc;
+        H_(0, k, 0) = tr2 + tr3;
+        H_(0, k, 2) = tr2 - tr3;
+        H_(0, k, 1) = tr1 - tr4;
+        H_(0, k, 3) = tr1 + tr4;
+    }
+    if (ido < 2) {
+        return;
+    }
+    if (ido != 2) {
+        for (int k = 0; k < l1; ++k) {
+            for (int i = 2; i < ido; i += 2) {
+                const int ic = ido - i;
+                const float tr1 = C_(i - 1, 0, k) - C_(ic - 1, 3, k), tr2 = C_(i - 1, 0, k) + C_(ic - 1, 3, k);
+                const float ti4 = C_(i - 1, 2, k) - C_(ic - 1, 1, k), tr3 = C_(i - 1, 2, k) + C_(ic - 1, 1, k);
+                H_(i - 1, k, 0) = tr2 + tr3;
+                float r3 = tr2 - tr3;
+                const float ti3 = C_(i, 2, k) - C_(ic, 1, k), tr4 = C_(i, 2, k) + C_(ic, 1, k);
+                float r2 = tr1 - tr4, r4 = tr1 + tr4;
+                const float ti1 = C_(i, 0, k) + C_(ic, 3, k), ti2 = C_(i, 0, k) - C_(ic, 3, k);
+                H_(i, k, 0) = ti2 + ti3;
+                float q3 = ti2 - ti3, q2 = ti1 + ti4, q4 = ti1 - ti4;
+                CMUL_FWD(r2, q2, w1[i - 2], w1[i - 1]);
+                H_(i - 1, k, 1) = r2;
+                H_(i, k, 1) = q2;
+                CMUL_FWD(r3, q3, w2[i - 2], w2[i - 1]);
+                H_(i - 1, k, 2) = r3;
+                H_(i, k, 2) = q3;
+                CMUL_FWD(r4, q4, w3[i - 2], w3[i - 1]);
+                H_(i - 1, k, 3) = r4;
+                H_(i, k, 3) = q4;
+            }
+        }
+    }
+    for (int k = 0; k < l1; ++k) {
+        const float cc = C_(ido - 1, 0, k), d = C_(ido - 1, 2, k), a = C_(0, 1, k), b = C_(0, 3, k);
+        const float tr1 = cc - d, tr2 = cc + d, ti1 = b + a, ti2 = b - a;
+        H_(ido - 1, k, 0) = tr2 + tr2;
+        H_(ido - 1, k, 1) = minus_sqrt2 * (ti1 - tr1);
+        H_(ido - 1, k, 2) = ti2 + ti2;
+        H_(ido - 1, k, 3) = minus_sqrt2 * (ti1 + tr1);
+    }
+#undef C_
+#undef H_
+}
+
+/* forward: 256 real samples -> [X0.re, X128.re, X1.re, X1.im, ..., X127.re, X127.im] (the library's "ordered" layout) */
+static void
+real_fft256_forward(const float in[256], float out[256]) {
+    if (!g_rtw_ready) {
+        real_twiddles_256();
+    }
+    float a[256], b[256];
+    /* (l1, ido, twiddle offset): 64,1,252 -> 16,4,240 -> 4,16,192 -> 1,64,0 */
+    real_pass4_forward(1, 64, in, a, &g_rtw[252], &g_rtw[253], &g_rtw[254]);
+    real_pass4_forward(4, 16, a, b, &g_rtw[240], &g_rtw[244], &g_rtw[248]);
+    real_pass4_forward(16, 4, b, a, &g_rtw[192], &g_rtw[208], &g_rtw[224]);
+    real_pass4_forward(64, 1, a, b, &g_rtw[0], &g_rtw[64], &g_rtw[128]);
+    out[0] = b[0];
+    out[1] = b[255];
+    for (int k = 255; k > 1; --k) {
+        out[k] = b[k - 1];
+    }
+}
+
+/* backward of the above, unnormalised (backward(forward(x)) = 256 x) */
+static void
+real_fft256_backward(const float in[256], float out[256]) {
+    if (!g_rtw_ready) {
+        real_twiddles_256();
+    }
+    float a[256], b[256];
+    a[0] = in[0];
+    a[255] = in[1];
+    for (int k = 1; k < 255; ++k) {
+        a[k] = in[k + 1];
+    }
+    real_pass4_backward(64, 1, a, b, &g_rtw[0], &g_rtw[64], &g_rtw[128]);
+    real_pass4_backward(16, 4, b, a, &g_rtw[192], &g_rtw[208], &g_rtw[224]);
+    real_pass4_backward(4, 16, a, b, &g_rtw[240], &g_rtw[244], &g_rtw[248]);
+    real_pass4_backward(1, 64, b, out, &g_rtw[252], &g_rtw[253], &g_rtw[254]);
+}
+
+/* =====================================================================================
  * Unvoiced synthesis (a18)  ref: src/core/mbe_unvoiced_fft.c:643-761
  * ===================================================================================== */
 static void
@@ -1962,15 +2176,31 @@ synth_unvoiced(float* out, mbe_parms* cur, const mbe_parms* prev, const float no
     }
     /* window, forward transform */
     double re[256], im[256];
-    for (int i = 0; i < 256; ++i) {
-        re[i] = (double)(noise[i] * T->uv_window[i]);
-        im[i] = 0.0;
-    }
-    fft256(re, im, 0);
     float Xr[129], Xi[129];
-    for (int k = 0; k <= 128; ++k) {
-        Xr[k] = (float)re[k];
-        Xi[k] = (k == 0 || k == 128) ? 0.0f : (float)im[k];
+    float fbuf[256], fspec[256];
+    if (g_fft_float) { /* the reference's own float transform (see above) */
+        for (int i = 0; i < 256; ++i) {
+            fbuf[i] = noise[i] * T->uv_window[i];
+        }
+        real_fft256_forward(fbuf, fspec);
+        Xr[0] = fspec[0];
+        Xi[0] = 0.0f;
+        Xr[128] = fspec[1];
+        Xi[128] = 0.0f;
+        for (int k = 1; k < 128; ++k) {
+            Xr[k] = fspec[2 * k];
+            Xi[k] = fspec[2 * k + 1];
+        }
+    } else {
+        for (int i = 0; i < 256; ++i) {
+            re[i] = (double)(noise[i] * T->uv_window[i]);
+            im[i] = 0.0;
+        }
+        fft256(re, im, 0);
+        for (int k = 0; k <= 128; ++k) {
+            Xr[k] = (float)re[k];
+            Xi[k] = (k == 0 || k == 128) ? 0.0f : (float)im[k];
+        }
     }
 
     /* band edges (:643-661) and per-band scale (:663-686); voiced/uncovered bins stay 0 */
@@ -2019,20 +2249,34 @@ synth_unvoiced(float* out, mbe_parms* cur, const mbe_parms* prev, const float no
     }
 
     /* scale, inverse transform, 1/256 */
-    for (int k = 0; k <= 128; ++k) {
-        re[k] = (double)(Xr[k] * scale[k]);
-        im[k] = (double)(Xi[k] * scale[k]);
-    }
-    for (int k = 1; k < 128; ++k) {
-        re[256 - k] = re[k];
-        im[256 - k] = -im[k];
-    }
-    im[0] = 0.0;
-    im[128] = 0.0;
-    fft256(re, im, 1);
     float Uw[256];
-    for (int i = 0; i < 256; ++i) {
-        Uw[i] = (float)re[i] * (1.0f / 256.0f);
+    if (g_fft_float) { /* ref src/core/mbe_unvoiced_fft.c:236-272 (bins scaled in the ordered layout), :689-712 (1/256) */
+        fspec[0] *= scale[0];
+        for (int k = 1; k < 128; ++k) {
+            fspec[2 * k] *= scale[k];
+            fspec[2 * k + 1] *= scale[k];
+        }
+        fspec[1] *= scale[128];
+        real_fft256_backward(fspec, Uw);
+        const float norm = 1.0f / (float)256;
+        for (int i = 0; i < 256; ++i) {
+            Uw[i] *= norm;
+        }
+    } else {
+        for (int k = 0; k <= 128; ++k) {
+            re[k] = (double)(Xr[k] * scale[k]);
+            im[k] = (double)(Xi[k] * scale[k]);
+        }
+        for (int k = 1; k < 128; ++k) {
+            re[256 - k] = re[k];
+            im[256 - k] = -im[k];
+        }
+        im[0] = 0.0;
+        im[128] = 0.0;
+        fft256(re, im, 1);
+        for (int i = 0; i < 256; ++i) {
+            Uw[i] = (float)re[i] * (1.0f / 256.0f);
+        }
     }
 
     /* weighted overlap-add with the previous block (:385-411, :511-530) */

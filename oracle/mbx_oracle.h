@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 /* tables -------------------------------------------------------------------------- */
+void mbxo_set_fft_float(int on); /* 1: the unvoiced FFT as FFTPACK's float real transform (= the reference's PFFFT, bit for bit); 0 (default): double precision */
 int mbxo_load_tables(const void* blob, size_t n); /* 0, or -1 on bad magic/size/checksum */
 
 /* frame packing (host side of the boundary) ---------------------------------------- */

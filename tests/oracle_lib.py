@@ -69,6 +69,8 @@ class Oracle:
         h.mbxo_rng_default.argtypes = [_vp]
         h.mbxo_rng_seed.restype = None
         h.mbxo_rng_seed.argtypes = [_vp, C.c_uint32]
+        h.mbxo_set_fft_float.restype = None
+        h.mbxo_set_fft_float.argtypes = [C.c_int]
         h.mbxo_fnv1a32.restype = C.c_uint32
         h.mbxo_fnv1a32.argtypes = [_vp, C.c_size_t]
         h.mbxo_tonef.restype = None
@@ -244,6 +246,11 @@ class Oracle:
         out = np.zeros(pcmf.shape, dtype=np.int16)
         self.h.mbxo_floattoshort_batch(pcmf.ctypes.data, out.ctypes.data, pcmf.shape[0])
         return out
+
+    def set_fft_float(self, on):
+        """1: the unvoiced FFT as FFTPACK's float real transform (what the reference's PFFFT runs: float PCM identical to the
+        reference's to the last bit); 0 (the default every HIP comparison uses): double precision"""
+        self.h.mbxo_set_fft_float(1 if on else 0)
 
     def fnv(self, arr):
         arr = np.ascontiguousarray(arr)

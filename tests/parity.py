@@ -10,10 +10,11 @@ by the fixture below (SURVEY.md section 8(c) says 3 everywhere; this is the one 
 fails when more than 35 % of a workload's frames fall under the clipped bound (random channel bits: 20 %), so a workload
 cannot drift under the looser bound unnoticed.
 
-WHICH CHECKER: `ref_*` arguments come either from the ORACLE (oracle/mbx_oracle.c: the CPU restatement, whose unvoiced FFT
-is double precision -- 6e-8 relative away from the reference's float PFFFT; every integer and every decision identical to
-the real reference on 131,072 random frames per codec, oracle/_ref/cmp_ref) or from a GOLDEN FIXTURE written by the real
-reference (tests/golden/*.bin via oracle/_ref: float PFFFT).  Each test says in its docstring which of the two it uses.
+WHICH CHECKER: `ref_*` arguments come either from the ORACLE (oracle/mbx_oracle.c: the CPU restatement.  Its unvoiced FFT is
+double precision by default -- 6e-8 relative away from the reference's float PFFFT, every integer and every decision identical
+to the real reference on 131,072 random frames per codec, oracle/_ref/cmp_ref -- and, after set_fft_float(1), FFTPACK's float
+transform as PFFFT runs it: then the oracle is the reference bit for bit, tests/test_oracle_golden.py) or from a GOLDEN FIXTURE
+written by the real reference (tests/golden/*.bin via oracle/_ref).  Each test says in its docstring which it uses.
 
 Why the clipped frames have their own bound (tests/golden/tail_cases.npz, test_tail_cases_*): the samples that are NOT
 clipped in such a frame are where a sum of amplitude ~1e5 happens to cross the output range, so an error of 5e-6 of the

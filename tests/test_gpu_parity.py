@@ -236,6 +236,16 @@ def test_random_streams_vs_oracle(mbx, oracle, codec, S, T):
     print(f"codec {codec} S={S} T={T}:", m)
     parity.check_state(ref["state"], got["state"])
     assert np.array_equal(ref["rng"], got["rng"])
+    # the same against the oracle in its "reference, bit for bit" form (set_fft_float: FFTPACK's float transform as the reference's
+    # PFFFT runs it; tests/test_oracle_golden.py pins that form on the reference's float hash and on every golden stream)
+    oracle.set_fft_float(1)
+    try:
+        ref_f = oracle.process_batch(codec, S, T, frames, oracle.init_state(S), oracle.rng_seeded(seeds))
+    finally:
+        oracle.set_fft_float(0)
+    parity.check_results(ref_f["results"], got["results"])
+    parity.check_pcm(ref_f["pcmf"], got["pcmf"], ref_f["pcm16"], got["pcm16"])
+    parity.check_state(ref_f["state"], got["state"])
 
 
 def test_clean_voiced_imbe_vs_oracle(mbx, oracle):

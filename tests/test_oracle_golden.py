@@ -34,6 +34,16 @@ def test_golden_synth_hashes(oracle):
     assert m["int16_exact"] == 1.0
     parity.check_state(g["cur_out"].reshape(1), cur, rel=1e-6)
     parity.check_state(g["prev_out"].reshape(1), prev, rel=1e-6)
+    # with the reference's own float transform restated (FFTPACK's real radix-4 passes, what PFFFT's scalar build runs) the
+    # oracle IS the reference: the float hash of the reference's golden test, and every float of PCM and state bit for bit
+    oracle.set_fft_float(1)
+    try:
+        pcmf2, cur2, prev2, _ = oracle.synthesize_speech(g["cur_in"].reshape(1), g["prev_in"].reshape(1), oracle.rng_seeded([0xC0FFEE]))
+    finally:
+        oracle.set_fft_float(0)
+    assert oracle.fnv(pcmf2.astype(np.float32)) == REF_F32_HASH_SCALAR
+    assert pcmf2.tobytes() == np.asarray(g["pcmf"], dtype=np.float32).tobytes()
+    assert cur2.tobytes() == g["cur_out"].reshape(1).tobytes() and prev2.tobytes() == g["prev_out"].reshape(1).tobytes()
 
 
 def test_ecc_known_answers(oracle):
@@ -92,6 +102,16 @@ def test_stream_fixtures(oracle, codec):
         assert (flags & 0x40).any() and (flags & 0x80).any()  # repeat and mute are covered
     else:
         assert (flags & 0x20).any() and (flags & 0x10).any() and (flags & 0x40).any()  # erasure, tone, repeat
+    # ... and with the reference's float transform restated (oracle.set_fft_float) NOTHING differs: every float of the PCM and of
+    # the final state of all 64 golden streams is the real reference's, bit for bit (fixtures written by oracle/_ref)
+    oracle.set_fft_float(1)
+    try:
+        exact = oracle.process_batch(codec, S, T, packed, oracle.init_state(S), oracle.rng_seeded([1234 + s for s in range(S)]))
+    finally:
+        oracle.set_fft_float(0)
+    assert np.asarray(exact["pcmf"], dtype=np.float32).tobytes() == np.ascontiguousarray(frames["pcmf"], dtype=np.float32).tobytes()
+    assert np.array_equal(np.asarray(exact["pcm16"]).reshape(-1), np.asarray(frames["pcm16"]).reshape(-1))
+    assert np.asarray(exact["state"]).tobytes() == np.ascontiguousarray(fx["final"]).tobytes()
 
 
 def test_synth_sequences(oracle):
