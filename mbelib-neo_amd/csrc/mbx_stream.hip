@@ -37,6 +37,21 @@
 #include "mbx_expand_ambe.h"
 #include "mbx_fec_frame.h"
 
+// Wave priorities (s_setprio): a wave raises its priority while it is in one of the two VALU-dense stretches of a frame -- the
+// voiced bank's harmonic loop and the unvoiced transform pair -- and (IMBE launches with several frames per stream) in the front
+// part of a frame, whose table look-ups should go out as early as possible.  With five or six waves per SIMD in different
+// phases of their frames the arbiter otherwise serves them oldest first, whatever they are doing.  Measured by interleaved
+// A/B on one box (round 4): 65,536 x 16 IMBE -1.7 %, 8,192 x 128 AMBE+2 -3.6 %; the one-frame-per-stream launches do not care
+// (and lose 1-6 % when a new wave's loads or a finishing wave's stores are given priority: tried, dropped).
+#ifndef MBX_PRIO_BANK
+#define MBX_PRIO_BANK 2
+#endif
+#ifndef MBX_PRIO_FFT
+#define MBX_PRIO_FFT 1
+#endif
+#ifndef MBX_PRIO_FRONT_IMBE
+#define MBX_PRIO_FRONT_IMBE 3
+#endif
 #ifndef MBX_PARK_N
 #define MBX_PARK_N 8   // how many per-lane values wait in LDS across the unvoiced transform pair (synth_core)
 #endif
@@ -892,6 +907,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     GlobalDerived D = (GlobalDerived)tabs.d;
     constexpr int N = 160;
     out[0] = out[1] = out[2] = 0.0f;
+    __builtin_amdgcn_s_setprio(0);   // (the front part of an IMBE frame runs at a raised priority, see MBX_PRIO_FRONT_IMBE)
     if (cur.L < 1 || cur.L > 56 || prev.L < 1 || prev.L > 56) {
         return false;   // silence
     }
@@ -1115,6 +1131,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const v2f w_plus = {Ws(N + kMidPrev + kk), Ws(kMidCur + (kk < 52 ? kk : 51))};
             const v2f w_minus = {Ws(N + kMidPrev - kk), Ws(kMidCur - kk)};
             wave_lds_sync();
+            __builtin_amdgcn_s_setprio(MBX_PRIO_BANK);
             v2f Qc = Ec, Qs = Es;   // harmonic 1
             v2f even = {0.0f, 0.0f}, odd = {0.0f, 0.0f}, even_d = {0.0f, 0.0f}, odd_d = {0.0f, 0.0f};
             const int last = uni(maxl);
@@ -1147,6 +1164,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             }
 #endif
             // sample centre + k: even - odd - k (even_d + odd_d); centre - k: even + odd + k (even_d - odd_d)
+            __builtin_amdgcn_s_setprio(0);
             const v2f kf = splat((float)lane);
             const v2f v_plus = ((even - odd) - (kf * (even_d + odd_d))) * w_plus;
             const v2f v_minus = ((even + odd) + (kf * (even_d - odd_d))) * w_minus;
@@ -1241,6 +1259,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         // access pattern below (first / last stage and the bin passes: lane + 64 r; stages with spans 16, 4, 1); being
         // linear, fsw(base + r q) = fsw(base) ^ fsw(r q) whenever base has no bit in r q's digit: one swizzle per stage
         // and three XORs with literals.  (tools/fft_swizzle.py searches the family and prints the conflict counts.)
+        __builtin_amdgcn_s_setprio(MBX_PRIO_FFT);
         v2f* const F = reinterpret_cast<v2f*>(S.fft);
         // (Round 3 kept plain indices in the HBM-slot instances: three more address registers across a butterfly were a spill under
         // their 72 / 80-register caps.  With the products and rotations in two / one instruction the registers are there.)
@@ -1413,6 +1432,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             cur.uw[2] = (s02 - s13) * (1.0f / 256.0f);
             cur.uw[3] = (d02 + d13y) * (1.0f / 256.0f);   // Re(d02 - i*d13)
         }
+        __builtin_amdgcn_s_setprio(0);
         asm volatile("" ::: "memory");
         if constexpr (kParkN > 2) {
             acc[0] = S.park[2][lane];
@@ -1635,6 +1655,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     }
     const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const int lane_in = lane_id();
+
     // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
     // registers for the whole launch; `prev` is only needed from the start of a frame to the
     // snapshot and `enh` only from the snapshot to the end of synthesis, so both are parked in
@@ -1701,6 +1722,9 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             lane &= 63;
         }
         const DeviceTables& tabs = ft;
+        if constexpr (kPark && !kFrame) {
+            __builtin_amdgcn_s_setprio(MBX_PRIO_FRONT_IMBE);
+        }
         // Frame parameters: expanded here from the FEC record (the normal path), or taken from the
         // workspace row a separate mbx_expand_records() launch has written.  Either way decode reads LDS.
         // The table requests go out BEFORE the state loads (vector memory returns in order, and the
@@ -2128,6 +2152,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     }
     const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const int lane_in = lane_id();
+
     // Same register discipline as the IMBE kernel: `cur` resident, `prev` / `enh` parked in their slots.
     // batch row s (frames, records, PCM, results) belongs to state / rng slot `slot`: the same number unless the caller
     // passed an index (mbx_process_batch_indexed: the streams that have frames this tick, out of a larger resident pool)
