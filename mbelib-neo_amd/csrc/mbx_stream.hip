@@ -42,7 +42,8 @@
 // part of a frame, whose table look-ups should go out as early as possible.  With five or six waves per SIMD in different
 // phases of their frames the arbiter otherwise serves them oldest first, whatever they are doing.  Measured by interleaved
 // A/B on one box (round 4): 65,536 x 16 IMBE -1.7 %, 8,192 x 128 AMBE+2 -3.6 %; the one-frame-per-stream launches do not care
-// (and lose 1-6 % when a new wave's loads or a finishing wave's stores are given priority: tried, dropped).
+// (and lose 1-6 % when a new wave's loads or a finishing wave's stores are given priority: tried, dropped); the AMBE bodies
+// lose 1-4 % with a raised priority in their front part or in the eight-frame expansion pass: not there.
 #ifndef MBX_PRIO_BANK
 #define MBX_PRIO_BANK 2
 #endif
@@ -2269,6 +2270,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     wave_lds_sync();
                 }
                 fp = xrows[t & (kXRows - 1)];
+
             }
         }
         // The parts of prev_mp_enhanced that synthesis reads are requested together with prev_mp, so that one
