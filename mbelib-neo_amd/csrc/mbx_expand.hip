@@ -17,6 +17,7 @@
 // (expand_imbe_wave, mbx_stream.hip).  Workgroups are four independent waves.
 //
 // Output record (FrameParams, 64 dwords): v[1..56] T_l, v[57..58] voicing bits, v[59] w0, v[60] L,
+// (AMBE rows: v[60] = 0.2046 / sqrt(w0), L in bits 8.. of v[63]),
 // v[61] K (IMBE) / mean residual Sum42 (AMBE), v[62] error-context word, v[63] frame class
 // (0 voice, 1 invalid IMBE fundamental, 2 AMBE+2 erasure, 7 AMBE+2 tone; D-STAR: 3 tone class without a usable index,
 // 5..122 tone index), v[0] AMBE gain increment.

@@ -227,10 +227,13 @@ __device__ __forceinline__ void expand_ambe_frame_rec(bool have, const u32x4 rec
         row[57] = __uint_as_float(vlo);
         row[58] = __uint_as_float(vhi);
         row[59] = w0;
-        row[60] = __int_as_float(L);
+        // v[60]: the unvoiced-band factor 0.2046 / sqrt(w0) of the prediction (ref src/ambe/ambe3600x2450.c:389-459) -- an IEEE
+        // square root and an IEEE division, ~25 dependent instructions, here once per frame on one lane instead of in every
+        // wave of the stream kernel; L moves into the class word (v[63] = class | L << 8)
+        row[60] = (bad == 0) ? ((float)0.2046 / sqrtf(w0)) : 0.0f;
         row[61] = sum42;
         row[62] = __uint_as_float(errw);
-        row[63] = __int_as_float(bad);
+        row[63] = __int_as_float(bad | (L << 8));
     }
 }
 

@@ -43,7 +43,8 @@
 // phases of their frames the arbiter otherwise serves them oldest first, whatever they are doing.  Measured by interleaved
 // A/B on one box (round 4): 65,536 x 16 IMBE -1.7 %, 8,192 x 128 AMBE+2 -3.6 %; the one-frame-per-stream launches do not care
 // (and lose 1-6 % when a new wave's loads or a finishing wave's stores are given priority: tried, dropped); the AMBE bodies
-// lose 1-4 % with a raised priority in their front part or in the eight-frame expansion pass: not there.
+// lose 1-4 % with a raised priority in their front part or in the eight-frame expansion pass: not there.  Raising the rest of the
+// synthesiser (noise / phases, between bank and transform, overlap-add) as well costs 0.2-3.6 %: the point is the contrast.
 #ifndef MBX_PRIO_BANK
 #define MBX_PRIO_BANK 2
 #endif
@@ -473,7 +474,7 @@ __device__ __forceinline__ int rec_bit(const uint32_t w[3], int i) { return (int
 
 // Frame parameters from the expand stage (mbx_expand.hip): v[1..56] prediction residuals T_l,
 // v[57..58] voicing bits, v[59] w0, v[60] L, v[61] K (IMBE) / mean residual (AMBE), v[62] error
-// context word, v[63] frame class, v[0] AMBE gain increment.
+// context word, v[63] frame class, v[0] AMBE gain increment.  AMBE rows: v[60] = 0.2046 / sqrt(w0), v[63] = class | L << 8.
 __device__ int decode_imbe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DerivedTables* Dg, int lane, float* tmp) {
     const int bad = uni(__float_as_int(fp[63]));
     if (bad != 0) {
@@ -1964,14 +1965,15 @@ __device__ __forceinline__ int pick_bits(const uint32_t w[3], int i0, int i1, in
 
 // Returns 0 voice, 2 erasure, 7 tone (classified by the expand stage).
 __device__ int decode_ambe(const float* __restrict__ fp, Parms& cur, Parms& prev, const DeviceTables& tabs, int lane, float* tmp) {
-    const int bad = uni(__float_as_int(fp[63]));
+    const int word = uni(__float_as_int(fp[63]));   // AMBE rows: frame class | L << 8 (mbx_expand_ambe.h)
+    const int bad = word & 0xff;
     if (bad != 0) {
         return bad;
     }
     cur.w0 = uni(fp[59]);
-    const int L = uni(__float_as_int(fp[60]));
+    const int L = word >> 8;
     cur.L = L;
-    const float unvc = (float)0.2046 / sqrtf(cur.w0);
+    const float unvc = uni(fp[60]);   // 0.2046 / sqrtf(w0), formed by the expand stage with the reference's IEEE operations
     const unsigned long long vbits = ((unsigned long long)__float_as_uint(fp[58]) << 32) | __float_as_uint(fp[57]);
     cur.gamma = uni(fp[0] + ((float)0.5 * prev.gamma));
     float Tl = 0.0f;
@@ -2319,7 +2321,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             if constexpr (kPark) {
                 // a frame that will leave prev_mp_enhanced alone (AMBE+2 tone class, valid D-STAR tone) while it changes cur_mp:
                 // `cur` is still prev_mp_enhanced field for field here (see `synced` above) -- write it home first
-                const int cls = uni(__float_as_int(fp[63]));
+                const int cls = uni(__float_as_int(fp[63])) & 0xff;
                 const int c0v_early = ((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? c0 : 0;
                 const bool keeps_enh = k2400 ? ((cls >= 7) && (cls <= 122) && (c0v_early < 2) && (total < 3)) : (cls == 7);
                 if (keeps_enh && synced) {
