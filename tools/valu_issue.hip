@@ -37,16 +37,21 @@ constexpr int kBody = 64;     // instructions per trip (8 accumulators x 8)
     op " %0, %0" tail "\n" op " %1, %1" tail "\n" op " %2, %2" tail "\n" op " %3, %3" tail "\n" op " %4, %4" tail "\n" \
        op " %5, %5" tail "\n" op " %6, %6" tail "\n" op " %7, %7" tail "\n"
 
-enum Op { kFma, kPkFma, kPkMul, kCos, kFma64, kAddDpp, kMulLoU32, kMov, kReadlane, kDsReadB128, kBankLoop, kAddE32, kMulE32, kFmacE32, kCndmaskE32, kMulSgpr, kFmaSgpr, kPkFmaSgpr, kCndmaskE64, kCndmaskVccE64, kCndmaskVccFresh, kCmpThenCndmask, kNumOps };
+enum Op { kFma, kPkFma, kPkMul, kCos, kFma64, kAddDpp, kMulLoU32, kMov, kReadlane, kDsReadB128, kBankLoop, kAddE32, kMulE32, kFmacE32, kCndmaskE32, kMulSgpr, kFmaSgpr, kPkFmaSgpr, kCndmaskE64, kCndmaskVccE64, kCndmaskVccFresh, kCmpThenCndmask, kMulInline, kMulLiteral, kAddU32Inline, kLshlInline, kAndVgpr, kCmpVcc, kCmpE64, kCvtI2F, kMulOtherDst, kMixPkMul, kSubrevInline, kMaxInline, kNumOps };
 static const char* kNames[kNumOps] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cos_f32", "v_fma_f64", "v_add_f32 dpp",
                                       "v_mul_lo_u32", "v_mov_b32", "v_readlane_b32", "ds_read_b128 (broadcast)",
                                       "bank loop body (8 pk + 2 ds_read_b128)", "v_add_f32_e32 (VOP2, 4 B)", "v_mul_f32_e32 (VOP2, 4 B)",
                                       "v_fmac_f32_e32 (VOP2, 4 B)", "v_cndmask_b32_e32 (VOP2, 4 B, mask in VCC)",
                                       "v_mul_f32_e32 with an SGPR source", "v_fma_f32 with an SGPR source", "v_pk_fma_f32 with an SGPR-pair source",
                                       "v_cndmask_b32_e64 (mask in an SGPR pair)", "v_cndmask_b32_e64 (mask in VCC)",
-                                      "v_cndmask_b32_e32 (VCC written by s_mov once per 8)", "v_cmp_gt_f32_e32 + 7 x v_cndmask_b32_e32 (per 8)"};
+                                      "v_cndmask_b32_e32 (VCC written by s_mov once per 8)", "v_cmp_gt_f32_e32 + 7 x v_cndmask_b32_e32 (per 8)",
+                                      "v_mul_f32_e32 with an inline constant (2.0)", "v_mul_f32_e32 with a 32-bit literal (8 B)",
+                                      "v_add_u32_e32 with an inline constant", "v_lshlrev_b32_e32 by an inline constant", "v_and_b32_e32 (two VGPRs)",
+                                      "v_cmp_gt_f32_e32 (to VCC)", "v_cmp_gt_f32_e64 (to an SGPR pair)", "v_cvt_f32_i32_e32 (one source)",
+                                      "v_mul_f32_e32, destination distinct from both sources", "4 x v_pk_fma_f32 + 4 x v_mul_f32_e32 interleaved (per instruction)",
+                                      "v_sub_f32_e32 with an inline constant (1.0 - x)", "v_max_f32_e32 with an inline constant (0)"};
 // instructions of the measured class per loop trip
-static const int kPerTrip[kNumOps] = {kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, 8 * 8, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody};
+static const int kPerTrip[kNumOps] = {kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, 8 * 8, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody, kBody};
 
 template <int kOp>
 __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* cycles, float* sink, float seed) {
@@ -154,6 +159,60 @@ __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* cycles,
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                          : "v"(k)
                          : "vcc");
+        } else if constexpr (kOp == kMulInline) {
+            asm volatile(R8("v_mul_f32_e32 %0, 2.0, %0\n v_mul_f32_e32 %1, 2.0, %1\n v_mul_f32_e32 %2, 0.5, %2\n v_mul_f32_e32 %3, 0.5, %3\n"
+                            "v_mul_f32_e32 %4, 2.0, %4\n v_mul_f32_e32 %5, 2.0, %5\n v_mul_f32_e32 %6, 0.5, %6\n v_mul_f32_e32 %7, 0.5, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (kOp == kMulLiteral) {
+            asm volatile(R8("v_mul_f32_e32 %0, 0x3f7fbe77, %0\n v_mul_f32_e32 %1, 0x3f7fbe77, %1\n v_mul_f32_e32 %2, 0x3f7fbe77, %2\n v_mul_f32_e32 %3, 0x3f7fbe77, %3\n"
+                            "v_mul_f32_e32 %4, 0x3f7fbe77, %4\n v_mul_f32_e32 %5, 0x3f7fbe77, %5\n v_mul_f32_e32 %6, 0x3f7fbe77, %6\n v_mul_f32_e32 %7, 0x3f7fbe77, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (kOp == kAddU32Inline) {
+            asm volatile(R8("v_add_u32_e32 %0, 3, %0\n v_add_u32_e32 %1, 3, %1\n v_add_u32_e32 %2, 3, %2\n v_add_u32_e32 %3, 3, %3\n"
+                            "v_add_u32_e32 %4, 3, %4\n v_add_u32_e32 %5, 3, %5\n v_add_u32_e32 %6, 3, %6\n v_add_u32_e32 %7, 3, %7\n")
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if constexpr (kOp == kLshlInline) {
+            asm volatile(R8("v_lshlrev_b32_e32 %0, 1, %0\n v_lshlrev_b32_e32 %1, 1, %1\n v_lshlrev_b32_e32 %2, 1, %2\n v_lshlrev_b32_e32 %3, 1, %3\n"
+                            "v_lshlrev_b32_e32 %4, 1, %4\n v_lshlrev_b32_e32 %5, 1, %5\n v_lshlrev_b32_e32 %6, 1, %6\n v_lshlrev_b32_e32 %7, 1, %7\n")
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+        } else if constexpr (kOp == kAndVgpr) {
+            asm volatile(R8(OPS8("v_and_b32_e32", ", %8"))
+                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7)
+                         : "v"(~tid));
+        } else if constexpr (kOp == kCmpVcc) {
+            asm volatile(R8("v_cmp_gt_f32_e32 vcc, %0, %8\n v_cmp_gt_f32_e32 vcc, %1, %8\n v_cmp_gt_f32_e32 vcc, %2, %8\n v_cmp_gt_f32_e32 vcc, %3, %8\n"
+                            "v_cmp_gt_f32_e32 vcc, %4, %8\n v_cmp_gt_f32_e32 vcc, %5, %8\n v_cmp_gt_f32_e32 vcc, %6, %8\n v_cmp_gt_f32_e32 vcc, %7, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(k)
+                         : "vcc");
+        } else if constexpr (kOp == kCmpE64) {
+            unsigned long long m0, m1, m2, m3;
+            asm volatile(R8("v_cmp_gt_f32_e64 %8, %0, %12\n v_cmp_gt_f32_e64 %9, %1, %12\n v_cmp_gt_f32_e64 %10, %2, %12\n v_cmp_gt_f32_e64 %11, %3, %12\n"
+                            "v_cmp_gt_f32_e64 %8, %4, %12\n v_cmp_gt_f32_e64 %9, %5, %12\n v_cmp_gt_f32_e64 %10, %6, %12\n v_cmp_gt_f32_e64 %11, %7, %12\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                         : "v"(k));
+            sacc += (int)(m0 ^ m1 ^ m2 ^ m3);
+        } else if constexpr (kOp == kCvtI2F) {
+            asm volatile(R8(OPS8("v_cvt_f32_i32_e32", ""))
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (kOp == kMulOtherDst) {
+            asm volatile(R8("v_mul_f32_e32 %0, %8, %9\n v_mul_f32_e32 %1, %8, %9\n v_mul_f32_e32 %2, %8, %9\n v_mul_f32_e32 %3, %8, %9\n"
+                            "v_mul_f32_e32 %4, %8, %9\n v_mul_f32_e32 %5, %8, %9\n v_mul_f32_e32 %6, %8, %9\n v_mul_f32_e32 %7, %8, %9\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(k), "v"(seed));
+        } else if constexpr (kOp == kMixPkMul) {
+            asm volatile(R8("v_pk_fma_f32 %0, %0, %8, %8\n v_mul_f32_e32 %4, %4, %9\n v_pk_fma_f32 %1, %1, %8, %8\n v_mul_f32_e32 %5, %5, %9\n"
+                            "v_pk_fma_f32 %2, %2, %8, %8\n v_mul_f32_e32 %6, %6, %9\n v_pk_fma_f32 %3, %3, %8, %8\n v_mul_f32_e32 %7, %7, %9\n")
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(pk), "v"(k));
+        } else if constexpr (kOp == kSubrevInline) {
+            asm volatile(R8("v_sub_f32_e32 %0, 1.0, %0\n v_sub_f32_e32 %1, 1.0, %1\n v_sub_f32_e32 %2, 1.0, %2\n v_sub_f32_e32 %3, 1.0, %3\n"
+                            "v_sub_f32_e32 %4, 1.0, %4\n v_sub_f32_e32 %5, 1.0, %5\n v_sub_f32_e32 %6, 1.0, %6\n v_sub_f32_e32 %7, 1.0, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (kOp == kMaxInline) {
+            asm volatile(R8("v_max_f32_e32 %0, 0, %0\n v_max_f32_e32 %1, 0, %1\n v_max_f32_e32 %2, 0, %2\n v_max_f32_e32 %3, 0, %3\n"
+                            "v_max_f32_e32 %4, 0, %4\n v_max_f32_e32 %5, 0, %5\n v_max_f32_e32 %6, 0, %6\n v_max_f32_e32 %7, 0, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         } else if constexpr (kOp == kReadlane) {
             int s0, s1, s2, s3, s4, s5, s6, s7;
             asm volatile(R8("v_readlane_b32 %0, %8, 1\n v_readlane_b32 %1, %9, 2\n v_readlane_b32 %2, %10, 3\n v_readlane_b32 %3, %11, 4\n"
@@ -262,5 +321,17 @@ int main(int argc, char** argv) {
     run<kCndmaskVccE64>(cus, d_cycles, d_sink, only_w);
     run<kCndmaskVccFresh>(cus, d_cycles, d_sink, only_w);
     run<kCmpThenCndmask>(cus, d_cycles, d_sink, only_w);
+    run<kMulInline>(cus, d_cycles, d_sink, only_w);
+    run<kMulLiteral>(cus, d_cycles, d_sink, only_w);
+    run<kAddU32Inline>(cus, d_cycles, d_sink, only_w);
+    run<kLshlInline>(cus, d_cycles, d_sink, only_w);
+    run<kAndVgpr>(cus, d_cycles, d_sink, only_w);
+    run<kCmpVcc>(cus, d_cycles, d_sink, only_w);
+    run<kCmpE64>(cus, d_cycles, d_sink, only_w);
+    run<kCvtI2F>(cus, d_cycles, d_sink, only_w);
+    run<kMulOtherDst>(cus, d_cycles, d_sink, only_w);
+    run<kMixPkMul>(cus, d_cycles, d_sink, only_w);
+    run<kSubrevInline>(cus, d_cycles, d_sink, only_w);
+    run<kMaxInline>(cus, d_cycles, d_sink, only_w);
     return 0;
 }
