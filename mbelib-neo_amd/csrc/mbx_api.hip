@@ -29,6 +29,12 @@ __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const Fram
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void frame_server_kernel(mbx_frame_mailbox*, unsigned, mbe_parms*, mbx_stream_rng*, int16_t*, float*, mbe_process_result*,
                                     mbx_param_record*, DeviceTables);
+__global__ void imbe_stream_kernel_one(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                       int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe_stream_kernel_one(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                       int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe2400_stream_kernel_one(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                           int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res1(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                         int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
@@ -809,6 +815,11 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
                                params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
             return check_launch("imbe_stream_kernel_lds");
         }
+        if (T == 1) {
+            hipLaunchKernelGGL(mbx::imbe_stream_kernel_one, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                               params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+            return check_launch("imbe_stream_kernel_one");
+        }
         hipLaunchKernelGGL(mbx::imbe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         return check_launch("imbe_stream_kernel");
@@ -818,6 +829,11 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
             hipLaunchKernelGGL(mbx::ambe2400_stream_kernel_lds, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                                params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
             return check_launch("ambe2400_stream_kernel_lds");
+        }
+        if (T == 1) {
+            hipLaunchKernelGGL(mbx::ambe2400_stream_kernel_one, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                               params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+            return check_launch("ambe2400_stream_kernel_one");
         }
         hipLaunchKernelGGL(mbx::ambe2400_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
@@ -830,6 +846,11 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
         hipLaunchKernelGGL(mbx::ambe_stream_kernel_lds, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                            params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         return check_launch("ambe_stream_kernel_lds");
+    }
+    if (T == 1) {
+        hipLaunchKernelGGL(mbx::ambe_stream_kernel_one, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
+                           params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+        return check_launch("ambe_stream_kernel_one");
     }
     hipLaunchKernelGGL(mbx::ambe_stream_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                        params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
@@ -1411,12 +1432,12 @@ const char* mbx_stream_kernel_name(int codec, int T) {
     }
     const bool lds = T >= kLdsResidentMinFrames && lds_resident_enabled();
     if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {
-        return lds ? "imbe_stream_kernel_lds" : "imbe_stream_kernel";
+        return lds ? "imbe_stream_kernel_lds" : (T == 1 ? "imbe_stream_kernel_one" : "imbe_stream_kernel");
     }
     if (codec == MBX_CODEC_AMBE3600X2400) {
-        return lds ? "ambe2400_stream_kernel_lds" : "ambe2400_stream_kernel";
+        return lds ? "ambe2400_stream_kernel_lds" : (T == 1 ? "ambe2400_stream_kernel_one" : "ambe2400_stream_kernel");
     }
-    return lds ? "ambe_stream_kernel_lds" : "ambe_stream_kernel";
+    return lds ? "ambe_stream_kernel_lds" : (T == 1 ? "ambe_stream_kernel_one" : "ambe_stream_kernel");
 }
 
 // ---- host-buffer conveniences ------------------------------------------------------------

@@ -6,10 +6,78 @@
 //   IMBE 7100x4400  ref src/imbe/imbe7100x4400.c:100-122, 292-334, 153-212, 381-479; src/ecc/ecc.c:422-464
 //   ECC             ref src/ecc/ecc.c:221-301 (Golay(23,12) by syndrome table), :366-408 (Hamming(15,11))
 // Integer work only: bit-exact.
+// Two table readers (the FEC is templated on them): TabVector reads mbx_tables with ordinary per-thread loads (batch kernels);
+// TabScalar reads it with s_load (single-frame kernels: the whole FEC is wave-uniform there and runs on the scalar unit, and --
+// the point -- scalar loads do not queue behind the wave's vector loads, which return IN ORDER: the frame's FEC really runs
+// while the three structs are still on their way over PCIe instead of waiting for them at its first table read).
 #pragma once
 #include "mbx_device.h"
 
 namespace mbx {
+
+struct TabVector {
+    const mbx_tables* T;
+    static constexpr bool kUniform = false;
+    __device__ uint32_t golay_gen(int i) const { return T->golay_gen[i]; }
+    __device__ uint32_t golay_fix(uint32_t syndrome) const { return T->golay_matrix[syndrome]; }
+    __device__ uint32_t hamming_gen(bool v7100, int i) const { return v7100 ? T->hamming7100_gen[i] : T->hamming_gen[i]; }
+    __device__ uint32_t hamming_fix(bool v7100, int syndrome) const { return v7100 ? T->hamming7100_fix[syndrome] : T->hamming_fix[syndrome]; }
+    __device__ uint32_t imbe_K(int b0) const { return T->imbe_K[b0]; }
+};
+
+// wave-uniform reads of the table blob through the scalar cache.  `T` must be uniform (a kernel argument), offsets too.
+__device__ __forceinline__ uint32_t sload_dword(const void* base, uint32_t byte_off) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byte_off & ~3u) : "memory");
+    return v;
+}
+template <typename E>   // element `index` of an array of 8- or 16-bit E at byte offset `array_off` (a multiple of 4) of the blob
+__device__ __forceinline__ uint32_t sload_elem(const void* base, uint32_t array_off, uint32_t index) {
+    const uint32_t byte = index * (uint32_t)sizeof(E);
+    const uint32_t w = sload_dword(base, array_off + byte);
+    return (w >> (8u * (byte & 3u))) & ((1u << (8u * (uint32_t)sizeof(E))) - 1u);
+}
+
+struct TabScalar {
+    const mbx_tables* T;
+    uint32_t gen[6];   // golay_gen[12], two per dword, fetched once
+    static constexpr bool kUniform = true;
+    __device__ explicit TabScalar(const mbx_tables* t) : T(t) {
+        static_assert(offsetof(mbx_tables, golay_gen) % 4 == 0 && offsetof(mbx_tables, golay_matrix) % 4 == 0
+                          && offsetof(mbx_tables, hamming_gen) % 4 == 0 && offsetof(mbx_tables, hamming_fix) % 4 == 0
+                          && offsetof(mbx_tables, hamming7100_gen) % 4 == 0 && offsetof(mbx_tables, hamming7100_fix) % 4 == 0
+                          && offsetof(mbx_tables, imbe_K) % 4 == 0,
+                      "scalar loads read whole dwords");
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        u4 a;
+        u2 b;
+        asm volatile("s_load_dwordx4 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(a), "=&s"(b)
+                     : "s"(t), "s"((uint32_t)offsetof(mbx_tables, golay_gen)), "s"((uint32_t)offsetof(mbx_tables, golay_gen) + 16u)
+                     : "memory");
+        gen[0] = a.x;
+        gen[1] = a.y;
+        gen[2] = a.z;
+        gen[3] = a.w;
+        gen[4] = b.x;
+        gen[5] = b.y;
+    }
+    __device__ uint32_t golay_gen(int i) const { return (gen[i >> 1] >> (16 * (i & 1))) & 0xffffu; }
+    __device__ uint32_t golay_fix(uint32_t syndrome) const { return sload_elem<uint16_t>(T, offsetof(mbx_tables, golay_matrix), syndrome); }
+    __device__ uint32_t hamming_gen(bool v7100, int i) const {
+        return sload_elem<uint16_t>(T, v7100 ? offsetof(mbx_tables, hamming7100_gen) : offsetof(mbx_tables, hamming_gen), (uint32_t)i);
+    }
+    __device__ uint32_t hamming_fix(bool v7100, int syndrome) const {
+        return sload_elem<uint16_t>(T, v7100 ? offsetof(mbx_tables, hamming7100_fix) : offsetof(mbx_tables, hamming_fix), (uint32_t)syndrome);
+    }
+    __device__ uint32_t imbe_K(int b0) const { return sload_elem<uint8_t>(T, offsetof(mbx_tables, imbe_K), (uint32_t)b0); }
+};
+
+// The wire frame as values.  IMBE (18 bytes): nine big-endian 16-bit halves; AMBE (9 bytes): the nine bytes.
+struct Wire {
+    uint32_t h[9];
+};
 
 struct BitReader {            // 160 bits, big-endian bit order
     uint32_t w[5];
@@ -26,25 +94,33 @@ __device__ __forceinline__ uint32_t load_be16(const uint8_t* p) {
 }
 
 // Golay(23,12): cw bit j = cell j.  Data bits 22..11, parity 10..0 (parity passes through).
-__device__ __forceinline__ int golay2312(const mbx_tables* T, uint32_t cw, uint32_t& fixed) {
+template <typename Tab>
+__device__ __forceinline__ int golay2312_t(const Tab& tab, uint32_t cw, uint32_t& fixed) {
     uint32_t expect = 0;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-        expect ^= (cw & (0x400000u >> i)) ? (uint32_t)T->golay_gen[i] : 0u;
+        expect ^= (cw & (0x400000u >> i)) ? tab.golay_gen(i) : 0u;
     }
-    const uint32_t fix = T->golay_matrix[expect ^ (cw & 0x7ffu)];
+    const uint32_t fix = tab.golay_fix(expect ^ (cw & 0x7ffu));
     fixed = cw ^ (fix << 11);
     return __popc(fix);
 }
+__device__ __forceinline__ int golay2312(const mbx_tables* T, uint32_t cw, uint32_t& fixed) {
+    return golay2312_t(TabVector{T}, cw, fixed);
+}
 
-__device__ __forceinline__ int hamming1511(const mbx_tables* T, uint32_t cw, uint32_t& fixed) {
+template <bool v7100, typename Tab>
+__device__ __forceinline__ int hamming1511_t(const Tab& tab, uint32_t cw, uint32_t& fixed) {
     int syndrome = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        syndrome |= (__popc(cw & (uint32_t)T->hamming_gen[i]) & 1) << i;
+        syndrome |= (__popc(cw & tab.hamming_gen(v7100, i)) & 1) << i;
     }
-    fixed = syndrome ? (cw ^ (uint32_t)T->hamming_fix[syndrome]) : cw;
+    fixed = syndrome ? (cw ^ tab.hamming_fix(v7100, syndrome)) : cw;
     return syndrome != 0;
+}
+__device__ __forceinline__ int hamming1511(const mbx_tables* T, uint32_t cw, uint32_t& fixed) {
+    return hamming1511_t<false>(TabVector{T}, cw, fixed);
 }
 
 // The demodulation sequence: x0 = 16*seed, x_k = 173*x_{k-1} + 13849 mod 2^16, bit_k = x_k >> 15.
@@ -84,14 +160,35 @@ struct RecordWriter {
 };
 
 // f: the frame's 18 wire bytes (even address)
-__device__ __forceinline__ uint4 fec_imbe7200x4400_frame(const mbx_tables* T, const uint8_t* f) {
-
+__device__ __forceinline__ Wire load_wire_imbe(const uint8_t* f) {
+    Wire w;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        w.h[k] = load_be16(f + 2 * k);
+    }
+    return w;
+}
+__device__ __forceinline__ Wire load_wire_ambe(const uint8_t* f) {   // 9-byte frames: byte loads
+    Wire w;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        w.h[k] = f[k];
+    }
+    return w;
+}
+__device__ __forceinline__ BitReader imbe_bits(const Wire& wire) {
     BitReader br;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        br.w[k] = (load_be16(f + 4 * k) << 16) | load_be16(f + 4 * k + 2);
+        br.w[k] = (wire.h[2 * k] << 16) | wire.h[2 * k + 1];
     }
-    br.w[4] = load_be16(f + 16) << 16;
+    br.w[4] = wire.h[8] << 16;
+    return br;
+}
+
+template <typename Tab>
+__device__ __forceinline__ uint4 fec_imbe7200x4400_wire(const Tab& tab, const Wire& wire) {
+    const BitReader br = imbe_bits(wire);
 
     uint32_t row[8];
     row[0] = br.take(0, 23);
@@ -103,7 +200,7 @@ __device__ __forceinline__ uint4 fec_imbe7200x4400_frame(const mbx_tables* T, co
     row[6] = br.take(122, 15);
     row[7] = br.take(137, 7);
 
-    const int c0 = golay2312(T, row[0], row[0]);
+    const int c0 = golay2312_t(tab, row[0], row[0]);
     PrSequence pr(row[0] >> 11);
     row[1] ^= pr.mask_for(23);
     row[2] ^= pr.mask_for(23);
@@ -117,13 +214,13 @@ __device__ __forceinline__ uint4 fec_imbe7200x4400_frame(const mbx_tables* T, co
     rw.push(row[0], 23, 12);
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
-        prot += golay2312(T, row[r], row[r]);
+        prot += golay2312_t(tab, row[r], row[r]);
         rw.push(row[r], 23, 12);
     }
     int c4 = 0;
 #pragma unroll
     for (int r = 4; r < 7; ++r) {
-        const int e = hamming1511(T, row[r], row[r]);
+        const int e = hamming1511_t<false>(tab, row[r], row[r]);
         prot += e;
         if (r == 4) {
             c4 = e;
@@ -140,21 +237,25 @@ __device__ __forceinline__ uint4 fec_imbe7200x4400_frame(const mbx_tables* T, co
                | ((MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24);
     return make_uint4(rec.w[0], rec.w[1], rec.w[2], rec.w[3]);
 }
+__device__ __forceinline__ uint4 fec_imbe7200x4400_frame(const mbx_tables* T, const uint8_t* f) {
+    return fec_imbe7200x4400_wire(TabVector{T}, load_wire_imbe(f));
+}
 
 
-// f: the frame's 9 wire bytes
-__device__ __forceinline__ uint4 fec_ambe3600x2450_frame(const mbx_tables* T, const uint8_t* f) {
+// the frame's 9 wire bytes
+template <typename Tab>
+__device__ __forceinline__ uint4 fec_ambe3600x2450_wire(const Tab& tab, const Wire& f) {
 
     BitReader br;
-    br.w[0] = ((uint32_t)f[0] << 24) | ((uint32_t)f[1] << 16) | ((uint32_t)f[2] << 8) | f[3];
-    br.w[1] = ((uint32_t)f[4] << 24) | ((uint32_t)f[5] << 16) | ((uint32_t)f[6] << 8) | f[7];
-    br.w[2] = (uint32_t)f[8] << 24;
+    br.w[0] = (f.h[0] << 24) | (f.h[1] << 16) | (f.h[2] << 8) | f.h[3];
+    br.w[1] = (f.h[4] << 24) | (f.h[5] << 16) | (f.h[6] << 8) | f.h[7];
+    br.w[2] = f.h[8] << 24;
     br.w[3] = br.w[4] = 0;
 
     uint32_t row0 = br.take(0, 24), row1 = br.take(24, 23), row2 = br.take(47, 11), row3 = br.take(58, 14);
 
     uint32_t cw;
-    int c0 = golay2312(T, row0 >> 1, cw);
+    int c0 = golay2312_t(tab, row0 >> 1, cw);
     row0 = (cw << 1) | (row0 & 1u);
     if (c0 == 0 && (__popc(row0) & 1)) {   // Golay24 overall parity, only when no data bit was fixed
         row0 ^= 1u;
@@ -162,7 +263,7 @@ __device__ __forceinline__ uint4 fec_ambe3600x2450_frame(const mbx_tables* T, co
     }
     PrSequence pr((row0 >> 12) & 0xfffu);
     row1 ^= pr.mask_for(23);
-    const int prot = golay2312(T, row1, row1);
+    const int prot = golay2312_t(tab, row1, row1);
 
     RecordWriter rw;
     rw.push(row0, 24, 12);
@@ -172,16 +273,13 @@ __device__ __forceinline__ uint4 fec_ambe3600x2450_frame(const mbx_tables* T, co
     return make_uint4((uint32_t)(rw.hi >> 32), (uint32_t)rw.hi, (uint32_t)(rw.lo >> 32),
                    (uint32_t)c0 | ((uint32_t)prot << 8) | (MBE_PROCESS_FLAG_C0_VALID << 24));
 }
+__device__ __forceinline__ uint4 fec_ambe3600x2450_frame(const mbx_tables* T, const uint8_t* f) {
+    return fec_ambe3600x2450_wire(TabVector{T}, load_wire_ambe(f));
+}
 
 
 __device__ __forceinline__ int hamming1511_7100(const mbx_tables* T, uint32_t cw, uint32_t& fixed) {
-    int syndrome = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        syndrome |= (__popc(cw & (uint32_t)T->hamming7100_gen[i]) & 1) << i;
-    }
-    fixed = syndrome ? (cw ^ (uint32_t)T->hamming7100_fix[syndrome]) : cw;
-    return syndrome != 0;
+    return hamming1511_t<true>(TabVector{T}, cw, fixed);
 }
 
 struct Bits88 {   // bit i (0 = first parameter bit) at bit 127 - i of hi:lo
@@ -196,15 +294,10 @@ struct Bits88 {   // bit i (0 = first parameter bit) at bit 127 - i of hi:lo
     }
 };
 
-// f: the frame's 18 wire bytes (even address); the record holds the 88 bits in 7200x4400 order
-__device__ __forceinline__ uint4 fec_imbe7100x4400_frame(const mbx_tables* T, const uint8_t* f) {
-
-    BitReader br;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        br.w[k] = (load_be16(f + 4 * k) << 16) | load_be16(f + 4 * k + 2);
-    }
-    br.w[4] = load_be16(f + 16) << 16;
+// the frame's 18 wire bytes; the record holds the 88 bits in 7200x4400 order
+template <typename Tab>
+__device__ __forceinline__ uint4 fec_imbe7100x4400_wire(const Tab& tab, const Wire& wire) {
+    const BitReader br = imbe_bits(wire);
 
     uint32_t row[7];
     row[0] = br.take(0, 19);
@@ -216,7 +309,7 @@ __device__ __forceinline__ uint4 fec_imbe7100x4400_frame(const mbx_tables* T, co
     row[6] = br.take(119, 23);
 
     uint32_t w;
-    const int c0 = golay2312(T, (row[0] >> 1) & 0x3ffffu, w);   // the five missing positions are zeros
+    const int c0 = golay2312_t(tab, (row[0] >> 1) & 0x3ffffu, w);   // the five missing positions are zeros
     row[0] = ((w & 0x3ffffu) << 1) | (row[0] & 1u);
     PrSequence pr((row[0] >> 12) & 0x7fu);
     row[1] ^= pr.mask_for(24);
@@ -228,16 +321,16 @@ __device__ __forceinline__ uint4 fec_imbe7100x4400_frame(const mbx_tables* T, co
     int prot = 0, c4 = 0;
     RecordWriter rw;                       // 7100 order: 7 + 12 + 12 + 12 + 11 + 11 + 23 bits
     rw.push(row[0] >> 12, 7, 7);
-    prot += golay2312(T, row[1] >> 1, w);   // C1 = cells 1..23
+    prot += golay2312_t(tab, row[1] >> 1, w);   // C1 = cells 1..23
     rw.push(w, 23, 12);
-    prot += golay2312(T, row[2], w);
+    prot += golay2312_t(tab, row[2], w);
     rw.push(w, 23, 12);
-    prot += golay2312(T, row[3], w);
+    prot += golay2312_t(tab, row[3], w);
     rw.push(w, 23, 12);
-    c4 = hamming1511_7100(T, row[4], w);
+    c4 = hamming1511_t<true>(tab, row[4], w);
     prot += c4;
     rw.push(w, 15, 11);
-    prot += hamming1511_7100(T, row[5], w);
+    prot += hamming1511_t<true>(tab, row[5], w);
     rw.push(w, 15, 11);
     rw.push(row[6], 23, 23);
 
@@ -246,7 +339,7 @@ __device__ __forceinline__ uint4 fec_imbe7100x4400_frame(const mbx_tables* T, co
     d.lo = rw.lo;
     // mbe_convertImbe7100to7200
     const int b0 = (int)(((d.hi >> 56) & 0x7eull) << 1) | (d.get(86) << 1) | d.get(87);   // bits 1..6, 86, 87
-    const int K = (b0 < 208) ? (int)T->imbe_K[b0] : 12;   // the reference's expression gives 12 for every b0 >= 208
+    const int K = (b0 < 208) ? (int)tab.imbe_K(b0) : 12;   // the reference's expression gives 12 for every b0 >= 208
     t.put(87, d.get(0));
     t.put(48 + K, d.get(42));
     t.put(49 + K, d.get(43));
@@ -266,6 +359,9 @@ __device__ __forceinline__ uint4 fec_imbe7100x4400_frame(const mbx_tables* T, co
     return make_uint4((uint32_t)(t.hi >> 32), (uint32_t)t.hi, (uint32_t)(t.lo >> 32),
                    (uint32_t)c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
                        | ((MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24));
+}
+__device__ __forceinline__ uint4 fec_imbe7100x4400_frame(const mbx_tables* T, const uint8_t* f) {
+    return fec_imbe7100x4400_wire(TabVector{T}, load_wire_imbe(f));
 }
 
 }  // namespace mbx

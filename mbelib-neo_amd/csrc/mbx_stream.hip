@@ -35,6 +35,10 @@
 
 #include "mbx_device.h"
 #include "mbx_expand_ambe.h"
+#ifdef MBX_FRAME_STAMPS
+namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
+#define MBX_FSTAMP(i) do { g_frame_stamps[i] = wall_clock64(); } while (0)
+#endif
 #include "mbx_fec_frame.h"
 
 // Wave priorities (s_setprio): a wave raises its priority while it is in one of the two VALU-dense stretches of a frame -- the
@@ -97,18 +101,75 @@ enum : int {
     O_ERR4 = 295, O_REPEAT = 296, O_MUTETHR = 297, O_UW = 298, O_NOISESEED = 554, O_OVERLAP = 555, PARMS_DWORDS = 651
 };
 
-__device__ __forceinline__ void load_parms(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+// The fourteen wave-uniform fields of a struct come in ONE vector load: lane j fetches header field j (H_*), and the values
+// are read out of that register with v_readlane once they are needed.  Written as `uni(f[O_W0])` etc. every field was a load
+// of its own followed by a v_readfirstlane -- and because vector memory returns in order and the read-out waits for its load,
+// every group of them was a full memory round trip in the middle of the struct's other requests: six to seven serialised
+// round trips at the start of every wave of a one-frame launch (and as many PCIe round trips in the single-frame kernels).
+// Now every request of a launch's first frame is issued before the first wait.
+enum : int {
+    H_W0 = 0, H_L = 1, H_K = 2, H_GAMMA = 3, H_TONEPHASE = 4, H_SWN = 5, H_LOCALENERGY = 6, H_AMPTHR = 7, H_ERRORRATE = 8,
+    H_ERRTOTAL = 9, H_ERR4 = 10, H_REPEAT = 11, H_MUTETHR = 12, H_NOISESEED = 13
+};
+__device__ __forceinline__ uint32_t load_header(const mbe_parms* __restrict__ p, int lane) {
+    const int j = lane & 15;   // (the lanes above 13 repeat a field: same cache lines, no mask to set up)
+    const int idx = (j < 3) ? j : ((j < 13) ? (O_GAMMA - H_GAMMA) + j : O_NOISESEED);
+    static_assert(O_MUTETHR - O_GAMMA == H_MUTETHR - H_GAMMA, "fields 3..12 of the header are contiguous in mbe_parms");
+    return reinterpret_cast<const uint32_t*>(p)[idx];
+}
+__device__ __forceinline__ int hdr_i(uint32_t h, int k) { return __builtin_amdgcn_readlane((int)h, k); }
+__device__ __forceinline__ float hdr_f(uint32_t h, int k) { return __int_as_float(__builtin_amdgcn_readlane((int)h, k)); }
+
+__device__ __forceinline__ void load_parms_arrays(Parms& r, const mbe_parms* __restrict__ p, int lane) {
     const float* f = reinterpret_cast<const float*>(p);
     const int* i = reinterpret_cast<const int*>(p);
     const bool band = lane < MBX_BAND_SLOTS;
-    r.w0 = uni(f[O_W0]);
-    r.L = uni(i[O_L]);
-    r.K = uni(i[O_K]);
     r.Vl = band ? i[O_VL + lane] : 0;
     r.Ml = band ? f[O_ML + lane] : 0.0f;
     r.log2Ml = band ? f[O_LOG2ML + lane] : 0.0f;
     r.PHIl = band ? f[O_PHI + lane] : 0.0f;
     r.PSIl = band ? f[O_PSI + lane] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.uw[j] = f[O_UW + lane + 64 * j];
+    }
+    r.ov[0] = f[O_OVERLAP + lane];
+    r.ov[1] = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
+}
+__device__ __forceinline__ void set_parms_header(Parms& r, uint32_t h) {
+    r.w0 = hdr_f(h, H_W0);
+    r.L = hdr_i(h, H_L);
+    r.K = hdr_i(h, H_K);
+    r.gamma = hdr_f(h, H_GAMMA);
+    r.tonePhase = (uint32_t)hdr_i(h, H_TONEPHASE);
+    r.swn = hdr_i(h, H_SWN);
+    r.localEnergy = hdr_f(h, H_LOCALENERGY);
+    r.amplitudeThreshold = hdr_i(h, H_AMPTHR);
+    r.errorRate = hdr_f(h, H_ERRORRATE);
+    r.errorCountTotal = hdr_i(h, H_ERRTOTAL);
+    r.errorCount4 = hdr_i(h, H_ERR4);
+    r.repeatCount = hdr_i(h, H_REPEAT);
+    r.mutingThreshold = hdr_f(h, H_MUTETHR);
+    r.noiseSeed = hdr_f(h, H_NOISESEED);
+}
+// The whole struct in one call, every scalar field by a load of its own: for the places that are not at the start of a launch
+// (a repeat copying prev_mp, copies between slots, the other kernels).  Measured: with the gathered header here too, and in the
+// start of the LDS-resident AMBE+2 instances, ambe_stream_kernel_lds is 6.7 % SLOWER over a 128-frame launch (8,192 x 128:
+// 2.63 -> 2.81 ms; same instruction counts -- register allocation of the frame loop), so those keep this form.
+template <bool kGather = false>
+__device__ __forceinline__ void load_parms(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+    if constexpr (kGather) {   // the one-frame instances: their register budget (72) is met with this form and not with the other
+        const uint32_t h = load_header(p, lane);
+        load_parms_arrays(r, p, lane);
+        set_parms_header(r, h);
+        return;
+    }
+    const float* f = reinterpret_cast<const float*>(p);
+    const int* i = reinterpret_cast<const int*>(p);
+    r.w0 = uni(f[O_W0]);
+    r.L = uni(i[O_L]);
+    r.K = uni(i[O_K]);
+    load_parms_arrays(r, p, lane);
     r.gamma = uni(f[O_GAMMA]);
     r.tonePhase = (uint32_t)uni(i[O_TONEPHASE]);
     r.swn = uni(i[O_SWN]);
@@ -119,13 +180,7 @@ __device__ __forceinline__ void load_parms(Parms& r, const mbe_parms* __restrict
     r.errorCount4 = uni(i[O_ERR4]);
     r.repeatCount = uni(i[O_REPEAT]);
     r.mutingThreshold = uni(f[O_MUTETHR]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r.uw[j] = f[O_UW + lane + 64 * j];
-    }
     r.noiseSeed = uni(f[O_NOISESEED]);
-    r.ov[0] = f[O_OVERLAP + lane];
-    r.ov[1] = (lane < 32) ? f[O_OVERLAP + 64 + lane] : 0.0f;
 }
 
 __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restrict__ p, int lane) {
@@ -171,36 +226,61 @@ __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restric
 //   * synthesis reads from prev_mp_enhanced only w0, L, Vl, Ml, PHIl, PSIl, the second half of
 //     previousUw and the two smoothing memories.
 // Unread fields stay zero and are optimised away: fewer registers, and ~40 % less state read traffic.
-__device__ __forceinline__ void load_prev_view(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+__device__ __forceinline__ void load_prev_arrays(Parms& r, const mbe_parms* __restrict__ p, int lane) {
     const float* f = reinterpret_cast<const float*>(p);
-    const int* i = reinterpret_cast<const int*>(p);
     const bool band = lane < MBX_BAND_SLOTS;
     r = Parms{};
-    r.L = uni(i[O_L]);
     r.Ml = band ? f[O_ML + lane] : 0.0f;
     r.log2Ml = band ? f[O_LOG2ML + lane] : 0.0f;
     r.PHIl = band ? f[O_PHI + lane] : 0.0f;
+}
+__device__ __forceinline__ void set_prev_header(Parms& r, uint32_t h) {
+    r.L = hdr_i(h, H_L);
+    r.gamma = hdr_f(h, H_GAMMA);
+    r.errorRate = hdr_f(h, H_ERRORRATE);
+    r.repeatCount = hdr_i(h, H_REPEAT);
+    r.mutingThreshold = hdr_f(h, H_MUTETHR);
+}
+__device__ __forceinline__ void load_prev_view(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+    const uint32_t h = load_header(p, lane);
+    load_prev_arrays(r, p, lane);
+    set_prev_header(r, h);
+}
+
+// the same from the LDS copy of prev_mp (LDS-resident instances, once per frame): broadcast reads, nothing to reorder
+__device__ __forceinline__ void load_prev_view_lds(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+    const float* f = reinterpret_cast<const float*>(p);
+    const int* i = reinterpret_cast<const int*>(p);
+    load_prev_arrays(r, p, lane);
+    r.L = uni(i[O_L]);
     r.gamma = uni(f[O_GAMMA]);
     r.errorRate = uni(f[O_ERRORRATE]);
     r.repeatCount = uni(i[O_REPEAT]);
     r.mutingThreshold = uni(f[O_MUTETHR]);
 }
 
-__device__ __forceinline__ void load_enh_view(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+__device__ __forceinline__ void load_enh_arrays(Parms& r, const mbe_parms* __restrict__ p, int lane) {
     const float* f = reinterpret_cast<const float*>(p);
     const int* i = reinterpret_cast<const int*>(p);
     const bool band = lane < MBX_BAND_SLOTS;
     r = Parms{};
-    r.w0 = uni(f[O_W0]);
-    r.L = uni(i[O_L]);
     r.Vl = band ? i[O_VL + lane] : 0;
     r.Ml = band ? f[O_ML + lane] : 0.0f;
     r.PHIl = band ? f[O_PHI + lane] : 0.0f;
     r.PSIl = band ? f[O_PSI + lane] : 0.0f;
-    r.localEnergy = uni(f[O_LOCALENERGY]);
-    r.amplitudeThreshold = uni(i[O_AMPTHR]);
     r.uw[2] = f[O_UW + lane + 128];
     r.uw[3] = f[O_UW + lane + 192];
+}
+__device__ __forceinline__ void set_enh_header(Parms& r, uint32_t h) {
+    r.w0 = hdr_f(h, H_W0);
+    r.L = hdr_i(h, H_L);
+    r.localEnergy = hdr_f(h, H_LOCALENERGY);
+    r.amplitudeThreshold = hdr_i(h, H_AMPTHR);
+}
+__device__ __forceinline__ void load_enh_view(Parms& r, const mbe_parms* __restrict__ p, int lane) {
+    const uint32_t h = load_header(p, lane);
+    load_enh_arrays(r, p, lane);
+    set_enh_header(r, h);
 }
 
 // the synthesis-continuity fields an AMBE erasure keeps from prev_mp
@@ -1606,15 +1686,34 @@ __device__ __forceinline__ void copy_prev_view(mbe_parms* dst, const mbe_parms* 
     }
 }
 
+template <bool kGather = false>
 __device__ __forceinline__ void copy_parms(mbe_parms* dst, const mbe_parms* src, int lane) {
     Parms t;
-    load_parms(t, src, lane);
+    load_parms<kGather>(t, src, lane);
     store_parms(t, dst, lane);
 }
 
 // ------------------------------------------------------------------------------------------
 // IMBE 7200x4400 stream kernel: grid = S workgroups of one wave.
 // ------------------------------------------------------------------------------------------
+// Development instrumentation (-DMBX_FRAME_STAMPS, never in the product build): where a synchronous single-frame call spends
+// its time on the device -- 100 MHz wall-clock stamps of the single-frame bodies, read back through mbx_debug_frame_stamps().
+#ifdef MBX_FRAME_STAMPS
+#define MBX_STAMP(i, drain)                                                     \
+    do {                                                                        \
+        if constexpr (kFrame) {                                                 \
+            if (drain) {                                                        \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+            }                                                                   \
+            if (lane_id() == 0) {                                               \
+                g_frame_stamps[i] = wall_clock64();                             \
+            }                                                                   \
+        }                                                                       \
+    } while (0)
+#else
+#define MBX_STAMP(i, drain) do { } while (0)
+#endif
+
 __device__ __forceinline__ void frame_done(uint32_t* done, uint32_t token, int lane) {
     __threadfence_system();   // the wave's stores (one wave: s_waitcnt vmcnt(0) covers every lane) are visible to the host ...
     if (done && lane == 0) {
@@ -1629,20 +1728,30 @@ __device__ __forceinline__ uint4 broadcast_record(uint4 r, mbx_param_record* out
     return make_uint4(uni(r.x), uni(r.y), uni(r.z), uni(r.w));
 }
 
-// the frame's record by lane 0 of the wave (kFrame kernels); fec_codec: MBX_CODEC_* of the FRONT END (both AMBE codecs share one)
-__device__ __forceinline__ uint4 frame_record(int fec_codec, const uint8_t* frame, mbx_param_record* record, const mbx_tables* T, int lane) {
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
-    if (lane == 0) {
-        r = (fec_codec == MBX_CODEC_IMBE7200X4400)   ? fec_imbe7200x4400_frame(T, frame)
-            : (fec_codec == MBX_CODEC_IMBE7100X4400) ? fec_imbe7100x4400_frame(T, frame)
-                                                     : fec_ambe3600x2450_frame(T, frame);
+// Single-frame kernels: the frame's wire bytes are REQUESTED first of all (frame_fetch: vector memory returns in order, so
+// whatever is requested before the state is not held up by it) and its FEC runs wave-uniformly on the scalar unit with scalar
+// table loads (frame_record: TabScalar, mbx_fec_frame.h) while the three structs are on their way.
+// fec_codec: MBX_CODEC_* of the FRONT END (both AMBE codecs share one)
+__device__ __forceinline__ Wire frame_fetch(bool ambe, const uint8_t* frame) {
+    return ambe ? load_wire_ambe(frame) : load_wire_imbe(frame);
+}
+__device__ __forceinline__ uint4 frame_record(int fec_codec, Wire wire, mbx_param_record* record, const mbx_tables* T, int lane) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        wire.h[k] = uni(wire.h[k]);   // every lane loaded the same bytes
     }
+    const TabScalar tab(T);
+    const uint4 r = (fec_codec == MBX_CODEC_IMBE7200X4400)   ? fec_imbe7200x4400_wire(tab, wire)
+                    : (fec_codec == MBX_CODEC_IMBE7100X4400) ? fec_imbe7100x4400_wire(tab, wire)
+                                                             : fec_ambe3600x2450_wire(tab, wire);
     return broadcast_record(r, record, lane);
 }
 
 // kFrame: the single-frame kernels behind the synchronous per-frame API (S = T = 1): the record comes in registers from
 // the FEC the same wave has just run (rec_in), not from memory.
-template <bool kPark, bool kFrame = false, bool kRes = false>
+// kOne (HBM-slot instances only): the launch has ONE frame per stream -- no frame loop, and the views of prev_mp / prev_mp_enhanced
+// are requested together with cur_mp.  (With a loop the pre-requested views stay allocated through every frame: spills.)
+template <bool kPark, bool kFrame = false, bool kRes = false, bool kOne = false>
 __device__ __forceinline__ void
 imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
@@ -1657,6 +1766,11 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     }
     const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const int lane_in = lane_id();
+    MBX_STAMP(0, false);
+    Wire wire_in = {};
+    if constexpr (kFrame) {
+        wire_in = frame_fetch(false, frame_in);   // ahead of every state load
+    }
 
     // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
     // registers for the whole launch; `prev` is only needed from the start of a frame to the
@@ -1681,35 +1795,62 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     uint32_t* const res1 = (!kPark && kRes) ? tabs_in.resident : nullptr;
     const bool elided1 = res1 && (uni(res1[slot]) != 0u);
     bool prev_partial = false;   // wave-uniform: the LDS copy of prev_mp holds only the decode's view of it
+    // Every request of the launch's first frame goes out before anything waits (see load_header): the three headers first
+    // (vector memory returns in order: what is asked for first is there first), then the per-lane arrays.
+    Parms enh_first, prev_first;       // !kPark: the first frame's views of prev_mp_enhanced / prev_mp ...
+    uint32_t h_enh_first = 0u, h_prev_first = 0u;   // ... and their headers, read out where the frame loop needs them
     if constexpr (kPark) {
         slot_prev = &park.prev;
         slot_enh = nullptr;
         const bool elided = res && (uni(res[slot]) != 0u);
-        load_enh_view(enh_keep, elided ? slot_cur : home_enh, lane_in);
+        const mbe_parms* const enh_src = elided ? slot_cur : home_enh;
+        const uint32_t h_enh = load_header(enh_src, lane_in);
+        const uint32_t h_cur = load_header(slot_cur, lane_in);
         if (res) {
+            load_enh_arrays(enh_keep, enh_src, lane_in);
             copy_prev_view(slot_prev, home_prev, lane_in);
             prev_partial = true;
-            load_parms(cur, slot_cur, lane_in);
+            load_parms_arrays(cur, slot_cur, lane_in);
             load_rng(rng, &rngs[slot]);
         } else {
             Parms home;
-            load_parms(home, home_prev, lane_in);
-            load_parms(cur, slot_cur, lane_in);
+            const uint32_t h_home = load_header(home_prev, lane_in);
+            load_enh_arrays(enh_keep, enh_src, lane_in);
+            load_parms_arrays(home, home_prev, lane_in);
+            load_parms_arrays(cur, slot_cur, lane_in);
             load_rng(rng, &rngs[slot]);
             if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
-                rec_in = frame_record(fec_codec, frame_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+                rec_in = frame_record(fec_codec, wire_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+                MBX_STAMP(1, false);
             }
+            set_parms_header(home, h_home);
             store_parms(home, slot_prev, lane_in);
         }
+        set_enh_header(enh_keep, h_enh);
+        set_parms_header(cur, h_cur);
         wave_lds_sync();
+        MBX_STAMP(2, true);
+    } else if constexpr (kOne) {
+        slot_prev = home_prev;
+        slot_enh = home_enh;
+        const mbe_parms* const enh_src = elided1 ? slot_cur : slot_enh;
+        const uint32_t h_cur = load_header(slot_cur, lane_in);
+        h_prev_first = load_header(slot_prev, lane_in);
+        h_enh_first = load_header(enh_src, lane_in);
+        load_rng(rng, &rngs[slot]);
+        load_prev_arrays(prev_first, slot_prev, lane_in);
+        load_parms_arrays(cur, slot_cur, lane_in);
+        load_enh_arrays(enh_first, enh_src, lane_in);
+        set_parms_header(cur, h_cur);
     } else {
         slot_prev = home_prev;
         slot_enh = home_enh;
-        load_parms(cur, slot_cur, lane_in);
+        load_parms<kOne>(cur, slot_cur, lane_in);
         load_rng(rng, &rngs[slot]);
     }
 
-    for (int t = 0; t < Tn; ++t) {
+    const int frames = (kOne && Tn > 1) ? 1 : Tn;
+    for (int t = 0; t < frames; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
         // Keep per-frame table values out of the loop-carried register set: without this the compiler
         // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
@@ -1734,19 +1875,26 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         // The parts of prev_mp_enhanced that synthesis reads are requested now, together with prev_mp,
         // so that one memory latency covers both (they are first used after the decode).
         Parms enh;
+        Parms prev;
         if constexpr (kPark) {
             enh = enh_keep;
+            load_prev_view_lds(prev, slot_prev, lane);
+        } else if constexpr (kOne) {   // requested at the start, together with cur_mp
+            enh = enh_first;
+            prev = prev_first;
+            set_prev_header(prev, h_prev_first);
+            set_enh_header(enh, h_enh_first);
         } else {
             load_enh_view(enh, elided1 ? slot_cur : slot_enh, lane);
+            load_prev_view(prev, slot_prev, lane);
         }
-        Parms prev;
-        load_prev_view(prev, slot_prev, lane);
         if (params) {
             scratch.x.fp[lane] = params[f].v[lane];
             wave_lds_sync();
         } else {
             expand_imbe_wave(kFrame ? rec_in : load_record_scalar(&records[f]), scratch, tabs.t, tabs.d, lane);
         }
+        MBX_STAMP(3, false);
         const float* fp = scratch.x.fp;
         const uint32_t errw = uni(__float_as_uint(fp[62]));
         const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
@@ -1775,10 +1923,10 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     // cur_mp := prev_mp.  Only the prediction memory was loaded (and padded by the
                     // decode); everything else is fetched from the slot now.
                     if (prev_partial) {   // resident launch: the rest of prev_mp has not been brought in yet
-                        copy_parms(slot_prev, home_prev, lane);
+                        copy_parms<kOne>(slot_prev, home_prev, lane);
                         slot_fence<kPark>();
                     }
-                    load_parms(cur, slot_prev, lane);
+                    load_parms<kOne>(cur, slot_prev, lane);
                     cur.Ml = prev.Ml;
                     cur.log2Ml = prev.log2Ml;
                     cur.repeatCount++;
@@ -1789,6 +1937,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         // prev_mp := cur_mp (snapshot before enhancement).  The scheduling barriers keep the 14 stores in one piece: mixed
         // into the decode before them or the enhancement after them they stretch live ranges past the 72-register budget.
+        MBX_STAMP(4, false);
         if (!MBX_ABL(tabs, 256)) store_parms(cur, slot_prev, lane);
         prev_partial = false;
         // Register diet for the synthesiser: what the snapshot holds and the synthesiser does not change (log2Ml) or
@@ -1800,9 +1949,11 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         bool fresh = false;
         {
             const float rm0 = MBX_ABL(tabs, 2) ? 1.0f : enhance(cur, lane, scratch.x.C);
+            MBX_STAMP(5, false);
             if (!MBX_ABL(tabs, 128)) {
                 fresh = synth_core<true, kPark>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
             }
+            MBX_STAMP(6, false);
         }
         {
             slot_fence<kPark>();
@@ -1872,9 +2023,11 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         wave_lds_sync();
         if (!prev_partial) {
-            copy_parms(home_prev, slot_prev, lane_in);
+            copy_parms<kOne>(home_prev, slot_prev, lane_in);
         }
     }
+    MBX_STAMP(7, false);
+    MBX_STAMP(8, true);
 }
 
 __global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
@@ -1882,6 +2035,15 @@ imbe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, 
                    mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                    float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     imbe_stream_body<false>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// T = 1 (a tick of the per-tick API, BASELINE configs[1]): the HBM-slot body without a frame loop, every request of the frame
+// issued before the first wait.
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe_stream_kernel_one(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                       mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                       float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<false, false, false, true>(S, Tn > 1 ? 1 : Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 // T >= 4: prev_mp resident in LDS (see ParkedPrevOnly).  5,200 B of LDS per wave allow 25 waves per CU, so the register
@@ -2132,7 +2294,7 @@ __device__ void tone_dstar_frame(float out[3], int id1, Parms& cur, int lane) {
 
 // k2400: AMBE 3600x2400 (D-STAR) frame policy, ref src/ambe/ambe3600x2400.c:629-763 -- no erasure class, D-STAR
 // tones, repeats decided by the total error count alone.  The prediction (decode_ambe) is common.
-template <bool k2400, bool kPark, bool kFrame = false, bool kRes = false>
+template <bool k2400, bool kPark, bool kFrame = false, bool kRes = false, bool kOne = false>   // kOne: see imbe_stream_body
 __device__ __forceinline__ void
 ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
@@ -2155,6 +2317,10 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     }
     const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const int lane_in = lane_id();
+    Wire wire_in = {};
+    if constexpr (kFrame) {
+        wire_in = frame_fetch(true, frame_in);   // ahead of every state load
+    }
 
     // Same register discipline as the IMBE kernel: `cur` resident, `prev` / `enh` parked in their slots.
     // batch row s (frames, records, PCM, results) belongs to state / rng slot `slot`: the same number unless the caller
@@ -2179,29 +2345,69 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     // prev_mp_enhanced is neither read nor written while it holds, and prev_mp comes into LDS lazily (see the IMBE kernel)
     uint32_t* const res = (kPark && kRes) ? tabs_in.resident : nullptr;
     bool prev_partial = false;
+    // every request of the launch's first frame goes out before anything waits: see the IMBE body and load_header
+    Parms enh_first, prev_first;
+    uint32_t h_enh_first = 0u, h_prev_first = 0u;
+    float row_first = 0.0f;
     if constexpr (kPark) {
         slot_prev = &park.prev;
         synced = res && (uni(res[slot]) != 0u);
-        load_enh_view(enh_keep, synced ? slot_cur : home_enh, lane_in);
+        if constexpr (!kFrame) {   // (the long launches keep the struct-by-struct start: see load_parms)
+            load_enh_view(enh_keep, synced ? slot_cur : home_enh, lane_in);
+            if (res) {
+                copy_prev_view(slot_prev, home_prev, lane_in);
+                prev_partial = true;
+                load_parms<kOne>(cur, slot_cur, lane_in);
+                load_rng(rng, &rngs[slot]);
+            } else {
+                Parms home;
+                load_parms<kOne>(home, home_prev, lane_in);
+                load_parms<kOne>(cur, slot_cur, lane_in);
+                load_rng(rng, &rngs[slot]);
+                store_parms(home, slot_prev, lane_in);
+            }
+            wave_lds_sync();
+        } else {
+        const mbe_parms* const enh_src = synced ? slot_cur : home_enh;
+        const uint32_t h_enh = load_header(enh_src, lane_in);
+        const uint32_t h_cur = load_header(slot_cur, lane_in);
         if (res) {
+            load_enh_arrays(enh_keep, enh_src, lane_in);
             copy_prev_view(slot_prev, home_prev, lane_in);
             prev_partial = true;
-            load_parms(cur, slot_cur, lane_in);
+            load_parms_arrays(cur, slot_cur, lane_in);
             load_rng(rng, &rngs[slot]);
         } else {
             Parms home;
-            load_parms(home, home_prev, lane_in);
-            load_parms(cur, slot_cur, lane_in);
+            const uint32_t h_home = load_header(home_prev, lane_in);
+            load_enh_arrays(enh_keep, enh_src, lane_in);
+            load_parms_arrays(home, home_prev, lane_in);
+            load_parms_arrays(cur, slot_cur, lane_in);
             load_rng(rng, &rngs[slot]);
             if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
-                rec_in = frame_record(MBX_CODEC_AMBE3600X2450, frame_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
+                rec_in = frame_record(MBX_CODEC_AMBE3600X2450, wire_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
             }
+            set_parms_header(home, h_home);
             store_parms(home, slot_prev, lane_in);
         }
+        set_enh_header(enh_keep, h_enh);
+        set_parms_header(cur, h_cur);
         wave_lds_sync();
+        }
+    } else if constexpr (kOne) {
+        slot_prev = home_prev;
+        row_first = params[(size_t)s * (size_t)Tn].v[lane_in];   // the frame's FrameParams row: needed first, requested first
+        const uint32_t h_cur = load_header(slot_cur, lane_in);
+        h_prev_first = load_header(slot_prev, lane_in);
+        h_enh_first = load_header(slot_enh, lane_in);
+        load_rng(rng, &rngs[slot]);
+        load_prev_arrays(prev_first, slot_prev, lane_in);
+        load_parms_arrays(cur, slot_cur, lane_in);
+        load_enh_arrays(enh_first, slot_enh, lane_in);
+        set_parms_header(cur, h_cur);
     } else {
         slot_prev = home_prev;
-        load_parms(cur, slot_cur, lane_in);
+        load_parms<kOne>(cur, slot_cur, lane_in);
         load_rng(rng, &rngs[slot]);
     }
     auto keep_enh_view = [&](const Parms& from) {
@@ -2219,7 +2425,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     };
     auto complete_prev = [&](int lane) {   // resident launch: a frame is about to read more of prev_mp than the decode's view
         if (prev_partial) {
-            copy_parms(slot_prev, home_prev, lane);
+            copy_parms<kOne>(slot_prev, home_prev, lane);
             slot_fence<kPark>();
             prev_partial = false;
         }
@@ -2231,7 +2437,8 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
     }
 
-    for (int t = 0; t < Tn; ++t) {
+    const int frames = (kOne && Tn > 1) ? 1 : Tn;
+    for (int t = 0; t < frames; ++t) {
         const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
         // Keep per-frame table values out of the loop-carried register set: without this the compiler
         // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
@@ -2284,7 +2491,15 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         Parms prev;
         if constexpr (kPark) {
             enh = enh_keep;
-            load_prev_view(prev, slot_prev, lane);
+            load_prev_view_lds(prev, slot_prev, lane);
+        } else if constexpr (kOne) {   // requested at the start, together with cur_mp
+            enh = enh_first;
+            prev = prev_first;
+            scratch.x.fp[lane] = row_first;
+            set_prev_header(prev, h_prev_first);
+            set_enh_header(enh, h_enh_first);
+            wave_lds_sync();
+            fp = scratch.x.fp;
         } else {
             const float row = params[f].v[lane];
             load_enh_view(enh, slot_enh, lane);
@@ -2345,7 +2560,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 } else if (valid_tone) {
                 } else if (total > 3) {
                     complete_prev(lane);
-                    load_parms(cur, slot_prev, lane);   // cur_mp := prev_mp
+                    load_parms<kOne>(cur, slot_prev, lane);   // cur_mp := prev_mp
                     if (bad == 0) {                     // (the decode padded the prediction memory in registers)
                         cur.Ml = prev.Ml;
                         cur.log2Ml = prev.log2Ml;
@@ -2366,7 +2581,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 cur.repeatCount = 0;
             } else if (((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? ((c0 >= 4) || ((c0 >= 2) && (total >= 6))) : (total > 3)) {
                 complete_prev(lane);
-                load_parms(cur, slot_prev, lane);   // cur_mp := prev_mp (see the IMBE kernel)
+                load_parms<kOne>(cur, slot_prev, lane);   // cur_mp := prev_mp (see the IMBE kernel)
                 cur.Ml = prev.Ml;
                 cur.log2Ml = prev.log2Ml;
                 cur.repeatCount++;
@@ -2416,15 +2631,15 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 // its HBM home.  prev_mp_enhanced is current in ITS home: this is a tone-class frame (see `synced`).
                 wave_lds_sync();
                 if (!prev_partial) {   // (a resident launch that has only the view in LDS: the home is current as it is)
-                    copy_parms(home_prev, slot_prev, lane);
+                    copy_parms<kOne>(home_prev, slot_prev, lane);
                 }
                 __threadfence_block();
-                copy_parms(slot_prev, home_enh, lane);
+                copy_parms<kOne>(slot_prev, home_enh, lane);
                 slot_fence<kPark>();
-                load_parms(cur, slot_prev, lane);
+                load_parms<kOne>(cur, slot_prev, lane);
             } else {
                 __threadfence_block();               // (slot_cur is always the HBM slot)
-                load_parms(cur, slot_enh, lane);     // the copy that is synthesised ...
+                load_parms<kOne>(cur, slot_enh, lane);     // the copy that is synthesised ...
                 load_enh_view(enh, slot_enh, lane);  // ... against the enhanced model itself (only the fields synthesis reads)
             }
             cur.log2Ml = 0.0f;   // slot_enh itself is the snapshot of this copy
@@ -2459,7 +2674,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     store_parms(cur, home_enh, lane);    // the replayed copy is NOT cur_mp: it goes to the home (synced stays false)
                     wave_lds_sync();
                     __threadfence_block();
-                    copy_parms(slot_prev, home_prev, lane);   // prev_mp returns to LDS
+                    copy_parms<kOne>(slot_prev, home_prev, lane);   // prev_mp returns to LDS
                     prev_partial = false;
                 }
             } else {
@@ -2467,7 +2682,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             }
             if (action == kToneFallback) {
                 __threadfence_block();
-                load_parms(cur, slot_cur, lane);
+                load_parms<kOne>(cur, slot_cur, lane);
             }
         } else if (action == kTone) {
             tone_frame(out, tw, cur, lane);
@@ -2517,7 +2732,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         wave_lds_sync();
         if (!prev_partial) {
-            copy_parms(home_prev, slot_prev, lane_in);
+            copy_parms<kOne>(home_prev, slot_prev, lane_in);
         }
     }
 }
@@ -2538,6 +2753,12 @@ imbe_frame_kernel(int codec, const uint8_t* __restrict__ frame, mbx_param_record
                   mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs) {
     imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, frame, codec);
     frame_done(done, token, lane_id());
+#ifdef MBX_FRAME_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane_id() == 0) {
+        g_frame_stamps[9] = wall_clock64();
+    }
+#endif
 }
 
 template <bool k2400>
@@ -2616,6 +2837,11 @@ frame_server_kernel(mbx_frame_mailbox* mb, unsigned idle_ticks /* of the 100 MHz
             }
             frame_done(&mb->seq_out, in, lane);   // system-scope fence, then the completion word
             t_last = wall_clock64();
+#ifdef MBX_FRAME_STAMPS
+            if (lane == 0) {
+                g_frame_stamps[9] = t_last;
+            }
+#endif
             polls = 0u;
             continue;
         }
@@ -2632,6 +2858,23 @@ frame_server_kernel(mbx_frame_mailbox* mb, unsigned idle_ticks /* of the 100 MHz
 }
 
 // mbe_synthesizeSpeechf for S independent (cur, prev) pairs.
+
+// T = 1: the HBM-slot bodies without a frame loop (see imbe_stream_kernel_one)
+#ifndef MBX_AMBE_ONE_WAVES_PER_SIMD
+#define MBX_AMBE_ONE_WAVES_PER_SIMD 6   // asked for six, the allocator lands at 72 VGPRs without a spill = SEVEN waves resident (asked for
+#endif                                  // seven it spills 8 B); the looped instance needs 80 + 12 B of scratch at six
+__global__ void __launch_bounds__(64, MBX_AMBE_ONE_WAVES_PER_SIMD)
+ambe_stream_kernel_one(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                       mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                       float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<false, false, false, false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+__global__ void __launch_bounds__(64, MBX_AMBE2400_WAVES_PER_SIMD)
+ambe2400_stream_kernel_one(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                           mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                           float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<true, false, false, false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
 
 __global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)
 ambe_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
@@ -2679,7 +2922,7 @@ __global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
 imbe_stream_kernel_res1(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                         mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                         float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
-    imbe_stream_body<false, false, true>(S, Tn > 1 ? 1 : Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+    imbe_stream_body<false, false, true, true>(S, Tn > 1 ? 1 : Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 __global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
@@ -2846,3 +3089,10 @@ state_copy_kernel(int S, mbe_parms* __restrict__ state) {
 }
 
 }  // namespace mbx
+
+#ifdef MBX_FRAME_STAMPS
+// development builds only (tools/frame_stamps.py): the stamps of the last single-frame call, in 10 ns ticks
+extern "C" int mbx_debug_frame_stamps(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(mbx::g_frame_stamps), 16 * sizeof(unsigned long long));
+}
+#endif

@@ -397,7 +397,7 @@ def _full_shape_run(codec, S, splits, frames, seeds, d_pick, resident=False):
 
 def test_ambe_fec_config3_full_shape(mbx, oracle):
     """BASELINE configs[2] at its full shape through the kernel bench.py times for it: 65,536 AMBE+2 streams x T = 1 per launch
-    (`ambe_stream_kernel`, the HBM-slot instance), clean voice frames with 1 % bit flips, four ticks in a row so that the
+    (`ambe_stream_kernel_one`, the HBM-slot instance for one-frame launches), clean voice frames with 1 % bit flips, four ticks in a row so that the
     state is warm.  HIP vs ORACLE (the CPU restatement, double-precision FFT) on a strided sample of 264 streams: results
     exact, PCM / state in tolerance; every other stream through determinism (a second run is bit-identical in every int16
     sample, state and RNG) and through the resident form (bit-identical again)."""
@@ -412,7 +412,7 @@ def test_ambe_fec_config3_full_shape(mbx, oracle):
     assert len(pick) >= 256
     d_pick = torch.from_numpy(pick).cuda()
     a = _full_shape_run(1, S, [1, 1, 1, 1], frames, seeds, d_pick)
-    assert mbx.lib().mbx_stream_kernel_name(1, 1) == b"ambe_stream_kernel"
+    assert mbx.lib().mbx_stream_kernel_name(1, 1) == b"ambe_stream_kernel_one"
     ref = oracle.process_batch(1, len(pick), T, frames[pick].reshape(-1, 9), oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
     parity.check_results(ref["results"], np.ascontiguousarray(a[2]).view(RESULT_DTYPE).reshape(-1))
     m = parity.check_pcm(ref["pcmf"], a[1].reshape(-1, 160), ref["pcm16"], a[0].reshape(-1, 160))
