@@ -23,6 +23,8 @@ struct TabVector {
     __device__ uint32_t hamming_gen(bool v7100, int i) const { return v7100 ? T->hamming7100_gen[i] : T->hamming_gen[i]; }
     __device__ uint32_t hamming_fix(bool v7100, int syndrome) const { return v7100 ? T->hamming7100_fix[syndrome] : T->hamming_fix[syndrome]; }
     __device__ uint32_t imbe_K(int b0) const { return T->imbe_K[b0]; }
+    template <typename Seq, typename Wav>
+    __device__ Seq pr(uint32_t seed12) const { return Seq(seed12); }
 };
 
 // wave-uniform reads of the table blob through the scalar cache.  `T` must be uniform (a kernel argument), offsets too.
@@ -72,6 +74,9 @@ struct TabScalar {
         return sload_elem<uint16_t>(T, v7100 ? offsetof(mbx_tables, hamming7100_fix) : offsetof(mbx_tables, hamming_fix), (uint32_t)syndrome);
     }
     __device__ uint32_t imbe_K(int b0) const { return sload_elem<uint8_t>(T, offsetof(mbx_tables, imbe_K), (uint32_t)b0); }
+    template <typename Seq, typename Wav>
+    __device__ Wav pr(uint32_t seed12) const { return Wav(*lanes, seed12); }
+    const struct PrLane* lanes = nullptr;   // the wave's demodulation-sequence constants (set by the caller)
 };
 
 // The wire frame as values.  IMBE (18 bytes): nine big-endian 16-bit halves; AMBE (9 bytes): the nine bytes.
@@ -138,6 +143,54 @@ struct PrSequence {
     }
 };
 
+// The same sequence for a whole wave at once (single-frame kernels): x_k = A_k x_0 + C_k mod 2^16 in closed form, lane j
+// holding (A, C) of k = j + 1 and k = j + 65 -- constants of the lane, computed BEFORE the frame's bytes have arrived -- so the
+// 114 bits are two multiply-adds and two ballots instead of 114 dependent steps (1,231 scalar instructions, 2.7 us of a lone
+// wave's time).  mask_for() then cuts the masks out of the 128-bit ballot pair.
+struct PrLane {
+    uint32_t a1, c1, a2, c2;   // k = lane + 1, k = lane + 65
+    __device__ explicit PrLane(int lane) {
+        // (P, Q) of 2^b steps: P_0 = 173, Q_0 = 13849; P_{b+1} = P_b^2, Q_{b+1} = Q_b (P_b + 1)   (all mod 2^16)
+        uint32_t P = 173u, Q = 13849u, a = 1u, c = 0u;
+        const uint32_t k = (uint32_t)lane + 1u;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            if (k & (1u << b)) {   // after the map so far: x -> P (a x + c) + Q
+                a = (a * P) & 0xffffu;
+                c = (c * P + Q) & 0xffffu;
+            }
+            Q = (Q * (P + 1u)) & 0xffffu;
+            P = (P * P) & 0xffffu;
+        }
+        a1 = a;
+        c1 = c;
+        // 64 more steps: after the seven doublings (P, Q) is the map of 128 steps; the 64-step map is one doubling earlier
+        uint32_t P64 = 173u, Q64 = 13849u;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            Q64 = (Q64 * (P64 + 1u)) & 0xffffu;
+            P64 = (P64 * P64) & 0xffffu;
+        }
+        a2 = (a * P64) & 0xffffu;
+        c2 = (c * P64 + Q64) & 0xffffu;
+    }
+};
+struct PrWave {
+    uint64_t lo, hi;   // bit j of lo: the sequence bit of step j + 1; of hi: step j + 65
+    int      pos = 0;
+    __device__ PrWave(const PrLane& L, uint32_t seed12) {
+        const uint32_t x0 = (16u * seed12) & 0xffffu;
+        lo = __ballot((((L.a1 * x0 + L.c1) >> 15) & 1u) != 0u);
+        hi = __ballot((((L.a2 * x0 + L.c2) >> 15) & 1u) != 0u);
+    }
+    __device__ uint32_t mask_for(int width) {   // the next `width` bits, the first of them at bit width-1
+        const int p = pos;
+        pos += width;
+        const uint64_t cut = (p < 64) ? ((lo >> p) | ((p > 0) ? (hi << (64 - p)) : 0ull)) : (hi >> (p - 64));
+        return __brev((uint32_t)cut) >> (32 - width);
+    }
+};
+
 struct RecordWriter {
     uint64_t hi = 0, lo = 0;   // 128-bit shift register, only the first 96 bits are used
     int      n = 0;
@@ -201,7 +254,7 @@ __device__ __forceinline__ uint4 fec_imbe7200x4400_wire(const Tab& tab, const Wi
     row[7] = br.take(137, 7);
 
     const int c0 = golay2312_t(tab, row[0], row[0]);
-    PrSequence pr(row[0] >> 11);
+    auto pr = tab.template pr<PrSequence, PrWave>(row[0] >> 11);
     row[1] ^= pr.mask_for(23);
     row[2] ^= pr.mask_for(23);
     row[3] ^= pr.mask_for(23);
@@ -261,7 +314,7 @@ __device__ __forceinline__ uint4 fec_ambe3600x2450_wire(const Tab& tab, const Wi
         row0 ^= 1u;
         c0 = 1;
     }
-    PrSequence pr((row0 >> 12) & 0xfffu);
+    auto pr = tab.template pr<PrSequence, PrWave>((row0 >> 12) & 0xfffu);
     row1 ^= pr.mask_for(23);
     const int prot = golay2312_t(tab, row1, row1);
 
@@ -311,7 +364,7 @@ __device__ __forceinline__ uint4 fec_imbe7100x4400_wire(const Tab& tab, const Wi
     uint32_t w;
     const int c0 = golay2312_t(tab, (row[0] >> 1) & 0x3ffffu, w);   // the five missing positions are zeros
     row[0] = ((w & 0x3ffffu) << 1) | (row[0] & 1u);
-    PrSequence pr((row[0] >> 12) & 0x7fu);
+    auto pr = tab.template pr<PrSequence, PrWave>((row[0] >> 12) & 0x7fu);
     row[1] ^= pr.mask_for(24);
     row[2] ^= pr.mask_for(23);
     row[3] ^= pr.mask_for(23);

@@ -1736,11 +1736,13 @@ __device__ __forceinline__ Wire frame_fetch(bool ambe, const uint8_t* frame) {
     return ambe ? load_wire_ambe(frame) : load_wire_imbe(frame);
 }
 __device__ __forceinline__ uint4 frame_record(int fec_codec, Wire wire, mbx_param_record* record, const mbx_tables* T, int lane) {
+    const PrLane pr_lanes(lane);   // (before the first use of the frame's bytes: work for the time they are still on their way)
+    TabScalar tab(T);
+    tab.lanes = &pr_lanes;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         wire.h[k] = uni(wire.h[k]);   // every lane loaded the same bytes
     }
-    const TabScalar tab(T);
     const uint4 r = (fec_codec == MBX_CODEC_IMBE7200X4400)   ? fec_imbe7200x4400_wire(tab, wire)
                     : (fec_codec == MBX_CODEC_IMBE7100X4400) ? fec_imbe7100x4400_wire(tab, wire)
                                                              : fec_ambe3600x2450_wire(tab, wire);
