@@ -244,7 +244,10 @@ int mbx_stage_in(void* d_dst, const void* pinned_src, size_t bytes, void* stream
  * mbx_frame_server_start launches the wavefront on `stream` (a stream of its own: it occupies the stream while it lives).
  * (struct mbx_frame_mailbox: include/mbx_types.h) */
 int mbx_frame_server_start(mbx_frame_mailbox* mailbox, unsigned idle_us, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
-                           float* d_pcmf, mbe_process_result* d_result, mbx_param_record* d_record, void* stream);
+                           float* d_pcmf, mbe_process_result* d_result, mbx_param_record* d_record, mbe_parms* d_shadow_state,
+                           mbx_stream_rng* d_shadow_rng, uint32_t* d_shadow_ok, void* stream);
+/*   d_shadow_*: the device copy of the state as in mbx_process_frame_shadow (all three NULL: none); a request whose `want` has
+ *   MBX_FRAME_WANT_SHADOW set reads its state from the copy. */
 
 /* ONE frame of ONE stream as one launch of one wavefront (FEC + parameter decode + policy + synthesis + float->int16):
  * what the synchronous mbe_process*Frame[f] of libmbe_neo_amd.so issue.
@@ -259,6 +262,19 @@ int mbx_frame_server_start(mbx_frame_mailbox* mailbox, unsigned idle_us, mbe_par
  * synchronisation to know that the outputs are complete. */
 int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
                       mbe_process_result* d_result, mbx_param_record* d_record, uint32_t* d_done, uint32_t token, void* stream);
+
+/* The same with a DEVICE COPY of the state kept between calls: d_shadow_state (3 structs) and d_shadow_rng in device memory,
+ * d_shadow_ok a word of pinned memory.  The frame's results always go to d_state / d_rng AND to the copy; with use_shadow != 0
+ * the frame READS its state from the copy instead of d_state / d_rng -- for a caller that knows (by comparing on the host) that
+ * the structs it passes still are what the previous call returned, and *d_shadow_ok was 1 after that call: the 7.8 KB then
+ * come from HBM (~1 us) instead of across PCIe (~3 us).  The kernel stores 1 to *d_shadow_ok when the copy is complete after
+ * this frame and 0 when it is not (an AMBE tone frame, which leaves prev_mp_enhanced alone).
+ * h_frame (may be NULL): the frame's bytes where the HOST can read them (for pinned memory: d_frame itself) -- they then travel
+ * with the launch as kernel arguments and the kernel does not fetch d_frame at all. */
+int mbx_process_frame_shadow(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                             mbe_process_result* d_result, mbx_param_record* d_record, uint32_t* d_done, uint32_t token,
+                             mbe_parms* d_shadow_state, mbx_stream_rng* d_shadow_rng, uint32_t* d_shadow_ok, int use_shadow,
+                             const uint8_t* h_frame, void* stream);
 
 /* FEC stage + stream stage back to back:
  * ref: mbe_processImbe7200x4400Frame[f] include/mbelib-neo/mbelib.h:505-511,

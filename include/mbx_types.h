@@ -152,11 +152,15 @@ typedef struct mbx_frame_mailbox {
      * so a snapshot that shows the new seq_in shows the whole request */
     uint32_t seq_in, quit;
     int32_t  codec;
-    uint32_t want;                                   /* bit 0: int16 PCM, bit 1: float PCM */
+    uint32_t want;                                   /* bit 0: int16 PCM, bit 1: float PCM, bit 2 (MBX_FRAME_WANT_SHADOW): state from the device copy */
     uint8_t  frame[24];                              /* the wire frame (18 | 9 bytes) */
     uint32_t pad0[6];
     uint32_t seq_out, alive, served, pad1[13];       /* written by the server (its own line); served: requests since its start */
 } mbx_frame_mailbox;
 MBX_STATIC_ASSERT(offsetof(mbx_frame_mailbox, seq_out) == 64 && offsetof(mbx_frame_mailbox, frame) == 16 && sizeof(mbx_frame_mailbox) == 128, "mbx_frame_mailbox");
+
+#define MBX_FRAME_WANT_PCM16  1u
+#define MBX_FRAME_WANT_PCMF   2u
+#define MBX_FRAME_WANT_SHADOW 4u
 
 #endif /* MBX_TYPES_H */

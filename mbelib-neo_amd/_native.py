@@ -51,8 +51,9 @@ _SIGNATURES = {
     "mbx_stream_expanded": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_stage_in": (C.c_int, [_vp, _vp, _sz, _vp]),
-    "mbx_frame_server_start": (C.c_int, [_vp, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mbx_frame_server_start": (C.c_int, [_vp, C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_frame": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp]),
+    "mbx_process_frame_shadow": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "mbx_process_batch_indexed": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_process_batch_resident": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_resident_materialize": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),

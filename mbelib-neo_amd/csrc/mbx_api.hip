@@ -28,7 +28,7 @@ __global__ void expand_ambe2400_kernel(const mbx_param_record*, size_t, FramePar
 __global__ void imbe_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void frame_server_kernel(mbx_frame_mailbox*, unsigned, mbe_parms*, mbx_stream_rng*, int16_t*, float*, mbe_process_result*,
-                                    mbx_param_record*, DeviceTables);
+                                    mbx_param_record*, DeviceTables, FrameShadow);
 __global__ void imbe_stream_kernel_one(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                        int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel_one(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
@@ -54,11 +54,11 @@ __global__ void ambe_stream_kernel(int, int, const mbx_param_record*, const Fram
 __global__ void ambe2400_stream_kernel(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                    int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_frame_kernel(int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
-                                  mbe_process_result*, uint32_t*, uint32_t, DeviceTables);
+                                  mbe_process_result*, uint32_t*, uint32_t, DeviceTables, FrameShadow);
 __global__ void ambe_frame_kernel(const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*, mbe_process_result*,
-                                  uint32_t*, uint32_t, DeviceTables);
+                                  uint32_t*, uint32_t, DeviceTables, FrameShadow);
 __global__ void ambe2400_frame_kernel(const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
-                                      mbe_process_result*, uint32_t*, uint32_t, DeviceTables);
+                                      mbe_process_result*, uint32_t*, uint32_t, DeviceTables, FrameShadow);
 __global__ void synth_speech_kernel(int, mbe_parms*, mbe_parms*, mbx_stream_rng*, float*, int16_t*, DeviceTables);
 __global__ void enhance_kernel(int, mbe_parms*);
 __global__ void smoothing_kernel(int, mbe_parms*, const mbe_parms*);
@@ -1086,8 +1086,9 @@ int mbx_stage_in(void* d_dst, const void* pinned_src, size_t bytes, void* stream
     return check_launch("stage_in_kernel");
 }
 
-int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
-                      mbe_process_result* d_result, mbx_param_record* d_record, uint32_t* d_done, uint32_t token, void* stream) {
+static int launch_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                        mbe_process_result* d_result, mbx_param_record* d_record, uint32_t* d_done, uint32_t token, void* stream,
+                        const mbx::FrameShadow& shadow) {
     REQUIRE_CTX(c);
     if (!d_frame || !d_state || !d_rng || !d_record || codec < MBX_CODEC_IMBE7200X4400 || codec > MBX_CODEC_AMBE3600X2400) {
         return MBE_STATUS_INVALID_ARGUMENT;
@@ -1098,29 +1099,60 @@ int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx
     tabs.resident = nullptr;
     if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {
         hipLaunchKernelGGL(mbx::imbe_frame_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, codec, d_frame, d_record, d_state, d_rng,
-                           d_pcm16, d_pcmf, d_result, d_done, token, tabs);
+                           d_pcm16, d_pcmf, d_result, d_done, token, tabs, shadow);
     } else if (codec == MBX_CODEC_AMBE3600X2400) {
         hipLaunchKernelGGL(mbx::ambe2400_frame_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_frame, d_record, d_state, d_rng,
-                           d_pcm16, d_pcmf, d_result, d_done, token, tabs);
+                           d_pcm16, d_pcmf, d_result, d_done, token, tabs, shadow);
     } else {
         hipLaunchKernelGGL(mbx::ambe_frame_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_frame, d_record, d_state, d_rng, d_pcm16,
-                           d_pcmf, d_result, d_done, token, tabs);
+                           d_pcmf, d_result, d_done, token, tabs, shadow);
     }
     return check_launch("frame_kernel");
 }
 
-int mbx_frame_server_start(mbx_frame_mailbox* mailbox, unsigned idle_us, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
-                           float* d_pcmf, mbe_process_result* d_result, mbx_param_record* d_record, void* stream) {
-    REQUIRE_CTX(c);
-    if (!mailbox || (reinterpret_cast<uintptr_t>(mailbox) & 63u) || idle_us == 0 || idle_us > 1000000u || !d_state || !d_rng || !d_record) {
+int mbx_process_frame(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                      mbe_process_result* d_result, mbx_param_record* d_record, uint32_t* d_done, uint32_t token, void* stream) {
+    return launch_frame(codec, d_frame, d_state, d_rng, d_pcm16, d_pcmf, d_result, d_record, d_done, token, stream, mbx::FrameShadow{});
+}
+
+int mbx_process_frame_shadow(int codec, const uint8_t* d_frame, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                             mbe_process_result* d_result, mbx_param_record* d_record, uint32_t* d_done, uint32_t token,
+                             mbe_parms* d_shadow_state, mbx_stream_rng* d_shadow_rng, uint32_t* d_shadow_ok, int use_shadow,
+                             const uint8_t* h_frame, void* stream) {
+    if (!d_shadow_state || !d_shadow_rng || !d_shadow_ok) {
         return MBE_STATUS_INVALID_ARGUMENT;
     }
+    mbx::FrameShadow shadow;
+    shadow.state = d_shadow_state;
+    shadow.rng = d_shadow_rng;
+    shadow.ok = d_shadow_ok;
+    shadow.use = use_shadow ? 1u : 0u;
+    if (h_frame) {   // the frame's bytes travel with the launch
+        const size_t nb = (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? 18u : 9u;
+        memcpy(shadow.frame_words, h_frame, nb);
+        shadow.have_frame = 1u;
+    }
+    return launch_frame(codec, d_frame, d_state, d_rng, d_pcm16, d_pcmf, d_result, d_record, d_done, token, stream, shadow);
+}
+
+int mbx_frame_server_start(mbx_frame_mailbox* mailbox, unsigned idle_us, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
+                           float* d_pcmf, mbe_process_result* d_result, mbx_param_record* d_record, mbe_parms* d_shadow_state,
+                           mbx_stream_rng* d_shadow_rng, uint32_t* d_shadow_ok, void* stream) {
+    REQUIRE_CTX(c);
+    if (!mailbox || (reinterpret_cast<uintptr_t>(mailbox) & 63u) || idle_us == 0 || idle_us > 1000000u || !d_state || !d_rng || !d_record
+        || ((d_shadow_state != nullptr) != (d_shadow_rng != nullptr)) || ((d_shadow_state != nullptr) != (d_shadow_ok != nullptr))) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    mbx::FrameShadow shadow;
+    shadow.state = d_shadow_state;
+    shadow.rng = d_shadow_rng;
+    shadow.ok = d_shadow_ok;
     mbx::DeviceTables tabs = c->tabs;
     tabs.reverse = 0;
     tabs.stream_map = nullptr;
     tabs.resident = nullptr;
     hipLaunchKernelGGL(mbx::frame_server_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mailbox, idle_us * 100u, d_state, d_rng,
-                       d_pcm16, d_pcmf, d_result, d_record, tabs);
+                       d_pcm16, d_pcmf, d_result, d_record, tabs, shadow);
     return check_launch("frame_server_kernel");
 }
 

@@ -63,6 +63,21 @@ struct DeviceTables {
     uint32_t*            resident;
 };
 
+// Single-frame kernels: a copy of the caller's three structs (and RNG state) in DEVICE memory, kept by the per-frame library
+// between synchronous calls.  When the caller's structs still are what the previous call returned (the library compares them on
+// the host), the frame reads its state from this copy -- HBM, ~1 us -- instead of pulling 7.8 KB across PCIe (~3 us); results
+// always go to both.  `ok` (pinned) tells the host whether the copy is complete after this frame.
+struct FrameShadow {
+    mbe_parms*      state = nullptr;   // 3 structs: cur_mp, prev_mp, prev_mp_enhanced
+    mbx_stream_rng* rng = nullptr;
+    uint32_t*       ok = nullptr;
+    uint32_t        use = 0u;          // read the state from the copy
+    // the wire frame BY VALUE (kernel arguments): a launch whose host could read the frame's bytes passes them here, and the FEC
+    // starts with the kernel instead of after a PCIe round trip for 18 bytes
+    uint32_t        have_frame = 0u;
+    uint32_t        frame_words[6] = {0u, 0u, 0u, 0u, 0u, 0u};   // the bytes, little-endian packed
+};
+
 // Stage masks for timing experiments exist only in the development build (make ablate -> libmbx_hip_ablate.so, used by
 // tools/); in the product library the tests are compile-time zeros and no entry point can switch a stage off.
 #ifdef MBX_ABLATE

@@ -23,6 +23,15 @@ struct TabVector {
     __device__ uint32_t hamming_gen(bool v7100, int i) const { return v7100 ? T->hamming7100_gen[i] : T->hamming_gen[i]; }
     __device__ uint32_t hamming_fix(bool v7100, int syndrome) const { return v7100 ? T->hamming7100_fix[syndrome] : T->hamming_fix[syndrome]; }
     __device__ uint32_t imbe_K(int b0) const { return T->imbe_K[b0]; }
+    // the corrections of up to three Golay and three Hamming syndromes at once (the scalar reader turns them into ONE round trip)
+    template <bool v7100>
+    __device__ void fixes(const uint32_t gs[3], const int hs[3], uint32_t gf[3], uint32_t hf[3]) const {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            gf[r] = golay_fix(gs[r]);
+            hf[r] = hamming_fix(v7100, hs[r]);
+        }
+    }
     template <typename Seq, typename Wav>
     __device__ Seq pr(uint32_t seed12) const { return Seq(seed12); }
 };
@@ -42,7 +51,8 @@ __device__ __forceinline__ uint32_t sload_elem(const void* base, uint32_t array_
 
 struct TabScalar {
     const mbx_tables* T;
-    uint32_t gen[6];   // golay_gen[12], two per dword, fetched once
+    uint32_t gen[6];    // golay_gen[12], two per dword, fetched once
+    uint32_t hgen[4];   // hamming_gen[4] | hamming7100_gen[4], likewise
     static constexpr bool kUniform = true;
     __device__ explicit TabScalar(const mbx_tables* t) : T(t) {
         static_assert(offsetof(mbx_tables, golay_gen) % 4 == 0 && offsetof(mbx_tables, golay_matrix) % 4 == 0
@@ -53,10 +63,12 @@ struct TabScalar {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         typedef uint32_t u2 __attribute__((ext_vector_type(2)));
         u4 a;
-        u2 b;
-        asm volatile("s_load_dwordx4 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(a), "=&s"(b)
-                     : "s"(t), "s"((uint32_t)offsetof(mbx_tables, golay_gen)), "s"((uint32_t)offsetof(mbx_tables, golay_gen) + 16u)
+        u2 b, h0, h1;
+        asm volatile("s_load_dwordx4 %0, %4, %5\n\ts_load_dwordx2 %1, %4, %6\n\ts_load_dwordx2 %2, %4, %7\n\ts_load_dwordx2 %3, %4, %8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(a), "=&s"(b), "=&s"(h0), "=&s"(h1)
+                     : "s"(t), "s"((uint32_t)offsetof(mbx_tables, golay_gen)), "s"((uint32_t)offsetof(mbx_tables, golay_gen) + 16u),
+                       "s"((uint32_t)offsetof(mbx_tables, hamming_gen)), "s"((uint32_t)offsetof(mbx_tables, hamming7100_gen))
                      : "memory");
         gen[0] = a.x;
         gen[1] = a.y;
@@ -64,11 +76,31 @@ struct TabScalar {
         gen[3] = a.w;
         gen[4] = b.x;
         gen[5] = b.y;
+        hgen[0] = h0.x;
+        hgen[1] = h0.y;
+        hgen[2] = h1.x;
+        hgen[3] = h1.y;
     }
     __device__ uint32_t golay_gen(int i) const { return (gen[i >> 1] >> (16 * (i & 1))) & 0xffffu; }
     __device__ uint32_t golay_fix(uint32_t syndrome) const { return sload_elem<uint16_t>(T, offsetof(mbx_tables, golay_matrix), syndrome); }
-    __device__ uint32_t hamming_gen(bool v7100, int i) const {
-        return sload_elem<uint16_t>(T, v7100 ? offsetof(mbx_tables, hamming7100_gen) : offsetof(mbx_tables, hamming_gen), (uint32_t)i);
+    __device__ uint32_t hamming_gen(bool v7100, int i) const { return (hgen[(v7100 ? 2 : 0) + (i >> 1)] >> (16 * (i & 1))) & 0xffffu; }
+    template <bool v7100>
+    __device__ void fixes(const uint32_t gs[3], const int hs[3], uint32_t gf[3], uint32_t hf[3]) const {
+        const uint32_t hbase = v7100 ? (uint32_t)offsetof(mbx_tables, hamming7100_fix) : (uint32_t)offsetof(mbx_tables, hamming_fix);
+        const uint32_t gbase = (uint32_t)offsetof(mbx_tables, golay_matrix);
+        uint32_t w[6];
+        asm volatile("s_load_dword %0, %6, %7\n\ts_load_dword %1, %6, %8\n\ts_load_dword %2, %6, %9\n\t"
+                     "s_load_dword %3, %6, %10\n\ts_load_dword %4, %6, %11\n\ts_load_dword %5, %6, %12\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(w[0]), "=&s"(w[1]), "=&s"(w[2]), "=&s"(w[3]), "=&s"(w[4]), "=&s"(w[5])
+                     : "s"(T), "s"((gbase + 2u * gs[0]) & ~3u), "s"((gbase + 2u * gs[1]) & ~3u), "s"((gbase + 2u * gs[2]) & ~3u),
+                       "s"((hbase + 2u * (uint32_t)hs[0]) & ~3u), "s"((hbase + 2u * (uint32_t)hs[1]) & ~3u),
+                       "s"((hbase + 2u * (uint32_t)hs[2]) & ~3u)
+                     : "memory");
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            gf[r] = (w[r] >> (16u * (gs[r] & 1u))) & 0xffffu;
+            hf[r] = (w[3 + r] >> (16u * ((uint32_t)hs[r] & 1u))) & 0xffffu;
+        }
     }
     __device__ uint32_t hamming_fix(bool v7100, int syndrome) const {
         return sload_elem<uint16_t>(T, v7100 ? offsetof(mbx_tables, hamming7100_fix) : offsetof(mbx_tables, hamming_fix), (uint32_t)syndrome);
@@ -126,6 +158,34 @@ __device__ __forceinline__ int hamming1511_t(const Tab& tab, uint32_t cw, uint32
 }
 __device__ __forceinline__ int hamming1511(const mbx_tables* T, uint32_t cw, uint32_t& fixed) {
     return hamming1511_t<false>(TabVector{T}, cw, fixed);
+}
+
+// the same two decoders in two steps, so that a frame's table lookups can go out together (Tab::fixes)
+template <typename Tab>
+__device__ __forceinline__ uint32_t golay_syndrome(const Tab& tab, uint32_t cw) {
+    uint32_t expect = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        expect ^= (cw & (0x400000u >> i)) ? tab.golay_gen(i) : 0u;
+    }
+    return expect ^ (cw & 0x7ffu);
+}
+__device__ __forceinline__ int golay_apply(uint32_t cw, uint32_t fix, uint32_t& fixed) {
+    fixed = cw ^ (fix << 11);
+    return __popc(fix);
+}
+template <bool v7100, typename Tab>
+__device__ __forceinline__ int hamming_syndrome(const Tab& tab, uint32_t cw) {
+    int syndrome = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        syndrome |= (__popc(cw & tab.hamming_gen(v7100, i)) & 1) << i;
+    }
+    return syndrome;
+}
+__device__ __forceinline__ int hamming_apply(uint32_t cw, int syndrome, uint32_t fix, uint32_t& fixed) {
+    fixed = syndrome ? (cw ^ fix) : cw;
+    return syndrome != 0;
 }
 
 // The demodulation sequence: x0 = 16*seed, x_k = 173*x_{k-1} + 13849 mod 2^16, bit_k = x_k >> 15.
@@ -265,15 +325,23 @@ __device__ __forceinline__ uint4 fec_imbe7200x4400_wire(const Tab& tab, const Wi
     int prot = 0;
     RecordWriter rw;
     rw.push(row[0], 23, 12);
+    uint32_t gs[3], gf[3], hf[3];
+    int hs[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        gs[r] = golay_syndrome(tab, row[1 + r]);
+        hs[r] = hamming_syndrome<false>(tab, row[4 + r]);
+    }
+    tab.template fixes<false>(gs, hs, gf, hf);
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
-        prot += golay2312_t(tab, row[r], row[r]);
+        prot += golay_apply(row[r], gf[r - 1], row[r]);
         rw.push(row[r], 23, 12);
     }
     int c4 = 0;
 #pragma unroll
     for (int r = 4; r < 7; ++r) {
-        const int e = hamming1511_t<false>(tab, row[r], row[r]);
+        const int e = hamming_apply(row[r], hs[r - 4], hf[r - 4], row[r]);
         prot += e;
         if (r == 4) {
             c4 = e;
@@ -374,16 +442,26 @@ __device__ __forceinline__ uint4 fec_imbe7100x4400_wire(const Tab& tab, const Wi
     int prot = 0, c4 = 0;
     RecordWriter rw;                       // 7100 order: 7 + 12 + 12 + 12 + 11 + 11 + 23 bits
     rw.push(row[0] >> 12, 7, 7);
-    prot += golay2312_t(tab, row[1] >> 1, w);   // C1 = cells 1..23
-    rw.push(w, 23, 12);
-    prot += golay2312_t(tab, row[2], w);
-    rw.push(w, 23, 12);
-    prot += golay2312_t(tab, row[3], w);
-    rw.push(w, 23, 12);
-    c4 = hamming1511_t<true>(tab, row[4], w);
+    const uint32_t gcw[3] = {row[1] >> 1, row[2], row[3]};   // C1 = cells 1..23
+    uint32_t gs[3], gf[3], hf[3];
+    int hs[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        gs[r] = golay_syndrome(tab, gcw[r]);
+    }
+    hs[0] = hamming_syndrome<true>(tab, row[4]);
+    hs[1] = hamming_syndrome<true>(tab, row[5]);
+    hs[2] = 0;
+    tab.template fixes<true>(gs, hs, gf, hf);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        prot += golay_apply(gcw[r], gf[r], w);
+        rw.push(w, 23, 12);
+    }
+    c4 = hamming_apply(row[4], hs[0], hf[0], w);
     prot += c4;
     rw.push(w, 15, 11);
-    prot += hamming1511_t<true>(tab, row[5], w);
+    prot += hamming_apply(row[5], hs[1], hf[1], w);
     rw.push(w, 15, 11);
     rw.push(row[6], 23, 23);
 

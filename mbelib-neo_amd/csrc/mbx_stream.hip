@@ -49,6 +49,9 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 // (and lose 1-6 % when a new wave's loads or a finishing wave's stores are given priority: tried, dropped); the AMBE bodies
 // lose 1-4 % with a raised priority in their front part or in the eight-frame expansion pass: not there.  Raising the rest of the
 // synthesiser (noise / phases, between bank and transform, overlap-add) as well costs 0.2-3.6 %: the point is the contrast.
+#ifndef MBX_AMBE_GATHER_STORES
+#define MBX_AMBE_GATHER_STORES 1   // gathered header stores in the one-frame AMBE instances too: 78 VGPRs = six waves, and still 1.7 % faster than seven waves with fourteen one-lane stores per struct (with a 16 B spill at seven: 2.4 % slower)
+#endif
 #ifndef MBX_PRIO_BANK
 #define MBX_PRIO_BANK 2
 #endif
@@ -183,10 +186,37 @@ __device__ __forceinline__ void load_parms(Parms& r, const mbe_parms* __restrict
     r.noiseSeed = uni(f[O_NOISESEED]);
 }
 
+__device__ __forceinline__ int write_lane(int v, int uniform_value, int k) {   // v with lane k replaced (v_writelane_b32)
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(uniform_value)), "n"(k));
+    return v;
+}
+// kGather: the fourteen scalar fields leave in ONE store (lane j writes header field j, as load_header reads them) instead of
+// fourteen one-lane stores -- for the instances whose structs live in HBM (a one-lane store occupies the memory pipeline like any other)
+template <bool kGather = false>
 __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restrict__ p, int lane) {
     float* f = reinterpret_cast<float*>(p);
     int* i = reinterpret_cast<int*>(p);
-    if (lane == 0) {
+    if constexpr (kGather) {
+        int h = 0;
+        h = write_lane(h, __float_as_int(r.w0), H_W0);
+        h = write_lane(h, r.L, H_L);
+        h = write_lane(h, r.K, H_K);
+        h = write_lane(h, __float_as_int(r.gamma), H_GAMMA);
+        h = write_lane(h, (int)r.tonePhase, H_TONEPHASE);
+        h = write_lane(h, r.swn, H_SWN);
+        h = write_lane(h, __float_as_int(r.localEnergy), H_LOCALENERGY);
+        h = write_lane(h, r.amplitudeThreshold, H_AMPTHR);
+        h = write_lane(h, __float_as_int(r.errorRate), H_ERRORRATE);
+        h = write_lane(h, r.errorCountTotal, H_ERRTOTAL);
+        h = write_lane(h, r.errorCount4, H_ERR4);
+        h = write_lane(h, r.repeatCount, H_REPEAT);
+        h = write_lane(h, __float_as_int(r.mutingThreshold), H_MUTETHR);
+        h = write_lane(h, __float_as_int(r.noiseSeed), H_NOISESEED);
+        if (lane < 14) {
+            const int idx = (lane < 3) ? lane : ((lane < 13) ? (O_GAMMA - H_GAMMA) + lane : O_NOISESEED);
+            i[idx] = h;
+        }
+    } else if (lane == 0) {
         f[O_W0] = r.w0;
         i[O_L] = r.L;
         i[O_K] = r.K;
@@ -1690,7 +1720,7 @@ template <bool kGather = false>
 __device__ __forceinline__ void copy_parms(mbe_parms* dst, const mbe_parms* src, int lane) {
     Parms t;
     load_parms<kGather>(t, src, lane);
-    store_parms(t, dst, lane);
+    store_parms<kGather>(t, dst, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1735,6 +1765,17 @@ __device__ __forceinline__ uint4 broadcast_record(uint4 r, mbx_param_record* out
 __device__ __forceinline__ Wire frame_fetch(bool ambe, const uint8_t* frame) {
     return ambe ? load_wire_ambe(frame) : load_wire_imbe(frame);
 }
+__device__ __forceinline__ Wire frame_from_args(bool ambe, const FrameShadow& x) {   // the same from bytes that came as kernel arguments
+    Wire w;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const uint32_t b0 = (x.frame_words[(2 * k) >> 2] >> (8 * ((2 * k) & 3))) & 0xffu;
+        const uint32_t b1 = (x.frame_words[(2 * k + 1) >> 2] >> (8 * ((2 * k + 1) & 3))) & 0xffu;
+        const uint32_t bk = (x.frame_words[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        w.h[k] = ambe ? bk : ((b0 << 8) | b1);
+    }
+    return w;
+}
 __device__ __forceinline__ uint4 frame_record(int fec_codec, Wire wire, mbx_param_record* record, const mbx_tables* T, int lane) {
     const PrLane pr_lanes(lane);   // (before the first use of the frame's bytes: work for the time they are still on their way)
     TabScalar tab(T);
@@ -1759,7 +1800,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr,
-                 int fec_codec = 0) {
+                 int fec_codec = 0, FrameShadow shadow = FrameShadow{}) {
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;
     uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
@@ -1771,7 +1812,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     MBX_STAMP(0, false);
     Wire wire_in = {};
     if constexpr (kFrame) {
-        wire_in = frame_fetch(false, frame_in);   // ahead of every state load
+        wire_in = shadow.have_frame ? frame_from_args(false, shadow) : frame_fetch(false, frame_in);   // ahead of every state load
     }
 
     // Register budget: at most TWO of the three structs are live at any time.  `cur` stays in
@@ -1805,9 +1846,13 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         slot_prev = &park.prev;
         slot_enh = nullptr;
         const bool elided = res && (uni(res[slot]) != 0u);
-        const mbe_parms* const enh_src = elided ? slot_cur : home_enh;
+        // single-frame kernels: the state comes from the device copy when the host says it is current (FrameShadow)
+        const bool from_shadow = kFrame && shadow.use != 0u;
+        const mbe_parms* const in_cur = from_shadow ? &shadow.state[0] : slot_cur;
+        const mbe_parms* const in_prev = from_shadow ? &shadow.state[1] : home_prev;
+        const mbe_parms* const enh_src = from_shadow ? &shadow.state[2] : (elided ? slot_cur : home_enh);
         const uint32_t h_enh = load_header(enh_src, lane_in);
-        const uint32_t h_cur = load_header(slot_cur, lane_in);
+        const uint32_t h_cur = load_header(in_cur, lane_in);
         if (res) {
             load_enh_arrays(enh_keep, enh_src, lane_in);
             copy_prev_view(slot_prev, home_prev, lane_in);
@@ -1816,17 +1861,17 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             load_rng(rng, &rngs[slot]);
         } else {
             Parms home;
-            const uint32_t h_home = load_header(home_prev, lane_in);
+            const uint32_t h_home = load_header(in_prev, lane_in);
             load_enh_arrays(enh_keep, enh_src, lane_in);
-            load_parms_arrays(home, home_prev, lane_in);
-            load_parms_arrays(cur, slot_cur, lane_in);
-            load_rng(rng, &rngs[slot]);
+            load_parms_arrays(home, in_prev, lane_in);
+            load_parms_arrays(cur, in_cur, lane_in);
+            load_rng(rng, from_shadow ? shadow.rng : &rngs[slot]);
             if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
                 rec_in = frame_record(fec_codec, wire_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
                 MBX_STAMP(1, false);
             }
             set_parms_header(home, h_home);
-            store_parms(home, slot_prev, lane_in);
+            store_parms<kOne>(home, slot_prev, lane_in);
         }
         set_enh_header(enh_keep, h_enh);
         set_parms_header(cur, h_cur);
@@ -1940,7 +1985,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         // prev_mp := cur_mp (snapshot before enhancement).  The scheduling barriers keep the 14 stores in one piece: mixed
         // into the decode before them or the enhancement after them they stretch live ranges past the 72-register budget.
         MBX_STAMP(4, false);
-        if (!MBX_ABL(tabs, 256)) store_parms(cur, slot_prev, lane);
+        if (!MBX_ABL(tabs, 256)) store_parms<kOne>(cur, slot_prev, lane);
         prev_partial = false;
         // Register diet for the synthesiser: what the snapshot holds and the synthesiser does not change (log2Ml) or
         // replaces only at its end (previousUw, the noise overlap) is dropped here and read back from the snapshot
@@ -1995,7 +2040,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 res1[slot] = 1u;   // prev_mp_enhanced := cur_mp, elided
             }
         } else {
-            if (!MBX_ABL(tabs, 512)) store_parms(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
+            if (!MBX_ABL(tabs, 512)) store_parms<kOne>(cur, slot_enh, lane);    // prev_mp_enhanced := cur_mp
         }
         if (t + 1 < Tn) {
             slot_fence<kPark>();             // the next frame of this wave reloads both slots
@@ -2013,7 +2058,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
     }
 
-    if (!MBX_ABL(tabs_in, 1024)) store_parms(cur, slot_cur, lane_in);
+    if (!MBX_ABL(tabs_in, 1024)) store_parms<kOne>(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
     if constexpr (kPark) {   // prev_mp goes home from LDS; prev_mp_enhanced IS cur_mp after the last frame
         if (res) {
@@ -2021,11 +2066,22 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 res[slot] = 1u;   // ... and is not written at all by a resident launch
             }
         } else {
-            store_parms(cur, home_enh, lane_in);
+            store_parms<kOne>(cur, home_enh, lane_in);
         }
         wave_lds_sync();
         if (!prev_partial) {
             copy_parms<kOne>(home_prev, slot_prev, lane_in);
+        }
+        if constexpr (kFrame) {
+            if (shadow.state) {   // the device copy of what has just gone to the caller (prev_mp_enhanced is cur_mp after an IMBE frame)
+                store_parms<kOne>(cur, &shadow.state[0], lane_in);
+                store_parms<kOne>(cur, &shadow.state[2], lane_in);
+                copy_parms(&shadow.state[1], slot_prev, lane_in);
+                store_rng(rng, shadow.rng, lane_in);
+                if (lane_in == 0) {
+                    *shadow.ok = 1u;
+                }
+            }
         }
     }
     MBX_STAMP(7, false);
@@ -2301,7 +2357,8 @@ __device__ __forceinline__ void
 ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                 mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr) {
+                 mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr,
+                 FrameShadow shadow = FrameShadow{}) {
     uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;   // T >= 4: prev_mp resident in LDS
@@ -2321,7 +2378,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     const int lane_in = lane_id();
     Wire wire_in = {};
     if constexpr (kFrame) {
-        wire_in = frame_fetch(true, frame_in);   // ahead of every state load
+        wire_in = shadow.have_frame ? frame_from_args(true, shadow) : frame_fetch(true, frame_in);   // ahead of every state load
     }
 
     // Same register discipline as the IMBE kernel: `cur` resident, `prev` / `enh` parked in their slots.
@@ -2366,13 +2423,16 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 load_parms<kOne>(home, home_prev, lane_in);
                 load_parms<kOne>(cur, slot_cur, lane_in);
                 load_rng(rng, &rngs[slot]);
-                store_parms(home, slot_prev, lane_in);
+                store_parms<kOne && MBX_AMBE_GATHER_STORES>(home, slot_prev, lane_in);
             }
             wave_lds_sync();
         } else {
-        const mbe_parms* const enh_src = synced ? slot_cur : home_enh;
+        const bool from_shadow = shadow.use != 0u;   // (single-frame kernels: see FrameShadow)
+        const mbe_parms* const in_cur = from_shadow ? &shadow.state[0] : slot_cur;
+        const mbe_parms* const in_prev = from_shadow ? &shadow.state[1] : home_prev;
+        const mbe_parms* const enh_src = from_shadow ? &shadow.state[2] : (synced ? slot_cur : home_enh);
         const uint32_t h_enh = load_header(enh_src, lane_in);
-        const uint32_t h_cur = load_header(slot_cur, lane_in);
+        const uint32_t h_cur = load_header(in_cur, lane_in);
         if (res) {
             load_enh_arrays(enh_keep, enh_src, lane_in);
             copy_prev_view(slot_prev, home_prev, lane_in);
@@ -2381,16 +2441,16 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             load_rng(rng, &rngs[slot]);
         } else {
             Parms home;
-            const uint32_t h_home = load_header(home_prev, lane_in);
+            const uint32_t h_home = load_header(in_prev, lane_in);
             load_enh_arrays(enh_keep, enh_src, lane_in);
-            load_parms_arrays(home, home_prev, lane_in);
-            load_parms_arrays(cur, slot_cur, lane_in);
-            load_rng(rng, &rngs[slot]);
+            load_parms_arrays(home, in_prev, lane_in);
+            load_parms_arrays(cur, in_cur, lane_in);
+            load_rng(rng, from_shadow ? shadow.rng : &rngs[slot]);
             if constexpr (kFrame) {   // the FEC of the frame runs while the three structs are on their way (pinned host memory: PCIe)
                 rec_in = frame_record(MBX_CODEC_AMBE3600X2450, wire_in, const_cast<mbx_param_record*>(records), tabs_in.t, lane_in);
             }
             set_parms_header(home, h_home);
-            store_parms(home, slot_prev, lane_in);
+            store_parms<kOne && MBX_AMBE_GATHER_STORES>(home, slot_prev, lane_in);
         }
         set_enh_header(enh_keep, h_enh);
         set_parms_header(cur, h_cur);
@@ -2522,14 +2582,14 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             if (fabsf(prev.mutingThreshold - MBE_MUTING_THRESHOLD_AMBE) > 1e-6f) {
                 init_ambe_parms(prev, lane);
                 cur = prev;
-                store_parms(prev, slot_prev, lane);
+                store_parms<kOne && MBX_AMBE_GATHER_STORES>(prev, slot_prev, lane);
                 prev_partial = false;
                 if constexpr (kPark) {
                     keep_enh_view(prev);
                     enh = enh_keep;
                     synced = true;
                 } else {
-                    store_parms(prev, slot_enh, lane);
+                    store_parms<kOne && MBX_AMBE_GATHER_STORES>(prev, slot_enh, lane);
                     slot_fence<kPark>();
                     load_enh_view(enh, slot_enh, lane);
                 }
@@ -2542,7 +2602,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 const int c0v_early = ((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? c0 : 0;
                 const bool keeps_enh = k2400 ? ((cls >= 7) && (cls <= 122) && (c0v_early < 2) && (total < 3)) : (cls == 7);
                 if (keeps_enh && synced) {
-                    store_parms(cur, home_enh, lane);
+                    store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, home_enh, lane);
                     synced = false;
                 }
             }
@@ -2619,7 +2679,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         float out[3];
         float rm0 = 0.0f;
         if (action == kVoice) {
-            store_parms(cur, slot_prev, lane);   // prev_mp := cur_mp
+            store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_prev, lane);   // prev_mp := cur_mp
             prev_partial = false;
             cur.log2Ml = 0.0f;                   // read back from the snapshot after the synthesiser (see the IMBE kernel)
             cur.uw[0] = cur.uw[1] = cur.uw[2] = cur.uw[3] = 0.0f;
@@ -2627,7 +2687,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         } else if (action == kToneFallback) {
             // invalid tone id: run the synthesiser on a copy of the enhanced model.  `cur` is parked in
             // its slot meanwhile so that still only two structs are live.
-            store_parms(cur, slot_cur, lane);
+            store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_cur, lane);
             if constexpr (kPark) {
                 // The copy takes the LDS home of prev_mp for the duration (it is the synthesiser's snapshot), prev_mp waits in
                 // its HBM home.  prev_mp_enhanced is current in ITS home: this is a tone-class frame (see `synced`).
@@ -2673,14 +2733,14 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 if (action == kVoice) {
                     synced = true;
                 } else {
-                    store_parms(cur, home_enh, lane);    // the replayed copy is NOT cur_mp: it goes to the home (synced stays false)
+                    store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, home_enh, lane);    // the replayed copy is NOT cur_mp: it goes to the home (synced stays false)
                     wave_lds_sync();
                     __threadfence_block();
                     copy_parms<kOne>(slot_prev, home_prev, lane);   // prev_mp returns to LDS
                     prev_partial = false;
                 }
             } else {
-                store_parms(cur, slot_enh, lane);
+                store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_enh, lane);
             }
             if (action == kToneFallback) {
                 __threadfence_block();
@@ -2690,20 +2750,20 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             tone_frame(out, tw, cur, lane);
         } else if (action == kToneDstar) {
             tone_dstar_frame(out, bad, cur, lane);
-            store_parms(cur, slot_prev, lane);   // mbe_moveMbeParms(cur_mp, prev_mp)
+            store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_prev, lane);   // mbe_moveMbeParms(cur_mp, prev_mp)
             prev_partial = false;
         } else {
             comfort_noise(out, rng, lane);
             if (action == kNoiseReinit) {   // mbe_initAmbeParms_common(cur, prev, prev_enhanced)
                 init_ambe_parms(cur, lane);
             }
-            store_parms(cur, slot_prev, lane);
+            store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_prev, lane);
             prev_partial = false;
             if constexpr (kPark) {
                 keep_enh_view(cur);
                 synced = true;
             } else {
-                store_parms(cur, slot_enh, lane);
+                store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_enh, lane);
             }
         }
         if (t + 1 < Tn) {
@@ -2722,7 +2782,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
     }
 
-    store_parms(cur, slot_cur, lane_in);
+    store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
     if constexpr (kPark) {   // prev_mp goes home from LDS; prev_mp_enhanced from `cur` unless its home is already current
         if (res) {
@@ -2730,11 +2790,24 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 res[slot] = synced ? 1u : 0u;   // a resident launch leaves the struct elided while it equals cur_mp
             }
         } else if (synced) {
-            store_parms(cur, home_enh, lane_in);
+            store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, home_enh, lane_in);
         }
         wave_lds_sync();
         if (!prev_partial) {
             copy_parms<kOne>(home_prev, slot_prev, lane_in);
+        }
+        if constexpr (kFrame) {
+            if (shadow.state) {   // the device copy of what has just gone to the caller; complete only if prev_mp_enhanced is cur_mp
+                store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, &shadow.state[0], lane_in);   // (a tone frame leaves prev_mp_enhanced at its pinned home alone: the next
+                if (synced) {                                  //  call then takes the state from the caller's structs again)
+                    store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, &shadow.state[2], lane_in);
+                }
+                copy_parms(&shadow.state[1], slot_prev, lane_in);
+                store_rng(rng, shadow.rng, lane_in);
+                if (lane_in == 0) {
+                    *shadow.ok = synced ? 1u : 0u;
+                }
+            }
         }
     }
 }
@@ -2752,8 +2825,8 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 __global__ void __launch_bounds__(64)
 imbe_frame_kernel(int codec, const uint8_t* __restrict__ frame, mbx_param_record* __restrict__ record, mbe_parms* __restrict__ state,
                   mbx_stream_rng* __restrict__ rng, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                  mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs) {
-    imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, frame, codec);
+                  mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs, FrameShadow shadow) {
+    imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, frame, codec, shadow);
     frame_done(done, token, lane_id());
 #ifdef MBX_FRAME_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -2768,23 +2841,23 @@ __device__ __forceinline__ void ambe_frame_body(const uint8_t* __restrict__ fram
                                                 mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rng,
                                                 int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                                                 mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token,
-                                                const DeviceTables& tabs) {
-    ambe_stream_body<k2400, true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, frame);
+                                                const DeviceTables& tabs, const FrameShadow& shadow) {
+    ambe_stream_body<k2400, true, true>(1, 1, record, nullptr, state, rng, pcm16, pcmf, result, tabs, frame, shadow);
     frame_done(done, token, lane_id());
 }
 
 __global__ void __launch_bounds__(64)
 ambe_frame_kernel(const uint8_t* __restrict__ frame, mbx_param_record* __restrict__ record, mbe_parms* __restrict__ state,
                   mbx_stream_rng* __restrict__ rng, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                  mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs) {
-    ambe_frame_body<false>(frame, record, state, rng, pcm16, pcmf, result, done, token, tabs);
+                  mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs, FrameShadow shadow) {
+    ambe_frame_body<false>(frame, record, state, rng, pcm16, pcmf, result, done, token, tabs, shadow);
 }
 
 __global__ void __launch_bounds__(64)
 ambe2400_frame_kernel(const uint8_t* __restrict__ frame, mbx_param_record* __restrict__ record, mbe_parms* __restrict__ state,
                       mbx_stream_rng* __restrict__ rng, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
-                      mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs) {
-    ambe_frame_body<true>(frame, record, state, rng, pcm16, pcmf, result, done, token, tabs);
+                      mbe_process_result* __restrict__ result, uint32_t* done, uint32_t token, DeviceTables tabs, FrameShadow shadow) {
+    ambe_frame_body<true>(frame, record, state, rng, pcm16, pcmf, result, done, token, tabs, shadow);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2796,7 +2869,8 @@ ambe2400_frame_kernel(const uint8_t* __restrict__ frame, mbx_param_record* __res
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 frame_server_kernel(mbx_frame_mailbox* mb, unsigned idle_ticks /* of the 100 MHz wall clock */, mbe_parms* state, mbx_stream_rng* rng,
-                    int16_t* pcm16, float* pcmf, mbe_process_result* result, mbx_param_record* record, DeviceTables tabs) {
+                    int16_t* pcm16, float* pcmf, mbe_process_result* result, mbx_param_record* record, DeviceTables tabs,
+                    FrameShadow shadow_in) {
     __shared__ uint32_t frame_words[8];
     const int lane = lane_id();
     const uint32_t* const line = reinterpret_cast<const uint32_t*>(mb);   // the request line: dword `lane` of it, lanes 0..15
@@ -2825,12 +2899,14 @@ frame_server_kernel(mbx_frame_mailbox* mb, unsigned idle_ticks /* of the 100 MHz
             const uint8_t* frame = reinterpret_cast<const uint8_t*>(frame_words);
             int16_t* const o16 = (want & 1u) ? pcm16 : nullptr;
             float* const of = (want & 2u) ? pcmf : nullptr;
+            FrameShadow shadow = shadow_in;
+            shadow.use = (shadow_in.state && (want & 4u)) ? 1u : 0u;   // MBX_FRAME_WANT_SHADOW: the device copy of the state is current
             if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {
-                imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame, codec);
+                imbe_stream_body<true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame, codec, shadow);
             } else if (codec == MBX_CODEC_AMBE3600X2400) {
-                ambe_stream_body<true, true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame);
+                ambe_stream_body<true, true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame, shadow);
             } else {
-                ambe_stream_body<false, true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame);
+                ambe_stream_body<false, true, true>(1, 1, record, nullptr, state, rng, o16, of, result, tabs, frame, shadow);
             }
             last = in;
             ++served;

@@ -401,6 +401,113 @@ def test_streams_frame_by_frame_through_the_frame_server():
     assert out.returncode == 0 and "served ok" in out.stdout, out.stderr[-2000:]
 
 
+def _wire_to_cells(wire, widths, shape):
+    """wire frames [n, bytes] (rows of `widths` bits, first bit = most significant) -> the per-frame API's cells [n, rows, cols]:
+    cell j of a row is bit j of the row's value (ref imbe_fr[8][23] / ambe_fr[4][24])"""
+    bits = np.unpackbits(np.ascontiguousarray(wire, dtype=np.uint8), axis=1)
+    cells = np.zeros((wire.shape[0],) + shape, dtype=np.int8)
+    pos = 0
+    for r, w in enumerate(widths):
+        cells[:, r, :w] = bits[:, pos:pos + w][:, ::-1]
+        pos += w
+    return cells
+
+
+def _voice_cells(name, n, seed):
+    from mbelib_neo_amd import framegen
+    rng = framegen.rng_for(seed)
+    if name == "imbe":
+        wire = framegen.flip_bits(framegen.imbe_clean_voiced_frames(n, rng), 0, 0.02, rng)
+        return _wire_to_cells(wire, (23, 23, 23, 23, 15, 15, 15, 7), (8, 23))
+    return _wire_to_cells(framegen.ambe_noisy_voice_frames(n, rng, ber=0.02), (24, 23, 11, 14), (4, 24))
+
+
+def _interleaved_channels(mbe, fn, frames, ncell_shape, nd, order):
+    """decode `frames` [2, n, ...] of two channels through fn in the given call order; returns PCM [2, n, 160] and final states"""
+    st = [new_state(mbe), new_state(mbe)]
+    n = frames.shape[1]
+    out = np.zeros((2, n, 160), dtype=np.float32)
+    pos = [0, 0]
+    for ch in order:
+        i = pos[ch]
+        pos[ch] += 1
+        d = np.zeros(nd, dtype=np.int8)
+        r = np.zeros(1, dtype=RESULT_DTYPE)
+        fr = np.ascontiguousarray(frames[ch, i])
+        fn(p(out[ch, i]), p(r), p(fr), p(d), p(st[ch][0]), p(st[ch][1]), p(st[ch][2]))
+    return out, st
+
+
+def test_sync_calls_device_copy_of_the_state_is_invisible(mbe):
+    """The synchronous calls keep a device copy of the state and read from it when the caller's structs still are what the
+    previous call returned (mbx_process_frame_shadow).  Two channels decoded (a) one after the other -- every call but the
+    first finds its structs unchanged: device copy -- and (b) alternating call by call -- every call finds the OTHER channel's
+    structs in the pinned block: state taken from the caller -- and (c) with a struct modified by the caller between two calls
+    must give bit-identical PCM and states.  HIP vs HIP (the golden-stream tests pin the values)."""
+    n = 24
+    for name, fn, shape, nd in (("imbe", mbe.mbe_processImbe7200x4400Framef, (8, 23), 88),
+                                ("ambe", mbe.mbe_processAmbe3600x2450Framef, (4, 24), 49)):
+        cells = _voice_cells(name, 2 * n, 911).reshape(2, n, *shape)
+        mbe.mbe_setThreadRngSeed(77)
+        a, sa = _interleaved_channels(mbe, fn, cells, shape, nd, [0] * n + [1] * n)
+        mbe.mbe_setThreadRngSeed(77)
+        b, sb = _interleaved_channels(mbe, fn, cells, shape, nd, [0] * n + [1] * n)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+        # (b) alternating: the thread RNG is shared between the channels, so compare against the same order decoded with the
+        # device copy switched off in a process of its own
+        mbe.mbe_setThreadRngSeed(77)
+        c, sc = _interleaved_channels(mbe, fn, cells, shape, nd, [0, 1] * n)
+        import subprocess
+        import sys
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); import test_gpu_shim_api as t, shim_lib; "
+                "m = shim_lib.load(); n = %d; name = %r; "
+                "fn, shape, nd = ((m.mbe_processImbe7200x4400Framef, (8, 23), 88) if name == 'imbe' else (m.mbe_processAmbe3600x2450Framef, (4, 24), 49)); "
+                "cells = t._voice_cells(name, 2 * n, 911).reshape(2, n, *shape); "
+                "m.mbe_setThreadRngSeed(77); c, sc = t._interleaved_channels(m, fn, cells, shape, nd, [0, 1] * n); "
+                "m.mbe_setThreadRngSeed(77); a, sa = t._interleaved_channels(m, fn, cells, shape, nd, [0] * n + [1] * n); "
+                "np.save(sys.argv[1], np.stack([c, a]))" % (os.path.dirname(os.path.abspath(__file__)), n, name))
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "off.npy")
+            out = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MBE_NEO_FRAME_SHADOW="0"), capture_output=True,
+                                 text=True, timeout=300)
+            assert out.returncode == 0, out.stderr[-2000:]
+            off = np.load(path)
+        assert np.array_equal(c.view(np.uint32), off[0].view(np.uint32)), name + ": alternating channels"
+        assert np.array_equal(a.view(np.uint32), off[1].view(np.uint32)), name + ": channel after channel"
+        # (c) the caller changes a struct between two calls: the call after it must see the change
+        mbe.mbe_setThreadRngSeed(5)
+        st = new_state(mbe)
+        outs = []
+        for rep in range(2):
+            cur, prev, enh = (x.copy() for x in st)
+            got = np.zeros((4, 160), dtype=np.float32)
+            mbe.mbe_setThreadRngSeed(5)
+            for i in range(4):
+                d = np.zeros(nd, dtype=np.int8)
+                r = np.zeros(1, dtype=RESULT_DTYPE)
+                fr = np.ascontiguousarray(cells[0, i])
+                if i == 2:
+                    mbe.mbe_initMbeParms(p(cur), p(prev), p(enh))   # a host that re-initialises its channel
+                fn(p(got[i]), p(r), p(fr), p(d), p(cur), p(prev), p(enh))
+            outs.append(got)
+        fresh = np.zeros((2, 160), dtype=np.float32)
+        cur, prev, enh = new_state(mbe)
+        mbe.mbe_setThreadRngSeed(5)
+        for i in range(4):   # the same calls on a channel that really is new at frame 2 (the thread RNG keeps running)
+            d = np.zeros(nd, dtype=np.int8)
+            r = np.zeros(1, dtype=RESULT_DTYPE)
+            fr = np.ascontiguousarray(cells[0, i])
+            if i == 2:
+                cur, prev, enh = new_state(mbe)
+            tmp_out = np.zeros(160, dtype=np.float32)
+            fn(p(tmp_out), p(r), p(fr), p(d), p(cur), p(prev), p(enh))
+            if i >= 2:
+                fresh[i - 2] = tmp_out
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), name
+        assert np.array_equal(outs[0][2:].view(np.uint32), fresh.view(np.uint32)), name + ": re-initialised channel"
+
+
 def test_soft_entry_points_match_reference_fixture(mbe):
     kat = golden_io.soft_kat()
     for row in kat["golay"][:60]:
