@@ -346,3 +346,74 @@ def test_exact_shortcuts_of_the_stream_kernel_are_exact():
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), L
     src = open(os.path.join(ROOT, "mbelib-neo_amd", "csrc", "mbx_stream.hip")).read()
     assert "truncf(x * (0.15915494f * 1.000001f))" in src and "return fmaf(r, rcp_b, q);" in src   # the kernel's expressions are these
+
+
+def test_single_frame_fec_closed_form_sequence_and_header_gather():
+    """Two restatements inside the kernels that the GPU tests exercise only through whole frames, checked here on their own:
+    (1) the single-frame FEC's demodulation sequence in closed form (mbx_fec_frame.h, PrLane / PrWave: lane j holds (A, C) of
+        steps j + 1 and j + 65 by seven doublings; x_k = A_k x_0 + C_k mod 2^16; mask_for() cuts a row's mask out of the two
+        64-bit ballots, first bit to the top) against the serial recurrence x_k = 173 x_{k-1} + 13849 mod 2^16
+        (ref src/imbe/imbe7200x4400.c:469-515, src/ambe/ambe_common.c:127-157) for all 4,096 seeds and the three codecs' row widths;
+    (2) the lane -> dword map of the gathered header load / store (mbx_stream.hip, load_header / store_parms<kGather>) against the
+        byte offsets of the fourteen scalar fields of mbe_parms (include/mbx_types.h layout via mbelib_neo_amd.layout)."""
+    def serial(seed, n=128):
+        x = (16 * seed) & 0xFFFF
+        out = []
+        for _ in range(n):
+            x = (173 * x + 13849) & 0xFFFF
+            out.append(x >> 15)
+        return out
+
+    def lane_consts(lane):
+        P, Q, a, c = 173, 13849, 1, 0
+        k = lane + 1
+        for b in range(7):
+            if k & (1 << b):
+                a, c = (a * P) & 0xFFFF, (c * P + Q) & 0xFFFF
+            Q, P = (Q * (P + 1)) & 0xFFFF, (P * P) & 0xFFFF
+        P64, Q64 = 173, 13849
+        for b in range(6):
+            Q64, P64 = (Q64 * (P64 + 1)) & 0xFFFF, (P64 * P64) & 0xFFFF
+        return a, c, (a * P64) & 0xFFFF, (c * P64 + Q64) & 0xFFFF
+
+    lanes = [lane_consts(l) for l in range(64)]
+
+    def brev32(v):
+        return int(f"{v & 0xFFFFFFFF:032b}"[::-1], 2)
+
+    for seed in range(4096):
+        x0 = (16 * seed) & 0xFFFF
+        lo = sum(((((a1 * x0 + c1) >> 15) & 1) << j) for j, (a1, c1, _, _) in enumerate(lanes))
+        hi = sum(((((a2 * x0 + c2) >> 15) & 1) << j) for j, (_, _, a2, c2) in enumerate(lanes))
+        bits = serial(seed)
+        assert [(lo >> j) & 1 for j in range(64)] + [(hi >> j) & 1 for j in range(64)] == bits, seed
+        if seed % 37 == 0:
+            for widths in ((23, 23, 23, 15, 15, 15), (24, 23, 23, 15, 15), (23,)):
+                pos = 0
+                for w in widths:
+                    cut = ((lo >> pos) | ((hi << (64 - pos)) if pos > 0 else 0)) if pos < 64 else (hi >> (pos - 64))
+                    got = brev32(cut & 0xFFFFFFFF) >> (32 - w)
+                    want = 0
+                    for j in range(w):
+                        want = (want << 1) | bits[pos + j]
+                    assert got == want, (seed, widths, pos)
+                    pos += w
+    src = open(os.path.join(ROOT, "mbelib-neo_amd", "csrc", "mbx_fec_frame.h")).read()
+    assert "a = (a * P) & 0xffffu;" in src and "c = (c * P + Q) & 0xffffu;" in src and "return __brev((uint32_t)cut) >> (32 - width);" in src
+
+    from mbelib_neo_amd.layout import PARMS_DTYPE
+    names = ["w0", "L", "K", "gamma", "tonePhase", "swn", "localEnergy", "amplitudeThreshold", "errorRate", "errorCountTotal",
+             "errorCount4", "repeatCount", "mutingThreshold", "noiseSeed"]
+    fields = {n.lower(): PARMS_DTYPE.fields[n][1] for n in PARMS_DTYPE.names}
+
+    def offset_of(name):   # the layout module may spell a field differently from the kernel's Parms: match loosely
+        key = name.lower()
+        cands = [k for k in fields if k == key] or [k for k in fields if k.replace("_", "") == key.replace("_", "")]
+        assert cands, (name, sorted(fields))
+        return fields[cands[0]]
+
+    for j, name in enumerate(names):
+        idx = j if j < 3 else ((288 - 3) + j if j < 13 else 554)   # load_header's map (O_GAMMA = 288, O_NOISESEED = 554)
+        assert offset_of(name) == 4 * idx, (name, offset_of(name), idx)
+    ksrc = open(os.path.join(ROOT, "mbelib-neo_amd", "csrc", "mbx_stream.hip")).read()
+    assert "(j < 3) ? j : ((j < 13) ? (O_GAMMA - H_GAMMA) + j : O_NOISESEED)" in ksrc and "O_GAMMA = 288" in ksrc and "O_NOISESEED = 554" in ksrc
