@@ -759,6 +759,12 @@ def main():
                 import host_path_rate
 
                 hp = json.loads(host_path_rate.run(65536, local_rank))
+                sync_variants = {}
+                for key, env in (("frame_server", {"MBE_NEO_FRAME_SERVER": "1"}), ("no_device_copy", {"MBE_NEO_FRAME_SHADOW": "0"})):
+                    try:
+                        sync_variants[key] = json.loads(host_path_rate.run(4096, local_rank, dict(env, MBX_HOST_BENCH_SYNC_ONLY="1")))["sync_call_us"]
+                    except Exception as e:   # noqa: BLE001
+                        sync_variants[key] = str(e)[:200]
                 one_core = [b for b in line.get("cpu_baselines", []) if b["cores"] == 1 and b["recipe"].startswith("full path")]
                 line["host_path"] = {
                     "frames_per_s": hp["session_pinned_frames_per_s"],
@@ -771,6 +777,8 @@ def main():
                     "devices": hp.get("devices"), "all_devices_frames_per_s": hp.get("session_all_devices_frames_per_s"),
                     "per_frame_api": {
                         "sync_call_us": hp["sync_call_us"],
+                        "sync_call_us_frame_server": sync_variants.get("frame_server"),       # MBE_NEO_FRAME_SERVER=1 (opt-in)
+                        "sync_call_us_no_device_copy": sync_variants.get("no_device_copy"),   # MBE_NEO_FRAME_SHADOW=0
                         "reference_call_us": (1e6 / one_core[0]["value"]) if one_core else None,
                         "queue_mode_resident_frames_per_s": hp["queue_resident_frames_per_s"],
                         "queue_mode_writeback_frames_per_s": hp["queue_writeback_frames_per_s"],

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(streams=65536, device=0):
+def run(streams=65536, device=0, env=None):
+    """env: extra environment of the child (e.g. MBE_NEO_FRAME_SERVER=1 with MBX_HOST_BENCH_SYNC_ONLY=1: only the synchronous call)"""
     import mbelib_neo_amd as m
     from mbelib_neo_amd import framegen
 
@@ -21,7 +22,8 @@ def run(streams=65536, device=0):
     try:
         exe = os.path.join(ROOT, "mbelib-neo_amd", "host_bench")
         tables = os.path.join(ROOT, "mbelib-neo_amd", "data", "mbx_tables.bin")
-        out = subprocess.run([exe, tables, path, str(device)], capture_output=True, text=True, timeout=600)
+        out = subprocess.run([exe, tables, path, str(device)], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, **env) if env else None)
         if out.returncode != 0:
             raise RuntimeError(f"host_bench failed ({out.returncode}): {out.stderr[-500:]}")
         return out.stdout.strip().splitlines()[-1]

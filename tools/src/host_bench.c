@@ -210,6 +210,10 @@ int main(int argc, char** argv) {
         }
         sync_us = (now() - t0) / n * 1e6;
     }
+    if (getenv("MBX_HOST_BENCH_SYNC_ONLY")) {   /* bench.py: the same figure again under another switch of the per-frame library */
+        printf("{\"streams\": %d, \"sync_call_us\": %.2f}\n", S, sync_us);
+        return 0;
+    }
 
     /* ---- queue mode: C channels, one frame per channel and tick ---- */
     const int C = S < 16384 ? S : 16384, ticks = 12;
