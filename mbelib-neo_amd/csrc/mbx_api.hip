@@ -326,6 +326,7 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     for (int k = 0; k <= 160; ++k) {
         d.lcg_mul[k] = a;
         d.lcg_add[k] = c;
+        d.lcg_pack[k] = a | (c << 16);
         a = (uint32_t)(((uint64_t)a * 171u) % 53125u);
         c = (uint32_t)(((uint64_t)c * 171u + 11213u) % 53125u);
     }

@@ -17,6 +17,7 @@ constexpr int kWave = 64;
 struct DerivedTables {
     uint32_t lcg_mul[161];    // 171^k mod 53125           (unvoiced-noise LCG jump-ahead)
     uint32_t lcg_add[161];    // additive term after k steps
+    uint32_t lcg_pack[161];   // both in one word (each is below 53,125 < 2^16): lcg_mul[k] | lcg_add[k] << 16 -- one load per sample
     float    log2_int[64];    // log2f((float)L) from the host libm (AMBE gain term)
     // Wave-uniform quotients of the parameter decode: one scalar load each instead of a 12-instruction IEEE
     // division executed by all 64 lanes.  Made on the host with the same float expressions (correctly rounded

@@ -371,6 +371,21 @@ using WaveScratch = WaveScratchT<MBX_PARK_N>;
 // L - 1 dependent additions like the reference's loop, and no LDS traffic at all (round 2 sent the terms through LDS and
 // read them back as broadcast ds_read_b128: 4 LDS-array cycles per 4 terms in a kernel whose LDS pipe is its busiest unit).
 // v must be 0.0f in lanes outside 1..L.  `tmp` (unused) keeps the call sites' shape.
+// the unvoiced-noise generator x -> 171 x + 11213 mod 53125 (ref src/core/mbe_unvoiced_fft.c), n steps at once: x_n = mul x_0 + add
+constexpr uint32_t lcg_mul_steps(int n) {
+    uint64_t a = 1;
+    for (int k = 0; k < n; ++k) {
+        a = (a * 171u) % 53125u;
+    }
+    return (uint32_t)a;
+}
+constexpr uint32_t lcg_add_steps(int n) {
+    uint64_t c = 0;
+    for (int k = 0; k < n; ++k) {
+        c = (c * 171u + 11213u) % 53125u;
+    }
+    return (uint32_t)c;
+}
 constexpr int kDppWaveShr1 = 0x138;   // gfx9 DPP: whole-wave shift right by one lane
 __device__ __forceinline__ float seq_sum4(float v, int L, float* /*tmp*/, int /*lane*/) {
     float acc = v;
@@ -1043,12 +1058,20 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
     float nz[4];
     const bool cold = cur.noiseSeed < 0.0f;   // cold start: a block of zeros, then prime the generator
     const uint32_t x0 = cold ? 0u : (((uint32_t)cur.noiseSeed) % 53125u);
-    auto at = [&](int k) -> float {   // k-th value of the LCG started at x0
+    // k-th value of the LCG started at x0: x_k = (mul_k x_0 + add_k) mod 53125 with (mul_k, add_k) from a host table, ONE packed
+    // word per k.  Request (lcg_req) and arithmetic (lcg_val) are separate so that the five samples a frame needs after the voiced
+    // bank go out together: written as five look-ups in a row they were five L2 round trips in a row (the compiler keeps each
+    // load next to its use), 2-3 us of a wave that lives for 20.
+    auto lcg_req = [&](int k) -> uint32_t {
         k = k < 0 ? 0 : k;
-        const uint32_t mul = tab_at<uint32_t>(tabs.d, offsetof(DerivedTables, lcg_mul), 4u * (uint32_t)k);
-        const uint32_t add = tab_at<uint32_t>(tabs.d, offsetof(DerivedTables, lcg_add), 4u * (uint32_t)k);
-        return (float)((__umul24(mul, x0) + add) % 53125u);   // both factors are below 53,125: a 24-bit multiply is exact
+        return tab_at<uint32_t>(tabs.d, offsetof(DerivedTables, lcg_pack), 4u * (uint32_t)k);
     };
+    auto lcg_val = [&](uint32_t w) -> float {
+        return (float)((__umul24(w & 0xffffu, x0) + (w >> 16)) % 53125u);   // both factors are below 53,125: a 24-bit multiply is exact
+    };
+    auto at = [&](int k) -> float { return lcg_val(lcg_req(k)); };
+    // the seed of the next frame is 160 steps on: constants of the generator, no table
+    constexpr uint32_t kMul160 = lcg_mul_steps(160), kAdd160 = lcg_add_steps(160);
     if (cold) {
         nz[0] = nz[1] = nz[2] = nz[3] = 0.0f;
         cur.ov[0] = cur.ov[1] = 0.0f;
@@ -1067,7 +1090,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             cur.ov[0] = at(lane + 64);
             cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
         }
-        cur.noiseSeed = uni(at(160));
+        cur.noiseSeed = (float)((kMul160 * x0 + kAdd160) % 53125u);   // x0 is wave-uniform: scalar arithmetic
     }
     if (snap) {   // only nz[0] is needed before the FFT (phase randomisation); the rest is rebuilt there
         nz[1] = nz[2] = nz[3] = 0.0f;
@@ -1318,19 +1341,28 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         } else {
             __threadfence_block();   // the snapshot was stored by this wave; its stores have long been issued
         }
-        const float old0 = snap_f(O_OVERLAP + lane);
-        const float old1 = (lane < 32) ? snap_f(O_OVERLAP + 64 + lane) : 0.0f;
+        float old0 = snap_f(O_OVERLAP + lane);
+        float old1 = (lane < 32) ? snap_f(O_OVERLAP + 64 + lane) : 0.0f;
+        // every request of this stage first (see lcg_req), then ONE wait
+        uint32_t q64 = lcg_req(lane + 64), q128 = lcg_req(lane < 32 ? lane + 128 : 160), qm32 = 0u, q32 = 0u, q96 = 0u;
+        const bool fft_noise = !MBX_ABL(tabs, 32) && any_unvoiced;   // the fresh samples of the transform's input (a voiced frame never needs them)
+        if (fft_noise) {
+            qm32 = lcg_req(lane - 32);
+            q32 = lcg_req(lane + 32);
+            q96 = lcg_req(lane + 96);
+        }
+        asm volatile("" : "+v"(old0), "+v"(old1), "+v"(q64), "+v"(q128), "+v"(qm32), "+v"(q32), "+v"(q96));
         nz[0] = old0;
         nz[1] = old1;
-        cur.ov[0] = at(lane + 64);
-        cur.ov[1] = (lane < 32) ? at(lane + 128) : 0.0f;
+        cur.ov[0] = lcg_val(q64);
+        cur.ov[1] = (lane < 32) ? lcg_val(q128) : 0.0f;
+        if (fft_noise) {
+            nz[1] = (lane < 32) ? nz[1] : lcg_val(qm32);
+            nz[2] = lcg_val(q32);
+            nz[3] = lcg_val(q96);
+        }
     }
     if (!MBX_ABL(tabs, 32) && any_unvoiced) {
-        if (snap && !cold) {   // the fresh LCG samples of the transform's input (a voiced frame never needs them)
-            nz[1] = (lane < 32) ? nz[1] : at(lane - 32);
-            nz[2] = at(lane + 32);
-            nz[3] = at(lane + 96);
-        }
         // Register diet: the transform pair is the kernel's register peak, and everything that merely crosses it
         // would cost a wave of occupancy for ALL frames.  Those values wait in the lane's own LDS column instead
         // (same lane writes and reads: no synchronisation).
