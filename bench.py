@@ -551,6 +551,31 @@ def convert_rate(local_rank, nframes=1 << 20, steps=20):
             "what": "float PCM resident in HBM -> int16 PCM, 1,048,576 frames per launch (the device counterpart of the reference's bench_convert)"}
 
 
+def copy_floor(local_rank, S=65536, steps=20):
+    """state_copy_kernel: every stream's three structs loaded and stored with exactly the stream kernels' accesses (one wave per
+    stream, a dword per lane) and nothing else -- what the chip gives THIS access pattern, timed in this very run.  The T = 1
+    stream kernels are priced against it beside the 8 TB/s datasheet roofline (roofline.copy_floor)."""
+    import torch
+
+    from mbelib_neo_amd import _native, decoder
+
+    L = _native.lib()
+    dec = decoder.BatchDecoder(0, S, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        _native.check(L.mbx_state_copy(S, dec.state.data_ptr(), stream), "mbx_state_copy")
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        _native.check(L.mbx_state_copy(S, dec.state.data_ptr(), stream), "mbx_state_copy")
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    nbytes = 2 * S * 3 * 2604
+    return {"kernel": "state_copy_kernel", "bytes_per_launch": nbytes, "kernel_ms": ms, "rate_GBps": nbytes / (ms * 1e-3) / 1e9,
+            "what": "load + store of the three structs of 65,536 streams with the stream kernels' access pattern, no arithmetic"}
+
+
 def roofline_of(name, S, T, m):
     traffic, source = measured_traffic(name, S, T)
     achieved = m["alg_bytes"] / (m["kernel_ms"] * 1e-3) / 1e9
@@ -746,6 +771,18 @@ def main():
             line["convert"] = convert_rate(local_rank)
         except Exception as e:   # noqa: BLE001 -- the headline must not depend on the extras
             line["convert"] = {"error": str(e)[:300]}
+        if T == 1:
+            try:   # the same bytes through a kernel that only copies them: how far the stream kernel is from what this access pattern can reach
+                cf = copy_floor(local_rank)
+                rf = line["roofline"]
+                moved = rf.get("traffic") or rf["algorithmic_bytes_per_launch"]
+                cf["stream_kernel_bytes"] = moved
+                cf["stream_kernel_bytes_source"] = "PMC counters of this build" if rf.get("traffic") else "algorithmic bytes"
+                cf["stream_kernel_rate_GBps"] = moved / (rf["kernel_ms"] * 1e-3) / 1e9
+                cf["frac_of_copy_rate"] = cf["stream_kernel_rate_GBps"] / cf["rate_GBps"]
+                rf["copy_floor"] = cf
+            except Exception as e:   # noqa: BLE001
+                line["roofline"]["copy_floor"] = {"error": str(e)[:300]}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # timed at N = 1 only, on rank 0
             lst, ncpu = cpu_baselines(args.workload, codec, T, full=extras)

@@ -35,6 +35,28 @@
 
 #include "mbx_device.h"
 #include "mbx_expand_ambe.h"
+// Development instrumentation (-DMBX_STAGE_TIMES, never in the product build; tools/stage_times.py): where the waves of a LAUNCH
+// spend their lives -- every wave adds the 100 MHz wall-clock time between consecutive marks of the one-frame IMBE body and of
+// the synthesiser to device-wide accumulators.
+#ifdef MBX_STAGE_TIMES
+namespace mbx {
+constexpr int kStageWaves = 65536;
+__device__ unsigned g_stage_buf[kStageWaves * 16];   // per workgroup (= wave = stream of the launch) and mark: ticks since the mark before
+__shared__ unsigned long long s_stage_prev;          // one wave per workgroup
+}
+#define MBX_TS(i)                                                                          \
+    do {                                                                                   \
+        const unsigned long long t_ = wall_clock64();                                      \
+        if ((threadIdx.x & 63) == 0) {                                                     \
+            if ((i) > 0 && blockIdx.x < (unsigned)mbx::kStageWaves) {                      \
+                mbx::g_stage_buf[blockIdx.x * 16u + (unsigned)(i)] = (unsigned)(t_ - mbx::s_stage_prev);   \
+            }                                                                              \
+            mbx::s_stage_prev = t_;                                                        \
+        }                                                                                  \
+    } while (0)
+#else
+#define MBX_TS(i) do { } while (0)
+#endif
 #ifdef MBX_FRAME_STAMPS
 namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #define MBX_FSTAMP(i) do { g_frame_stamps[i] = wall_clock64(); } while (0)
@@ -1266,6 +1288,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const v2f w_plus = {Ws(N + kMidPrev + kk), Ws(kMidCur + (kk < 52 ? kk : 51))};
             const v2f w_minus = {Ws(N + kMidPrev - kk), Ws(kMidCur - kk)};
             wave_lds_sync();
+            MBX_TS(5);   // smoothing, phases, bank coefficients
             __builtin_amdgcn_s_setprio(MBX_PRIO_BANK);
             v2f Qc = Ec, Qs = Es;   // harmonic 1
             v2f even = {0.0f, 0.0f}, odd = {0.0f, 0.0f}, even_d = {0.0f, 0.0f}, odd_d = {0.0f, 0.0f};
@@ -1341,6 +1364,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         } else {
             __threadfence_block();   // the snapshot was stored by this wave; its stores have long been issued
         }
+        MBX_TS(6);   // voiced bank + its output through LDS
         float old0 = snap_f(O_OVERLAP + lane);
         float old1 = (lane < 32) ? snap_f(O_OVERLAP + 64 + lane) : 0.0f;
         // every request of this stage first (see lcg_req), then ONE wait
@@ -1403,6 +1427,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         // access pattern below (first / last stage and the bin passes: lane + 64 r; stages with spans 16, 4, 1); being
         // linear, fsw(base + r q) = fsw(base) ^ fsw(r q) whenever base has no bit in r q's digit: one swizzle per stage
         // and three XORs with literals.  (tools/fft_swizzle.py searches the family and prints the conflict counts.)
+        MBX_TS(7);   // noise samples (table round trip)
         __builtin_amdgcn_s_setprio(MBX_PRIO_FFT);
         v2f* const F = reinterpret_cast<v2f*>(S.fft);
         // (Round 3 kept plain indices in the HBM-slot instances: three more address registers across a butterfly were a spill under
@@ -1604,6 +1629,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             cur.Vl = __float_as_int(S.park[1][lane]);
         }
     }
+    MBX_TS(8);   // transform pair (or nothing)
     if (!MBX_ABL(tabs, 32)) {
         // weighted overlap-add: out[n] += (w(n) prevUw[n+128] + w(n-160) Uw[n-32]) / (w(n)^2 + w(n-160)^2);
         // Uw[n-32] sits 32 lanes away: lanes >= 32 take slot j of lane-32, lanes < 32 slot j-1 of lane+32
@@ -1633,6 +1659,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         wave_lds_sync();
     }
 
+    MBX_TS(9);   // overlap-add
     // ---- soft clip ---------------------------------------------------------------------------
     const float clip = (32767.0f * 0.95f) / 7.0f;
 #pragma unroll
@@ -1842,6 +1869,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
     const int lane_in = lane_id();
     MBX_STAMP(0, false);
+    if constexpr (kOne) { MBX_TS(0); }
     Wire wire_in = {};
     if constexpr (kFrame) {
         wire_in = shadow.have_frame ? frame_from_args(false, shadow) : frame_fetch(false, frame_in);   // ahead of every state load
@@ -1874,6 +1902,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     // (vector memory returns in order: what is asked for first is there first), then the per-lane arrays.
     Parms enh_first, prev_first;       // !kPark: the first frame's views of prev_mp_enhanced / prev_mp ...
     uint32_t h_enh_first = 0u, h_prev_first = 0u;   // ... and their headers, read out where the frame loop needs them
+    float row_first = 0.0f;
     if constexpr (kPark) {
         slot_prev = &park.prev;
         slot_enh = nullptr;
@@ -1913,6 +1942,9 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         slot_prev = home_prev;
         slot_enh = home_enh;
         const mbe_parms* const enh_src = elided1 ? slot_cur : slot_enh;
+        if (params) {   // the frame's FrameParams row is what the frame needs first: requested first (tools/stage_times.py: asked for
+            row_first = params[(size_t)s * (size_t)Tn].v[lane_in];   // after the scalars of cur_mp had arrived, it cost 2.5 us of a wave's 22)
+        }
         const uint32_t h_cur = load_header(slot_cur, lane_in);
         h_prev_first = load_header(slot_prev, lane_in);
         h_enh_first = load_header(enh_src, lane_in);
@@ -1921,6 +1953,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         load_parms_arrays(cur, slot_cur, lane_in);
         load_enh_arrays(enh_first, enh_src, lane_in);
         set_parms_header(cur, h_cur);
+        MBX_TS(1);   // cur_mp's scalars are there (first round trip)
     } else {
         slot_prev = home_prev;
         slot_enh = home_enh;
@@ -1968,12 +2001,13 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             load_prev_view(prev, slot_prev, lane);
         }
         if (params) {
-            scratch.x.fp[lane] = params[f].v[lane];
+            scratch.x.fp[lane] = kOne ? row_first : params[f].v[lane];
             wave_lds_sync();
         } else {
             expand_imbe_wave(kFrame ? rec_in : load_record_scalar(&records[f]), scratch, tabs.t, tabs.d, lane);
         }
         MBX_STAMP(3, false);
+        if constexpr (kOne) { MBX_TS(2); }   // the frame's parameters are in LDS (row or expansion)
         const float* fp = scratch.x.fp;
         const uint32_t errw = uni(__float_as_uint(fp[62]));
         const int c0 = (int)(errw & 0xffu), prot = (int)((errw >> 8) & 0xffu), c4 = (int)((errw >> 16) & 0xffu);
@@ -2017,6 +2051,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         // prev_mp := cur_mp (snapshot before enhancement).  The scheduling barriers keep the 14 stores in one piece: mixed
         // into the decode before them or the enhancement after them they stretch live ranges past the 72-register budget.
         MBX_STAMP(4, false);
+        if constexpr (kOne) { MBX_TS(3); }   // decoded, policy applied
         if (!MBX_ABL(tabs, 256)) store_parms<kOne>(cur, slot_prev, lane);
         prev_partial = false;
         // Register diet for the synthesiser: what the snapshot holds and the synthesiser does not change (log2Ml) or
@@ -2029,10 +2064,12 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         {
             const float rm0 = MBX_ABL(tabs, 2) ? 1.0f : enhance(cur, lane, scratch.x.C);
             MBX_STAMP(5, false);
+            if constexpr (kOne) { MBX_TS(4); }   // snapshot stored, enhanced
             if (!MBX_ABL(tabs, 128)) {
                 fresh = synth_core<true, kPark>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
             }
             MBX_STAMP(6, false);
+            if constexpr (kOne) { MBX_TS(12); }   // synthesised (soft clip)
         }
         {
             slot_fence<kPark>();
@@ -2117,6 +2154,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
     }
     MBX_STAMP(7, false);
+    if constexpr (kOne) { MBX_TS(13); }   // every store issued
     MBX_STAMP(8, true);
 }
 
@@ -3204,5 +3242,15 @@ state_copy_kernel(int S, mbe_parms* __restrict__ state) {
 // development builds only (tools/frame_stamps.py): the stamps of the last single-frame call, in 10 ns ticks
 extern "C" int mbx_debug_frame_stamps(unsigned long long* out16) {
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(mbx::g_frame_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
+
+#ifdef MBX_STAGE_TIMES
+// development builds only (tools/stage_times.py): the marks of the LAST launch, 16 per wave, in 10 ns ticks
+extern "C" int mbx_debug_stage_times(unsigned* out, int waves) {
+    if (waves > mbx::kStageWaves) {
+        waves = mbx::kStageWaves;
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mbx::g_stage_buf), (size_t)waves * 16 * sizeof(unsigned));
 }
 #endif

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""stage_times.py <workload> -- GPU box, DEVELOPMENT BUILD ONLY: where the waves of a one-frame launch spend their lives.
+Build:  make -C mbelib-neo_amd/csrc OUT=$PWD/mbelib-neo_amd/libmbx_hip_stage.so EXTRA=-DMBX_STAGE_TIMES $PWD/mbelib-neo_amd/libmbx_hip_stage.so
+Run:    MBX_HIP_LIBRARY=$PWD/mbelib-neo_amd/libmbx_hip_stage.so MBX_HIP_LIBRARY_ALLOW_OLDER=1 python tools/stage_times.py imbe_voiced
+Every wave of the one-frame IMBE body adds the 100 MHz wall-clock time between consecutive marks (MBX_TS in mbx_stream.hip) to
+device-wide accumulators; this runs the bench workload for a few steps and prints the mean per wave and stage.  The marks drain
+the scalar / LDS queues (s_memrealtime is waited for) and cost an atomic each, so the total is a little above the product's."""
+import ctypes as C
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+NAMES = {1: "entry -> cur_mp's scalars there (first round trip)", 2: "-> frame parameters in LDS", 3: "-> decoded, policy applied",
+         4: "-> snapshot stored, enhanced", 5: "-> smoothing, phases, bank coefficients", 6: "-> voiced bank (+ output through LDS)",
+         7: "-> noise samples (table round trip)", 8: "-> transform pair (or nothing)", 9: "-> overlap-add",
+         12: "-> soft clip, back in the body", 13: "-> every store issued"}
+# (a mark a wave does not pass -- the transform pair of an all-voiced frame has none of its own -- keeps the value of an earlier launch
+#  or zero; marks 7 / 8 are only meaningful for workloads with unvoiced bands)
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "imbe_voiced"
+    import bench
+    from mbelib_neo_amd import _native
+    lib = _native.lib()
+    fn = lib.mbx_debug_stage_times
+    fn.argtypes = [C.c_void_p, C.c_int]
+    sys.argv = ["bench.py", "--workload", wl, "--steps", "6", "--warmup", "2", "--min-time-ms", "0", "--no-cpu-baseline", "--no-extras"]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    line = json.loads(buf.getvalue().strip().splitlines()[-1])
+    import numpy as np
+    S = int(line["config"]["streams_per_gpu"])
+    marks = np.zeros((S, 16), dtype=np.uint32)
+    assert fn(marks.ctypes.data, S) == 0
+    t = marks.astype(np.float64) * 0.01
+    life = t[:, sorted(NAMES)].sum(axis=1)
+    print(f"{wl}: kernel {line['roofline']['kernel']} {line['roofline']['kernel_ms']:.4f} ms (instrumented build), {S} waves of the last launch")
+    print(f"  wave life, entry to last store: mean {life.mean():.2f} us, median {np.median(life):.2f}, p10 {np.percentile(life, 10):.2f}, p90 {np.percentile(life, 90):.2f}")
+    for i in sorted(NAMES):
+        print(f"  {NAMES[i]:52s} mean {t[:, i].mean():6.2f} us  median {np.median(t[:, i]):6.2f}  {100.0 * t[:, i].mean() / life.mean():5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
