@@ -457,8 +457,10 @@ def test_imbe_mixed_config4_full_shape(mbx, oracle):
 def test_lds_resident_and_hbm_slot_kernel_instances_are_identical(mbx, oracle, codec):
     """Launches with T >= 4 frames per stream take the stream-kernel instance that keeps prev_mp / prev_mp_enhanced in LDS
     for the whole launch; shorter ones park them in their HBM slots (mbx_api.hip launch_stream, mbx_stream.hip
-    ParkedState).  Same arithmetic, different home for two structs: 4,096 streams x 12 frames as one launch (LDS), as
-    3 x 4 (LDS, state through HBM between launches) and as 4 x 3 (HBM slots) must be bit-identical in PCM and state, and
+    ParkedState), and launches of ONE frame per stream have instances of their own without a frame loop (`*_stream_kernel_one`:
+    every request of the frame before the first wait, gathered header loads / stores).  Same arithmetic, different homes and
+    orders of memory operations: 4,096 streams x 12 frames as one launch (LDS), as 3 x 4 (LDS, state through HBM between
+    launches), as 4 x 3 (HBM slots, looped) and as 12 x 1 (the one-frame instances) must be bit-identical in PCM and state, and
     a strided sample must match the oracle."""
     import torch
     from mbelib_neo_amd import decoder, framegen
@@ -480,7 +482,7 @@ def test_lds_resident_and_hbm_slot_kernel_instances_are_identical(mbx, oracle, c
         return torch.cat(p16, dim=1).cpu().numpy(), torch.cat(pf, dim=1).cpu().numpy(), dec.state_numpy(), dec.rng_numpy()
 
     a = run(12)
-    for split in (4, 3):
+    for split in (4, 3, 1):
         b = run(split)
         assert np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes(), f"PCM differs between T=12 and T={split} launches"
         assert a[2].tobytes() == b[2].tobytes() and a[3].tobytes() == b[3].tobytes()
