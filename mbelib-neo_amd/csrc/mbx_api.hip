@@ -381,11 +381,18 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
             }
         }
     }
-    memset(d.imbe_blk_rows, 0, sizeof(d.imbe_blk_rows));
     for (int b0 = 0; b0 < 208; ++b0) {
         uint32_t wbits;
         memcpy(&wbits, &host->imbe_w0[b0], 4);
         d.imbe_b0[b0] = make_uint2(wbits, (uint32_t)host->imbe_L[b0] | ((uint32_t)host->imbe_K[b0] << 8));
+    }
+    memset(d.imbe_len_rows, 0, sizeof(d.imbe_len_rows));
+    for (int ji = 1; ji <= 10; ++ji) {
+        for (int j = 1; j <= ji; ++j) {
+            for (int k = 1; k <= ji; ++k) {
+                d.imbe_len_rows[ji][j - 1][k - 1] = host->imbe_idct_cos[ji][j][k];
+            }
+        }
     }
     memset(d.imbe_blk_info, 0, sizeof(d.imbe_blk_info));
     memset(d.imbe_blk_bm, 0, sizeof(d.imbe_blk_bm));
@@ -400,11 +407,6 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
                 d.imbe_blk_bm[l9][blk][k] = (uint8_t)Bm;
                 d.imbe_blk_step[l9][blk][k] = (Bm > 0 && Bm <= 11) ? (host->imbe_quantstep[Bm - 1] * host->imbe_standdev[k - 2]) : 0.0f;
                 ++m;
-            }
-            for (int j = 1; j <= ji && j <= 10; ++j) {
-                for (int k = 1; k <= ji && k <= 10; ++k) {
-                    d.imbe_blk_rows[l9][blk][j - 1][k - 1] = host->imbe_idct_cos[ji][j][k];
-                }
             }
             l += ji;
         }

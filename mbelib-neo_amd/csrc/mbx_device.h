@@ -39,7 +39,10 @@ struct DerivedTables {
     uint32_t imbe_blk_info[48][8];        // first word m | first harmonic l << 8 | block length << 16
     uint8_t  imbe_blk_bm[48][8][12];      // bit count of the higher-order coefficient k = 2..10 of the block (0 = none)
     float    imbe_blk_step[48][8][12];    // quantstep[Bm - 1] * standdev[k - 2] of that coefficient
-    float    imbe_blk_rows[48][8][10][10]; // idct_cos[ji][j][1..10] of output j = 1..10 of the block (zero past its length)
+    float    imbe_len_rows[11][10][10];    // idct_cos[ji][j][1..10] of output j = 1..10 of a block of LENGTH ji = 0..10 (zero past the length).
+                                           // (Until round 4 a copy per (L, block): 154 KB of gathers that did not stay in L1 -- the expansion
+                                           //  kernel's time was their volume.  4.4 KB by length: 24.6 -> 21.1 us for 65,536 frames.)
+    uint32_t pad_len_rows[52];             // (to 18 x 256 B: the tables behind keep their alignment to cache lines)
     uint2    imbe_b0[208];                // b0 -> (w0 bits, L | K << 8): one look-up instead of three
     float    wola_inv[160];       // 1 / wola_denom[n] (0 where the reference skips the sample: denom <= 1e-10)
     float    ambep_f0[128];       // AMBE 3600x2400: exp2f(-4.311767578125f - 2.1336e-2f * (b0 + 0.5f)) from the host libm

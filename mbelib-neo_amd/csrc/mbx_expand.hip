@@ -119,7 +119,10 @@ expand_imbe_kernel(const mbx_param_record* __restrict__ recs, size_t n, FramePar
             qstep[k] = D->imbe_blk_step[L9][blk][k];
         }
     }
-    const float* rows = &D->imbe_blk_rows[L9][blk][0][0];   // cosine rows of the block's outputs; the first one now
+    // cosine rows of the block's outputs, from the table indexed by the block's LENGTH (one round trip later than everything else:
+    // the length comes with `info` -- but 4.4 KB that stay in L1 instead of rows scattered over 154 KB; the first one now)
+    const int ji_rows = (int)((info >> 16) & 0xffu);
+    const float* rows = &D->imbe_len_rows[ji_rows <= 10 ? ji_rows : 10][0][0];
     float cosr[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
