@@ -5,8 +5,10 @@ Metric (BASELINE.json): 20 ms frames/s, whole job, IMBE 7200x4400.
 Workload (default, BASELINE.json configs[1]): 65,536 streams per GPU x T=1 frame per step,
 clean-encoded all-voiced IMBE frames, state warmed by one identical frame so both the
 previous and the current model are voiced.  One "step" = one pass of the hot path
-(mbx_process_batch: FEC kernel, parameter-expansion kernel, stream kernel) over the whole batch
-with every input already resident in HBM.  Streams are independent, so N GPUs = N independent
+(mbx_process_batch: for this shape ONE launch, imbe_stream_kernel_one_fused -- FEC, parameter expansion and stream stage in
+the stream's own wave; other shapes: FEC kernel, [parameter-expansion kernel,] stream kernel) over the whole batch
+with every input already resident in HBM.  After the timed region a strided sample of the timed streams is replayed through
+the CPU oracle and the line carries the PCM error (`parity`: the metric's second half).  Streams are independent, so N GPUs = N independent
 shards (weak scaling, no data-path collective); the only collective is the RCCL broadcast of the
 constant-table blob at start-up (plus the timing reduction and the checksum all-gather).
 
@@ -349,8 +351,62 @@ def self_launch(argv, n, script=None):
 
 
 # ---- one workload on this rank's GPU ----------------------------------------------------------------------------------
+def parity_vs_oracle(name, codec, S, T, frames, seeds, launches, dec, out, step, streams=264):
+    """CHECKER, after the timed region (never inside it, never the thing measured): a strided sample of the streams of the workload
+    that was just timed, replayed through the CPU oracle (oracle/, the restatement pinned on the reference's golden vectors) over
+    the SAME history -- every launch the decoder has seen since its construction, warm-up and timed steps alike -- and compared
+    with what the device left: the mbe_process_result and int16 PCM of the LAST TIMED step, the float PCM of one more (untimed)
+    step, and the final state.  This is the second half of BASELINE.json's metric ("+ PCM RMS error vs reference"); the tolerances
+    are the ones tests/parity.py states (ref tests/test_golden_pcm.c:67-211 holds the reference's own golden-PCM check)."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import parity as par
+    from mbelib_neo_amd import decoder
+    from mbelib_neo_amd.layout import FRAME_BYTES, RESULT_DTYPE
+
+    fb = FRAME_BYTES[codec]
+    pick = np.arange(S // (2 * streams), S, max(1, S // streams))[:streams]
+    d_pick = torch.from_numpy(pick).to(out["pcm16"].device)
+    last16 = out["pcm16"].reshape(S, T, 160)[d_pick].cpu().numpy()
+    last_res = out["results"].reshape(S, T, 5)[d_pick].cpu().numpy()
+    extra = dec.make_outputs(T, want_pcm16=True, want_float=True, want_results=True)
+    t0 = time.perf_counter()
+    dec.decode(frames, T, out=extra)        # one more launch of the same batch, float PCM on
+    torch.cuda.synchronize()
+    pf = extra["pcmf"].reshape(S, T, 160)[d_pick].cpu().numpy()
+    p16 = extra["pcm16"].reshape(S, T, 160)[d_pick].cpu().numpy()
+    state = dec.state_numpy()[pick]
+    o = oracle_lib.load()
+    n = launches + 1
+    fr = np.asarray(frames).reshape(S, T, fb)[pick]
+    hist = np.ascontiguousarray(np.tile(fr, (1, n, 1))).reshape(-1, fb)    # the same T frames per launch, n launches
+    ref = o.process_batch(codec, len(pick), n * T, hist, o.init_state(len(pick)), o.rng_seeded(seeds[pick]))
+    r16 = ref["pcm16"].reshape(len(pick), n, T, 160)
+    rf = ref["pcmf"].reshape(len(pick), n, T, 160)
+    rres = ref["results"].reshape(len(pick), n, T)
+    par.check_results(rres[:, n - 2].reshape(-1), np.ascontiguousarray(last_res).view(RESULT_DTYPE).reshape(-1), what="last timed step")
+    m = par.check_pcm(rf[:, n - 1], pf, r16[:, n - 1], p16, what="bench parity (untimed extra step)")
+    d_last = np.abs(r16[:, n - 2].astype(np.int32) - last16.astype(np.int32))
+    par.check_state(ref["state"], state)
+    return {
+        "rel_rms": m["rel_rms"], "worst_frame": m["worst_frame"],
+        "int16_within_1": float(np.mean(d_last <= 1)), "int16_max": int(max(d_last.max(), m["int16_max"])),
+        "int16_exact": float(np.mean(d_last == 0)),
+        "streams_checked": int(len(pick)), "launches_replayed": int(n), "frames_checked": int(len(pick) * T),
+        "results_exact": True, "state_in_tolerance": True,
+        "tolerance": {"rel_rms": par.PCM_REL_RMS, "worst_frame": par.PCM_WORST_FRAME, "int16_max_lsb": par.INT16_MAX_LSB,
+                      "int16_max_lsb_clipped_frames": par.INT16_MAX_LSB_CLIPPED},
+        "oracle": "oracle/mbx_oracle.c (CPU restatement pinned on the reference's golden vectors; double-precision FFT form)",
+        "what": "strided sample of the timed workload's streams replayed through the oracle over every launch since the decoder's "
+                "construction: results + int16 PCM of the last timed step, float PCM of one more untimed step, final state",
+        "seconds": time.perf_counter() - t0,
+    }
+
+
 def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob, world, dist, args, use_dist=False, coll_device=None,
-                 alternate=False, min_time_s=None, serial=None):
+                 alternate=False, min_time_s=None, serial=None, parity=False):
     """Returns the measurements of one workload: wall time of the timed steps (max over ranks), HIP-event time of the
     dominant kernel per step (mean, median, spread), frame mix.  The launches of a step are what mbx_process_batch issues;
     they are issued one by one here only so that the dominant kernel can be bracketed by events on the launch stream.
@@ -390,7 +446,10 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     # mbx_process_records is ONE launch where the stream kernel expands the records itself (IMBE at T > 1, the AMBE codecs
     # at T >= 4); otherwise it is the expand launch + the stream launch, issued separately here so that the events bracket
     # the stream kernel alone.  --split-expand forces the separate launch everywhere (development aid).
-    split = bool(L.mbx_uses_expand_launch(stream_codec, S, T)) and not (T == 1 and args.fuse_expand) or args.split_expand
+    split = bool(L.mbx_uses_expand_launch(stream_codec, S, T)) or args.split_expand
+    # IMBE at T = 1: mbx_process_batch is ONE launch (imbe_stream_kernel_one_fused: FEC + expansion + stream stage in the stream's
+    # own wave) unless MBX_FUSE_ONE=0; the step is then that call, and the events bracket it.
+    fused = (not soft) and L.mbx_batch_kernel_name(codec, S, T, 1 if resident else 0).decode().endswith("_fused") and not args.split_expand
     # Front-end overlap (round 4).  FEC + parameter expansion of a batch depend only on its frames; the stream stage of the batch
     # before it depends only on ITS records / rows and on the state.  So the front end of step k + 1 is issued on a second HIP
     # stream into alternating record / workspace buffers (the *_ws entry points) and runs while the stream kernel of step k does;
@@ -429,6 +488,20 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
             if ev is not None:
                 ev[1].record()
             b["free"].record(main_stream)
+    def step_fused(ev=None):
+        if ev is not None:
+            ev[0].record()
+        if resident:
+            rc = L.mbx_process_batch_resident(codec, S, T, None, d_frames.data_ptr(), dec.state.data_ptr(), dec.resident.data_ptr(),
+                                              dec.rng.data_ptr(), out["pcm16"].data_ptr(), None, out["results"].data_ptr(),
+                                              out["records"].data_ptr(), stream)
+        else:
+            rc = L.mbx_process_batch(codec, S, T, d_frames.data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(), out["pcm16"].data_ptr(),
+                                     None, out["results"].data_ptr(), out["records"].data_ptr(), stream)
+        _native.check(rc, "mbx_process_batch")
+        if ev is not None:
+            ev[1].record()
+
     def step_serial(ev=None):
         if ev is not None and soft:
             ev[0].record()
@@ -457,8 +530,17 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
         if ev is not None and not soft:
             ev[1].record()
 
-    if not overlap:
+    if fused:
+        step = step_fused
+        overlap = False
+    elif not overlap:
         step = step_serial
+    launches = [0]
+    inner_step = step
+
+    def step(ev=None):   # noqa: F811 -- counts the launches the state has seen (the parity replay needs the whole history)
+        launches[0] += 1
+        inner_step(ev)
     previous_order = L.mbx_set_stream_order(1 if alternate else 0)
     for _ in range(max(1, warmup)):  # the first pass also warms the model state
         step()
@@ -500,19 +582,27 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     L.mbx_set_stream_order(previous_order)
     flags = decoder.results_numpy(out["results"])["flags"]
     pcm_digest = int(out["pcm16"].to(torch.int64).sum().item())
+    parity_obj = None
+    if parity and not soft and not overlap and not args.ablate:
+        try:
+            parity_obj = parity_vs_oracle(name, codec, S, T, frames, np.arange(first_stream, first_stream + S) + 1234, launches[0], dec, out, step,
+                                          streams=264 if T <= 4 else 64)
+        except AssertionError as e:   # a parity failure is reported in the line, loudly, not swallowed
+            parity_obj = {"FAILED": str(e)[:400]}
     if soft:
         kernel = {0: "fec_imbe7200x4400_soft_kernel", 1: "fec_ambe3600x2450_soft_kernel", 2: "fec_imbe7100x4400_soft_kernel",
                   3: "fec_ambe3600x2450_soft_kernel"}[codec]
         alg_bytes = soft_fec_bytes_per_launch(codec, n)
     else:
-        kernel = L.mbx_stream_kernel_name(codec, -T if resident else T).decode()   # (T < 0: the instances of the resident launches)
+        kernel = (L.mbx_batch_kernel_name(codec, S, T, 1 if resident else 0) if fused
+                  else L.mbx_stream_kernel_name(codec, -T if resident else T)).decode()   # (T < 0: the instances of the resident launches)
         alg_bytes = algorithmic_bytes_per_launch(codec, S, T, resident)
     del dec, d_frames, out
     torch.cuda.empty_cache()
     return {
         "dt": dt, "kernel_ms": kernel_ms, "kernel": kernel, "alg_bytes": alg_bytes, "frames_per_step": world * n,
         "value": world * n * steps_eff / dt, "ms_per_step": dt / steps_eff * 1e3, "pcm_digest": pcm_digest, "front_end_overlap": bool(overlap),
-        "steps_effective": steps_eff, "rank_value": n * steps_eff / dt_local,
+        "steps_effective": steps_eff, "rank_value": n * steps_eff / dt_local, "parity": parity_obj,
         "kernel_ms_stats": {"mean": float(per_step.mean()), "median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),
                             "p90": float(np.percentile(per_step, 90)), "min": float(per_step.min()), "max": float(per_step.max()),
                             "launches": int(per_step.size)},
@@ -610,13 +700,13 @@ def main():
     ap.add_argument("--workload", default="imbe_voiced", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle replay of a sample of the timed workload (the line's `parity` object)")
     ap.add_argument("--no-extras", action="store_true", help="headline (and cpu_baseline) only: no other_configs, host_path, infinity_cache_assisted")
     ap.add_argument("--split-expand", action="store_true", help="run the parameter expansion as a separate launch")
     ap.add_argument("--overlap-front-end", action="store_true",
                     help="development aid: FEC + expansion of step k + 1 on a second stream while the stream stage of step k runs "
                          "(mbx_*_ws entry points).  Measured SLOWER than one stream (imbe_voiced 255 vs 265 M frames/s on one box: the "
                          "stream kernel shares the chip, and the cross-stream events cost what the overlap saves) -- not the default")
-    ap.add_argument("--fuse-expand", action="store_true", help="development aid: IMBE at T = 1 through the fused (one-launch) path")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the collectives even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -675,7 +765,8 @@ def main():
         S = args.streams
     first, count = shard_range(S * world, world, rank)  # weak scaling: S streams on every rank
     assert count == S
-    m = run_workload(args.workload, S, T, args.steps, args.warmup, rank, first, local_rank, blob, world, dist, args, use_dist, coll_device)
+    m = run_workload(args.workload, S, T, args.steps, args.warmup, rank, first, local_rank, blob, world, dist, args, use_dist, coll_device,
+                     parity=(rank == 0 and not args.no_parity and not args.no_extras))
     rank_values = [m["rank_value"]]
     if use_dist:   # what every rank measured on its own clock (the line's value is the max-over-ranks time)
         rv = torch.tensor([m["rank_value"]], dtype=torch.float64, device=coll_device)
@@ -684,7 +775,7 @@ def main():
         rank_values = [float(g) for g in gathered]
 
     line = {
-        "metric": "20ms frames/sec (whole node), " + CODEC_NAME[codec],
+        "metric": "20ms frames/sec (whole node) + PCM RMS error vs reference, " + CODEC_NAME[codec],
         "value": m["value"],
         "unit": "frames/s",
         "n_gpus": world,
@@ -708,6 +799,8 @@ def main():
             "frame_mix": m["frame_mix"],
         },
         "roofline": roofline_of(args.workload, S, T, m),
+        # the metric's second half: PCM error of the timed workload against the CPU oracle (a strided sample of its streams; checker only)
+        "parity": m["parity"],
         "distributed": {
             "process_group": (dist.get_backend() if use_dist else None),
             "world_size": (dist.get_world_size() if use_dist else 1),

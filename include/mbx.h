@@ -417,6 +417,12 @@ void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed);
  * instance that keeps prev_mp / prev_mp_enhanced in LDS for the whole launch (*_lds), otherwise the HBM-slot one; T < 0:
  * the instance a resident launch (mbx_process_batch_resident) with -T frames per stream takes (*_res, *_res1) */
 const char* mbx_stream_kernel_name(int codec, int T);
+/* the dominant kernel of mbx_process_batch (resident != 0: of mbx_process_batch_resident) for a batch of S streams x T frames:
+ * the IMBE codecs at T = 1 and S > 256 take ONE fused launch (imbe_stream_kernel_one_fused: FEC + parameter expansion + stream
+ * stage, ref src/imbe/imbe7200x4400.c:935-948 -- decode and process in one call); every other shape the kernel
+ * mbx_stream_kernel_name() names, behind its FEC (and expansion) launches.  MBX_FUSE_ONE=0 in the environment switches the
+ * fused launch off (A/B timing). */
+const char* mbx_batch_kernel_name(int codec, int S, int T, int resident);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,14 @@ __global__ void ambe_stream_kernel_one(int, int, const mbx_param_record*, const 
                                        int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe2400_stream_kernel_one(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                            int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void imbe_stream_kernel_one_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                             mbe_process_result*, DeviceTables);
+__global__ void imbe_stream_kernel_res1_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                              mbe_process_result*, DeviceTables);
+__global__ void imbe7100_stream_kernel_one_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                                 mbe_process_result*, DeviceTables);
+__global__ void imbe7100_stream_kernel_res1_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                                  mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res1(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                         int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
@@ -385,6 +393,10 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
         uint32_t wbits;
         memcpy(&wbits, &host->imbe_w0[b0], 4);
         d.imbe_b0[b0] = make_uint2(wbits, (uint32_t)host->imbe_L[b0] | ((uint32_t)host->imbe_K[b0] << 8));
+    }
+    memset(d.imbe_L_lanes, 0, sizeof(d.imbe_L_lanes));
+    for (int b0 = 0; b0 < 208; ++b0) {
+        d.imbe_L_lanes[b0 & 63] |= (uint32_t)host->imbe_L[b0] << (8 * (b0 >> 6));
     }
     memset(d.imbe_len_rows, 0, sizeof(d.imbe_len_rows));
     for (int ji = 1; ji <= 10; ++ji) {
@@ -881,6 +893,61 @@ static bool needs_workspace(int codec, int S, int T) {
     return !(T >= kLdsResidentMinFrames && lds_resident_enabled());
 }
 
+// The whole T = 1 step of the IMBE codecs as ONE launch (imbe_stream_kernel_one_fused, mbx_stream.hip): wire frames in, every
+// output out.  Taken by the mbx_process_batch* entry points (which have the frames); the records-based entry points keep the
+// expand + stream pair.  MBX_FUSE_ONE=0 switches it off (A/B timing; read once).
+static bool fused_one_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MBX_FUSE_ONE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+static bool fused_one_ok(int codec, int S, int T, const void* d_frames) {
+    return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) && T == 1 && S > kSmallBatchFrames
+           && (reinterpret_cast<uintptr_t>(d_frames) & 3u) == 0 && fused_one_enabled();
+}
+static int launch_fused_one(Context* c, bool reverse, int codec, int S, const uint8_t* d_frames, mbx_param_record* d_records,
+                            mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                            void* stream, const int32_t* d_stream_index, uint32_t* d_resident) {
+    mbx::DeviceTables tabs = c->tabs;
+    tabs.reverse = (reverse && reverse_enabled()) ? 1 : 0;
+    tabs.stream_map = d_stream_index;
+    tabs.resident = d_resident;
+    const bool v7100 = codec == MBX_CODEC_IMBE7100X4400;
+    auto* const kernel = d_resident ? (v7100 ? mbx::imbe7100_stream_kernel_res1_fused : mbx::imbe_stream_kernel_res1_fused)
+                                    : (v7100 ? mbx::imbe7100_stream_kernel_one_fused : mbx::imbe_stream_kernel_one_fused);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, codec, d_frames, d_records, d_state, d_rng, d_pcm16,
+                       d_pcmf, d_results, tabs);
+    return check_launch("imbe_stream_kernel_one_fused");
+}
+// one fused launch if the shape allows it: returns 1 when it was issued (*rc = its status), 0 when the caller goes on with the stages
+static int try_fused_one(int codec, int S, int T, const uint8_t* d_frames, mbx_param_record* d_records, mbe_parms* d_state,
+                         mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, void* stream,
+                         const int32_t* d_stream_index, uint32_t* d_resident, int* rc) {
+    if (!fused_one_ok(codec, S, T, d_frames)) {
+        return 0;
+    }
+    int crc;
+    Context* c = current_ctx(&crc);
+    if (!c) {
+        *rc = crc;
+        return 1;
+    }
+    if (!d_state || !d_rng) {
+        *rc = MBE_STATUS_INVALID_ARGUMENT;
+        return 1;
+    }
+    unsigned order;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        order = c->slots[stream].launches++;
+    }
+    *rc = launch_fused_one(c, (order & 1u) != 0u, codec, S, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
+                           d_stream_index, d_resident);
+    return 1;
+}
+
 extern "C" int mbx_uses_expand_launch(int codec, int S, int T) { return needs_workspace(codec == MBX_CODEC_IMBE7100X4400 ? MBX_CODEC_IMBE7200X4400 : codec, S, T) ? 1 : 0; }
 
 // expand (where needed) + stream kernel with the workspace at `ws` (nullptr when none is needed); `order` = the launch
@@ -1066,7 +1133,11 @@ int mbx_process_batch(int codec, int S, int T, const uint8_t* d_frames, mbe_parm
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     int stream_codec;
-    int rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
+    int rc;
+    if (try_fused_one(codec, S, T, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream, nullptr, nullptr, &rc)) {
+        return rc;
+    }
+    rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
     if (rc < 0) {
         return rc;
     }
@@ -1166,7 +1237,11 @@ int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_p
         return MBE_STATUS_INVALID_ARGUMENT;
     }
     int stream_codec;
-    int rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
+    int rc;
+    if (try_fused_one(codec, S, T, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream, nullptr, nullptr, &rc)) {
+        return rc;   // (needs no workspace)
+    }
+    rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
     if (rc < 0) {
         return rc;
     }
@@ -1185,7 +1260,12 @@ int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_i
         return 0;
     }
     int stream_codec;
-    int rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
+    int rc;
+    if (try_fused_one(codec, S, T, d_frames, d_records, d_state_pool, d_rng_pool, d_pcm16, d_pcmf, d_results, stream, d_stream_index, nullptr,
+                      &rc)) {
+        return rc;
+    }
+    rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
     if (rc < 0) {
         return rc;
     }
@@ -1221,7 +1301,12 @@ int mbx_process_batch_resident(int codec, int S, int T, const int32_t* d_stream_
         return 0;
     }
     int stream_codec;
-    int rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
+    int rc;
+    if (try_fused_one(codec, S, T, d_frames, d_records, d_state_pool, d_rng_pool, d_pcm16, d_pcmf, d_results, stream, d_stream_index,
+                      d_resident, &rc)) {
+        return rc;
+    }
+    rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
     if (rc < 0) {
         return rc;
     }
@@ -1457,6 +1542,17 @@ int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe
     hipLaunchKernelGGL(mbx::decode_parms_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, codec, (int)n, slot.workspace,
                        d_cur, d_prev, d_rc, c->tabs);
     return check_launch("decode_parms_kernel");
+}
+
+// the dominant kernel of mbx_process_batch / _resident for a batch shape (frames 4-byte aligned, as device allocations are)
+const char* mbx_batch_kernel_name(int codec, int S, int T, int resident) {
+    if (fused_one_ok(codec, S, T, nullptr)) {
+        if (codec == MBX_CODEC_IMBE7100X4400) {
+            return resident ? "imbe7100_stream_kernel_res1_fused" : "imbe7100_stream_kernel_one_fused";
+        }
+        return resident ? "imbe_stream_kernel_res1_fused" : "imbe_stream_kernel_one_fused";
+    }
+    return mbx_stream_kernel_name(codec, resident ? -T : T);
 }
 
 const char* mbx_stream_kernel_name(int codec, int T) {

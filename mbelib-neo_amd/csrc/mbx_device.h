@@ -46,6 +46,8 @@ struct DerivedTables {
     uint2    imbe_b0[208];                // b0 -> (w0 bits, L | K << 8): one look-up instead of three
     float    wola_inv[160];       // 1 / wola_denom[n] (0 where the reference skips the sample: denom <= 1e-10)
     float    ambep_f0[128];       // AMBE 3600x2400: exp2f(-4.311767578125f - 2.1336e-2f * (b0 + 0.5f)) from the host libm
+    uint32_t imbe_L_lanes[64];    // byte k of entry j: IMBE L of b0 = j + 64 k (0: no such b0 / invalid L) -- ONE dword per lane holds the
+                                  // whole b0 -> L law, so a wave that asks for it before it knows b0 has L without a memory round trip
 };
 
 // Output of the expand stage, input of the stream stage: 64 dwords per frame (layout in mbx_expand.hip).

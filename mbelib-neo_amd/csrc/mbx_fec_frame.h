@@ -54,32 +54,29 @@ struct TabScalar {
     uint32_t gen[6];    // golay_gen[12], two per dword, fetched once
     uint32_t hgen[4];   // hamming_gen[4] | hamming7100_gen[4], likewise
     static constexpr bool kUniform = true;
+    __device__ TabScalar() : T(nullptr) {}
     __device__ explicit TabScalar(const mbx_tables* t) : T(t) {
         static_assert(offsetof(mbx_tables, golay_gen) % 4 == 0 && offsetof(mbx_tables, golay_matrix) % 4 == 0
                           && offsetof(mbx_tables, hamming_gen) % 4 == 0 && offsetof(mbx_tables, hamming_fix) % 4 == 0
                           && offsetof(mbx_tables, hamming7100_gen) % 4 == 0 && offsetof(mbx_tables, hamming7100_fix) % 4 == 0
                           && offsetof(mbx_tables, imbe_K) % 4 == 0,
                       "scalar loads read whole dwords");
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-        u4 a;
-        u2 b, h0, h1;
-        asm volatile("s_load_dwordx4 %0, %4, %5\n\ts_load_dwordx2 %1, %4, %6\n\ts_load_dwordx2 %2, %4, %7\n\ts_load_dwordx2 %3, %4, %8\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&s"(a), "=&s"(b), "=&s"(h0), "=&s"(h1)
-                     : "s"(t), "s"((uint32_t)offsetof(mbx_tables, golay_gen)), "s"((uint32_t)offsetof(mbx_tables, golay_gen) + 16u),
-                       "s"((uint32_t)offsetof(mbx_tables, hamming_gen)), "s"((uint32_t)offsetof(mbx_tables, hamming7100_gen))
-                     : "memory");
-        gen[0] = a.x;
-        gen[1] = a.y;
-        gen[2] = a.z;
-        gen[3] = a.w;
-        gen[4] = b.x;
-        gen[5] = b.y;
-        hgen[0] = h0.x;
-        hgen[1] = h0.y;
-        hgen[2] = h1.x;
-        hgen[3] = h1.y;
+        // plain scalar loads (constant address space): the compiler places the wait at the first USE of a generator row, so a caller
+        // that constructs the reader at the start of its wave has them in flight together with everything else it asks for
+        const __attribute__((address_space(4))) uint32_t* g =
+            (const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)t + offsetof(mbx_tables, golay_gen));
+        const __attribute__((address_space(4))) uint32_t* h0 =
+            (const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)t + offsetof(mbx_tables, hamming_gen));
+        const __attribute__((address_space(4))) uint32_t* h1 =
+            (const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)t + offsetof(mbx_tables, hamming7100_gen));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            gen[i] = g[i];
+        }
+        hgen[0] = h0[0];
+        hgen[1] = h0[1];
+        hgen[2] = h1[0];
+        hgen[3] = h1[1];
     }
     __device__ uint32_t golay_gen(int i) const { return (gen[i >> 1] >> (16 * (i & 1))) & 0xffffu; }
     __device__ uint32_t golay_fix(uint32_t syndrome) const { return sload_elem<uint16_t>(T, offsetof(mbx_tables, golay_matrix), syndrome); }
@@ -299,21 +296,38 @@ __device__ __forceinline__ BitReader imbe_bits(const Wire& wire) {
     return br;
 }
 
-template <typename Tab>
-__device__ __forceinline__ uint4 fec_imbe7200x4400_wire(const Tab& tab, const Wire& wire) {
-    const BitReader br = imbe_bits(wire);
-
+// The IMBE 7200x4400 FEC in two halves.  The HEAD (rows out of the wire frame, Golay on C0) is all the fundamental needs:
+// b0's six high bits are C0's first data bits, its two low bits sit in the unprotected row 7 -- so the one-launch T = 1 kernels
+// know L, and can request every table value of the parameter expansion, before the TAIL (demodulation, three Golay and three
+// Hamming words, the record) has run.
+struct ImbeFecHead {
     uint32_t row[8];
-    row[0] = br.take(0, 23);
-    row[1] = br.take(23, 23);
-    row[2] = br.take(46, 23);
-    row[3] = br.take(69, 23);
-    row[4] = br.take(92, 15);
-    row[5] = br.take(107, 15);
-    row[6] = br.take(122, 15);
-    row[7] = br.take(137, 7);
-
-    const int c0 = golay2312_t(tab, row[0], row[0]);
+    int      c0;
+    __device__ int b0() const { return (int)((((row[0] >> 17) & 0x3fu) << 2) | ((row[7] >> 1) & 3u)); }   // record bits 0..5, 85, 86
+};
+template <typename Tab>
+__device__ __forceinline__ ImbeFecHead fec_imbe7200x4400_head(const Tab& tab, const Wire& wire) {
+    const BitReader br = imbe_bits(wire);
+    ImbeFecHead h;
+    h.row[0] = br.take(0, 23);
+    h.row[1] = br.take(23, 23);
+    h.row[2] = br.take(46, 23);
+    h.row[3] = br.take(69, 23);
+    h.row[4] = br.take(92, 15);
+    h.row[5] = br.take(107, 15);
+    h.row[6] = br.take(122, 15);
+    h.row[7] = br.take(137, 7);
+    h.c0 = golay2312_t(tab, h.row[0], h.row[0]);
+    return h;
+}
+template <typename Tab>
+__device__ __forceinline__ uint4 fec_imbe7200x4400_tail(const Tab& tab, const ImbeFecHead& h) {
+    uint32_t row[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        row[r] = h.row[r];
+    }
+    const int c0 = h.c0;
     auto pr = tab.template pr<PrSequence, PrWave>(row[0] >> 11);
     row[1] ^= pr.mask_for(23);
     row[2] ^= pr.mask_for(23);
@@ -357,6 +371,10 @@ __device__ __forceinline__ uint4 fec_imbe7200x4400_wire(const Tab& tab, const Wi
     rec.w[3] = (uint32_t)c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
                | ((MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24);
     return make_uint4(rec.w[0], rec.w[1], rec.w[2], rec.w[3]);
+}
+template <typename Tab>
+__device__ __forceinline__ uint4 fec_imbe7200x4400_wire(const Tab& tab, const Wire& wire) {
+    return fec_imbe7200x4400_tail(tab, fec_imbe7200x4400_head(tab, wire));
 }
 __device__ __forceinline__ uint4 fec_imbe7200x4400_frame(const mbx_tables* T, const uint8_t* f) {
     return fec_imbe7200x4400_wire(TabVector{T}, load_wire_imbe(f));

@@ -83,6 +83,9 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #ifndef MBX_PRIO_FRONT_IMBE
 #define MBX_PRIO_FRONT_IMBE 3
 #endif
+#ifndef MBX_FLAT_LOADS
+#define MBX_FLAT_LOADS 1   // one-launch T = 1 kernels: unconditional struct loads (see load_parms_arrays)
+#endif
 #ifndef MBX_PARK_N
 #define MBX_PARK_N 8   // how many per-lane values wait in LDS across the unvoiced transform pair (synth_core)
 #endif
@@ -145,10 +148,33 @@ __device__ __forceinline__ uint32_t load_header(const mbe_parms* __restrict__ p,
 __device__ __forceinline__ int hdr_i(uint32_t h, int k) { return __builtin_amdgcn_readlane((int)h, k); }
 __device__ __forceinline__ float hdr_f(uint32_t h, int k) { return __int_as_float(__builtin_amdgcn_readlane((int)h, k)); }
 
+// kFlat: every load unconditional (lanes past the 57 band slots read the dwords that follow inside the same struct and drop them;
+// the short second half of the noise overlap reads lane & 31).  A load under `band ? ... : 0` is compiled as a branch around it, and
+// the compiler's s_waitcnt bookkeeping must then assume the path that skipped it: a wait for an OLDER load is given a count that
+// leaves only the unconditional younger ones outstanding -- with forty-odd loads in flight at the start of a one-launch wave that is
+// the difference between waiting for the table reads and waiting for nearly the whole state.
+template <bool kFlat = false>
 __device__ __forceinline__ void load_parms_arrays(Parms& r, const mbe_parms* __restrict__ p, int lane) {
     const float* f = reinterpret_cast<const float*>(p);
     const int* i = reinterpret_cast<const int*>(p);
     const bool band = lane < MBX_BAND_SLOTS;
+    if constexpr (kFlat) {
+        const int vl = i[O_VL + lane];
+        const float ml = f[O_ML + lane], l2 = f[O_LOG2ML + lane], ph = f[O_PHI + lane], ps = f[O_PSI + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r.uw[j] = f[O_UW + lane + 64 * j];
+        }
+        r.ov[0] = f[O_OVERLAP + lane];
+        const float o1 = f[O_OVERLAP + 64 + (lane & 31)];
+        r.Vl = band ? vl : 0;
+        r.Ml = band ? ml : 0.0f;
+        r.log2Ml = band ? l2 : 0.0f;
+        r.PHIl = band ? ph : 0.0f;
+        r.PSIl = band ? ps : 0.0f;
+        r.ov[1] = (lane < 32) ? o1 : 0.0f;
+        return;
+    }
     r.Vl = band ? i[O_VL + lane] : 0;
     r.Ml = band ? f[O_ML + lane] : 0.0f;
     r.log2Ml = band ? f[O_LOG2ML + lane] : 0.0f;
@@ -278,10 +304,18 @@ __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restric
 //   * synthesis reads from prev_mp_enhanced only w0, L, Vl, Ml, PHIl, PSIl, the second half of
 //     previousUw and the two smoothing memories.
 // Unread fields stay zero and are optimised away: fewer registers, and ~40 % less state read traffic.
+template <bool kFlat = false>
 __device__ __forceinline__ void load_prev_arrays(Parms& r, const mbe_parms* __restrict__ p, int lane) {
     const float* f = reinterpret_cast<const float*>(p);
     const bool band = lane < MBX_BAND_SLOTS;
     r = Parms{};
+    if constexpr (kFlat) {
+        const float ml = f[O_ML + lane], l2 = f[O_LOG2ML + lane], ph = f[O_PHI + lane];
+        r.Ml = band ? ml : 0.0f;
+        r.log2Ml = band ? l2 : 0.0f;
+        r.PHIl = band ? ph : 0.0f;
+        return;
+    }
     r.Ml = band ? f[O_ML + lane] : 0.0f;
     r.log2Ml = band ? f[O_LOG2ML + lane] : 0.0f;
     r.PHIl = band ? f[O_PHI + lane] : 0.0f;
@@ -311,11 +345,23 @@ __device__ __forceinline__ void load_prev_view_lds(Parms& r, const mbe_parms* __
     r.mutingThreshold = uni(f[O_MUTETHR]);
 }
 
+template <bool kFlat = false>
 __device__ __forceinline__ void load_enh_arrays(Parms& r, const mbe_parms* __restrict__ p, int lane) {
     const float* f = reinterpret_cast<const float*>(p);
     const int* i = reinterpret_cast<const int*>(p);
     const bool band = lane < MBX_BAND_SLOTS;
     r = Parms{};
+    if constexpr (kFlat) {
+        const int vl = i[O_VL + lane];
+        const float ml = f[O_ML + lane], ph = f[O_PHI + lane], ps = f[O_PSI + lane];
+        r.uw[2] = f[O_UW + lane + 128];
+        r.uw[3] = f[O_UW + lane + 192];
+        r.Vl = band ? vl : 0;
+        r.Ml = band ? ml : 0.0f;
+        r.PHIl = band ? ph : 0.0f;
+        r.PSIl = band ? ps : 0.0f;
+        return;
+    }
     r.Vl = band ? i[O_VL + lane] : 0;
     r.Ml = band ? f[O_ML + lane] : 0.0f;
     r.PHIl = band ? f[O_PHI + lane] : 0.0f;
@@ -477,19 +523,76 @@ __device__ __forceinline__ uint4 load_record_scalar(const mbx_param_record* rp) 
     return make_uint4(rq[0], rq[1], rq[2], rq[3]);
 }
 
-template <class Scratch>
-__device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane) {
-    ConstTables T = (ConstTables)Tgen;
-    int b0 = (int)(rec.x >> 26);
-    b0 = (b0 << 2) | (int)((rec.z >> 9) & 3u);   // payload bits 85, 86
-    int bad = 1, L = 0, K = 0;
-    float w0 = 0.0f;
-    if (b0 <= 207) {
-        w0 = T->imbe_w0[b0];
-        L = T->imbe_L[b0];
-        K = T->imbe_K[b0];
-        bad = (L == 0) ? 1 : 0;   // the reference has stored w0 but not L in this case
+// The expansion in two halves: expand_imbe_request() issues every table read (they depend on b0 / L and the lane only, not on
+// the rest of the record), expand_imbe_finish() does the arithmetic once the record is there.  The one-launch T = 1 kernels put
+// the second half of the frame's FEC between the two.
+struct ImbeExpandReq {
+    int      bad, L;
+    uint32_t w0_bits, lk;   // the b0 entry as loaded (w0; L | K << 8): decoded in the second half
+    uint32_t e0, e1, own;
+    v2f      bas;   // (bit count, step) of the lane's gain
+    float    b2, qs, sd;
+    int      Bm;
+    float    cosr[11], ric[7];
+};
+// L_known >= 0: the caller has L already (from the lane-held b0 -> L law, DerivedTables::imbe_L_lanes) -- the table reads then do
+// not wait for the scalar load of (w0, L, K), which is only needed by the second half.
+__device__ __forceinline__ void expand_imbe_request(ImbeExpandReq& q, int b0, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane,
+                                                    int L_known = -1) {
+    q.bad = 1;
+    q.L = 0;
+    q.w0_bits = 0u;
+    q.lk = 0u;
+    if (b0 <= 207) {   // ONE scalar load (host-made table: w0 bits, L | K << 8); byte-wide table entries would be vector loads,
+        const __attribute__((address_space(4))) uint32_t* e =   // which queue behind whatever the wave has in flight
+            (const __attribute__((address_space(4))) uint32_t*)&((ConstDerived)Dgen)->imbe_b0[b0];
+        q.w0_bits = e[0];
+        q.lk = e[1];
+        q.L = (L_known >= 0) ? L_known : (int)(q.lk & 0xffu);
+        q.bad = (q.L == 0) ? 1 : 0;   // the reference has stored w0 but not L in this case
     }
+    if (!q.bad) {
+        const int L9 = q.L - 9;
+        // ---- every per-lane table value is requested here ----
+        const uint32_t ul = (uint32_t)lane;
+        const size_t uL9 = (size_t)(uint32_t)L9;
+        q.e0 = tab_at<uint16_t>(Tgen, offsetof(mbx_tables, imbe_bo) + uL9 * sizeof(Tgen->imbe_bo[0]), 2u * ul);
+        q.e1 = tab_at<uint16_t>(Tgen, offsetof(mbx_tables, imbe_bo) + uL9 * sizeof(Tgen->imbe_bo[0]), 2u * (lane < 15 ? ul + 64u : 78u));
+        const uint32_t g = (lane >= 2 && lane <= 6) ? ul - 2u : 0u;
+        q.bas = tab_at<v2f>(Tgen, offsetof(mbx_tables, imbe_ba) + uL9 * sizeof(Tgen->imbe_ba[0]), 8u * g);
+        q.b2 = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_B2), 4u * ul);
+        q.qs = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_quantstep), 4u * (lane < 11 ? ul : 0u));
+        // which higher-order coefficient / harmonic a lane owns depends on L only: host-made tables (mbx_init)
+        q.own = tab_at<uint32_t>(Dgen, offsetof(DerivedTables, imbe_lane_map) + uL9 * sizeof(Dgen->imbe_lane_map[0]), 4u * ul);
+        q.Bm = tab_at<uint8_t>(Tgen, offsetof(mbx_tables, imbe_hoba) + uL9 * sizeof(Tgen->imbe_hoba[0]), lane < 50 ? ul : 0u);
+        q.sd = tab_at<float>(Dgen, offsetof(DerivedTables, imbe_hoc_sd) + uL9 * sizeof(Dgen->imbe_hoc_sd[0]), 4u * ul);
+        {   // fetched now: loads cannot move up across the LDS fences of the second half
+            const size_t rows = offsetof(DerivedTables, imbe_idct_rows) + uL9 * sizeof(Dgen->imbe_idct_rows[0]);
+            typedef float v4f_u __attribute__((ext_vector_type(4), aligned(8)));   // a row is 40 bytes: 8-byte aligned
+            const v4f_u r0 = tab_at<v4f_u>(Dgen, rows, 40u * ul), r1 = tab_at<v4f_u>(Dgen, rows + 16u, 40u * ul);
+            const v2f r2 = tab_at<v2f>(Dgen, rows + 32u, 40u * ul);
+            q.cosr[1] = r0.x, q.cosr[2] = r0.y, q.cosr[3] = r0.z, q.cosr[4] = r0.w;
+            q.cosr[5] = r1.x, q.cosr[6] = r1.y, q.cosr[7] = r1.z, q.cosr[8] = r1.w;
+            q.cosr[9] = r2.x, q.cosr[10] = r2.y;
+            const uint32_t col = 4u * ((lane >= 1 && lane <= 6) ? ul : 0u);
+#pragma unroll
+            for (int m = 1; m <= 6; ++m) {
+                q.ric[m] = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_ri_cos) + 28u * (size_t)m, col);
+            }
+        }
+    }
+}
+__device__ __forceinline__ int imbe_record_b0(const uint4 rec) {
+    return (int)(((rec.x >> 26) << 2) | ((rec.z >> 9) & 3u));   // payload bits 0..5, 85, 86
+}
+
+template <class Scratch>
+__device__ __forceinline__ void expand_imbe_finish(const uint4 rec, const ImbeExpandReq& q, Scratch& S, int lane) {
+    const int bad = q.bad, L = q.L;
+    uint32_t w0_bits = q.w0_bits, lk = q.lk;
+    asm volatile("" : "+s"(w0_bits), "+s"(lk));   // (first touched here: see below)
+    const int K = (int)(lk >> 8);
+    const float w0 = __uint_as_float(w0_bits);
     S.x.words[lane] = 0u;
     S.x.fp[lane] = 0.0f;
     S.x.C[lane] = 0.0f;   // coefficients past a block's length stay zero: the inverse DCT below adds
@@ -497,40 +600,17 @@ __device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* 
         S.x.C[64 + lane] = 0.0f;
     }
     if (!bad) {
-        const int L9 = L - 9;
-        // ---- every per-lane table value is requested here ----
-        const uint32_t ul = (uint32_t)lane;
-        const size_t uL9 = (size_t)(uint32_t)L9;
-        const uint32_t e0 = tab_at<uint16_t>(Tgen, offsetof(mbx_tables, imbe_bo) + uL9 * sizeof(Tgen->imbe_bo[0]), 2u * ul);
-        const uint32_t e1 = tab_at<uint16_t>(Tgen, offsetof(mbx_tables, imbe_bo) + uL9 * sizeof(Tgen->imbe_bo[0]), 2u * (lane < 15 ? ul + 64u : 78u));
-        const uint32_t g = (lane >= 2 && lane <= 6) ? ul - 2u : 0u;
-        const v2f bas = tab_at<v2f>(Tgen, offsetof(mbx_tables, imbe_ba) + uL9 * sizeof(Tgen->imbe_ba[0]), 8u * g);
+        uint32_t e0 = q.e0, e1 = q.e1, own = q.own;
+        v2f bas = q.bas;
+        float b2 = q.b2, qs = q.qs, sd = q.sd;
+        int Bm = q.Bm;
+        // the requested values are first touched HERE: arithmetic on them hoisted into the request half would wait for them there,
+        // in front of everything the caller issues between the halves
+        asm volatile("" : "+v"(e0), "+v"(e1), "+v"(own), "+v"(bas), "+v"(b2), "+v"(qs), "+v"(sd), "+v"(Bm));
         const float nb = bas.x, step = bas.y;
-        const float b2 = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_B2), 4u * ul);
-        const float qs = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_quantstep), 4u * (lane < 11 ? ul : 0u));
-        // which higher-order coefficient / harmonic a lane owns depends on L only: host-made tables (mbx_init)
-        const uint32_t own = tab_at<uint32_t>(Dgen, offsetof(DerivedTables, imbe_lane_map) + uL9 * sizeof(Dgen->imbe_lane_map[0]), 4u * ul);
         const int hblk = (int)(own & 7u), hk = (int)((own >> 3) & 15u);
         const int iblk = (int)((own >> 7) & 7u);
-        const int Bm = tab_at<uint8_t>(Tgen, offsetof(mbx_tables, imbe_hoba) + uL9 * sizeof(Tgen->imbe_hoba[0]), lane < 50 ? ul : 0u);
-        const float sd = tab_at<float>(Dgen, offsetof(DerivedTables, imbe_hoc_sd) + uL9 * sizeof(Dgen->imbe_hoc_sd[0]), 4u * ul);
         const bool harm = lane >= 1 && lane <= L;
-        float cosr[11], ric[7];   // fetched now: loads cannot move up across the LDS fences below
-        {
-            const size_t rows = offsetof(DerivedTables, imbe_idct_rows) + uL9 * sizeof(Dgen->imbe_idct_rows[0]);
-            typedef float v4f_u __attribute__((ext_vector_type(4), aligned(8)));   // a row is 40 bytes: 8-byte aligned
-            const v4f_u r0 = tab_at<v4f_u>(Dgen, rows, 40u * ul), r1 = tab_at<v4f_u>(Dgen, rows + 16u, 40u * ul);
-            const v2f r2 = tab_at<v2f>(Dgen, rows + 32u, 40u * ul);
-            cosr[1] = r0.x, cosr[2] = r0.y, cosr[3] = r0.z, cosr[4] = r0.w;
-            cosr[5] = r1.x, cosr[6] = r1.y, cosr[7] = r1.z, cosr[8] = r1.w;
-            cosr[9] = r2.x, cosr[10] = r2.y;
-            const uint32_t col = 4u * ((lane >= 1 && lane <= 6) ? ul : 0u);
-#pragma unroll
-            for (int m = 1; m <= 6; ++m) {
-                ric[m] = tab_at<float>(Tgen, offsetof(mbx_tables, imbe_ri_cos) + 28u * (size_t)m, col);
-            }
-        }
-
         wave_lds_sync();
         {   // payload bit j + 6 feeds bit e[1] of word e[0] (:156-168)
             const int i0 = lane + 6, i1 = lane + 70;
@@ -564,17 +644,17 @@ __device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* 
 #pragma unroll
             for (int m = 1; m <= 6; ++m) {
                 const float am = (m == 1) ? 1.0f : 2.0f;
-                sum = sum + (am * S.x.gains[m] * ric[m]);
+                sum = sum + (am * S.x.gains[m] * q.ric[m]);
             }
             S.x.C[lane * 12 + 1] = sum;
         }
         {   // higher-order coefficient of word m = lane + 8 (:233-249)
-            const float q = lane_get(qs, Bm > 0 ? Bm - 1 : 0);
+            const float qv = lane_get(qs, Bm > 0 ? Bm - 1 : 0);
             if (lane < L - 6) {
                 float v = 0.0f;
                 if (Bm > 0) {
                     const int bm = (int)low_bits(S.x.words[lane + 8], Bm);
-                    v = ((q * sd) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
+                    v = ((qv * sd) * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
                 }
                 S.x.C[hblk * 12 + hk] = v;
             }
@@ -586,7 +666,7 @@ __device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* 
 #pragma unroll
             for (int k = 1; k <= 10; ++k) {
                 const float ak = (k == 1) ? 1.0f : 2.0f;
-                sum = sum + (ak * C[k] * cosr[k]);
+                sum = sum + (ak * C[k] * q.cosr[k]);
             }
             S.x.fp[lane] = sum;
         }
@@ -611,6 +691,13 @@ __device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* 
         S.x.fp[63] = __int_as_float(bad);
     }
     wave_lds_sync();
+}
+
+template <class Scratch>
+__device__ void expand_imbe_wave(const uint4 rec, Scratch& S, const mbx_tables* Tgen, const DerivedTables* Dgen, int lane) {
+    ImbeExpandReq q;
+    expand_imbe_request(q, imbe_record_b0(rec), Tgen, Dgen, lane);
+    expand_imbe_finish(rec, q, S, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1835,6 +1922,45 @@ __device__ __forceinline__ Wire frame_from_args(bool ambe, const FrameShadow& x)
     }
     return w;
 }
+// the 18 wire bytes of an IMBE frame at a WAVE-UNIFORM address by scalar loads (fused one-frame launches: one wave per stream, so
+// the frame's address depends on the workgroup only): they have a counter of their own and do not queue behind the state's vector
+// loads.  Frames are 18 bytes apart, i.e. 2-byte aligned: five dwords from the 4-byte boundary at or below the frame, shifted by
+// a uniform 0 or 16 bits.  (20 bytes from that boundary end at most 2 bytes past the frame, and never past the end of a batch whose
+// base is 4-byte aligned: the last frame of an even batch starts at 2 mod 4, and 18 S of an odd batch is not a page multiple.)
+struct FrameWords {
+    uint32_t d[5];
+};
+__device__ __forceinline__ FrameWords frame_fetch_scalar_imbe(const uint8_t* frame) {   // the request ...
+    const uintptr_t a = reinterpret_cast<uintptr_t>(frame);
+    const __attribute__((address_space(4))) uint32_t* q =
+        reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(a & ~(uintptr_t)3);
+    FrameWords w;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        w.d[i] = q[i];
+    }
+    return w;
+}
+__device__ __forceinline__ Wire frame_words_to_wire(const uint8_t* frame, FrameWords w) {   // ... and its first use: a wait for the bytes
+    // (the caller issues the wave's vector loads in between: written as one function, the shift below was scheduled -- and the frame
+    //  waited for -- in front of every one of them)
+    asm volatile("" : "+s"(w.d[0]), "+s"(w.d[1]), "+s"(w.d[2]), "+s"(w.d[3]), "+s"(w.d[4])::"memory");
+    uint32_t d[5] = {w.d[0], w.d[1], w.d[2], w.d[3], w.d[4]};
+    if (reinterpret_cast<uintptr_t>(frame) & 2u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i] = (d[i] >> 16) | (d[i + 1] << 16);
+        }
+        d[4] >>= 16;
+    }
+    Wire r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const uint32_t half = (d[k >> 1] >> (16 * (k & 1))) & 0xffffu;   // little-endian half: first wire byte in the low bits
+        r.h[k] = ((half & 0xffu) << 8) | (half >> 8);
+    }
+    return r;
+}
 __device__ __forceinline__ uint4 frame_record(int fec_codec, Wire wire, mbx_param_record* record, const mbx_tables* T, int lane) {
     const PrLane pr_lanes(lane);   // (before the first use of the frame's bytes: work for the time they are still on their way)
     TabScalar tab(T);
@@ -1853,7 +1979,13 @@ __device__ __forceinline__ uint4 frame_record(int fec_codec, Wire wire, mbx_para
 // the FEC the same wave has just run (rec_in), not from memory.
 // kOne (HBM-slot instances only): the launch has ONE frame per stream -- no frame loop, and the views of prev_mp / prev_mp_enhanced
 // are requested together with cur_mp.  (With a loop the pre-requested views stay allocated through every frame: spills.)
-template <bool kPark, bool kFrame = false, bool kRes = false, bool kOne = false>
+// kFuse (with kOne): the launch IS the whole T = 1 step -- the wave fetches its stream's wire frame by scalar loads, runs the FEC
+// wave-uniformly on the scalar unit while the structs are on their way (frame_record, as the single-frame kernels do) and expands
+// the record itself: no FEC launch, no expansion launch, no FrameParams row through HBM.  `frame_in` = the batch's frames.
+// kFuse = 1: IMBE 7200x4400 frames -- the FEC in two halves (mbx_fec_frame.h): after the head (C0) the fundamental is known, every
+// table read of the expansion goes out, then the rest of the state is requested, and the FEC's tail runs while all of that is on
+// its way.  kFuse = 2: IMBE 7100x4400 frames (own front end, whole; then the same).
+template <bool kPark, bool kFrame = false, bool kRes = false, bool kOne = false, int kFuse = 0>
 __device__ __forceinline__ void
 imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
@@ -1903,6 +2035,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     Parms enh_first, prev_first;       // !kPark: the first frame's views of prev_mp_enhanced / prev_mp ...
     uint32_t h_enh_first = 0u, h_prev_first = 0u;   // ... and their headers, read out where the frame loop needs them
     float row_first = 0.0f;
+    ImbeExpandReq xreq;   // kFuse: the expansion's table values, requested at the start
     if constexpr (kPark) {
         slot_prev = &park.prev;
         slot_enh = nullptr;
@@ -1942,16 +2075,59 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         slot_prev = home_prev;
         slot_enh = home_enh;
         const mbe_parms* const enh_src = elided1 ? slot_cur : slot_enh;
-        if (params) {   // the frame's FrameParams row is what the frame needs first: requested first (tools/stage_times.py: asked for
+        uint32_t l_lanes = 0u;
+        FrameWords frame_words = {};
+        TabScalar fused_tab;
+        if constexpr (kFuse != 0) {
+            frame_words = frame_fetch_scalar_imbe(frame_in + 18u * (size_t)s);   // scalar loads: first of all, own counter
+            fused_tab = TabScalar(tabs_in.t);                                     // (the generator rows of the two codes with them)
+            l_lanes = tab_at<uint32_t>(tabs_in.d, offsetof(DerivedTables, imbe_L_lanes), 4u * (uint32_t)lane_in);   // b0 -> L for every b0, a dword per lane
+            asm volatile("" ::: "memory");   // (the first vector load of the wave: what is asked for first is there first)
+        } else if (params) {   // the frame's FrameParams row is what the frame needs first: requested first (tools/stage_times.py: asked for
             row_first = params[(size_t)s * (size_t)Tn].v[lane_in];   // after the scalars of cur_mp had arrived, it cost 2.5 us of a wave's 22)
         }
+        constexpr bool kFlat = MBX_FLAT_LOADS && kFuse != 0;
         const uint32_t h_cur = load_header(slot_cur, lane_in);
         h_prev_first = load_header(slot_prev, lane_in);
         h_enh_first = load_header(enh_src, lane_in);
         load_rng(rng, &rngs[slot]);
-        load_prev_arrays(prev_first, slot_prev, lane_in);
-        load_parms_arrays(cur, slot_cur, lane_in);
-        load_enh_arrays(enh_first, enh_src, lane_in);
+        load_prev_arrays<kFlat>(prev_first, slot_prev, lane_in);
+        load_parms_arrays<kFlat>(cur, slot_cur, lane_in);
+        load_enh_arrays<kFlat>(enh_first, enh_src, lane_in);
+        if constexpr (kFuse != 0) {
+            // The front end of the frame while the state is on its way.  Its chain of dependent memory round trips is what a fused wave
+            // pays for (tools/stage_times.py): the frame's bytes -> C0's Golay correction -> [b0 -> L: from l_lanes, no trip] -> the
+            // expansion's table reads, with the FEC's tail (one more scalar trip) in their shadow.
+            asm volatile("" ::: "memory");
+            wire_in = frame_words_to_wire(frame_in + 18u * (size_t)s, frame_words);
+            mbx_param_record* const rec_out = const_cast<mbx_param_record*>(&records[(size_t)s * (size_t)Tn]);
+            const PrLane pr_lanes(lane_in);   // (lane constants of the demodulation sequence)
+            TabScalar& tab = fused_tab;
+            tab.lanes = &pr_lanes;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                wire_in.h[k] = uni(wire_in.h[k]);
+            }
+            MBX_TS(14);   // (fused) the frame's bytes are there
+            auto L_of = [&](int b0) -> int {   // wave-uniform b0
+                return (b0 <= 207) ? (int)((__builtin_amdgcn_readlane((int)l_lanes, b0 & 63) >> (8 * (b0 >> 6))) & 0xff) : 0;
+            };
+            if constexpr (kFuse == 1) {
+                const ImbeFecHead head = fec_imbe7200x4400_head(tab, wire_in);
+                const int b0 = head.b0();
+                expand_imbe_request(xreq, b0, tabs_in.t, tabs_in.d, lane_in, L_of(b0));
+                asm volatile("" ::: "memory");
+                MBX_TS(15);   // (fused) C0 corrected, L known, the expansion's table reads requested
+                rec_in = broadcast_record(fec_imbe7200x4400_tail(tab, head), rec_out, lane_in);   // scalar unit, in the table reads' shadow
+            } else {
+                rec_in = broadcast_record(fec_imbe7100x4400_wire(tab, wire_in), rec_out, lane_in);
+                const int b0 = imbe_record_b0(rec_in);
+                expand_imbe_request(xreq, b0, tabs_in.t, tabs_in.d, lane_in, L_of(b0));
+            }
+            MBX_TS(10);   // (fused) frame fetched, FEC done, every request issued
+            expand_imbe_finish(rec_in, xreq, scratch, lane_in);   // before anything reads the state out
+            MBX_TS(11);   // (fused) table values there, expanded
+        }
         set_parms_header(cur, h_cur);
         MBX_TS(1);   // cur_mp's scalars are there (first round trip)
     } else {
@@ -2003,6 +2179,8 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         if (params) {
             scratch.x.fp[lane] = kOne ? row_first : params[f].v[lane];
             wave_lds_sync();
+        } else if constexpr (kFuse != 0) {
+            // (expanded at the start of the wave)
         } else {
             expand_imbe_wave(kFrame ? rec_in : load_record_scalar(&records[f]), scratch, tabs.t, tabs.d, lane);
         }
@@ -2172,6 +2350,34 @@ imbe_stream_kernel_one(int S, int Tn, const mbx_param_record* __restrict__ recor
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     imbe_stream_body<false, false, false, true>(S, Tn > 1 ? 1 : Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// The whole T = 1 step as ONE launch (kFuse): wire frames in, PCM / results / records / state out.
+// fec_codec: MBX_CODEC_IMBE7200X4400 or MBX_CODEC_IMBE7100X4400 (own front end, the same stream stage).
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe_stream_kernel_one_fused(int S, int fec_codec, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
+                             mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                             float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<false, false, false, true, 1>(S, 1, records, nullptr, state, rngs, pcm16, pcmf, results, tabs_in, frames, fec_codec);
+}
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe_stream_kernel_res1_fused(int S, int fec_codec, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
+                              mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                              float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<false, false, true, true, 1>(S, 1, records, nullptr, state, rngs, pcm16, pcmf, results, tabs_in, frames, fec_codec);
+}
+// IMBE 7100x4400 frames: own front end (whole, then the expansion's requests), the same stream stage
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe7100_stream_kernel_one_fused(int S, int fec_codec, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
+                                 mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                                 float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<false, false, false, true, 2>(S, 1, records, nullptr, state, rngs, pcm16, pcmf, results, tabs_in, frames, fec_codec);
+}
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe7100_stream_kernel_res1_fused(int S, int fec_codec, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
+                                  mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                                  float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_stream_body<false, false, true, true, 2>(S, 1, records, nullptr, state, rngs, pcm16, pcmf, results, tabs_in, frames, fec_codec);
 }
 
 // T >= 4: prev_mp resident in LDS (see ParkedPrevOnly).  5,200 B of LDS per wave allow 25 waves per CU, so the register

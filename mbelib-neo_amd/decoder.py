@@ -120,9 +120,12 @@ class BatchDecoder:
         out["results"] = torch.empty((n, 5), dtype=torch.int32, device=self.device) if want_results else None
         return out
 
-    def decode(self, frames, T, want_pcm16=True, want_float=False, want_results=True, out=None):
+    def decode(self, frames, T, want_pcm16=True, want_float=False, want_results=True, out=None, staged=False):
         """S x T frames, stream-major (stream s, frame t at index s*T + t).  Asynchronous on the
-        current torch stream; returns device tensors."""
+        current torch stream; returns device tensors.
+        staged=True: the stages as separate calls (mbx_fec_* then mbx_process_records) instead of mbx_process_batch -- the
+        same results by contract; the IMBE codecs at T = 1 take one fused launch in mbx_process_batch and the FEC /
+        expansion / stream launches here (tests compare the two)."""
         torch = _torch()
         d_frames = self.to_device(frames)
         n = self.streams * int(T)
@@ -135,7 +138,17 @@ class BatchDecoder:
             return t.data_ptr() if t is not None else None
 
         with torch.cuda.device(self.device):   # the launcher works on the current device's context
-            if self.resident is not None:
+            if staged:
+                if self.resident is not None:
+                    raise ValueError("staged decoding is for the ABI-triplet form")
+                L = _native.lib()
+                strm = torch.cuda.current_stream().cuda_stream
+                fn = {0: L.mbx_fec_imbe7200x4400, 1: L.mbx_fec_ambe3600x2450, 2: L.mbx_fec_imbe7100x4400, 3: L.mbx_fec_ambe3600x2450}[self.codec]
+                _native.check(fn(d_frames.data_ptr(), n, out["records"].data_ptr(), strm), "mbx_fec")
+                rc = L.mbx_process_records(0 if self.codec == 2 else self.codec, self.streams, int(T), out["records"].data_ptr(),
+                                           self.state.data_ptr(), self.rng.data_ptr(), ptr(out["pcm16"]), ptr(out["pcmf"]),
+                                           ptr(out["results"]), strm)
+            elif self.resident is not None:
                 rc = _native.lib().mbx_process_batch_resident(
                     self.codec, self.streams, int(T), None, d_frames.data_ptr(), self.state.data_ptr(), self.resident.data_ptr(),
                     self.rng.data_ptr(), ptr(out["pcm16"]), ptr(out["pcmf"]), ptr(out["results"]), out["records"].data_ptr(),

@@ -424,6 +424,143 @@ def test_ambe_fec_config3_full_shape(mbx, oracle):
     assert a[5] == c[5] and a[3].tobytes() == c[3].tobytes() and a[1].tobytes() == c[1].tobytes()
 
 
+def _full_shape_run_staged(codec, S, ticks, frames, seeds, d_pick):
+    """the same ticks through the staged calls (mbx_fec_* + mbx_process_records: FEC, expansion and stream launches)"""
+    import torch
+    from mbelib_neo_amd import decoder
+    from mbelib_neo_amd.layout import FRAME_BYTES
+
+    fb = FRAME_BYTES[codec]
+    dec = decoder.BatchDecoder(codec, S, seeds=seeds)
+    pcs, pfs, res, recs, digest = [], [], [], [], 0
+    for t in range(ticks):
+        out = dec.decode(np.ascontiguousarray(frames[:, t:t + 1]).reshape(-1, fb), 1, want_float=True, staged=True)
+        pcs.append(out["pcm16"].reshape(S, 1, 160)[d_pick])
+        pfs.append(out["pcmf"].reshape(S, 1, 160)[d_pick])
+        res.append(out["results"].reshape(S, 1, 5)[d_pick])
+        recs.append(out["records"].to(torch.int64).sum().item())
+        digest += out["pcm16"].to(torch.int64).sum().item() * (t + 1)
+        del out
+    torch.cuda.synchronize()
+    return (torch.cat(pcs, dim=1).cpu().numpy(), torch.cat(pfs, dim=1).cpu().numpy(), torch.cat(res, dim=1).cpu().numpy(),
+            dec.state_numpy(), dec.rng_numpy(), digest, recs)
+
+
+def test_imbe_voiced_config2_full_shape(mbx, oracle):
+    """BASELINE configs[1] -- the HEADLINE -- at its full shape through the kernels bench.py times for it: 65,536 IMBE streams
+    x T = 1 per launch, clean all-voiced frames, one warm-up tick then four measured ticks (every tick a launch of its own, as a
+    decoder that is called every 20 ms issues them).  mbx_process_batch takes ONE fused launch for this shape
+    (`imbe_stream_kernel_one_fused`: FEC + expansion + stream stage in the stream's own wave); the staged calls take
+    `imbe_stream_kernel_one` behind the FEC and expansion launches -- both instances are run here and must agree bit for bit.
+    HIP vs ORACLE on a strided sample of 260 streams in BOTH transform forms (double-precision FFT; the reference's float PFFFT
+    restated): results exact, PCM / state in tolerance; every other stream through determinism (a second run is bit-identical in
+    every int16 sample, state and RNG) and through the resident form (`imbe_stream_kernel_res1_fused`, bit-identical again).
+    ref src/core/mbelib.c:1020-1040 (the voiced bank this workload isolates), tests/test_golden_pcm.c:67-211."""
+    import torch
+    from mbelib_neo_amd import framegen
+    from mbelib_neo_amd.layout import RESULT_DTYPE
+
+    S, T = 65536, 5
+    rng = framegen.rng_for(0xC2)
+    frames = np.stack([framegen.imbe_clean_voiced_frames(S, rng) for _ in range(T)], axis=1)   # [S, T, 18]
+    seeds = np.arange(S) + 1234
+    pick = np.arange(7, S, 251)
+    assert len(pick) >= 256
+    d_pick = torch.from_numpy(pick).cuda()
+    L = mbx.lib()
+    assert L.mbx_stream_kernel_name(0, 1) == b"imbe_stream_kernel_one"
+    fused = L.mbx_batch_kernel_name(0, S, 1, 0) == b"imbe_stream_kernel_one_fused"
+    assert fused or os.environ.get("MBX_FUSE_ONE") == "0"
+    a = _full_shape_run(0, S, [1] * T, frames, seeds, d_pick)                 # mbx_process_batch: the fused launch
+    st = _full_shape_run_staged(0, S, T, frames, seeds, d_pick)               # imbe_stream_kernel_one behind FEC + expansion
+    assert a[3].tobytes() == st[3].tobytes() and a[4].tobytes() == st[4].tobytes()
+    assert a[0].tobytes() == st[0].tobytes() and a[1].tobytes() == st[1].tobytes() and a[2].tobytes() == st[2].tobytes() and a[5] == st[5]
+    sel = frames[pick].reshape(-1, 18)
+    ref = oracle.process_batch(0, len(pick), T, sel, oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
+    assert int(ref["results"]["total_errors"].max()) == 0 and not (ref["results"]["flags"] & 0xC0).any()   # clean: no repeat, no mute
+    parity.check_results(ref["results"], np.ascontiguousarray(a[2]).view(RESULT_DTYPE).reshape(-1))
+    m = parity.check_pcm(ref["pcmf"], a[1].reshape(-1, 160), ref["pcm16"], a[0].reshape(-1, 160))
+    print("IMBE voiced 65,536 x 1 x 5 ticks (double FFT):", m)
+    parity.check_state(ref["state"], a[3][pick])
+    oracle.set_fft_float(1)
+    try:
+        ref_f = oracle.process_batch(0, len(pick), T, sel, oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
+    finally:
+        oracle.set_fft_float(0)
+    parity.check_results(ref_f["results"], np.ascontiguousarray(a[2]).view(RESULT_DTYPE).reshape(-1))
+    m = parity.check_pcm(ref_f["pcmf"], a[1].reshape(-1, 160), ref_f["pcm16"], a[0].reshape(-1, 160))
+    print("IMBE voiced 65,536 x 1 x 5 ticks (float FFT):", m)
+    parity.check_state(ref_f["state"], a[3][pick])
+    b = _full_shape_run(0, S, [1] * T, frames, seeds, d_pick)
+    assert a[5] == b[5] and a[3].tobytes() == b[3].tobytes() and a[4].tobytes() == b[4].tobytes() and a[0].tobytes() == b[0].tobytes()
+    c = _full_shape_run(0, S, [1] * T, frames, seeds, d_pick, resident=True)
+    assert a[5] == c[5] and a[3].tobytes() == c[3].tobytes() and a[1].tobytes() == c[1].tobytes()
+
+
+@pytest.mark.parametrize("codec", [0, 2])
+def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
+    """The IMBE codecs at T = 1 and S > 256: mbx_process_batch (one launch: scalar-unit FEC, in-wave expansion, stream stage)
+    against mbx_fec_* + mbx_process_records (FEC launch, expansion launch, `imbe_stream_kernel_one`) on RANDOM-BIT frames --
+    every error-count bucket, repeats, mutes, headroom resets, invalid fundamentals -- eight ticks of 8,192 + 3 streams (an odd
+    batch: frames alternate between the two alignments the scalar fetch handles, and the last one ends the buffer): records,
+    results, int16 / float PCM, state and RNG byte for byte; likewise through an index (mbx_process_batch_indexed) and with a
+    frame buffer that is only 2-byte aligned (the launcher then takes the staged launches)."""
+    import torch
+    from mbelib_neo_amd import _native, decoder, framegen
+
+    S, T = 8192 + 3, 8
+    frames = framegen.random_frames(codec, S * T, framegen.rng_for(0xF0 + codec)).reshape(S, T, 18)
+    frames[::5] &= framegen.random_frames(codec, ((S + 4) // 5) * T, framegen.rng_for(0xF8 + codec)).reshape(-1, T, 18)   # some with few errors
+    seeds = np.arange(S) + 77
+    L = mbx.lib()
+    assert L.mbx_batch_kernel_name(codec, S, 1, 0).endswith(b"stream_kernel_one_fused") or os.environ.get("MBX_FUSE_ONE") == "0"
+
+    def run(staged):
+        dec = decoder.BatchDecoder(codec, S, seeds=seeds)
+        outs = []
+        for t in range(T):
+            o = dec.decode(np.ascontiguousarray(frames[:, t]), 1, want_float=True, staged=staged)
+            outs.append({k: v.cpu().numpy().copy() for k, v in o.items()})
+        return outs, dec.state_numpy(), dec.rng_numpy()
+
+    fo, fs, fr = run(False)
+    so, ss, sr = run(True)
+    for t in range(T):
+        for k in ("records", "results", "pcm16", "pcmf"):
+            assert fo[t][k].tobytes() == so[t][k].tobytes(), (t, k)
+    assert fs.tobytes() == ss.tobytes() and fr.tobytes() == sr.tobytes()
+    flags = decoder.results_numpy(torch.from_numpy(np.concatenate([o["results"] for o in fo])))["flags"]
+    assert (flags & 0x40).any() and (flags & 0x80).any()   # repeats and mutes were in it
+
+    # a 2-byte aligned frame buffer: same results (the staged launches serve it)
+    dec = decoder.BatchDecoder(codec, S, seeds=seeds)
+    buf = torch.zeros(S * 18 + 2, dtype=torch.uint8, device="cuda")
+    out = dec.make_outputs(1, want_float=True)
+    strm = torch.cuda.current_stream().cuda_stream
+    buf[2:].copy_(torch.from_numpy(np.ascontiguousarray(frames[:, 0]).reshape(-1)))
+    _native.check(L.mbx_process_batch(codec, S, 1, buf.data_ptr() + 2, dec.state.data_ptr(), dec.rng.data_ptr(), out["pcm16"].data_ptr(),
+                                      out["pcmf"].data_ptr(), out["results"].data_ptr(), out["records"].data_ptr(), strm), "mbx_process_batch")
+    torch.cuda.synchronize()
+    for k in ("records", "results", "pcm16", "pcmf"):
+        assert out[k].cpu().numpy().tobytes() == fo[0][k].tobytes(), k
+
+    # through an index: the streams of a larger pool that have a frame this tick
+    pool = 2 * S
+    dec = decoder.BatchDecoder(codec, pool, seeds=np.repeat(seeds, 2))
+    idx = torch.arange(1, pool, 2, dtype=torch.int32, device="cuda")
+    d_frames = dec.to_device(np.ascontiguousarray(frames[:, 0]))
+    _native.check(L.mbx_process_batch_indexed(codec, S, 1, idx.data_ptr(), d_frames.data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(),
+                                              out["pcm16"].data_ptr(), out["pcmf"].data_ptr(), out["results"].data_ptr(),
+                                              out["records"].data_ptr(), strm), "mbx_process_batch_indexed")
+    torch.cuda.synchronize()
+    for k in ("records", "results", "pcm16", "pcmf"):
+        assert out[k].cpu().numpy().tobytes() == fo[0][k].tobytes(), k
+    st = dec.state_numpy()
+    ref0 = decoder.BatchDecoder(codec, S, seeds=seeds)
+    ref0.decode(np.ascontiguousarray(frames[:, 0]), 1, staged=True)
+    assert st[1::2].tobytes() == ref0.state_numpy().tobytes()
+
+
 def test_imbe_mixed_config4_full_shape(mbx, oracle):
     """BASELINE configs[3] at the shape bench.py runs it: 65,536 IMBE streams x T = 16 random-bit frames (mixed voiced /
     unvoiced, repeats, mutes) in ONE launch of `imbe_stream_kernel_lds`.  HIP vs ORACLE on a strided sample of 260 streams

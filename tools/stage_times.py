@@ -16,7 +16,9 @@ from contextlib import redirect_stdout
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES = {1: "entry -> cur_mp's scalars there (first round trip)", 2: "-> frame parameters in LDS", 3: "-> decoded, policy applied",
+NAMES = {14: "(fused) entry -> the frame's bytes are there", 15: "(fused) -> C0 corrected, L known, table reads requested",
+         10: "(fused) -> FEC done, record stored", 11: "(fused) -> table values there, expanded",
+         1: "entry -> cur_mp's scalars there (first round trip)", 2: "-> frame parameters in LDS", 3: "-> decoded, policy applied",
          4: "-> snapshot stored, enhanced", 5: "-> smoothing, phases, bank coefficients", 6: "-> voiced bank (+ output through LDS)",
          7: "-> noise samples (table round trip)", 8: "-> transform pair (or nothing)", 9: "-> overlap-add",
          12: "-> soft clip, back in the body", 13: "-> every store issued"}
@@ -44,7 +46,7 @@ def main():
     life = t[:, sorted(NAMES)].sum(axis=1)
     print(f"{wl}: kernel {line['roofline']['kernel']} {line['roofline']['kernel_ms']:.4f} ms (instrumented build), {S} waves of the last launch")
     print(f"  wave life, entry to last store: mean {life.mean():.2f} us, median {np.median(life):.2f}, p10 {np.percentile(life, 10):.2f}, p90 {np.percentile(life, 90):.2f}")
-    for i in sorted(NAMES):
+    for i in NAMES:
         print(f"  {NAMES[i]:52s} mean {t[:, i].mean():6.2f} us  median {np.median(t[:, i]):6.2f}  {100.0 * t[:, i].mean() / life.mean():5.1f} %")
 
 
