@@ -304,9 +304,11 @@ int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_i
 
 /* The two halves with a caller-owned workspace (mbx_workspace_bytes(S*T) bytes), free to run on DIFFERENT streams: the
  * front end of batch k + 1 (mbx_fec_* + mbx_expand_records_ws) depends only on its frames, not on the stream stage of batch k,
- * so a host that decodes batch after batch overlaps them and orders them with its own events (what bench.py's headline does:
- * front end on one stream into alternating record / workspace buffers, stream stage on another).  d_resident: NULL, or the
- * resident words of mbx_process_batch_resident. */
+ * so a host that decodes batch after batch MAY overlap them and order them with its own events (front end on one stream into
+ * alternating record / workspace buffers, stream stage on another).  The pair allows it; it is not a recommendation: on MI355X
+ * at T = 1 it measured SLOWER than a single stream (bench.py uses it only with --overlap-front-end: 255 against 265 M frames/s),
+ * and the IMBE codecs' T = 1 step is one fused launch in mbx_process_batch anyway.  d_resident: NULL, or the resident words of
+ * mbx_process_batch_resident. */
 int mbx_expand_records_ws(int codec, const mbx_param_record* d_records, size_t n, void* d_workspace, size_t workspace_bytes,
                           void* stream);
 int mbx_stream_expanded_ws(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state, uint32_t* d_resident,

@@ -183,6 +183,11 @@ int lds_min_frames() {   // frames per stream from which the LDS-resident instan
     return v;
 }
 #define kLdsResidentMinFrames lds_min_frames()
+bool res1_enabled() {   // MBX_NO_RES1 (A/B timing): resident one-frame launches through the LDS-resident instance; read once
+    static const bool on = getenv("MBX_NO_RES1") == nullptr;
+    return on;
+}
+
 bool lds_resident_enabled() {
     static const bool on = getenv("MBX_NO_LDS_RESIDENT") == nullptr;   // development switch for A/B timing; read once
     return on;
@@ -393,6 +398,26 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
         uint32_t wbits;
         memcpy(&wbits, &host->imbe_w0[b0], 4);
         d.imbe_b0[b0] = make_uint2(wbits, (uint32_t)host->imbe_L[b0] | ((uint32_t)host->imbe_K[b0] << 8));
+    }
+    for (int j = 0; j < 64; ++j) {
+        uint32_t hi = 0, lo = 0;
+        for (int i = 0; i < 6; ++i) {
+            if ((j >> (5 - i)) & 1) {
+                hi ^= host->golay_gen[i];
+                lo ^= host->golay_gen[6 + i];
+            }
+        }
+        d.golay_half_syn[j] = (hi << 16) | lo;
+        uint32_t ac[2];
+        for (int half = 0; half < 2; ++half) {   // x -> 173 x + 13849 mod 2^16, k = j + 1 + 64 half times
+            uint32_t a = 1, c = 0;
+            for (int k = 0; k < j + 1 + 64 * half; ++k) {
+                a = (a * 173u) & 0xffffu;
+                c = (c * 173u + 13849u) & 0xffffu;
+            }
+            ac[half] = a | (c << 16);
+        }
+        d.pr_lane[j] = make_uint2(ac[0], ac[1]);
     }
     memset(d.imbe_L_lanes, 0, sizeof(d.imbe_L_lanes));
     for (int b0 = 0; b0 < 208; ++b0) {
@@ -809,7 +834,7 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
     // Resident state (d_resident) is understood by those instances only, whatever T is.
     const bool lds_resident = T >= kLdsResidentMinFrames && lds_resident_enabled();
     if (d_resident) {
-        if (codec == MBX_CODEC_IMBE7200X4400 && T == 1 && !getenv("MBX_NO_RES1")) {
+        if (codec == MBX_CODEC_IMBE7200X4400 && T == 1 && res1_enabled()) {
             hipLaunchKernelGGL(mbx::imbe_stream_kernel_res1, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                                params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         } else if (codec == MBX_CODEC_IMBE7200X4400) {
@@ -994,7 +1019,9 @@ static int stream_expanded(int codec, int S, int T, const mbx_param_record* d_re
 
 // The two halves with a CALLER-OWNED workspace, so that they can run on DIFFERENT streams: the frame-parallel front end
 // (FEC + expansion) of batch k + 1 does not depend on the stream stage of batch k, only on the frames -- a host that decodes
-// batch after batch (recorded traffic, many sites) lets them overlap and orders them with events of its own (bench.py).
+// batch after batch (recorded traffic, many sites) MAY let them overlap and order them with events of its own.  Measured on
+// MI355X at T = 1 (bench.py --overlap-front-end): slower than everything on one stream (255 against 265 M frames/s) -- the
+// HBM-bound stream kernel slows down by what it shares, and two cross-stream hand-overs per step cost what the overlap saves.
 int mbx_expand_records_ws(int codec, const mbx_param_record* d_records, size_t n, void* d_workspace, size_t workspace_bytes,
                           void* stream) {
     REQUIRE_CTX(c);
@@ -1557,7 +1584,7 @@ const char* mbx_batch_kernel_name(int codec, int S, int T, int resident) {
 
 const char* mbx_stream_kernel_name(int codec, int T) {
     if (T < 0) {   // the instances of the resident launches (mbx_process_batch_resident) with -T frames per stream
-        return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? ((T == -1 && !getenv("MBX_NO_RES1")) ? "imbe_stream_kernel_res1" : "imbe_stream_kernel_res")
+        return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? ((T == -1 && res1_enabled()) ? "imbe_stream_kernel_res1" : "imbe_stream_kernel_res")
                : (codec == MBX_CODEC_AMBE3600X2400)                                    ? "ambe2400_stream_kernel_res"
                                                                                         : "ambe_stream_kernel_res";
     }

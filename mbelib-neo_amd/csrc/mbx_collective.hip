@@ -9,12 +9,23 @@
 //
 // RCCL is bound at RUN TIME (dlopen "librccl.so.1"): libmbx_hip.so carries no link-time dependency on it, so a
 // single-GPU host that never calls these entry points needs no RCCL at all, and inside a process that already has one
-// loaded (PyTorch) the same instance is used.  Host code only.
+// loaded (PyTorch) the same instance is used.  MBX_RCCL_LIBRARY in the environment names another library to bind instead
+// (read once, at the first call): a site's own RCCL build -- and tests/fake_rccl.c, whose collectives rendezvous host
+// threads on ONE device, which is how the N > 1 control flow below (non-root ranks, mismatching tables, a rank that fails)
+// is exercised on a single-GPU box.  Host code only.
+//
+// What "no rank hangs" covers: from the first collective on, a rank that fails LOCALLY -- its copy of the blob does not
+// arrive or does not pass mbx_init's magic / checksum test, a copy or a collective call returns an error -- still makes every
+// remaining collective call of the sequence (broadcast, all-reduce min, all-reduce max) and contributes a pair that cannot
+// agree, so its peers return MBX_EBADTABLE instead of waiting for it.  What it cannot cover: a rank that never reaches the
+// first collective (its device is gone, the 72 KB staging allocation fails) -- the peers of a rank that is not there wait in
+// ncclBroadcast like the peers of any dead RCCL rank; that is the launcher's time-out to catch.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types and enumerators only
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -48,10 +59,15 @@ const Rccl* rccl() {   // nullptr (with the error text set) when RCCL cannot be 
     static std::once_flag once;
     static bool ok = false;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.handle) {
-                break;
+        const char* override_name = getenv("MBX_RCCL_LIBRARY");
+        if (override_name && override_name[0]) {   // exactly that library or none: a typo must not fall back silently
+            r.handle = dlopen(override_name, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.handle) {
+                    break;
+                }
             }
         }
         if (!r.handle) {
@@ -100,15 +116,46 @@ struct DevBytes {
     }
 };
 
-// min and max over the ranks of one 32-bit value (two all-reduces of one word each); `failed`: this rank contributes
-// (0, 0xffffffff) instead, which no set of honest values can equal.  0 when every rank passed the same value.
-int agree(const Rccl* R, ncclComm_t c, uint32_t value, bool failed, uint32_t* d /* 4 words of device memory */, uint32_t out[2], hipStream_t st) {
-    const uint32_t in[2] = {failed ? 0u : value, failed ? 0xffffffffu : value};
-    H_TRY(hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, st));
-    N_TRY(R, R->AllReduce(d, d + 2, 1, ncclUint32, ncclMin, c, st));
-    N_TRY(R, R->AllReduce(d + 1, d + 3, 1, ncclUint32, ncclMax, c, st));
-    H_TRY(hipMemcpyAsync(out, d + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    H_TRY(hipStreamSynchronize(st));
+// `d`: four words of device memory whose first two words hold the POISON pair (0, 0xffffffff) -- no set of honest values can
+// reduce to equal words with it in -- written at allocation time (poison_words), so that a rank whose copy of its real pair
+// fails still takes part with the poison.
+int poison_words(uint32_t* d) {
+    if (hipMemset(d, 0x00, sizeof(uint32_t)) != hipSuccess || hipMemset(d + 1, 0xff, sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return cfail(MBX_ENODEVICE, "collective: could not initialise the agreement words");
+    }
+    return 0;
+}
+
+// min and max over the ranks of one 32-bit value (two all-reduces of one word each); `failed`: this rank contributes the
+// poison pair instead.  BOTH all-reduces are always issued, whatever fails locally on the way: the peers are in them.
+// 0 when every rank passed the same value; MBX_EBADTABLE when they differ or a rank failed; MBX_ENODEVICE for a local error.
+int agree(const Rccl* R, ncclComm_t c, uint32_t value, bool failed, uint32_t* d /* see poison_words */, uint32_t out[2], hipStream_t st) {
+    int local_rc = 0;
+    if (!failed) {
+        const uint32_t in[2] = {value, value};
+        if (hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            (void)hipGetLastError();
+            local_rc = cfail(MBX_ENODEVICE, "agree: the copy of this rank's value failed (it takes part with the poison pair)");
+            failed = true;
+        }
+    }
+    const ncclResult_t n0 = R->AllReduce(d, d + 2, 1, ncclUint32, ncclMin, c, st);
+    const ncclResult_t n1 = R->AllReduce(d + 1, d + 3, 1, ncclUint32, ncclMax, c, st);
+    if (n0 != ncclSuccess || n1 != ncclSuccess) {
+        local_rc = cfail(MBX_ENODEVICE, "agree: ncclAllReduce", R->GetErrorString(n0 != ncclSuccess ? n0 : n1));
+    }
+    out[0] = 0u;
+    out[1] = 0xffffffffu;
+    if (hipMemcpyAsync(out, d + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError();
+        out[0] = 0u;
+        out[1] = 0xffffffffu;
+        local_rc = cfail(MBX_ENODEVICE, "agree: the result did not come back on this rank");
+    }
+    if (local_rc < 0) {
+        return local_rc;
+    }
     return (out[0] == out[1] && !failed) ? 0 : MBX_EBADTABLE;
 }
 
@@ -174,26 +221,50 @@ int mbx_init_broadcast(void* comm, int root, int device, void* table_blob, size_
     if (root < 0 || root >= nranks) {
         return cfail(MBE_STATUS_INVALID_ARGUMENT, "mbx_init_broadcast: root is not a rank of the communicator");
     }
+    // (failures up to here and in the three lines below happen BEFORE this rank's first collective call: see the header comment)
     H_TRY(hipSetDevice(device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     DevBytes blob, sums;
     H_TRY(hipMalloc(&blob.p, table_bytes));
     H_TRY(hipMalloc(&sums.p, 4 * sizeof(uint32_t)));
-    if (rank == root) {
-        H_TRY(hipMemcpyAsync(blob.p, table_blob, table_bytes, hipMemcpyHostToDevice, st));
+    {
+        const int prc = poison_words(static_cast<uint32_t*>(sums.p));
+        if (prc < 0) {
+            return prc;
+        }
     }
-    // the one collective of the path: 71,908 bytes, root's GPU -> every GPU
-    N_TRY(R, R->Broadcast(blob.p, blob.p, table_bytes, ncclUint8, root, c, st));
-    if (rank != root) {
-        H_TRY(hipMemcpyAsync(table_blob, blob.p, table_bytes, hipMemcpyDeviceToHost, st));
-    }
-    // From here on every rank takes part in the agreement below WHATEVER happened to it locally: a rank that returned early
-    // (a blob that fails mbx_init's magic / checksum test is exactly the case this function exists to catch) would leave the
-    // others blocked in the all-reduce for ever.  A failed rank contributes a pair that cannot agree and reports its own error.
+    // From here on every rank makes EVERY collective call of the sequence whatever happens to it locally: a rank that returned
+    // early (a blob that fails mbx_init's magic / checksum test is exactly the case this function exists to catch) would leave
+    // the others blocked in a collective for ever.  A failed rank contributes a pair that cannot agree and reports its own error.
     int local_rc = 0;
+    auto local_fail = [&](const char* what, const char* detail) {
+        if (local_rc == 0) {   // the first error is the one reported
+            local_rc = cfail(MBX_ENODEVICE, what, detail);
+        }
+    };
+    if (rank == root) {
+        const hipError_t e = hipMemcpyAsync(blob.p, table_blob, table_bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            local_fail("mbx_init_broadcast: the root's copy of the blob to its device failed", hipGetErrorString(e));
+        }
+    }
+    {   // the one collective of the path: 71,908 bytes, root's GPU -> every GPU
+        const ncclResult_t n = R->Broadcast(blob.p, blob.p, table_bytes, ncclUint8, root, c, st);
+        if (n != ncclSuccess) {
+            local_fail("mbx_init_broadcast: ncclBroadcast", R->GetErrorString(n));
+        }
+    }
+    if (rank != root && local_rc == 0) {
+        const hipError_t e = hipMemcpyAsync(table_blob, blob.p, table_bytes, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            local_fail("mbx_init_broadcast: the copy of the received blob to the host failed", hipGetErrorString(e));
+        }
+    }
     if (hipStreamSynchronize(st) != hipSuccess) {
         (void)hipGetLastError();
-        local_rc = cfail(MBX_ENODEVICE, "mbx_init_broadcast: the broadcast did not complete on this rank");
+        local_fail("mbx_init_broadcast: the broadcast did not complete on this rank", nullptr);
     }
     if (local_rc == 0) {
         local_rc = mbx_init(device, table_blob, table_bytes);   // validates magic / version / checksum of what arrived
@@ -223,6 +294,12 @@ int mbx_comm_agree(void* comm, uint32_t value, uint32_t* min_max, void* stream) 
     }
     DevBytes sums;
     H_TRY(hipMalloc(&sums.p, 4 * sizeof(uint32_t)));
+    {
+        const int prc = poison_words(static_cast<uint32_t*>(sums.p));
+        if (prc < 0) {
+            return prc;
+        }
+    }
     uint32_t out[2] = {0u, 0u};
     const int rc = agree(R, static_cast<ncclComm_t>(comm), value, false, static_cast<uint32_t*>(sums.p), out, static_cast<hipStream_t>(stream));
     if (min_max) {

@@ -46,6 +46,11 @@ struct DerivedTables {
     uint2    imbe_b0[208];                // b0 -> (w0 bits, L | K << 8): one look-up instead of three
     float    wola_inv[160];       // 1 / wola_denom[n] (0 where the reference skips the sample: denom <= 1e-10)
     float    ambep_f0[128];       // AMBE 3600x2400: exp2f(-4.311767578125f - 2.1336e-2f * (b0 + 0.5f)) from the host libm
+    // Lane-parallel FEC of the one-launch T = 1 kernels (mbx_fec_frame.h, LaneFec): tables of 64 entries held ONE ENTRY PER LANE
+    uint32_t golay_half_syn[64];  // entry j: (parity of the data word whose six HIGH bits are j) << 16 | (... whose six LOW bits are j):
+                                  // the Golay syndrome of a code word is half_hi[data >> 6] ^ half_lo[data & 63] ^ its parity bits
+    uint2    pr_lane[64];         // demodulation sequence in closed form, x_k = A_k x_0 + C_k mod 2^16: entry j = (A | C << 16) of
+                                  // k = j + 1 (.x) and of k = j + 65 (.y)
     uint32_t imbe_L_lanes[64];    // byte k of entry j: IMBE L of b0 = j + 64 k (0: no such b0 / invalid L) -- ONE dword per lane holds the
                                   // whole b0 -> L law, so a wave that asks for it before it knows b0 has L without a memory round trip
 };

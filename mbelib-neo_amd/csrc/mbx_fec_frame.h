@@ -376,6 +376,176 @@ template <typename Tab>
 __device__ __forceinline__ uint4 fec_imbe7200x4400_wire(const Tab& tab, const Wire& wire) {
     return fec_imbe7200x4400_tail(tab, fec_imbe7200x4400_head(tab, wire));
 }
+// ------------------------------------------------------------------------------------------------------------------------
+// LaneFec: the IMBE 7200x4400 FEC of ONE frame by ONE WAVE with LANE r = ROW r of the frame (r = 0..7; the other lanes idle
+// along as copies of row 7) -- the front end of the one-launch T = 1 kernels (imbe_stream_kernel_one_fused).
+// Why not the scalar-unit form the single-frame kernels use (TabScalar above): there a lone wave hides a PCIe round trip behind
+// it; here 28 waves per CU run it at once, and ~700 scalar instructions per wave took the CU's one scalar ALU from 34 % to 70 %
+// busy (tools/stage_times.py: 6 us of a 23 us wave life before the expansion's table reads had even been requested).  By lanes
+// the same work is ~100 vector + ~40 scalar instructions:
+//   * rows: one 64-bit funnel shift per lane out of the frame's five words (byte order and the frame's 2-byte alignment in a
+//     byte permute with a wave-uniform selector);
+//   * Golay syndromes: the parity of a 12-bit data word is half_hi[data >> 6] ^ half_lo[data & 63], two 64-entry tables held one
+//     entry per lane (DerivedTables::golay_half_syn) and read with ds_bpermute -- three rows at once;
+//   * Hamming syndromes on lanes 4..6 by four popcounts, at the same time;
+//   * the demodulation sequence in closed form across the lanes (DerivedTables::pr_lane), two ballots, and every row cuts its own
+//     mask out of the 128-bit pair with its own shift;
+//   * the corrections: scalar loads (C0's first; then the other six in one round trip) -- NOT per-lane vector loads, which would
+//     return behind the wave's state loads.
+// Bit-exact with fec_imbe7200x4400_wire (integer work only); ref src/imbe/imbe7200x4400.c:424-443, 636-673, 469-515, 709-744,
+// src/ecc/ecc.c:221-301, 366-408.
+// ------------------------------------------------------------------------------------------------------------------------
+struct FrameWords {   // the five dwords that hold an 18-byte frame, as loaded (little-endian) from the 4-byte boundary at or below it
+    uint32_t d[5];
+};
+struct LaneFecTables {   // one entry per lane, requested at the start of the wave
+    uint32_t half_syn;   // golay_half_syn[lane]
+    uint32_t pr1, pr2;   // pr_lane[lane]
+};
+__device__ __forceinline__ LaneFecTables lane_fec_request(const DerivedTables* D, int lane) {
+    typedef const __attribute__((address_space(1))) char* G;
+    LaneFecTables t;
+    const G base = (G)D;
+    t.half_syn = *(const __attribute__((address_space(1))) uint32_t*)(base + offsetof(DerivedTables, golay_half_syn) + 4u * (uint32_t)lane);
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    const u2v pr = *(const __attribute__((address_space(1))) u2v*)(base + offsetof(DerivedTables, pr_lane) + 8u * (uint32_t)lane);
+    t.pr1 = pr.x;
+    t.pr2 = pr.y;
+    return t;
+}
+
+struct LaneFecHead {
+    uint32_t row;   // lane r: row r as received (lane 0: after the Golay correction of C0)
+    int      c0;    // errors corrected in C0 (wave-uniform)
+    int      b0;    // the fundamental's index (wave-uniform): C0's six high data bits, two bits of the unprotected row 7
+};
+
+__device__ __forceinline__ uint32_t lane_golay_syndrome(uint32_t cw, uint32_t half_syn) {
+    const uint32_t data = cw >> 11;
+    const uint32_t e_hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((data >> 6) << 2), (int)half_syn) >> 16;
+    const uint32_t e_lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((data & 63u) << 2), (int)half_syn) & 0xffffu;
+    return (e_hi ^ e_lo ^ cw) & 0x7ffu;
+}
+
+// `misaligned`: the frame starts two bytes into fw.d[0] (wave-uniform)
+__device__ __forceinline__ LaneFecHead lane_fec_imbe_head(const FrameWords& fw, bool misaligned, const LaneFecTables& lt, const mbx_tables* T,
+                                                          int lane) {
+    // the frame as five big-endian words (BitReader's layout): bytes 3,2,1,0 of a dword, or bytes 1,0 of the next and 3,2 of this one
+    const uint32_t sel = misaligned ? 0x02030405u : 0x00010203u;   // v_perm_b32 selectors: byte 0..3 = src1, 4..7 = src0
+    uint32_t w[6];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        w[k] = __builtin_amdgcn_perm(k < 4 ? fw.d[k + 1] : 0u, fw.d[k], sel);
+    }
+    if (misaligned) {
+        w[4] &= 0xffff0000u;   // (only two bytes of the fifth word belong to the frame; never read past bit 144 anyway)
+    }
+    w[5] = 0u;
+    const int r = lane < 7 ? lane : 7;
+    const int start = r < 4 ? 23 * r : 32 + 15 * r;          // 0, 23, 46, 69, 92, 107, 122, 137
+    const int width = r < 4 ? 23 : (r < 7 ? 15 : 7);
+    const int wi = start >> 5;
+    uint32_t hi = w[4], lo = w[5];
+    hi = wi == 3 ? w[3] : hi, lo = wi == 3 ? w[4] : lo;
+    hi = wi == 2 ? w[2] : hi, lo = wi == 2 ? w[3] : lo;
+    hi = wi == 1 ? w[1] : hi, lo = wi == 1 ? w[2] : lo;
+    hi = wi == 0 ? w[0] : hi, lo = wi == 0 ? w[1] : lo;
+    const uint64_t two = ((uint64_t)hi << 32) | lo;
+    LaneFecHead h;
+    h.row = (uint32_t)((two << (start & 31)) >> (64 - width));
+    // C0: Golay(23,12) on row 0.  Every lane forms the syndrome of its own row and reads a correction (rows 1..3 are still
+    // scrambled, rows 4..7 are no Golay words: their values are dropped) -- instructions are per wave either way.
+    const uint32_t syn = lane_golay_syndrome(h.row, lt.half_syn);
+    // the correction by a SCALAR load (own path, own counter): a vector load would come back behind the wave's forty state loads,
+    // which return in order -- measured, 2.5 us instead of 1 for this one look-up
+    const uint32_t fix0 = sload_elem<uint16_t>(T, offsetof(mbx_tables, golay_matrix), (uint32_t)__builtin_amdgcn_readlane((int)syn, 0));
+    if (lane == 0) {
+        h.row ^= fix0 << 11;
+    }
+    h.c0 = __popc(fix0);
+    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readlane((int)h.row, 0), row7 = (uint32_t)__builtin_amdgcn_readlane((int)h.row, 7);
+    h.b0 = (int)((((row0 >> 17) & 0x3fu) << 2) | ((row7 >> 1) & 3u));
+    return h;
+}
+
+// the rest: demodulation, Golay on rows 1..3, Hamming on rows 4..6 (syndromes by lanes, corrections by one batch of scalar loads),
+// the record.  hgen: hamming_gen[0..3], two per dword.
+__device__ __forceinline__ uint4 lane_fec_imbe_tail(const LaneFecHead& h, const LaneFecTables& lt, const uint32_t hgen[2], const mbx_tables* T,
+                                                    int lane) {
+    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readlane((int)h.row, 0);
+    const uint32_t x0 = (16u * (row0 >> 11)) & 0xffffu;
+    // bit j of plo: the sequence bit of step j + 1; of phi: of step j + 65
+    const uint64_t plo = __ballot(((((lt.pr1 & 0xffffu) * x0 + (lt.pr1 >> 16)) >> 15) & 1u) != 0u);
+    const uint64_t phi = __ballot(((((lt.pr2 & 0xffffu) * x0 + (lt.pr2 >> 16)) >> 15) & 1u) != 0u);
+    const int r = lane < 7 ? lane : 7;
+    const bool golay = r >= 1 && r <= 3, hamming = r >= 4 && r <= 6;
+    const int width = r < 4 ? 23 : 15;
+    const int p = golay ? 23 * (r - 1) : (15 * r + 9);   // where the row's mask starts in the sequence: 0, 23, 46 / 69, 84, 99
+    uint32_t cut = (p < 64) ? (uint32_t)((plo >> (p & 63)) | ((phi << 1) << (63 - (p & 63)))) : (uint32_t)(phi >> ((p - 64) & 63));
+    uint32_t row = h.row;
+    if (golay || hamming) {
+        row ^= __brev(cut) >> (32 - width);
+    }
+    // syndromes: Golay on lanes 1..3, Hamming(15,11) on lanes 4..6
+    const uint32_t gsyn = lane_golay_syndrome(row, lt.half_syn);
+    uint32_t hsyn = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t g = (hgen[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+        hsyn |= ((uint32_t)__popc(row & g) & 1u) << i;
+    }
+    // the six corrections in ONE scalar round trip (see the head), applied on the scalar unit: the rows are wave-uniform from here on
+    uint32_t gs[3], gf[3], hf[3], rw[8];
+    int hs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gs[k] = (uint32_t)__builtin_amdgcn_readlane((int)gsyn, 1 + k);
+        hs[k] = __builtin_amdgcn_readlane((int)hsyn, 4 + k);
+    }
+    {
+        const uint32_t hbase = (uint32_t)offsetof(mbx_tables, hamming_fix), gbase = (uint32_t)offsetof(mbx_tables, golay_matrix);
+        uint32_t wd[6];
+        asm volatile("s_load_dword %0, %6, %7\n\ts_load_dword %1, %6, %8\n\ts_load_dword %2, %6, %9\n\t"
+                     "s_load_dword %3, %6, %10\n\ts_load_dword %4, %6, %11\n\ts_load_dword %5, %6, %12\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(wd[0]), "=&s"(wd[1]), "=&s"(wd[2]), "=&s"(wd[3]), "=&s"(wd[4]), "=&s"(wd[5])
+                     : "s"(T), "s"((gbase + 2u * gs[0]) & ~3u), "s"((gbase + 2u * gs[1]) & ~3u), "s"((gbase + 2u * gs[2]) & ~3u),
+                       "s"((hbase + 2u * (uint32_t)hs[0]) & ~3u), "s"((hbase + 2u * (uint32_t)hs[1]) & ~3u),
+                       "s"((hbase + 2u * (uint32_t)hs[2]) & ~3u)
+                     : "memory");
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gf[k] = (wd[k] >> (16u * (gs[k] & 1u))) & 0xffffu;
+            hf[k] = (wd[3 + k] >> (16u * ((uint32_t)hs[k] & 1u))) & 0xffffu;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        rw[k] = (uint32_t)__builtin_amdgcn_readlane((int)row, k);
+    }
+    int prot = 0, c4 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rw[1 + k] ^= gf[k] << 11;
+        prot += __popc(gf[k]);
+        if (hs[k] != 0) {
+            rw[4 + k] ^= hf[k];
+            prot += 1;
+            c4 = (k == 0) ? 1 : c4;
+        }
+    }
+    // the record: 12 data bits of rows 0..3, 11 of rows 4..6, the 7 bits of row 7, in this order (88 bits, big-endian in three words)
+    uint32_t d[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        d[k] = k < 4 ? rw[k] >> 11 : (k < 7 ? rw[k] >> 4 : rw[k]);
+    }
+    const uint32_t x = (d[0] << 20) | (d[1] << 8) | (d[2] >> 4);
+    const uint32_t y = (d[2] << 28) | (d[3] << 16) | (d[4] << 5) | (d[5] >> 6);
+    const uint32_t z = (d[5] << 26) | (d[6] << 15) | (d[7] << 8);
+    return make_uint4(x, y, z, (uint32_t)h.c0 | ((uint32_t)prot << 8) | ((uint32_t)c4 << 16)
+                                   | ((MBE_PROCESS_FLAG_C0_VALID | MBE_PROCESS_FLAG_C4_VALID) << 24));
+}
+
 __device__ __forceinline__ uint4 fec_imbe7200x4400_frame(const mbx_tables* T, const uint8_t* f) {
     return fec_imbe7200x4400_wire(TabVector{T}, load_wire_imbe(f));
 }

@@ -360,7 +360,9 @@ int mbx_session_create(mbx_session** out, int codec, int streams, size_t max_fra
         C_TRY(hipMalloc(reinterpret_cast<void**>(&sl.d_frames), mf * s->frame_bytes));
         C_TRY(hipMalloc(reinterpret_cast<void**>(&sl.d_records), mf * sizeof(mbx_param_record)));
         C_TRY(hipMalloc(reinterpret_cast<void**>(&sl.d_index), (size_t)streams * sizeof(int32_t)));
-        C_TRY(hipMalloc(&sl.d_workspace, mbx_workspace_bytes(mf)));
+        if (!s->d_resident) {   // (the resident entry point uses the workspace the launcher keeps for the compute stream, reserved below)
+            C_TRY(hipMalloc(&sl.d_workspace, mbx_workspace_bytes(mf)));
+        }
         if (s->outputs & MBX_SESSION_PCM16) {
             C_TRY(hipMalloc(reinterpret_cast<void**>(&sl.d_pcm16), mf * 160 * sizeof(int16_t)));
         }

@@ -1602,8 +1602,10 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         float band_sc = 0.0f;
         int band_a = 0, band_b = 0;
         const float mult = (256.0f / (2.0f * 3.14159265358979323846f)) * cur.w0;
-        // b - a = ceil((l + .5) mult) - ceil((l - .5) mult) <= floor(mult) + 1: the widest band of the frame (wave-uniform)
-        const int span = uni((mult >= 0.0f && mult < 13.0f) ? ((int)mult + 1) : 14);
+        // b - a = ceil((l + .5) mult) - ceil((l - .5) mult) <= floor(mult) + 1 in exact arithmetic; a and b are ceilings of two
+        // separately ROUNDED float products, so with frac(mult) within ~1e-5 of 1 a band can be one bin wider still: + 2 (wave-uniform;
+        // bins[] is padded for it, and the tail loop below only starts at a + 14)
+        const int span = uni((mult >= 0.0f && mult < 12.0f) ? ((int)mult + 2) : 14);
         if (lane >= 1 && lane <= cur.L && band_unvoiced) {
             int a = (int)ceilf(((float)lane - 0.5f) * mult);
             int b = (int)ceilf(((float)lane + 0.5f) * mult);
@@ -1927,9 +1929,6 @@ __device__ __forceinline__ Wire frame_from_args(bool ambe, const FrameShadow& x)
 // loads.  Frames are 18 bytes apart, i.e. 2-byte aligned: five dwords from the 4-byte boundary at or below the frame, shifted by
 // a uniform 0 or 16 bits.  (20 bytes from that boundary end at most 2 bytes past the frame, and never past the end of a batch whose
 // base is 4-byte aligned: the last frame of an even batch starts at 2 mod 4, and 18 S of an odd batch is not a page multiple.)
-struct FrameWords {
-    uint32_t d[5];
-};
 __device__ __forceinline__ FrameWords frame_fetch_scalar_imbe(const uint8_t* frame) {   // the request ...
     const uintptr_t a = reinterpret_cast<uintptr_t>(frame);
     const __attribute__((address_space(4))) uint32_t* q =
@@ -2077,12 +2076,24 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         const mbe_parms* const enh_src = elided1 ? slot_cur : slot_enh;
         uint32_t l_lanes = 0u;
         FrameWords frame_words = {};
-        TabScalar fused_tab;
+        TabScalar fused_tab;       // kFuse == 2 (7100x4400): the scalar-unit FEC
+        LaneFecTables lane_tabs;   // kFuse == 1 (7200x4400): the lane-parallel FEC
+        uint32_t hgen[2] = {0u, 0u};
+        const uint8_t* const frame_ptr = frame_in + 18u * (size_t)s;
         if constexpr (kFuse != 0) {
-            frame_words = frame_fetch_scalar_imbe(frame_in + 18u * (size_t)s);   // scalar loads: first of all, own counter
-            fused_tab = TabScalar(tabs_in.t);                                     // (the generator rows of the two codes with them)
-            l_lanes = tab_at<uint32_t>(tabs_in.d, offsetof(DerivedTables, imbe_L_lanes), 4u * (uint32_t)lane_in);   // b0 -> L for every b0, a dword per lane
-            asm volatile("" ::: "memory");   // (the first vector load of the wave: what is asked for first is there first)
+            frame_words = frame_fetch_scalar_imbe(frame_ptr);   // scalar loads: first of all, own counter
+            if constexpr (kFuse == 1) {
+                const __attribute__((address_space(4))) uint32_t* hg =
+                    (const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)tabs_in.t
+                                                                        + offsetof(mbx_tables, hamming_gen));
+                hgen[0] = hg[0];
+                hgen[1] = hg[1];
+                lane_tabs = lane_fec_request(tabs_in.d, lane_in);   // the first vector loads of the wave: the FEC's lane-held tables ...
+            } else {
+                fused_tab = TabScalar(tabs_in.t);   // (the generator rows of the two codes with the frame)
+            }
+            l_lanes = tab_at<uint32_t>(tabs_in.d, offsetof(DerivedTables, imbe_L_lanes), 4u * (uint32_t)lane_in);   // ... and b0 -> L for every b0
+            asm volatile("" ::: "memory");   // (what is asked for first is there first)
         } else if (params) {   // the frame's FrameParams row is what the frame needs first: requested first (tools/stage_times.py: asked for
             row_first = params[(size_t)s * (size_t)Tn].v[lane_in];   // after the scalars of cur_mp had arrived, it cost 2.5 us of a wave's 22)
         }
@@ -2097,30 +2108,31 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         if constexpr (kFuse != 0) {
             // The front end of the frame while the state is on its way.  Its chain of dependent memory round trips is what a fused wave
             // pays for (tools/stage_times.py): the frame's bytes -> C0's Golay correction -> [b0 -> L: from l_lanes, no trip] -> the
-            // expansion's table reads, with the FEC's tail (one more scalar trip) in their shadow.
+            // expansion's table reads, with the FEC's tail (one more table trip) in their shadow.
             asm volatile("" ::: "memory");
-            wire_in = frame_words_to_wire(frame_in + 18u * (size_t)s, frame_words);
             mbx_param_record* const rec_out = const_cast<mbx_param_record*>(&records[(size_t)s * (size_t)Tn]);
-            const PrLane pr_lanes(lane_in);   // (lane constants of the demodulation sequence)
-            TabScalar& tab = fused_tab;
-            tab.lanes = &pr_lanes;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                wire_in.h[k] = uni(wire_in.h[k]);
-            }
-            MBX_TS(14);   // (fused) the frame's bytes are there
             auto L_of = [&](int b0) -> int {   // wave-uniform b0
                 return (b0 <= 207) ? (int)((__builtin_amdgcn_readlane((int)l_lanes, b0 & 63) >> (8 * (b0 >> 6))) & 0xff) : 0;
             };
             if constexpr (kFuse == 1) {
-                const ImbeFecHead head = fec_imbe7200x4400_head(tab, wire_in);
-                const int b0 = head.b0();
-                expand_imbe_request(xreq, b0, tabs_in.t, tabs_in.d, lane_in, L_of(b0));
+                asm volatile("" : "+s"(frame_words.d[0]), "+s"(frame_words.d[1]), "+s"(frame_words.d[2]), "+s"(frame_words.d[3]),
+                             "+s"(frame_words.d[4])::"memory");   // (the first use of the frame's bytes: not scheduled in front of the loads above)
+                MBX_TS(14);   // (fused) the frame's bytes are there
+                const LaneFecHead head = lane_fec_imbe_head(frame_words, (reinterpret_cast<uintptr_t>(frame_ptr) & 2u) != 0u, lane_tabs, tabs_in.t,
+                                                            lane_in);
+                expand_imbe_request(xreq, head.b0, tabs_in.t, tabs_in.d, lane_in, L_of(head.b0));
                 asm volatile("" ::: "memory");
                 MBX_TS(15);   // (fused) C0 corrected, L known, the expansion's table reads requested
-                rec_in = broadcast_record(fec_imbe7200x4400_tail(tab, head), rec_out, lane_in);   // scalar unit, in the table reads' shadow
+                rec_in = broadcast_record(lane_fec_imbe_tail(head, lane_tabs, hgen, tabs_in.t, lane_in), rec_out, lane_in);
             } else {
-                rec_in = broadcast_record(fec_imbe7100x4400_wire(tab, wire_in), rec_out, lane_in);
+                wire_in = frame_words_to_wire(frame_ptr, frame_words);
+                const PrLane pr_lanes(lane_in);   // (lane constants of the demodulation sequence)
+                fused_tab.lanes = &pr_lanes;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    wire_in.h[k] = uni(wire_in.h[k]);
+                }
+                rec_in = broadcast_record(fec_imbe7100x4400_wire(fused_tab, wire_in), rec_out, lane_in);
                 const int b0 = imbe_record_b0(rec_in);
                 expand_imbe_request(xreq, b0, tabs_in.t, tabs_in.d, lane_in, L_of(b0));
             }
@@ -3166,10 +3178,15 @@ frame_server_kernel(mbx_frame_mailbox* mb, unsigned idle_ticks /* of the 100 MHz
         if (in != last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // the caller's structs: not from stale cache lines
             __builtin_amdgcn_s_dcache_inv();                //   (the scalar cache is not covered by the fence)
-            const int codec = __builtin_amdgcn_readlane((int)v, 2);
-            const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)v, 3);
+            // The request line is read AGAIN after the acquire: nothing guarantees that the 64-byte poll above was one atomic read
+            // across PCIe -- split into 32-byte sectors it could pair a new seq_in (offset 0) with stale frame bytes 16.. (offset 32+).
+            // The host writes codec, want and the frame with plain stores and seq_in LAST with release, so every byte read after the
+            // new seq_in has been seen (and after the fence) is the request's.
+            const uint32_t v2 = poll();
+            const int codec = __builtin_amdgcn_readlane((int)v2, 2);
+            const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)v2, 3);
             if (lane >= 4 && lane < 10) {
-                frame_words[lane - 4] = v;   // the wire frame came with the request: the FEC starts without another trip to the host
+                frame_words[lane - 4] = v2;   // the wire frame came with the request: the FEC starts without another trip to the host
             }
             wave_lds_sync();
             const uint8_t* frame = reinterpret_cast<const uint8_t*>(frame_words);

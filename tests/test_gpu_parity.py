@@ -1457,6 +1457,57 @@ def test_c_abi_rccl_table_broadcast_every_visible_device(mbx):
     assert L.mbx_table_checksum() == out[0]["checksum"]
 
 
+def test_collective_control_flow_with_thread_ranks(mbx, tmp_path):
+    """mbx_init_broadcast / mbx_comm_agree with N = 2, 4 and 8 RANKS on the one GPU of a test box: the ranks are host threads of a
+    child process and RCCL is tests/fake_rccl.c (bound through MBX_RCCL_LIBRARY), whose collectives are rendezvous of those threads
+    around plain device copies -- real RCCL refuses two ranks on one device, so before this test the non-root, mismatch and
+    failed-rank branches of csrc/mbx_collective.hip had never run.  Checked: (a) every non-root rank receives the blob (root 0 and
+    root N - 1) and all end with one checksum; (b) a different value on one rank makes mbx_comm_agree return MBX_EBADTABLE with
+    (min, max) = (7, 8) on EVERY rank; (c) one rank's copy of the blob arrives corrupted -> that rank's mbx_init refuses it and every
+    rank returns MBX_EBADTABLE; (d) one rank's ncclBroadcast fails -> it reports its own error, the others MBX_EBADTABLE, nobody
+    hangs.  NOT a scaling measurement: no multi-GPU box has been available.
+    ref include/mbelib-neo/mbelib.h:28-30 (threading contract: per-thread state, re-entrant per stream)."""
+    import json
+    import subprocess
+    import sys
+
+    MBX_EBADTABLE, MBX_ENODEVICE = -102, -100   # include/mbx.h
+    here = os.path.dirname(os.path.abspath(__file__))
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(here, "fake_rccl.c"),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib", "-o", fake])
+
+    def run(n, root, **inject):
+        env = dict(os.environ, MBX_RCCL_LIBRARY=fake)
+        env.update({k: str(v) for k, v in inject.items()})
+        p = subprocess.run([sys.executable, os.path.join(here, "rccl_thread_ranks.py"), str(n), str(root)], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, (p.returncode, p.stdout[-600:], p.stderr[-600:])
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+        assert not any(d["stuck"]), d
+        for r, o in enumerate(d["ranks"]):
+            assert "exception" not in o and o["init"] == 0 and o["destroy"] == 0, (r, o)
+        return d
+
+    for n in (2, 4, 8):
+        for root in (0, n - 1):
+            d = run(n, root)
+            for r, o in enumerate(d["ranks"]):
+                assert o["bcast"] == 0 and o["blob_ok"], f"n={n} root={root} rank={r}: {json.dumps(o)}"
+                assert o["minmax"][0] == o["minmax"][1] == d["checksum"] != 0, (n, root, r, o)
+                assert o["agree_same"] == 0, (n, root, r, o)
+                assert o["agree_diff"] == MBX_EBADTABLE and tuple(o["agree_diff_minmax"]) == (7, 8), (n, root, r, o)
+        d = run(n, 0, FAKE_RCCL_CORRUPT_RANK=1)
+        for r, o in enumerate(d["ranks"]):
+            assert o["bcast"] == MBX_EBADTABLE, (n, r, o)                    # on EVERY rank: the corrupted one by mbx_init, the others by the agreement
+            assert o["blob_ok"] == (r != 1), (n, r, o)
+            assert o["agree_same"] == 0, (n, r, o)                           # the communicator is still usable afterwards
+        d = run(n, 0, FAKE_RCCL_FAIL_BCAST_RANK=n - 1)
+        for r, o in enumerate(d["ranks"]):
+            assert o["bcast"] == (MBX_ENODEVICE if r == n - 1 else MBX_EBADTABLE), (n, r, o)
+            assert o["agree_same"] == 0, (n, r, o)
+
+
 def test_every_visible_device_decodes(mbx, oracle):
     """One context per device: every device torch can see (one on the test box, eight on a node) is initialised and decodes
     a small batch against the oracle -- device index > 0 is exercised the moment a box has it."""
