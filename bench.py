@@ -468,7 +468,8 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     split = bool(L.mbx_uses_expand_launch(stream_codec, S, T)) or args.split_expand
     # IMBE at T = 1: mbx_process_batch is ONE launch (imbe_stream_kernel_one_fused: FEC + expansion + stream stage in the stream's
     # own wave) unless MBX_FUSE_ONE=0; the step is then that call, and the events bracket it.
-    fused = (not soft) and L.mbx_batch_kernel_name(codec, S, T, 1 if resident else 0).decode().endswith("_fused") and not args.split_expand
+    batch_kernel = L.mbx_batch_kernel_name(codec, S, T, 1 if resident else 0).decode()
+    fused = (not soft) and (batch_kernel.endswith("_fused") or "one_launch" in batch_kernel) and not args.split_expand
     # Front-end overlap (round 4).  FEC + parameter expansion of a batch depend only on its frames; the stream stage of the batch
     # before it depends only on ITS records / rows and on the state.  So the front end of step k + 1 is issued on a second HIP
     # stream into alternating record / workspace buffers (the *_ws entry points) and runs while the stream kernel of step k does;

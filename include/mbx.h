@@ -420,11 +420,16 @@ void mbx_rng_seed(mbx_stream_rng* rng, uint32_t seed);
  * the instance a resident launch (mbx_process_batch_resident) with -T frames per stream takes (*_res, *_res1) */
 const char* mbx_stream_kernel_name(int codec, int T);
 /* the dominant kernel of mbx_process_batch (resident != 0: of mbx_process_batch_resident) for a batch of S streams x T frames:
- * the IMBE codecs at T = 1 and S > 256 take ONE fused launch (imbe_stream_kernel_one_fused: FEC + parameter expansion + stream
- * stage, ref src/imbe/imbe7200x4400.c:935-948 -- decode and process in one call); every other shape the kernel
- * mbx_stream_kernel_name() names, behind its FEC (and expansion) launches.  MBX_FUSE_ONE=0 in the environment switches the
- * fused launch off (A/B timing). */
+ * the IMBE codecs at T = 1 and S > 256 take ONE launch (ref src/imbe/imbe7200x4400.c:935-948 -- decode and process in one
+ * call): 7200x4400 imbe_one_launch_kernel (front blocks -- FEC + parameter expansion of eight frames per wave -- and stream blocks
+ * in one grid), 7100x4400 imbe7100_stream_kernel_one_fused (the front end in the stream's own wave); every other shape the
+ * kernel mbx_stream_kernel_name() names, behind its FEC (and expansion) launches.  MBX_FUSE_ONE in the environment (A/B timing):
+ * 0 = the staged launches everywhere, 1 = the in-wave form for 7200x4400 too. */
 const char* mbx_batch_kernel_name(int codec, int S, int T, int resident);
+/* diagnostics of the one-launch kernel: the number of its stream blocks that did not find their front block's rows in time and
+ * expanded their own frame instead, since the workspace of `stream` was allocated (expected 0; results are the same either way).
+ * Synchronises the stream.  -1: the stream has no workspace yet. */
+long long mbx_debug_front_fallbacks(void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "mbx_rng_seed": (None, [_vp, C.c_uint32]),
     "mbx_stream_kernel_name": (C.c_char_p, [C.c_int, C.c_int]),
     "mbx_batch_kernel_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mbx_debug_front_fallbacks": (C.c_longlong, [C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -39,6 +39,10 @@ __global__ void imbe_stream_kernel_one_fused(int, int, const uint8_t*, mbx_param
                                              mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res1_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
                                               mbe_process_result*, DeviceTables);
+__global__ void imbe_one_launch_kernel(int, int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
+                                       mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void imbe_one_launch_kernel_res(int, int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
+                                           mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe7100_stream_kernel_one_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
                                                  mbe_process_result*, DeviceTables);
 __global__ void imbe7100_stream_kernel_res1_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
@@ -97,6 +101,8 @@ constexpr int kMaxDevices = 32;
 struct StreamSlot {                      // what a hipStream_t owns inside a context
     mbx::FrameParams* workspace = nullptr;   // expand-stage output of launches on this stream; grow-only
     size_t            frames = 0;
+    uint32_t*         flags = nullptr;       // one-launch T = 1 step: ready word per chunk of eight rows (behind the rows, same allocation)
+    uint32_t          epoch = 0;             // ... == the epoch of the launch that wrote them; a new value every launch
     unsigned          launches = 0;          // parity = direction in which the next stream-kernel launch walks the streams
     int               exp_codec = -1;        // what mbx_expand_records() last left in the workspace
     size_t            exp_n = 0;
@@ -419,6 +425,14 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
         }
         d.pr_lane[j] = make_uint2(ac[0], ac[1]);
     }
+    memset(d.pr_bits, 0, sizeof(d.pr_bits));
+    for (uint32_t seed = 0; seed < 4096; ++seed) {
+        uint32_t x = (16u * seed) & 0xffffu;
+        for (int k = 0; k < 114; ++k) {
+            x = (173u * x + 13849u) & 0xffffu;
+            d.pr_bits[seed][k >> 5] |= (x >> 15) << (31 - (k & 31));
+        }
+    }
     memset(d.imbe_L_lanes, 0, sizeof(d.imbe_L_lanes));
     for (int b0 = 0; b0 < 208; ++b0) {
         d.imbe_L_lanes[b0 & 63] |= (uint32_t)host->imbe_L[b0] << (8 * (b0 >> 6));
@@ -634,11 +648,16 @@ static int ensure_workspace(Context* c, StreamSlot& slot, size_t frames, void* s
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         HIP_TRY(hipFree(slot.workspace));
         slot.workspace = nullptr;
+        slot.flags = nullptr;
         slot.frames = 0;
         slot.exp_codec = -1;
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot.workspace), want * sizeof(mbx::FrameParams)));
+    const size_t flag_bytes = (((want + 7) / 8 + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;   // (+ 1: the fall-back counter)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot.workspace), want * sizeof(mbx::FrameParams) + flag_bytes));
     slot.frames = want;
+    slot.flags = reinterpret_cast<uint32_t*>(slot.workspace + want);
+    slot.epoch = 0;
+    HIP_TRY(hipMemset(slot.flags, 0, flag_bytes));   // (no launch has epoch 0)
     return 0;
 }
 
@@ -918,20 +937,37 @@ static bool needs_workspace(int codec, int S, int T) {
     return !(T >= kLdsResidentMinFrames && lds_resident_enabled());
 }
 
-// The whole T = 1 step of the IMBE codecs as ONE launch (imbe_stream_kernel_one_fused, mbx_stream.hip): wire frames in, every
-// output out.  Taken by the mbx_process_batch* entry points (which have the frames); the records-based entry points keep the
-// expand + stream pair.  MBX_FUSE_ONE=0 switches it off (A/B timing; read once).
-static bool fused_one_enabled() {
-    static const bool on = [] {
+// The whole T = 1 step of the IMBE codecs as ONE launch (mbx_stream.hip).  Taken by the mbx_process_batch* entry points (which have
+// the frames); the records-based entry points keep the expand + stream pair.  Two forms:
+//   2 (default, 7200x4400): imbe_one_launch_kernel -- front blocks (FEC + expansion of eight frames per wave) and stream blocks in one
+//     grid, rows handed over through the stream's workspace (mbx_front_imbe.h);
+//   1 (7100x4400; 7200x4400 with MBX_FUSE_ONE=1): imbe_stream_kernel_one_fused -- the front end in the stream's own wave.
+// MBX_FUSE_ONE=0 switches both off (A/B timing; read once).  MBX_FRONT_LEAD: by how many chunks of eight streams a front block
+// runs ahead of its stream blocks in the grid.  Default: all front blocks first.  Measured (65,536 x 1, interleaved A/B, one box):
+// lead 0 / 128 / 512: 0.37 / 0.36 / 0.35 ms (stream blocks start before their rows exist and wait); 1024 / 2048 / 4096: 0.2245 /
+// 0.2245 / 0.2230; all first: 0.2229 -- and with the front blocks at a raised wave priority 0.2259 / 0.2253 against 0.2194: what a
+// front block costs is the wave SLOT it holds for the ~10 us of its table-read chain, not its instructions, and slots are what an
+// interleaved front block takes away from stream blocks that could use them.
+static int fused_one_mode() {
+    static const int mode = [] {
         const char* e = getenv("MBX_FUSE_ONE");
-        return !(e && e[0] == '0');
+        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
     }();
-    return on;
+    return mode;
+}
+static int front_lead_chunks() {
+    static const int lead = [] {
+        const char* e = getenv("MBX_FRONT_LEAD");
+        const int v = e ? atoi(e) : 0x7fffffff;
+        return v < 0 ? 0 : v;
+    }();
+    return lead;
 }
 static bool fused_one_ok(int codec, int S, int T, const void* d_frames) {
     return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) && T == 1 && S > kSmallBatchFrames
-           && (reinterpret_cast<uintptr_t>(d_frames) & 3u) == 0 && fused_one_enabled();
+           && (reinterpret_cast<uintptr_t>(d_frames) & 3u) == 0 && fused_one_mode() != 0;
 }
+static bool one_launch_form(int codec) { return codec == MBX_CODEC_IMBE7200X4400 && fused_one_mode() == 2; }
 static int launch_fused_one(Context* c, bool reverse, int codec, int S, const uint8_t* d_frames, mbx_param_record* d_records,
                             mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                             void* stream, const int32_t* d_stream_index, uint32_t* d_resident) {
@@ -946,10 +982,28 @@ static int launch_fused_one(Context* c, bool reverse, int codec, int S, const ui
                        d_pcmf, d_results, tabs);
     return check_launch("imbe_stream_kernel_one_fused");
 }
+// caller holds c->mu; the slot's workspace holds S rows and its flags
+static int launch_one_launch(Context* c, StreamSlot& slot, bool reverse, int S, const uint8_t* d_frames, mbx_param_record* d_records,
+                             mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
+                             void* stream, const int32_t* d_stream_index, uint32_t* d_resident) {
+    mbx::DeviceTables tabs = c->tabs;
+    tabs.reverse = (reverse && reverse_enabled()) ? 1 : 0;
+    tabs.stream_map = d_stream_index;
+    tabs.resident = d_resident;
+    if (++slot.epoch == 0u) {
+        slot.epoch = 1u;
+    }
+    slot.exp_codec = -1;   // the rows of an earlier mbx_expand_records() are being replaced
+    const unsigned chunks = (unsigned)((S + 7) / 8);
+    auto* const kernel = d_resident ? mbx::imbe_one_launch_kernel_res : mbx::imbe_one_launch_kernel;
+    hipLaunchKernelGGL(kernel, dim3(9u * chunks), dim3(64), 0, (hipStream_t)stream, S, front_lead_chunks(), d_frames, d_records, slot.workspace,
+                       slot.flags, slot.flags + (slot.frames + 7) / 8, slot.epoch, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+    return check_launch("imbe_one_launch_kernel");
+}
 // one fused launch if the shape allows it: returns 1 when it was issued (*rc = its status), 0 when the caller goes on with the stages
 static int try_fused_one(int codec, int S, int T, const uint8_t* d_frames, mbx_param_record* d_records, mbe_parms* d_state,
                          mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, void* stream,
-                         const int32_t* d_stream_index, uint32_t* d_resident, int* rc) {
+                         const int32_t* d_stream_index, uint32_t* d_resident, int* rc, bool own_workspace = true) {
     if (!fused_one_ok(codec, S, T, d_frames)) {
         return 0;
     }
@@ -963,12 +1017,27 @@ static int try_fused_one(int codec, int S, int T, const uint8_t* d_frames, mbx_p
         *rc = MBE_STATUS_INVALID_ARGUMENT;
         return 1;
     }
-    unsigned order;
-    {
-        std::lock_guard<std::mutex> lock(c->mu);
-        order = c->slots[stream].launches++;
+    std::lock_guard<std::mutex> lock(c->mu);
+    StreamSlot& slot = c->slots[stream];
+    if (one_launch_form(codec) && own_workspace) {
+        // A launch that is being CAPTURED into a graph would be replayed with the same epoch, and a replay would find the flags of
+        // the replay before it: captured launches take the staged kernels.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        (void)hipGetLastError();
+        if (capturing) {
+            return 0;
+        }
+        const int wrc = ensure_workspace(c, slot, (size_t)S, stream);
+        if (wrc < 0) {
+            *rc = wrc;
+            return 1;
+        }
+        *rc = launch_one_launch(c, slot, (slot.launches++ & 1u) != 0u, S, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
+                                d_stream_index, d_resident);
+        return 1;
     }
-    *rc = launch_fused_one(c, (order & 1u) != 0u, codec, S, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
+    *rc = launch_fused_one(c, (slot.launches++ & 1u) != 0u, codec, S, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
                            d_stream_index, d_resident);
     return 1;
 }
@@ -1265,8 +1334,8 @@ int mbx_process_batch_ws(int codec, int S, int T, const uint8_t* d_frames, mbe_p
     }
     int stream_codec;
     int rc;
-    if (try_fused_one(codec, S, T, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream, nullptr, nullptr, &rc)) {
-        return rc;   // (needs no workspace)
+    if (try_fused_one(codec, S, T, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream, nullptr, nullptr, &rc, false)) {
+        return rc;   // (the form that needs no workspace: the caller's has no flag words)
     }
     rc = launch_fec(codec, d_frames, (size_t)S * (size_t)T, d_records, stream, &stream_codec);
     if (rc < 0) {
@@ -1571,11 +1640,36 @@ int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe
     return check_launch("decode_parms_kernel");
 }
 
+// diagnostics: how many stream blocks of the one-launch kernel have expanded their own frame since the stream's workspace was
+// allocated (a stream block does that when its front block's rows are not there in time); synchronises the stream.  -1: no workspace.
+long long mbx_debug_front_fallbacks(void* stream) {
+    int crc;
+    Context* c = current_ctx(&crc);
+    if (!c) {
+        return crc;
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->slots.find(stream);
+    if (it == c->slots.end() || !it->second.flags) {
+        return -1;
+    }
+    uint32_t v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess
+        || hipMemcpy(&v, it->second.flags + (it->second.frames + 7) / 8, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return MBX_ENODEVICE;
+    }
+    return (long long)v;
+}
+
 // the dominant kernel of mbx_process_batch / _resident for a batch shape (frames 4-byte aligned, as device allocations are)
 const char* mbx_batch_kernel_name(int codec, int S, int T, int resident) {
     if (fused_one_ok(codec, S, T, nullptr)) {
         if (codec == MBX_CODEC_IMBE7100X4400) {
             return resident ? "imbe7100_stream_kernel_res1_fused" : "imbe7100_stream_kernel_one_fused";
+        }
+        if (one_launch_form(codec)) {
+            return resident ? "imbe_one_launch_kernel_res" : "imbe_one_launch_kernel";
         }
         return resident ? "imbe_stream_kernel_res1_fused" : "imbe_stream_kernel_one_fused";
     }

@@ -51,6 +51,8 @@ struct DerivedTables {
                                   // the Golay syndrome of a code word is half_hi[data >> 6] ^ half_lo[data & 63] ^ its parity bits
     uint2    pr_lane[64];         // demodulation sequence in closed form, x_k = A_k x_0 + C_k mod 2^16: entry j = (A | C << 16) of
                                   // k = j + 1 (.x) and of k = j + 65 (.y)
+    uint32_t pr_bits[4096 + 1][4];   // the demodulation sequence of every 12-bit seed, 114 bits each, big-endian: bit 31 - (k & 31) of word
+                                     // k >> 5 = the sequence bit of step k + 1 (x_0 = 16 seed; bit = x >> 15); + one entry of padding
     uint32_t imbe_L_lanes[64];    // byte k of entry j: IMBE L of b0 = j + 64 k (0: no such b0 / invalid L) -- ONE dword per lane holds the
                                   // whole b0 -> L law, so a wave that asks for it before it knows b0 has L without a memory round trip
 };

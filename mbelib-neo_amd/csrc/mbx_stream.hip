@@ -62,6 +62,7 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #define MBX_FSTAMP(i) do { g_frame_stamps[i] = wall_clock64(); } while (0)
 #endif
 #include "mbx_fec_frame.h"
+#include "mbx_front_imbe.h"
 
 // Wave priorities (s_setprio): a wave raises its priority while it is in one of the two VALU-dense stretches of a frame -- the
 // voiced bank's harmonic loop and the unvoiced transform pair -- and (IMBE launches with several frames per stream) in the front
@@ -85,6 +86,9 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #endif
 #ifndef MBX_FLAT_LOADS
 #define MBX_FLAT_LOADS 1   // one-launch T = 1 kernels: unconditional struct loads (see load_parms_arrays)
+#endif
+#ifndef MBX_PRIO_FRONT_BLOCK
+#define MBX_PRIO_FRONT_BLOCK 3
 #endif
 #ifndef MBX_PARK_N
 #define MBX_PARK_N 8   // how many per-lane values wait in LDS across the unvoiced transform pair (synth_core)
@@ -1984,20 +1988,42 @@ __device__ __forceinline__ uint4 frame_record(int fec_codec, Wire wire, mbx_para
 // kFuse = 1: IMBE 7200x4400 frames -- the FEC in two halves (mbx_fec_frame.h): after the head (C0) the fundamental is known, every
 // table read of the expansion goes out, then the rest of the state is requested, and the FEC's tail runs while all of that is on
 // its way.  kFuse = 2: IMBE 7100x4400 frames (own front end, whole; then the same).
+// kFuse = 3: the stream blocks of imbe_one_launch_kernel -- the frame's FrameParams row comes from a FRONT BLOCK of the same launch
+// (mbx_front_imbe.h: FEC + expansion of eight frames by one wave), handed over through a flag word (FrontLink); should the row not
+// be there in time the wave runs the kFuse = 1 front end itself, so nothing here depends on the order in which blocks are dispatched.
+struct FrontLink {
+    const uint32_t* flag = nullptr;   // the ready word of this stream's chunk of eight: == epoch once the chunk's rows are in `params`
+    uint32_t        epoch = 0u;
+    int             pos = -1;         // the block's position among the stream blocks (its blockIdx.x when < 0)
+    void*           lds = nullptr;    // the workgroup's LDS block (shared with the front blocks' arrays: one allocation for both kinds)
+    uint32_t*       fallbacks = nullptr;   // counts the stream blocks that expanded their frame themselves (diagnostics: expected 0)
+};
+#ifndef MBX_FRONT_SPIN
+#define MBX_FRONT_SPIN 160   // polls, ~0.25 us apart (s_sleep 8 = 512 cycles), before a stream block gives up on its front block and
+#endif                       // expands its frame itself: ~40 us, four times a front block's life
 template <bool kPark, bool kFrame = false, bool kRes = false, bool kOne = false, int kFuse = 0>
 __device__ __forceinline__ void
 imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr,
-                 int fec_codec = 0, FrameShadow shadow = FrameShadow{}) {
-    __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
+                 int fec_codec = 0, FrameShadow shadow = FrameShadow{}, FrontLink link = FrontLink{}) {
+    using ScratchT = WaveScratchT<kPark ? 0 : MBX_PARK_N>;
+    ScratchT* scratch_ptr;
+    if constexpr (kFuse == 3) {
+        scratch_ptr = reinterpret_cast<ScratchT*>(link.lds);
+    } else {
+        __shared__ ScratchT scratch_own;
+        scratch_ptr = &scratch_own;
+    }
+    ScratchT& scratch = *scratch_ptr;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;
     uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
-    if ((int)blockIdx.x >= S) {
+    const int bpos = (kFuse == 3) ? link.pos : (int)blockIdx.x;
+    if (bpos >= S) {
         return;
     }
-    const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
+    const int s = tabs_in.reverse ? (S - 1 - bpos) : bpos;
     const int lane_in = lane_id();
     MBX_STAMP(0, false);
     if constexpr (kOne) { MBX_TS(0); }
@@ -2034,6 +2060,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     Parms enh_first, prev_first;       // !kPark: the first frame's views of prev_mp_enhanced / prev_mp ...
     uint32_t h_enh_first = 0u, h_prev_first = 0u;   // ... and their headers, read out where the frame loop needs them
     float row_first = 0.0f;
+    bool have_row = true;   // kFuse == 3: the frame's row came from a front block (else the wave expanded the frame itself)
     ImbeExpandReq xreq;   // kFuse: the expansion's table values, requested at the start
     if constexpr (kPark) {
         slot_prev = &park.prev;
@@ -2079,15 +2106,22 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         TabScalar fused_tab;       // kFuse == 2 (7100x4400): the scalar-unit FEC
         LaneFecTables lane_tabs;   // kFuse == 1 (7200x4400): the lane-parallel FEC
         uint32_t hgen[2] = {0u, 0u};
+        uint32_t flag_v = 0u;
         const uint8_t* const frame_ptr = frame_in + 18u * (size_t)s;
-        if constexpr (kFuse != 0) {
+        auto fetch_hgen = [&]() {
+            const __attribute__((address_space(4))) uint32_t* hg =
+                (const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)tabs_in.t
+                                                                    + offsetof(mbx_tables, hamming_gen));
+            hgen[0] = hg[0];
+            hgen[1] = hg[1];
+        };
+        if constexpr (kFuse == 3) {
+            flag_v = __hip_atomic_load(link.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the wave's first vector load (bypasses L1)
+            asm volatile("" ::: "memory");
+        } else if constexpr (kFuse != 0) {
             frame_words = frame_fetch_scalar_imbe(frame_ptr);   // scalar loads: first of all, own counter
             if constexpr (kFuse == 1) {
-                const __attribute__((address_space(4))) uint32_t* hg =
-                    (const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)tabs_in.t
-                                                                        + offsetof(mbx_tables, hamming_gen));
-                hgen[0] = hg[0];
-                hgen[1] = hg[1];
+                fetch_hgen();
                 lane_tabs = lane_fec_request(tabs_in.d, lane_in);   // the first vector loads of the wave: the FEC's lane-held tables ...
             } else {
                 fused_tab = TabScalar(tabs_in.t);   // (the generator rows of the two codes with the frame)
@@ -2105,25 +2139,57 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         load_prev_arrays<kFlat>(prev_first, slot_prev, lane_in);
         load_parms_arrays<kFlat>(cur, slot_cur, lane_in);
         load_enh_arrays<kFlat>(enh_first, enh_src, lane_in);
-        if constexpr (kFuse != 0) {
+        mbx_param_record* const rec_out = const_cast<mbx_param_record*>(&records[(size_t)s * (size_t)Tn]);
+        auto L_of = [&](int b0) -> int {   // wave-uniform b0
+            return (b0 <= 207) ? (int)((__builtin_amdgcn_readlane((int)l_lanes, b0 & 63) >> (8 * (b0 >> 6))) & 0xff) : 0;
+        };
+        auto front_in_wave_7200 = [&]() {   // FEC by lanes (mbx_fec_frame.h, LaneFec) + in-wave expansion of this stream's frame
+            asm volatile("" : "+s"(frame_words.d[0]), "+s"(frame_words.d[1]), "+s"(frame_words.d[2]), "+s"(frame_words.d[3]),
+                         "+s"(frame_words.d[4])::"memory");   // (the first use of the frame's bytes: not scheduled in front of the loads above)
+            MBX_TS(14);   // (fused) the frame's bytes are there
+            const LaneFecHead head = lane_fec_imbe_head(frame_words, (reinterpret_cast<uintptr_t>(frame_ptr) & 2u) != 0u, lane_tabs, tabs_in.t,
+                                                        lane_in);
+            expand_imbe_request(xreq, head.b0, tabs_in.t, tabs_in.d, lane_in, L_of(head.b0));
+            asm volatile("" ::: "memory");
+            MBX_TS(15);   // (fused) C0 corrected, L known, the expansion's table reads requested
+            rec_in = broadcast_record(lane_fec_imbe_tail(head, lane_tabs, hgen, tabs_in.t, lane_in), rec_out, lane_in);
+            MBX_TS(10);   // (fused) frame fetched, FEC done, every request issued
+            expand_imbe_finish(rec_in, xreq, scratch, lane_in);   // before anything reads the state out
+            MBX_TS(11);   // (fused) table values there, expanded
+        };
+        if constexpr (kFuse == 3) {
+            // The row of this stream's frame is written by a front block of the same launch, dispatched thousands of blocks earlier:
+            // normally the flag read at the very start already says so.  Hand-over per MI355X_MICROARCH.md (inter-workgroup
+            // visibility): the producer stores the rows with sc1 stores, drains them (s_waitcnt vmcnt(0)) and then stores the flag
+            // sc1; the consumer polls the flag with sc1 loads and, once it matches, reads the row with sc1 loads -- no L1 invalidate.
+            asm volatile("" ::: "memory");
+            bool ready = uni(flag_v) == link.epoch;
+            for (int tries = 0; !ready && tries < MBX_FRONT_SPIN; ++tries) {
+                __builtin_amdgcn_s_sleep(8);
+                ready = uni(__hip_atomic_load(link.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == link.epoch;
+            }
+            if (ready) {
+                const uint32_t* const rowp = reinterpret_cast<const uint32_t*>(&params[(size_t)s * (size_t)Tn].v[0]);
+                row_first = __uint_as_float(__hip_atomic_load(rowp + lane_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                have_row = true;
+            } else {   // (never observed: the dispatch order is not a contract, so the wave can also do without its front block)
+                frame_words = frame_fetch_scalar_imbe(frame_ptr);
+                fetch_hgen();
+                lane_tabs = lane_fec_request(tabs_in.d, lane_in);
+                l_lanes = tab_at<uint32_t>(tabs_in.d, offsetof(DerivedTables, imbe_L_lanes), 4u * (uint32_t)lane_in);
+                front_in_wave_7200();
+                have_row = false;
+                if (link.fallbacks && lane_in == 0) {
+                    atomicAdd(link.fallbacks, 1u);
+                }
+            }
+        } else if constexpr (kFuse != 0) {
             // The front end of the frame while the state is on its way.  Its chain of dependent memory round trips is what a fused wave
             // pays for (tools/stage_times.py): the frame's bytes -> C0's Golay correction -> [b0 -> L: from l_lanes, no trip] -> the
             // expansion's table reads, with the FEC's tail (one more table trip) in their shadow.
             asm volatile("" ::: "memory");
-            mbx_param_record* const rec_out = const_cast<mbx_param_record*>(&records[(size_t)s * (size_t)Tn]);
-            auto L_of = [&](int b0) -> int {   // wave-uniform b0
-                return (b0 <= 207) ? (int)((__builtin_amdgcn_readlane((int)l_lanes, b0 & 63) >> (8 * (b0 >> 6))) & 0xff) : 0;
-            };
             if constexpr (kFuse == 1) {
-                asm volatile("" : "+s"(frame_words.d[0]), "+s"(frame_words.d[1]), "+s"(frame_words.d[2]), "+s"(frame_words.d[3]),
-                             "+s"(frame_words.d[4])::"memory");   // (the first use of the frame's bytes: not scheduled in front of the loads above)
-                MBX_TS(14);   // (fused) the frame's bytes are there
-                const LaneFecHead head = lane_fec_imbe_head(frame_words, (reinterpret_cast<uintptr_t>(frame_ptr) & 2u) != 0u, lane_tabs, tabs_in.t,
-                                                            lane_in);
-                expand_imbe_request(xreq, head.b0, tabs_in.t, tabs_in.d, lane_in, L_of(head.b0));
-                asm volatile("" ::: "memory");
-                MBX_TS(15);   // (fused) C0 corrected, L known, the expansion's table reads requested
-                rec_in = broadcast_record(lane_fec_imbe_tail(head, lane_tabs, hgen, tabs_in.t, lane_in), rec_out, lane_in);
+                front_in_wave_7200();
             } else {
                 wire_in = frame_words_to_wire(frame_ptr, frame_words);
                 const PrLane pr_lanes(lane_in);   // (lane constants of the demodulation sequence)
@@ -2135,10 +2201,10 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 rec_in = broadcast_record(fec_imbe7100x4400_wire(fused_tab, wire_in), rec_out, lane_in);
                 const int b0 = imbe_record_b0(rec_in);
                 expand_imbe_request(xreq, b0, tabs_in.t, tabs_in.d, lane_in, L_of(b0));
+                MBX_TS(10);   // (fused) frame fetched, FEC done, every request issued
+                expand_imbe_finish(rec_in, xreq, scratch, lane_in);   // before anything reads the state out
+                MBX_TS(11);   // (fused) table values there, expanded
             }
-            MBX_TS(10);   // (fused) frame fetched, FEC done, every request issued
-            expand_imbe_finish(rec_in, xreq, scratch, lane_in);   // before anything reads the state out
-            MBX_TS(11);   // (fused) table values there, expanded
         }
         set_parms_header(cur, h_cur);
         MBX_TS(1);   // cur_mp's scalars are there (first round trip)
@@ -2188,7 +2254,12 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             load_enh_view(enh, elided1 ? slot_cur : slot_enh, lane);
             load_prev_view(prev, slot_prev, lane);
         }
-        if (params) {
+        if constexpr (kFuse == 3) {
+            if (have_row) {
+                scratch.x.fp[lane] = row_first;
+                wave_lds_sync();
+            }
+        } else if (params) {
             scratch.x.fp[lane] = kOne ? row_first : params[f].v[lane];
             wave_lds_sync();
         } else if constexpr (kFuse != 0) {
@@ -2390,6 +2461,105 @@ imbe7100_stream_kernel_res1_fused(int S, int fec_codec, const uint8_t* __restric
                                   mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                                   float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     imbe_stream_body<false, false, true, true, 2>(S, 1, records, nullptr, state, rngs, pcm16, pcmf, results, tabs_in, frames, fec_codec);
+}
+
+// ------------------------------------------------------------------------------------------
+// imbe_one_launch_kernel: the whole T = 1 step of the IMBE 7200x4400 codec as ONE launch whose grid holds two kinds of
+// one-wave workgroups: FRONT blocks (FEC + parameter expansion of eight frames each, mbx_front_imbe.h) and STREAM blocks
+// (the one-frame stream stage, imbe_stream_body kFuse = 3).  Order in the grid (C = chunks of eight streams, D = lead chunks):
+//   front 0 .. D-1 | front D, stream 0..7 | front D+1, stream 8..15 | ... | front C-1, ... | the last 8 D stream blocks
+// so the front block of a chunk sits 9 D blocks ahead of its stream blocks: by the time those start, its rows are in the
+// workspace, and its work -- table gathers and integer arithmetic -- has run in the shadow of stream blocks that wait for HBM.
+// A stream block that does not find its row (its flag word != this launch's epoch) after ~25 us expands its frame itself.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void front_block_imbe(int chunk, int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
+                                                 FrameParams* __restrict__ rows, uint32_t* __restrict__ flags, uint32_t epoch,
+                                                 const DeviceTables& tabs, void* lds) {
+    constexpr int kRowPad = 65;
+    float (*tile)[kRowPad] = reinterpret_cast<float (*)[kRowPad]>(lds);                                   // 8 x 65 floats
+    uint32_t (*words)[64] = reinterpret_cast<uint32_t (*)[64]>(reinterpret_cast<char*>(lds) + 8 * kRowPad * 4);   // 8 x 64 words
+    float (*gains)[8] = reinterpret_cast<float (*)[8]>(reinterpret_cast<char*>(lds) + 8 * kRowPad * 4 + 8 * 64 * 4);   // 8 x 8 floats
+    const int lane = lane_id();
+    const int fi = lane >> 3, sub = lane & 7;
+    const int j = 8 * chunk + fi;
+    const bool have = j < S;
+    __builtin_amdgcn_s_setprio(MBX_PRIO_FRONT_BLOCK);   // a front block holds a wave slot for as long as its chain of table reads takes: first in line
+    const int sj = have ? (tabs.reverse ? (S - 1 - j) : j) : 0;
+    const uint4 rec = front8_fec_imbe(have, frames + 18u * (size_t)sj, tabs, lane);
+    if (have && sub == 0) {
+        *reinterpret_cast<uint4*>(&records[sj]) = rec;   // (an output of the call, not read by the stream blocks)
+    }
+    xp::expand_imbe_frame_rec(have, rec, tile[fi], words[fi], gains[fi], sub, tabs);
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int jq = 8 * chunk + q;
+        if (jq < S) {   // one 256-byte row = two whole 128-byte lines by ONE store instruction of the wave, written through (sc1)
+            const int sq = tabs.reverse ? (S - 1 - jq) : jq;
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(&rows[sq].v[0]) + lane, __float_as_uint(tile[q][lane]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every row store of the wave has left ...
+    if (lane == 0) {
+        __hip_atomic_store(&flags[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag does
+    }
+}
+
+template <bool kRes>
+__device__ __forceinline__ void imbe_one_launch_body(int S, int lead, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
+                                                     FrameParams* __restrict__ rows, uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks,
+                                                     uint32_t epoch, mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                                                     float* __restrict__ pcmf, mbe_process_result* __restrict__ results, const DeviceTables& tabs_in) {
+    const int C = (S + 7) >> 3;
+    const int D = lead < C ? (lead < 0 ? 0 : lead) : C;
+    const int G = C - D;
+    const int bid = (int)blockIdx.x;   // 9 C blocks
+    int chunk = -1, pos = -1;
+    if (bid < D) {
+        chunk = bid;
+    } else {
+        const int q = bid - D;
+        if (q < 9 * G) {
+            const int g = q / 9, r = q - 9 * g;
+            if (r == 0) {
+                chunk = D + g;
+            } else {
+                pos = 8 * g + r - 1;
+            }
+        } else {
+            pos = 8 * G + (q - 9 * G);
+        }
+    }
+    constexpr size_t kFrontLds = 8 * 65 * 4 + 8 * 64 * 4 + 8 * 8 * 4, kStreamLds = sizeof(WaveScratchT<MBX_PARK_N>);
+    __shared__ alignas(16) char lds[kFrontLds > kStreamLds ? kFrontLds : kStreamLds];   // ONE block of LDS for either kind of workgroup
+    if (chunk >= 0) {
+        front_block_imbe(chunk, S, frames, records, rows, flags, epoch, tabs_in, lds);
+        return;
+    }
+    FrontLink link;
+    link.lds = lds;
+    link.fallbacks = fallbacks;
+    link.flag = &flags[pos >> 3];
+    link.epoch = epoch;
+    link.pos = pos;
+    imbe_stream_body<false, false, kRes, true, 3>(S, 1, records, rows, state, rngs, pcm16, pcmf, results, tabs_in, frames, MBX_CODEC_IMBE7200X4400,
+                                                  FrameShadow{}, link);
+}
+
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe_one_launch_kernel(int S, int lead, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
+                       uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks, uint32_t epoch, mbe_parms* __restrict__ state,
+                       mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                       mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_one_launch_body<false>(S, lead, frames, records, rows, flags, fallbacks, epoch, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+__global__ void __launch_bounds__(64, MBX_STREAM_WAVES_PER_SIMD)
+imbe_one_launch_kernel_res(int S, int lead, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
+                           uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks, uint32_t epoch, mbe_parms* __restrict__ state,
+                           mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                           mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    imbe_one_launch_body<true>(S, lead, frames, records, rows, flags, fallbacks, epoch, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 // T >= 4: prev_mp resident in LDS (see ParkedPrevOnly).  5,200 B of LDS per wave allow 25 waves per CU, so the register

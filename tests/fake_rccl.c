@@ -137,11 +137,13 @@ ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
 
 /* every rank deposits (pointer, word); when the last one is in, `combine` (if any) runs once; returns with all deposits visible.
  * leave = 0: the rendezvous BEFORE the data movement; call again with leave = 1 after it so that nobody's buffer goes away early */
-static void meet(Group* g, int rank, const void* p, uint32_t w, ncclRedOp_t op, int reduce) {
+static void meet(Group* g, int rank, const void* p, uint32_t w, ncclRedOp_t op, int reduce, int deposit) {
     pthread_mutex_lock(&g->mu);
     const int gen = g->generation;
-    g->ptr[rank] = p;
-    g->word[rank] = w;
+    if (deposit) {   /* (the rendezvous AFTER a data movement deposits nothing: a fast rank must not wipe what a slow one still reads) */
+        g->ptr[rank] = p;
+        g->word[rank] = w;
+    }
     if (++g->arrived == g->nranks) {
         if (reduce) {
             uint32_t r = g->word[0];
@@ -170,7 +172,7 @@ ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, n
     if (hipStreamSynchronize(stream) != hipSuccess) {   /* the root's upload is queued on its stream */
         rc = ncclUnhandledCudaError;
     }
-    meet(g, comm->rank, comm->rank == root ? sendbuff : recvbuff, 0u, ncclMin, 0);
+    meet(g, comm->rank, comm->rank == root ? sendbuff : recvbuff, 0u, ncclMin, 0, 1);
     if (comm->rank != root && rc == ncclSuccess) {
         if (hipMemcpy(recvbuff, g->ptr[root], count, hipMemcpyDeviceToDevice) != hipSuccess) {
             rc = ncclUnhandledCudaError;
@@ -183,7 +185,7 @@ ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, n
             }
         }
     }
-    meet(g, comm->rank, NULL, 0u, ncclMin, 0);   /* the root's buffer stays until everybody has copied */
+    meet(g, comm->rank, NULL, 0u, ncclMin, 0, 0);   /* the root's buffer stays until everybody has copied */
     if (comm->rank == g->fail_bcast_rank) {
         rc = ncclSystemError;
     }
@@ -202,9 +204,9 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
         rc = ncclUnhandledCudaError;
         w = (op == ncclMin) ? 0u : 0xffffffffu;   /* a rank that cannot read its value cannot agree */
     }
-    meet(g, comm->rank, NULL, w, op, 1);
+    meet(g, comm->rank, NULL, w, op, 1, 1);
     const uint32_t r = g->result;
-    meet(g, comm->rank, NULL, 0u, op, 0);        /* everybody has read the result before the next collective overwrites it */
+    meet(g, comm->rank, NULL, 0u, op, 0, 0);     /* everybody has read the result before the next collective overwrites it */
     if (hipMemcpy(recvbuff, &r, sizeof(r), hipMemcpyHostToDevice) != hipSuccess) {
         rc = ncclUnhandledCudaError;
     }

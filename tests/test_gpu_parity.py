@@ -469,8 +469,8 @@ def test_imbe_voiced_config2_full_shape(mbx, oracle):
     d_pick = torch.from_numpy(pick).cuda()
     L = mbx.lib()
     assert L.mbx_stream_kernel_name(0, 1) == b"imbe_stream_kernel_one"
-    fused = L.mbx_batch_kernel_name(0, S, 1, 0) == b"imbe_stream_kernel_one_fused"
-    assert fused or os.environ.get("MBX_FUSE_ONE") == "0"
+    one_launch = L.mbx_batch_kernel_name(0, S, 1, 0) in (b"imbe_one_launch_kernel", b"imbe_stream_kernel_one_fused")
+    assert one_launch or os.environ.get("MBX_FUSE_ONE") == "0"
     a = _full_shape_run(0, S, [1] * T, frames, seeds, d_pick)                 # mbx_process_batch: the fused launch
     st = _full_shape_run_staged(0, S, T, frames, seeds, d_pick)               # imbe_stream_kernel_one behind FEC + expansion
     assert a[3].tobytes() == st[3].tobytes() and a[4].tobytes() == st[4].tobytes()
@@ -513,7 +513,8 @@ def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
     frames[::5] &= framegen.random_frames(codec, ((S + 4) // 5) * T, framegen.rng_for(0xF8 + codec)).reshape(-1, T, 18)   # some with few errors
     seeds = np.arange(S) + 77
     L = mbx.lib()
-    assert L.mbx_batch_kernel_name(codec, S, 1, 0).endswith(b"stream_kernel_one_fused") or os.environ.get("MBX_FUSE_ONE") == "0"
+    assert L.mbx_batch_kernel_name(codec, S, 1, 0) in (b"imbe_one_launch_kernel", b"imbe_stream_kernel_one_fused", b"imbe7100_stream_kernel_one_fused") \
+        or os.environ.get("MBX_FUSE_ONE") == "0"
 
     def run(staged):
         dec = decoder.BatchDecoder(codec, S, seeds=seeds)
@@ -531,6 +532,25 @@ def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
     assert fs.tobytes() == ss.tobytes() and fr.tobytes() == sr.tobytes()
     flags = decoder.results_numpy(torch.from_numpy(np.concatenate([o["results"] for o in fo])))["flags"]
     assert (flags & 0x40).any() and (flags & 0x80).any()   # repeats and mutes were in it
+
+    # the caller-workspace entry point takes the in-wave form of the one-launch step (FEC by lanes + expansion in the stream's own
+    # wave -- also what a stream block of imbe_one_launch_kernel falls back to): same bytes again
+    ws_bytes = int(L.mbx_workspace_bytes(S))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    dec = decoder.BatchDecoder(codec, S, seeds=seeds)
+    strm = torch.cuda.current_stream().cuda_stream
+    for t in range(2):
+        out = dec.make_outputs(1, want_float=True)
+        d_fr = dec.to_device(np.ascontiguousarray(frames[:, t]))
+        _native.check(L.mbx_process_batch_ws(codec, S, 1, d_fr.data_ptr(), dec.state.data_ptr(), dec.rng.data_ptr(), out["pcm16"].data_ptr(),
+                                             out["pcmf"].data_ptr(), out["results"].data_ptr(), out["records"].data_ptr(), ws.data_ptr(), ws_bytes,
+                                             strm), "mbx_process_batch_ws")
+        torch.cuda.synchronize()
+        for k in ("records", "results", "pcm16", "pcmf"):
+            assert out[k].cpu().numpy().tobytes() == fo[t][k].tobytes(), (t, k)
+    fb = L.mbx_debug_front_fallbacks(strm)
+    print("front-block fall-backs so far on this stream:", fb)
+    assert fb <= 0 or fb < S // 50   # (a stream block that does not find its row in time expands its own frame: rare, never wrong)
 
     # a 2-byte aligned frame buffer: same results (the staged launches serve it)
     dec = decoder.BatchDecoder(codec, S, seeds=seeds)
