@@ -614,8 +614,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
                   3: "fec_ambe3600x2450_soft_kernel"}[codec]
         alg_bytes = soft_fec_bytes_per_launch(codec, n)
     else:
-        kernel = (L.mbx_batch_kernel_name(codec, S, T, 1 if resident else 0) if fused
-                  else L.mbx_stream_kernel_name(codec, -T if resident else T)).decode()   # (T < 0: the instances of the resident launches)
+        kernel = batch_kernel   # the dominant kernel of the step for this shape (one-launch / time-sliced / plain instance)
         alg_bytes = algorithmic_bytes_per_launch(codec, S, T, resident)
     del dec, d_frames, out
     torch.cuda.empty_cache()

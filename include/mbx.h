@@ -430,6 +430,13 @@ const char* mbx_batch_kernel_name(int codec, int S, int T, int resident);
  * expanded their own frame instead, since the workspace of `stream` was allocated (expected 0; results are the same either way).
  * Synchronises the stream.  -1: the stream has no workspace yet. */
 long long mbx_debug_front_fallbacks(void* stream);
+/* Sliced launches.  A launch of S streams x T >= 32 frames whose S does not fill the device's resident wave slots evenly (the
+ * last round of waves would run part-empty: 8,192 streams on 5,120 slots are 1.6 rounds) is cut into three groups of streams x
+ * slices of 16 frames, issued in order on three internal HIP streams that are forked from and joined to the caller's stream with
+ * events: the groups' kernels fill each other's empty slots.  Results are bit-identical to the plain launch (a slice IS a launch
+ * of 16 frames per stream).  Not taken under stream capture.  mbx_launch_slices: the slice length in frames for a shape (0: not
+ * sliced); MBX_SLICE=0 / =n in the environment switches it off / sets the slice length. */
+int mbx_launch_slices(int codec, int S, int T);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,12 @@ __global__ void imbe_stream_kernel_one_fused(int, int, const uint8_t*, mbx_param
                                              mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res1_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
                                               mbe_process_result*, DeviceTables);
+__global__ void imbe_stream_kernel_lds_slice(int, int, int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                             mbe_process_result*, DeviceTables);
+__global__ void ambe_stream_kernel_lds_slice(int, int, int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                             mbe_process_result*, DeviceTables);
+__global__ void ambe2400_stream_kernel_lds_slice(int, int, int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*, int16_t*,
+                                                 float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_one_launch_kernel(int, int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
                                        mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_one_launch_kernel_res(int, int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
@@ -103,6 +109,8 @@ struct StreamSlot {                      // what a hipStream_t owns inside a con
     size_t            frames = 0;
     uint32_t*         flags = nullptr;       // one-launch T = 1 step: ready word per chunk of eight rows (behind the rows, same allocation)
     uint32_t          epoch = 0;             // ... == the epoch of the launch that wrote them; a new value every launch
+    hipStream_t       side[4] = {nullptr, nullptr, nullptr, nullptr};   // sliced launches: the internal streams the groups' slices are issued on ...
+    hipEvent_t        fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};   // ... and the events that hang them between the caller's launches
     unsigned          launches = 0;          // parity = direction in which the next stream-kernel launch walks the streams
     int               exp_codec = -1;        // what mbx_expand_records() last left in the workspace
     size_t            exp_n = 0;
@@ -166,11 +174,30 @@ Context* current_ctx(int* rc) {
         return rc_ctx_;                \
     }
 
+void release_side_streams(StreamSlot& slot) {
+    for (int g = 0; g < 4; ++g) {
+        if (slot.side[g]) {
+            (void)hipStreamSynchronize(slot.side[g]);
+            (void)hipStreamDestroy(slot.side[g]);
+            slot.side[g] = nullptr;
+        }
+        if (slot.join[g]) {
+            (void)hipEventDestroy(slot.join[g]);
+            slot.join[g] = nullptr;
+        }
+    }
+    if (slot.fork) {
+        (void)hipEventDestroy(slot.fork);
+        slot.fork = nullptr;
+    }
+}
+
 void free_context(Context& c) {   // caller holds g_init_mu and c.mu
     (void)hipFree(c.d_blob);
     (void)hipFree(c.d_derived);
     for (auto& kv : c.slots) {
         (void)hipFree(kv.second.workspace);
+        release_side_streams(kv.second);
     }
     c.slots.clear();
     c.d_blob = c.d_derived = nullptr;
@@ -690,6 +717,7 @@ int mbx_release_stream(void* stream) {
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         HIP_TRY(hipFree(it->second.workspace));
     }
+    release_side_streams(it->second);
     c->slots.erase(it);
     return 0;
 }
@@ -832,6 +860,128 @@ static int launch_expand(Context* c, int codec, const mbx_param_record* d_record
     return check_launch("expand_kernel");
 }
 
+// ---- sliced launches (mbx_stream.hip, *_stream_kernel_lds_slice) ------------------------------------------------------------------
+// A launch of S streams x T frames is S workgroups of equal length; when S does not fill the device's resident wave slots evenly
+// the last round runs part-empty -- BASELINE configs[4]'s shard, 8,192 AMBE+2 streams on 5,120 slots, is 1.6 rounds: the second
+// holds 3,072 waves.  Frames of a stream are sequential, but nothing says they must be ONE launch's: the streams are split into
+// THREE groups and the frames into slices of 16, and the slices of each group are issued in order on an internal HIP stream of its
+// own (forked from and joined to the caller's stream with events).  Measured, 8,192 x 128 AMBE+2, interleaved A/B on one box: plain
+// 2.609 ms; two groups 2.518; three 2.481 (-4.7 %); FOUR 3.185 (+22 %: with the caller's stream that is five streams on HIP's four
+// hardware queues, and two groups then share one); slices of 8 / 16 / 32 frames with two groups: 2.512 / 2.524 / 2.585.  A slice IS a launch of 16 frames per stream (state in from HBM,
+// state out: results bit-identical by construction); the streams' kernels share the device, so the slots one group's slice
+// leaves empty are taken by another group's next one (ideal: work / slots = 2.29 ms for that shape instead of ceil(S / slots) rounds).
+// Kernel boundaries do the ordering: no in-kernel waiting, no assumption about dispatch.  (Built first as ONE grid of K x S
+// workgroups that waited for their stream's previous slice on a progress word: the agent-scope release / acquire pair every slice
+// then needs -- an L2 write-back with the PCM of 5,120 waves dirty in it -- made 8,192 x 128 in eight slices 34 % SLOWER.)
+// MBX_SLICE=0 switches it off, MBX_SLICE=n sets the slice length in frames (A/B timing; read once).
+static int slice_override() {
+    static const int v = [] {
+        const char* e = getenv("MBX_SLICE");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+// frames per slice for a launch of S streams x T frames on `slots` resident waves, or 0: the plain launch
+static int choose_slice_frames(int S, int T, int slots) {
+    const int forced = slice_override();
+    if (forced == 0 || slots <= 0 || S < 2) {
+        return 0;
+    }
+    const int Tc = forced > 0 ? ((forced + 7) & ~7) : 16;   // multiples of eight: the AMBE bodies expand eight frames at a time
+    if (T < 2 * Tc) {
+        return 0;
+    }
+    if (forced > 0) {
+        return Tc;
+    }
+    if (S <= slots) {   // every stream has a slot of its own: nothing to balance
+        return 0;
+    }
+    const double ideal = (double)S / (double)slots;
+    const double plain = (double)((S + slots - 1) / slots);
+    return (plain >= 1.06 * ideal) ? Tc : 0;   // what the part-empty last round costs must be worth the extra launches
+}
+// caller holds c->mu.  0: issued (*rc); 1: not applicable (take the plain launch)
+static int try_sliced_launch(Context* c, StreamSlot& slot, mbx::DeviceTables tabs, int codec, int S, int T, const mbx_param_record* d_records,
+                             const mbx::FrameParams* params, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
+                             mbe_process_result* d_results, void* stream, int* rc) {
+    const int waves = (codec == MBX_CODEC_IMBE7200X4400) ? 6 : 5;   // MBX_IMBE_LDS_WAVES_PER_SIMD / MBX_AMBE_LDS_WAVES_PER_SIMD (mbx_stream.hip)
+    const int Tc = choose_slice_frames(S, T, waves * c->simds);
+    if (Tc <= 0) {
+        return 1;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = stream && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+    if (capturing) {
+        return 1;
+    }
+    if (!slot.fork) {   // first sliced launch on this stream: its two internal streams and three events
+        bool ok = hipEventCreateWithFlags(&slot.fork, hipEventDisableTiming) == hipSuccess;
+        for (int g = 0; g < 4 && ok; ++g) {
+            ok = hipStreamCreateWithFlags(&slot.side[g], hipStreamNonBlocking) == hipSuccess
+                 && hipEventCreateWithFlags(&slot.join[g], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            release_side_streams(slot);
+            return 1;
+        }
+    }
+    if (hipEventRecord(slot.fork, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    int result = 0;
+    static const int groups = [] {
+        const char* e = getenv("MBX_SLICE_GROUPS");
+        const int v = e ? atoi(e) : 3;
+        return v < 2 ? 2 : (v > 4 ? 4 : v);
+    }();
+    for (int g = 0; g < groups; ++g) {
+        const int s0 = (int)((long long)S * g / groups), Sg = (int)((long long)S * (g + 1) / groups) - s0;
+        hipStream_t st = slot.side[g];
+        if (hipStreamWaitEvent(st, slot.fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            result = fail(MBX_ENODEVICE, "sliced launch: hipStreamWaitEvent");
+            break;
+        }
+        mbx::DeviceTables tg = tabs;
+        if (tg.stream_map) {
+            tg.stream_map += s0;
+        }
+        const size_t f0 = (size_t)s0 * (size_t)T;
+        const mbx_param_record* rg = d_records + f0;
+        const mbx::FrameParams* pg = params ? params + f0 : nullptr;
+        // (state and RNG state are addressed through the stream map when there is one: then only the batch rows are offset)
+        mbe_parms* sg = tabs.stream_map ? d_state : d_state + 3 * (size_t)s0;
+        mbx_stream_rng* ng = tabs.stream_map ? d_rng : d_rng + s0;
+        int16_t* p16 = d_pcm16 ? d_pcm16 + f0 * 160 : nullptr;
+        float* pf = d_pcmf ? d_pcmf + f0 * 160 : nullptr;
+        mbe_process_result* rs = d_results ? d_results + f0 : nullptr;
+        for (int t0 = 0; t0 < T; t0 += Tc) {
+            const int n = (T - t0) < Tc ? (T - t0) : Tc;
+            if (codec == MBX_CODEC_IMBE7200X4400) {
+                hipLaunchKernelGGL(mbx::imbe_stream_kernel_lds_slice, dim3((unsigned)Sg), dim3(64), 0, st, Sg, T, t0, n, rg, pg, sg, ng, p16, pf, rs, tg);
+            } else if (codec == MBX_CODEC_AMBE3600X2400) {
+                hipLaunchKernelGGL(mbx::ambe2400_stream_kernel_lds_slice, dim3((unsigned)Sg), dim3(64), 0, st, Sg, T, t0, n, rg, pg, sg, ng, p16, pf, rs, tg);
+            } else {
+                hipLaunchKernelGGL(mbx::ambe_stream_kernel_lds_slice, dim3((unsigned)Sg), dim3(64), 0, st, Sg, T, t0, n, rg, pg, sg, ng, p16, pf, rs, tg);
+            }
+        }
+        const int lrc = check_launch("stream_kernel_lds_slice");
+        if (lrc < 0) {
+            result = lrc;
+        }
+        if (hipEventRecord(slot.join[g], st) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, slot.join[g], 0) != hipSuccess) {
+            (void)hipGetLastError();
+            result = fail(MBX_ENODEVICE, "sliced launch: join");
+        }
+    }
+    *rc = result;
+    return 0;
+}
+
 // Stream-stage launch.  `params` = FrameParams rows written by the expand stage, or nullptr: the IMBE stream kernel
 // then expands each record itself (one launch less, no workspace traffic).
 //
@@ -843,7 +993,7 @@ static int launch_expand(Context* c, int codec, const mbx_param_record* d_record
 static int launch_stream(Context* c, bool reverse, int codec, int S, int T, const mbx_param_record* d_records,
                          const mbx::FrameParams* params, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16,
                          float* d_pcmf, mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr,
-                         uint32_t* d_resident = nullptr) {
+                         uint32_t* d_resident = nullptr, StreamSlot* slot = nullptr /* caller holds c->mu: time-sliced launches allowed */) {
     mbx::DeviceTables tabs = c->tabs;
     tabs.reverse = (reverse && reverse_enabled()) ? 1 : 0;
     tabs.stream_map = d_stream_index;
@@ -852,6 +1002,12 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
     // four waves per SIMD) instead of being parked in their HBM slots every frame: mbx_stream.hip, ParkedState.
     // Resident state (d_resident) is understood by those instances only, whatever T is.
     const bool lds_resident = T >= kLdsResidentMinFrames && lds_resident_enabled();
+    if (slot && lds_resident && !d_resident) {
+        int rc = 0;
+        if (try_sliced_launch(c, *slot, tabs, codec, S, T, d_records, params, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream, &rc) == 0) {
+            return rc;
+        }
+    }
     if (d_resident) {
         if (codec == MBX_CODEC_IMBE7200X4400 && T == 1 && res1_enabled()) {
             hipLaunchKernelGGL(mbx::imbe_stream_kernel_res1, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
@@ -1049,7 +1205,7 @@ extern "C" int mbx_uses_expand_launch(int codec, int S, int T) { return needs_wo
 static int run_stream_stage(Context* c, unsigned order, int codec, int S, int T, const mbx_param_record* d_records,
                             mbx::FrameParams* ws, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
                             mbe_process_result* d_results, void* stream, const int32_t* d_stream_index = nullptr,
-                            uint32_t* d_resident = nullptr) {
+                            uint32_t* d_resident = nullptr, StreamSlot* slot = nullptr) {
     if (needs_workspace(codec, S, T)) {
         int rc = launch_expand(c, codec, d_records, (size_t)S * (size_t)T, ws, stream);
         if (rc < 0) {
@@ -1059,7 +1215,7 @@ static int run_stream_stage(Context* c, unsigned order, int codec, int S, int T,
         ws = nullptr;
     }
     return launch_stream(c, (order & 1u) != 0u, codec, S, T, d_records, ws, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
-                         d_stream_index, d_resident);
+                         d_stream_index, d_resident, slot);
 }
 
 int mbx_expand_records(int codec, const mbx_param_record* d_records, size_t n, void* stream) {
@@ -1181,7 +1337,7 @@ int mbx_process_records(int codec, int S, int T, const mbx_param_record* d_recor
         slot.exp_codec = -1;   // the rows are about to be replaced
     }
     return run_stream_stage(c, slot.launches++, codec, S, T, d_records, slot.workspace, d_state, d_rng, d_pcm16, d_pcmf, d_results,
-                            stream);
+                            stream, nullptr, nullptr, &slot);
 }
 
 int mbx_process_records_ws(int codec, int S, int T, const mbx_param_record* d_records, mbe_parms* d_state,
@@ -1375,7 +1531,7 @@ int mbx_process_batch_indexed(int codec, int S, int T, const int32_t* d_stream_i
         slot.exp_codec = -1;
     }
     return run_stream_stage(c, slot.launches++, stream_codec, S, T, d_records, slot.workspace, d_state_pool, d_rng_pool, d_pcm16,
-                            d_pcmf, d_results, stream, d_stream_index);
+                            d_pcmf, d_results, stream, d_stream_index, nullptr, &slot);
 }
 
 // ---- resident state (sessions, queue mode) ------------------------------------------------------------------------------
@@ -1662,6 +1818,17 @@ long long mbx_debug_front_fallbacks(void* stream) {
     return (long long)v;
 }
 
+// 0, or the slice length in frames a launch of this shape is cut into (mbx_process_records and the batch calls on top of it)
+int mbx_launch_slices(int codec, int S, int T) {
+    int crc;
+    Context* c = current_ctx(&crc);
+    if (!c || !(T >= kLdsResidentMinFrames && lds_resident_enabled())) {
+        return 0;
+    }
+    const int sc = codec == MBX_CODEC_IMBE7100X4400 ? MBX_CODEC_IMBE7200X4400 : codec;
+    return choose_slice_frames(S, T, ((sc == MBX_CODEC_IMBE7200X4400) ? 6 : 5) * c->simds);
+}
+
 // the dominant kernel of mbx_process_batch / _resident for a batch shape (frames 4-byte aligned, as device allocations are)
 const char* mbx_batch_kernel_name(int codec, int S, int T, int resident) {
     if (fused_one_ok(codec, S, T, nullptr)) {
@@ -1672,6 +1839,11 @@ const char* mbx_batch_kernel_name(int codec, int S, int T, int resident) {
             return resident ? "imbe_one_launch_kernel_res" : "imbe_one_launch_kernel";
         }
         return resident ? "imbe_stream_kernel_res1_fused" : "imbe_stream_kernel_one_fused";
+    }
+    if (!resident && mbx_launch_slices(codec, S, T) > 0) {
+        return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? "imbe_stream_kernel_lds_slice"
+               : (codec == MBX_CODEC_AMBE3600X2400)                                    ? "ambe2400_stream_kernel_lds_slice"
+                                                                                        : "ambe_stream_kernel_lds_slice";
     }
     return mbx_stream_kernel_name(codec, resident ? -T : T);
 }

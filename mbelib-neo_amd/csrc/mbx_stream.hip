@@ -1991,6 +1991,13 @@ __device__ __forceinline__ uint4 frame_record(int fec_codec, Wire wire, mbx_para
 // kFuse = 3: the stream blocks of imbe_one_launch_kernel -- the frame's FrameParams row comes from a FRONT BLOCK of the same launch
 // (mbx_front_imbe.h: FEC + expansion of eight frames by one wave), handed over through a flag word (FrontLink); should the row not
 // be there in time the wave runs the kFuse = 1 front end itself, so nothing here depends on the order in which blocks are dispatched.
+// A launch may hand a workgroup only a SLICE of its stream's frames (the time-sliced launches, *_stream_kernel_lds_sliced): frames
+// t0 .. t0 + Tn - 1 of the `stride` the stream has in this call, for the stream at position `pos` of the walk.
+struct FrameSlice {
+    int stride = 0;   // frames per stream in the batch arrays (0: Tn, the whole stream)
+    int t0 = 0;       // first frame of the slice
+    int pos = -1;     // the workgroup's position among the streams (its blockIdx.x when < 0)
+};
 struct FrontLink {
     const uint32_t* flag = nullptr;   // the ready word of this stream's chunk of eight: == epoch once the chunk's rows are in `params`
     uint32_t        epoch = 0u;
@@ -2007,7 +2014,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr,
-                 int fec_codec = 0, FrameShadow shadow = FrameShadow{}, FrontLink link = FrontLink{}) {
+                 int fec_codec = 0, FrameShadow shadow = FrameShadow{}, FrontLink link = FrontLink{}, FrameSlice slice = FrameSlice{}) {
     using ScratchT = WaveScratchT<kPark ? 0 : MBX_PARK_N>;
     ScratchT* scratch_ptr;
     if constexpr (kFuse == 3) {
@@ -2019,11 +2026,12 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     ScratchT& scratch = *scratch_ptr;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;
     uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
-    const int bpos = (kFuse == 3) ? link.pos : (int)blockIdx.x;
+    const int bpos = (kFuse == 3) ? link.pos : (slice.pos >= 0 ? slice.pos : (int)blockIdx.x);
     if (bpos >= S) {
         return;
     }
     const int s = tabs_in.reverse ? (S - 1 - bpos) : bpos;
+    const size_t fbase = (size_t)s * (size_t)(slice.stride ? slice.stride : Tn) + (size_t)slice.t0;   // the batch index of the slice's first frame
     const int lane_in = lane_id();
     MBX_STAMP(0, false);
     if constexpr (kOne) { MBX_TS(0); }
@@ -2129,7 +2137,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             l_lanes = tab_at<uint32_t>(tabs_in.d, offsetof(DerivedTables, imbe_L_lanes), 4u * (uint32_t)lane_in);   // ... and b0 -> L for every b0
             asm volatile("" ::: "memory");   // (what is asked for first is there first)
         } else if (params) {   // the frame's FrameParams row is what the frame needs first: requested first (tools/stage_times.py: asked for
-            row_first = params[(size_t)s * (size_t)Tn].v[lane_in];   // after the scalars of cur_mp had arrived, it cost 2.5 us of a wave's 22)
+            row_first = params[fbase].v[lane_in];   // after the scalars of cur_mp had arrived, it cost 2.5 us of a wave's 22)
         }
         constexpr bool kFlat = MBX_FLAT_LOADS && kFuse != 0;
         const uint32_t h_cur = load_header(slot_cur, lane_in);
@@ -2139,7 +2147,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         load_prev_arrays<kFlat>(prev_first, slot_prev, lane_in);
         load_parms_arrays<kFlat>(cur, slot_cur, lane_in);
         load_enh_arrays<kFlat>(enh_first, enh_src, lane_in);
-        mbx_param_record* const rec_out = const_cast<mbx_param_record*>(&records[(size_t)s * (size_t)Tn]);
+        mbx_param_record* const rec_out = const_cast<mbx_param_record*>(&records[fbase]);
         auto L_of = [&](int b0) -> int {   // wave-uniform b0
             return (b0 <= 207) ? (int)((__builtin_amdgcn_readlane((int)l_lanes, b0 & 63) >> (8 * (b0 >> 6))) & 0xff) : 0;
         };
@@ -2169,7 +2177,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 ready = uni(__hip_atomic_load(link.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == link.epoch;
             }
             if (ready) {
-                const uint32_t* const rowp = reinterpret_cast<const uint32_t*>(&params[(size_t)s * (size_t)Tn].v[0]);
+                const uint32_t* const rowp = reinterpret_cast<const uint32_t*>(&params[fbase].v[0]);
                 row_first = __uint_as_float(__hip_atomic_load(rowp + lane_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 have_row = true;
             } else {   // (never observed: the dispatch order is not a contract, so the wave can also do without its front block)
@@ -2217,7 +2225,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 
     const int frames = (kOne && Tn > 1) ? 1 : Tn;
     for (int t = 0; t < frames; ++t) {
-        const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+        const size_t f = fbase + (size_t)t;
         // Keep per-frame table values out of the loop-carried register set: without this the compiler
         // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
         // across the frame loop, which halves the occupancy.
@@ -2816,7 +2824,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr,
-                 FrameShadow shadow = FrameShadow{}) {
+                 FrameShadow shadow = FrameShadow{}, FrameSlice slice = FrameSlice{}) {
     uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
     __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;   // T >= 4: prev_mp resident in LDS
@@ -2829,10 +2837,12 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 #endif
     constexpr int kXRows = MBX_AMBE_XROWS, kXStride = 65;
     __shared__ float xrows[kPark ? kXRows : 1][kPark ? kXStride : 1];
-    if ((int)blockIdx.x >= S) {
+    const int bpos = slice.pos >= 0 ? slice.pos : (int)blockIdx.x;
+    if (bpos >= S) {
         return;
     }
-    const int s = tabs_in.reverse ? (S - 1 - (int)blockIdx.x) : (int)blockIdx.x;
+    const int s = tabs_in.reverse ? (S - 1 - bpos) : bpos;
+    const size_t fbase = (size_t)s * (size_t)(slice.stride ? slice.stride : Tn) + (size_t)slice.t0;   // the batch index of the slice's first frame
     const int lane_in = lane_id();
     Wire wire_in = {};
     if constexpr (kFrame) {
@@ -2916,7 +2926,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
     } else if constexpr (kOne) {
         slot_prev = home_prev;
-        row_first = params[(size_t)s * (size_t)Tn].v[lane_in];   // the frame's FrameParams row: needed first, requested first
+        row_first = params[fbase].v[lane_in];   // the frame's FrameParams row: needed first, requested first
         const uint32_t h_cur = load_header(slot_cur, lane_in);
         h_prev_first = load_header(slot_prev, lane_in);
         h_enh_first = load_header(slot_enh, lane_in);
@@ -2953,13 +2963,13 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     float row_now = 0.0f;
     if constexpr (kPark) {
         if (params) {
-            row_now = params[(size_t)s * (size_t)Tn].v[lane_in];
+            row_now = params[fbase].v[lane_in];
         }
     }
 
     const int frames = (kOne && Tn > 1) ? 1 : Tn;
     for (int t = 0; t < frames; ++t) {
-        const size_t f = (size_t)s * (size_t)Tn + (size_t)t;
+        const size_t f = fbase + (size_t)t;
         // Keep per-frame table values out of the loop-carried register set: without this the compiler
         // hoists ~100 VGPRs of lane-dependent values (twiddles, windows, jump-ahead constants, indices)
         // across the frame loop, which halves the occupancy.
@@ -3447,6 +3457,41 @@ ambe2400_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ r
                            mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                            float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     ambe_stream_body<true, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// ------------------------------------------------------------------------------------------
+// Slice kernels (*_stream_kernel_lds_slice): the LDS-resident instances on a SLICE of every stream's frames -- frames t0 ..
+// t0 + n - 1 of the `stride` frames a stream has in the batch arrays.  A slice IS a launch of n frames per stream (state in from
+// HBM, state out to HBM); the launcher (mbx_api.hip, sliced_launch) cuts a launch whose stream count does not fill the device's
+// wave slots evenly into groups of streams x slices of frames and issues them on two internal HIP streams, so that the slots one
+// group's slice leaves empty are taken by the other group's.
+// ------------------------------------------------------------------------------------------
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_IMBE_LDS_WAVES_PER_SIMD)
+imbe_stream_kernel_lds_slice(int S, int stride, int t0, int n, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                             mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                             float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    FrameSlice sl;
+    sl.stride = stride;
+    sl.t0 = t0;
+    imbe_stream_body<true>(S, n, records, params, state, rngs, pcm16, pcmf, results, tabs_in, nullptr, 0, FrameShadow{}, FrontLink{}, sl);
+}
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
+ambe_stream_kernel_lds_slice(int S, int stride, int t0, int n, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                             mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                             float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    FrameSlice sl;
+    sl.stride = stride;
+    sl.t0 = t0;
+    ambe_stream_body<false, true>(S, n, records, params, state, rngs, pcm16, pcmf, results, tabs_in, nullptr, FrameShadow{}, sl);
+}
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
+ambe2400_stream_kernel_lds_slice(int S, int stride, int t0, int n, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                                 mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                                 float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    FrameSlice sl;
+    sl.stride = stride;
+    sl.t0 = t0;
+    ambe_stream_body<true, true>(S, n, records, params, state, rngs, pcm16, pcmf, results, tabs_in, nullptr, FrameShadow{}, sl);
 }
 
 // Resident state (DeviceTables::resident, mbx_process_batch_resident): the LDS-resident bodies with prev_mp_enhanced elided

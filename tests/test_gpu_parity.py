@@ -369,6 +369,18 @@ def test_ambe_long_streams_config5_shape(mbx, oracle):
     c = run([64, 64])
     assert a[3].tobytes() == c[3].tobytes() and a[4].tobytes() == c[4].tobytes()
     assert a[0].tobytes() == c[0].tobytes() and a[1].tobytes() == c[1].tobytes()
+    # 8,192 streams do not fill the device's wave slots evenly, so this shape is a SLICED launch (two groups of streams x slices of 16
+    # frames on two internal HIP streams, include/mbx.h): the comparisons above -- oracle, determinism, 64 + 64 -- are of that form; a
+    # launch of eight frames per stream is never sliced, so sixteen of them are the unsliced reference, bit for bit
+    L = mbx.lib()
+    Tc = L.mbx_launch_slices(1, S, T)
+    print("slice length for 8,192 x 128:", Tc)
+    if os.environ.get("MBX_SLICE") != "0":
+        assert Tc == 16 and L.mbx_launch_slices(1, S, 8) == 0 and L.mbx_launch_slices(0, 65536, 16) == 0
+        assert L.mbx_batch_kernel_name(1, S, T, 0) == b"ambe_stream_kernel_lds_slice"
+    d = run([8] * 16)
+    assert a[3].tobytes() == d[3].tobytes() and a[4].tobytes() == d[4].tobytes()
+    assert a[0].tobytes() == d[0].tobytes() and a[1].tobytes() == d[1].tobytes()
 
 
 def _full_shape_run(codec, S, splits, frames, seeds, d_pick, resident=False):
