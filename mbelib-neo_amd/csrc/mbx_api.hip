@@ -49,6 +49,10 @@ __global__ void imbe_one_launch_kernel(int, int, const uint8_t*, mbx_param_recor
                                        mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_one_launch_kernel_res(int, int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
                                            mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe_one_launch_kernel(int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*, mbx_stream_rng*,
+                                       int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe2400_one_launch_kernel(int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
+                                           mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe7100_stream_kernel_one_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
                                                  mbe_process_result*, DeviceTables);
 __global__ void imbe7100_stream_kernel_res1_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
@@ -1119,11 +1123,18 @@ static int front_lead_chunks() {
     }();
     return lead;
 }
-static bool fused_one_ok(int codec, int S, int T, const void* d_frames) {
-    return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) && T == 1 && S > kSmallBatchFrames
-           && (reinterpret_cast<uintptr_t>(d_frames) & 3u) == 0 && fused_one_mode() != 0;
+static bool ambe_codec(int codec) { return codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400; }
+// resident: the AMBE codecs have no one-launch form on resident state (their resident launches take the LDS-resident instances)
+static bool fused_one_ok(int codec, int S, int T, const void* d_frames, bool resident = false) {
+    if (T != 1 || S <= kSmallBatchFrames || fused_one_mode() == 0) {
+        return false;
+    }
+    if (ambe_codec(codec)) {
+        return fused_one_mode() == 2 && !resident;   // 9-byte frames: byte loads, any alignment
+    }
+    return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) && (reinterpret_cast<uintptr_t>(d_frames) & 3u) == 0;
 }
-static bool one_launch_form(int codec) { return codec == MBX_CODEC_IMBE7200X4400 && fused_one_mode() == 2; }
+static bool one_launch_form(int codec) { return (codec == MBX_CODEC_IMBE7200X4400 || ambe_codec(codec)) && fused_one_mode() == 2; }
 static int launch_fused_one(Context* c, bool reverse, int codec, int S, const uint8_t* d_frames, mbx_param_record* d_records,
                             mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                             void* stream, const int32_t* d_stream_index, uint32_t* d_resident) {
@@ -1139,7 +1150,7 @@ static int launch_fused_one(Context* c, bool reverse, int codec, int S, const ui
     return check_launch("imbe_stream_kernel_one_fused");
 }
 // caller holds c->mu; the slot's workspace holds S rows and its flags
-static int launch_one_launch(Context* c, StreamSlot& slot, bool reverse, int S, const uint8_t* d_frames, mbx_param_record* d_records,
+static int launch_one_launch(Context* c, StreamSlot& slot, bool reverse, int codec, int S, const uint8_t* d_frames, mbx_param_record* d_records,
                              mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results,
                              void* stream, const int32_t* d_stream_index, uint32_t* d_resident) {
     mbx::DeviceTables tabs = c->tabs;
@@ -1151,6 +1162,12 @@ static int launch_one_launch(Context* c, StreamSlot& slot, bool reverse, int S, 
     }
     slot.exp_codec = -1;   // the rows of an earlier mbx_expand_records() are being replaced
     const unsigned chunks = (unsigned)((S + 7) / 8);
+    if (ambe_codec(codec)) {
+        auto* const akernel = codec == MBX_CODEC_AMBE3600X2400 ? mbx::ambe2400_one_launch_kernel : mbx::ambe_one_launch_kernel;
+        hipLaunchKernelGGL(akernel, dim3(9u * chunks), dim3(64), 0, (hipStream_t)stream, S, d_frames, d_records, slot.workspace, slot.flags,
+                           slot.flags + (slot.frames + 7) / 8, slot.epoch, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+        return check_launch("ambe_one_launch_kernel");
+    }
     auto* const kernel = d_resident ? mbx::imbe_one_launch_kernel_res : mbx::imbe_one_launch_kernel;
     hipLaunchKernelGGL(kernel, dim3(9u * chunks), dim3(64), 0, (hipStream_t)stream, S, front_lead_chunks(), d_frames, d_records, slot.workspace,
                        slot.flags, slot.flags + (slot.frames + 7) / 8, slot.epoch, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
@@ -1160,7 +1177,7 @@ static int launch_one_launch(Context* c, StreamSlot& slot, bool reverse, int S, 
 static int try_fused_one(int codec, int S, int T, const uint8_t* d_frames, mbx_param_record* d_records, mbe_parms* d_state,
                          mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf, mbe_process_result* d_results, void* stream,
                          const int32_t* d_stream_index, uint32_t* d_resident, int* rc, bool own_workspace = true) {
-    if (!fused_one_ok(codec, S, T, d_frames)) {
+    if (!fused_one_ok(codec, S, T, d_frames, d_resident != nullptr)) {
         return 0;
     }
     int crc;
@@ -1189,9 +1206,12 @@ static int try_fused_one(int codec, int S, int T, const uint8_t* d_frames, mbx_p
             *rc = wrc;
             return 1;
         }
-        *rc = launch_one_launch(c, slot, (slot.launches++ & 1u) != 0u, S, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
-                                d_stream_index, d_resident);
+        *rc = launch_one_launch(c, slot, (slot.launches++ & 1u) != 0u, codec, S, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results,
+                                stream, d_stream_index, d_resident);
         return 1;
+    }
+    if (ambe_codec(codec)) {   // (no in-wave form for the AMBE codecs: a caller-owned workspace or a captured launch takes the staged kernels)
+        return 0;
     }
     *rc = launch_fused_one(c, (slot.launches++ & 1u) != 0u, codec, S, d_frames, d_records, d_state, d_rng, d_pcm16, d_pcmf, d_results, stream,
                            d_stream_index, d_resident);
@@ -1831,7 +1851,10 @@ int mbx_launch_slices(int codec, int S, int T) {
 
 // the dominant kernel of mbx_process_batch / _resident for a batch shape (frames 4-byte aligned, as device allocations are)
 const char* mbx_batch_kernel_name(int codec, int S, int T, int resident) {
-    if (fused_one_ok(codec, S, T, nullptr)) {
+    if (fused_one_ok(codec, S, T, nullptr, resident != 0)) {
+        if (ambe_codec(codec)) {
+            return codec == MBX_CODEC_AMBE3600X2400 ? "ambe2400_one_launch_kernel" : "ambe_one_launch_kernel";
+        }
         if (codec == MBX_CODEC_IMBE7100X4400) {
             return resident ? "imbe7100_stream_kernel_res1_fused" : "imbe7100_stream_kernel_one_fused";
         }

@@ -2818,15 +2818,24 @@ __device__ void tone_dstar_frame(float out[3], int id1, Parms& cur, int lane) {
 
 // k2400: AMBE 3600x2400 (D-STAR) frame policy, ref src/ambe/ambe3600x2400.c:629-763 -- no erasure class, D-STAR
 // tones, repeats decided by the total error count alone.  The prediction (decode_ambe) is common.
-template <bool k2400, bool kPark, bool kFrame = false, bool kRes = false, bool kOne = false>   // kOne: see imbe_stream_body
+// kFuse = 3 (with kOne): the stream blocks of ambe_one_launch_kernel -- see imbe_stream_body and FrontLink
+template <bool k2400, bool kPark, bool kFrame = false, bool kRes = false, bool kOne = false, int kFuse = 0>   // kOne: see imbe_stream_body
 __device__ __forceinline__ void
 ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                  mbe_parms* __restrict__ state,
                  mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                  mbe_process_result* __restrict__ results, DeviceTables tabs_in, const uint8_t* frame_in = nullptr,
-                 FrameShadow shadow = FrameShadow{}, FrameSlice slice = FrameSlice{}) {
+                 FrameShadow shadow = FrameShadow{}, FrameSlice slice = FrameSlice{}, FrontLink link = FrontLink{}) {
     uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
-    __shared__ WaveScratchT<kPark ? 0 : MBX_PARK_N> scratch;
+    using ScratchT = WaveScratchT<kPark ? 0 : MBX_PARK_N>;
+    ScratchT* scratch_ptr;
+    if constexpr (kFuse == 3) {
+        scratch_ptr = reinterpret_cast<ScratchT*>(link.lds);
+    } else {
+        __shared__ ScratchT scratch_own;
+        scratch_ptr = &scratch_own;
+    }
+    ScratchT& scratch = *scratch_ptr;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;   // T >= 4: prev_mp resident in LDS
     // kPark without a workspace (params == nullptr, the normal case): the wave expands the records of its next EIGHT frames
     // itself, eight lanes per frame exactly like the expand kernels (mbx_expand_ambe.h), into eight LDS rows -- no
@@ -2837,7 +2846,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 #endif
     constexpr int kXRows = MBX_AMBE_XROWS, kXStride = 65;
     __shared__ float xrows[kPark ? kXRows : 1][kPark ? kXStride : 1];
-    const int bpos = slice.pos >= 0 ? slice.pos : (int)blockIdx.x;
+    const int bpos = (kFuse == 3) ? link.pos : (slice.pos >= 0 ? slice.pos : (int)blockIdx.x);
     if (bpos >= S) {
         return;
     }
@@ -2926,7 +2935,13 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
     } else if constexpr (kOne) {
         slot_prev = home_prev;
-        row_first = params[fbase].v[lane_in];   // the frame's FrameParams row: needed first, requested first
+        uint32_t flag_v = 0u;
+        if constexpr (kFuse == 3) {
+            flag_v = __hip_atomic_load(link.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the wave's first vector load (bypasses L1)
+            asm volatile("" ::: "memory");
+        } else {
+            row_first = params[fbase].v[lane_in];   // the frame's FrameParams row: needed first, requested first
+        }
         const uint32_t h_cur = load_header(slot_cur, lane_in);
         h_prev_first = load_header(slot_prev, lane_in);
         h_enh_first = load_header(slot_enh, lane_in);
@@ -2934,6 +2949,30 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         load_prev_arrays(prev_first, slot_prev, lane_in);
         load_parms_arrays(cur, slot_cur, lane_in);
         load_enh_arrays(enh_first, slot_enh, lane_in);
+        if constexpr (kFuse == 3) {   // the row comes from a front block of the same launch: see the IMBE body
+            asm volatile("" ::: "memory");
+            bool ready = uni(flag_v) == link.epoch;
+            for (int tries = 0; !ready && tries < MBX_FRONT_SPIN; ++tries) {
+                __builtin_amdgcn_s_sleep(8);
+                ready = uni(__hip_atomic_load(link.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == link.epoch;
+            }
+            if (ready) {
+                const uint32_t* const rowp = reinterpret_cast<const uint32_t*>(&params[fbase].v[0]);
+                row_first = __uint_as_float(__hip_atomic_load(rowp + lane_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            } else {   // (never observed) the wave does its frame's front end itself: scalar-unit FEC, expansion by its first eight lanes
+                const Wire wire = frame_fetch(true, frame_in + 9u * (size_t)s);
+                rec_in = frame_record(MBX_CODEC_AMBE3600X2450, wire, const_cast<mbx_param_record*>(&records[fbase]), tabs_in.t, lane_in);
+                float (*tile)[65] = reinterpret_cast<float (*)[65]>(link.lds);   // eight rows: every group of eight lanes takes part
+                xp::expand_ambe_frame_rec<k2400>((lane_in >> 3) == 0, xp::u32x4{rec_in.x, rec_in.y, rec_in.z, rec_in.w}, tile[lane_in >> 3], lane_in & 7,
+                                                 tabs_in);
+                wave_lds_sync();
+                row_first = tile[0][lane_in];
+                wave_lds_sync();
+                if (link.fallbacks && lane_in == 0) {
+                    atomicAdd(link.fallbacks, 1u);
+                }
+            }
+        }
         set_parms_header(cur, h_cur);
     } else {
         slot_prev = home_prev;
@@ -3133,7 +3172,18 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 flags |= MBE_PROCESS_FLAG_MUTE;
             }
         } else if (bad == 7) {
-            const uint4 rec = kFrame ? rec_in : *reinterpret_cast<const uint4*>(&records[f]);
+            uint4 rec;
+            if constexpr (kFrame) {
+                rec = rec_in;
+            } else if constexpr (kFuse == 3) {   // written by a front block of this launch: read past the L1, like the row (see FrontLink)
+                const uint32_t* const rp = reinterpret_cast<const uint32_t*>(&records[f]);
+                rec = make_uint4(__hip_atomic_load(rp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(rp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(rp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            } else {
+                rec = *reinterpret_cast<const uint4*>(&records[f]);
+            }
             tw[0] = rec.x;
             tw[1] = rec.y;
             tw[2] = rec.z;
@@ -3425,6 +3475,88 @@ ambe2400_stream_kernel_one(int S, int Tn, const mbx_param_record* __restrict__ r
                            mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                            float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     ambe_stream_body<true, false, false, false, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// ambe_one_launch_kernel / ambe2400_one_launch_kernel: the T = 1 step of the AMBE codecs as ONE launch -- front blocks (the frame's
+// FEC by the first lane of its eight, then the eight-lane expansion of mbx_expand_ambe.h) and stream blocks in one grid, exactly as
+// imbe_one_launch_kernel (FrontLink; all front blocks first in the grid).
+template <bool k2400>
+__device__ __forceinline__ void front_block_ambe(int chunk, int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
+                                                 FrameParams* __restrict__ rows, uint32_t* __restrict__ flags, uint32_t epoch,
+                                                 const DeviceTables& tabs, void* lds) {
+    float (*tile)[65] = reinterpret_cast<float (*)[65]>(lds);   // 8 x 65 floats
+    const int lane = lane_id();
+    const int fi = lane >> 3, sub = lane & 7;
+    const int j = 8 * chunk + fi;
+    const bool have = j < S;
+    const int sj = have ? (tabs.reverse ? (S - 1 - j) : j) : 0;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (have && sub == 0) {   // two Golay words and a 23-step sequence: one lane per frame (ref src/ambe/ambe_common.c:22-157)
+        rec = fec_ambe3600x2450_frame(tabs.t, frames + 9u * (size_t)sj);
+        // (the stream block of a tone frame reads its record: written through like the rows, and before the flag)
+        uint32_t* const rp = reinterpret_cast<uint32_t*>(&records[sj]);
+        __hip_atomic_store(rp + 0, rec.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rp + 1, rec.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rp + 2, rec.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rp + 3, rec.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int src = (lane & ~7) << 2;
+    rec.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.x);
+    rec.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.y);
+    rec.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.z);
+    rec.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rec.w);
+    xp::expand_ambe_frame_rec<k2400>(have, xp::u32x4{rec.x, rec.y, rec.z, rec.w}, tile[fi], sub, tabs);
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int jq = 8 * chunk + q;
+        if (jq < S) {
+            const int sq = tabs.reverse ? (S - 1 - jq) : jq;
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(&rows[sq].v[0]) + lane, __float_as_uint(tile[q][lane]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        __hip_atomic_store(&flags[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <bool k2400>
+__device__ __forceinline__ void ambe_one_launch_body(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
+                                                     FrameParams* __restrict__ rows, uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks,
+                                                     uint32_t epoch, mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs,
+                                                     int16_t* __restrict__ pcm16, float* __restrict__ pcmf, mbe_process_result* __restrict__ results,
+                                                     const DeviceTables& tabs_in) {
+    const int C = (S + 7) >> 3;
+    const int bid = (int)blockIdx.x;   // C front blocks, then 8 C stream blocks
+    constexpr size_t kFrontLds = 8 * 65 * 4, kStreamLds = sizeof(WaveScratchT<MBX_PARK_N>);
+    __shared__ alignas(16) char lds[kFrontLds > kStreamLds ? kFrontLds : kStreamLds];
+    if (bid < C) {
+        front_block_ambe<k2400>(bid, S, frames, records, rows, flags, epoch, tabs_in, lds);
+        return;
+    }
+    FrontLink link;
+    link.pos = bid - C;
+    link.flag = &flags[link.pos >> 3];
+    link.epoch = epoch;
+    link.lds = lds;
+    link.fallbacks = fallbacks;
+    ambe_stream_body<k2400, false, false, false, true, 3>(S, 1, records, rows, state, rngs, pcm16, pcmf, results, tabs_in, frames, FrameShadow{},
+                                                          FrameSlice{}, link);
+}
+__global__ void __launch_bounds__(64, MBX_AMBE_ONE_WAVES_PER_SIMD)
+ambe_one_launch_kernel(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
+                       uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks, uint32_t epoch, mbe_parms* __restrict__ state,
+                       mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                       mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_one_launch_body<false>(S, frames, records, rows, flags, fallbacks, epoch, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+__global__ void __launch_bounds__(64, MBX_AMBE2400_WAVES_PER_SIMD)
+ambe2400_one_launch_kernel(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
+                           uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks, uint32_t epoch, mbe_parms* __restrict__ state,
+                           mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                           mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_one_launch_body<true>(S, frames, records, rows, flags, fallbacks, epoch, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 __global__ void __launch_bounds__(64, MBX_AMBE_WAVES_PER_SIMD)

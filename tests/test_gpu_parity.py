@@ -509,10 +509,11 @@ def test_imbe_voiced_config2_full_shape(mbx, oracle):
     assert a[5] == c[5] and a[3].tobytes() == c[3].tobytes() and a[1].tobytes() == c[1].tobytes()
 
 
-@pytest.mark.parametrize("codec", [0, 2])
+@pytest.mark.parametrize("codec", [0, 1, 2, 3])
 def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
-    """The IMBE codecs at T = 1 and S > 256: mbx_process_batch (one launch: scalar-unit FEC, in-wave expansion, stream stage)
-    against mbx_fec_* + mbx_process_records (FEC launch, expansion launch, `imbe_stream_kernel_one`) on RANDOM-BIT frames --
+    """T = 1 and S > 256, all four codecs: mbx_process_batch (ONE launch: `imbe_one_launch_kernel` / `ambe_one_launch_kernel` /
+    `ambe2400_one_launch_kernel` -- front blocks and stream blocks in one grid -- or, IMBE 7100x4400, the front end in the stream's
+    own wave) against mbx_fec_* + mbx_process_records (FEC launch, expansion launch, `*_stream_kernel_one`) on RANDOM-BIT frames --
     every error-count bucket, repeats, mutes, headroom resets, invalid fundamentals -- eight ticks of 8,192 + 3 streams (an odd
     batch: frames alternate between the two alignments the scalar fetch handles, and the last one ends the buffer): records,
     results, int16 / float PCM, state and RNG byte for byte; likewise through an index (mbx_process_batch_indexed) and with a
@@ -520,13 +521,17 @@ def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
     import torch
     from mbelib_neo_amd import _native, decoder, framegen
 
+    from mbelib_neo_amd.layout import FRAME_BYTES
+
+    fb = FRAME_BYTES[codec]
     S, T = 8192 + 3, 8
-    frames = framegen.random_frames(codec, S * T, framegen.rng_for(0xF0 + codec)).reshape(S, T, 18)
-    frames[::5] &= framegen.random_frames(codec, ((S + 4) // 5) * T, framegen.rng_for(0xF8 + codec)).reshape(-1, T, 18)   # some with few errors
+    frames = framegen.random_frames(codec, S * T, framegen.rng_for(0xF0 + codec)).reshape(S, T, fb)
+    frames[::5] &= framegen.random_frames(codec, ((S + 4) // 5) * T, framegen.rng_for(0xF8 + codec)).reshape(-1, T, fb)   # some with few errors
     seeds = np.arange(S) + 77
     L = mbx.lib()
-    assert L.mbx_batch_kernel_name(codec, S, 1, 0) in (b"imbe_one_launch_kernel", b"imbe_stream_kernel_one_fused", b"imbe7100_stream_kernel_one_fused") \
-        or os.environ.get("MBX_FUSE_ONE") == "0"
+    assert L.mbx_batch_kernel_name(codec, S, 1, 0) in (b"imbe_one_launch_kernel", b"imbe_stream_kernel_one_fused", b"imbe7100_stream_kernel_one_fused",
+                                                       b"ambe_one_launch_kernel", b"ambe2400_one_launch_kernel") \
+        or os.environ.get("MBX_FUSE_ONE") in ("0", "1")
 
     def run(staged):
         dec = decoder.BatchDecoder(codec, S, seeds=seeds)
@@ -543,7 +548,7 @@ def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
             assert fo[t][k].tobytes() == so[t][k].tobytes(), (t, k)
     assert fs.tobytes() == ss.tobytes() and fr.tobytes() == sr.tobytes()
     flags = decoder.results_numpy(torch.from_numpy(np.concatenate([o["results"] for o in fo])))["flags"]
-    assert (flags & 0x40).any() and (flags & 0x80).any()   # repeats and mutes were in it
+    assert (flags & 0x40).any() and ((flags & 0x80).any() or codec in (1, 3))   # repeats (and, IMBE, mutes) were in it
 
     # the caller-workspace entry point takes the in-wave form of the one-launch step (FEC by lanes + expansion in the stream's own
     # wave -- also what a stream block of imbe_one_launch_kernel falls back to): same bytes again
@@ -560,13 +565,13 @@ def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
         torch.cuda.synchronize()
         for k in ("records", "results", "pcm16", "pcmf"):
             assert out[k].cpu().numpy().tobytes() == fo[t][k].tobytes(), (t, k)
-    fb = L.mbx_debug_front_fallbacks(strm)
-    print("front-block fall-backs so far on this stream:", fb)
-    assert fb <= 0 or fb < S // 50   # (a stream block that does not find its row in time expands its own frame: rare, never wrong)
+    fallbacks = L.mbx_debug_front_fallbacks(strm)
+    print("front-block fall-backs so far on this stream:", fallbacks)
+    assert fallbacks <= 0 or fallbacks < S // 50   # (a stream block that does not find its row in time expands its own frame: rare, never wrong)
 
     # a 2-byte aligned frame buffer: same results (the staged launches serve it)
     dec = decoder.BatchDecoder(codec, S, seeds=seeds)
-    buf = torch.zeros(S * 18 + 2, dtype=torch.uint8, device="cuda")
+    buf = torch.zeros(S * fb + 2, dtype=torch.uint8, device="cuda")
     out = dec.make_outputs(1, want_float=True)
     strm = torch.cuda.current_stream().cuda_stream
     buf[2:].copy_(torch.from_numpy(np.ascontiguousarray(frames[:, 0]).reshape(-1)))
