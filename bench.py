@@ -840,7 +840,7 @@ def main():
     }
     issue = line["roofline"].get("issue") or {}
     # MODELLED from measured counts: VALU issue utilisation of the dominant kernel from the SQ counters of this build (instruction counts
-    # priced with the per-instruction costs tools/valu_issue.hip measured), None without a matching summary
+    # priced with the per-instruction costs tools/valu_issue.hip measured; EXPERIMENTS.md, rounds 3 / 4), None without a matching summary
     line["valu"]["modelled_valu_issue_utilisation"] = issue.get("valu_issue_utilisation")               # every instruction at the cost of the expensive class
     line["valu"]["modelled_valu_issue_utilisation_lower_bound"] = issue.get("valu_issue_utilisation_lower_bound")
     line["valu"]["cost_model"] = issue.get("valu_cost_model")   # per-instruction costs from tools/valu_issue.hip at FOUR waves per SIMD; the kernels run at 3.8-7

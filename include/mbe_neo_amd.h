@@ -15,9 +15,9 @@
  * message on stderr if that fails.  Like the reference (mbelib.h:28-30) the processing functions are re-entrant per
  * stream: each host thread has its own HIP stream, device scratch and RNG state.
  *
- * Throughput.  A synchronous call is one 20 ms frame = one device round trip (about 33 us measured,
- * against 18 us of CPU time in the reference), so a host that decodes many channels has two better
- * options, both measured in bench.py's `host_path`:
+ * Throughput.  A synchronous call is one 20 ms frame = one launch of one wavefront and one device round trip: 16.97 us per call
+ * in the driver's round-4 run (16.6-19.8 us by box), against 17.44 us of CPU time for the reference's own call on the same host.
+ * A host that decodes many channels has two better options, both measured in bench.py's `host_path`:
  *   * queue mode (below): keep calling the per-frame functions, mbe_flush() runs everything queued as batched launches;
  *   * sessions (include/mbx.h): hand whole batches of wire frames over, state stays on the device.
  */

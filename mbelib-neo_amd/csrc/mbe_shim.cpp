@@ -36,7 +36,7 @@ int g_device = 0;   // MBX_DEVICE: the one device the per-frame API runs on
 // OPT-IN: measured 20.9 us per call against 22.5 us (the state still crosses PCIe both ways in every call, which is what
 // bounds it), and a kernel that stays on the device occupies one of HIP's few hardware queues while it lives -- other streams
 // of the process that map onto the same queue wait for it (sessions from one host thread: 153 -> 104 M frames/s when the
-// server's extra stream shifted their streams onto a shared queue).  DESIGN.md section 1.
+// server's extra stream shifted their streams onto a shared queue).  EXPERIMENTS.md (round 4).
 bool g_frame_server = false;
 // MBE_NEO_FRAME_SHADOW=0 switches the device copy of the synchronous calls' state off (every call then takes its state from the
 // caller's structs across PCIe, as before round 4): for A/B timing and as a way out should a host ever trip over it.

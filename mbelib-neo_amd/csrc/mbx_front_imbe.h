@@ -3,13 +3,13 @@
 // (mbx_expand_imbe.h) -- wire frames in, parameter records + FrameParams rows out.
 //
 // Why eight frames per wave.  The first one-launch kernel of round 5 ran the front end of a stream's frame in the stream's own
-// wave (scalar-unit FEC, in-wave expansion).  Measured (tools/stage_times.py): 8 us of a 23 us wave life
+// wave (scalar-unit FEC, in-wave expansion).  Measured (tools/stage_times.py, EXPERIMENTS.md 5.1): 8 us of a 23 us wave life
 // before the frame was expanded, and a kernel 17-26 us slower than the stream stage alone -- not latency but INSTRUCTION ISSUE:
 // one frame per wave-instruction is 8x (expansion) to 64x (FEC) the issue slots of the frame-parallel kernels, on SIMDs that
 // are already ~60 % busy.  Here the work keeps the frame-parallel mappings and moves INTO the stream kernel's launch instead:
-// front blocks (this file) and stream blocks are workgroups of one grid, a front block is dispatched a few thousand streams
-// ahead of the stream blocks that consume its rows, and hands them over through a ready counter (see imbe_one_launch_kernel,
-// mbx_stream.hip).
+// front blocks (this file) and stream blocks are workgroups of ONE grid, the front blocks first, and a front block hands its
+// eight rows to the stream blocks that consume them through the workspace and a flag word (see imbe_one_launch_kernel and
+// FrontLink, mbx_stream.hip).
 //
 // The FEC by lanes (bit-exact with fec_imbe7200x4400_wire, mbx_fec_frame.h; ref src/imbe/imbe7200x4400.c:424-443, 636-673,
 // 469-515, 709-744; src/ecc/ecc.c:221-301, 366-408):
