@@ -15,8 +15,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -780,6 +784,96 @@ void unpack_bits_fast(const mbx_param_record& r, int nbits, char* out) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The pump: ONE thread per process that makes the HIP calls of the decoder threads' small flushes.
+// A host with a decoder thread per core flushes from sixteen or thirty-two threads at once; each flush is a few launches and an
+// event, and that many threads inside the HIP runtime (and that many streams on its four hardware queues) is what collapses:
+// measured without any CPU throttling (profiles/r05/fanin.json: nr_throttled = 0), queue mode gave 33 M frames/s from four threads
+// and 3-14 M, erratically, from sixteen.  A producer hands the pump the launch part of its flush as a closure and sleeps on a
+// condition variable; the pump issues it on the producer's own stream, records the producer's event, and polls the events of
+// everything in flight -- so exactly one thread talks to the runtime, nobody spins but the pump, and a producer is woken by a
+// futex instead of by the driver's interrupt path.  Only steady-state small flushes go this way (no new channels, rows < 8,192):
+// large flushes overlap their chunked copies with the host's scatter and stay with their thread.
+// MBE_NEO_PUMP=0 switches it off (A/B timing).  ref (threading contract): include/mbelib-neo/mbelib.h:28-30, README.md:299-302.
+// ------------------------------------------------------------------------------------------------------------------
+struct PumpJob {
+    std::function<void()>   issue;     // the HIP calls of one flush (launches on `stream`)
+    hipStream_t             stream = nullptr;
+    hipEvent_t              done_ev = nullptr;
+    std::mutex              mu;
+    std::condition_variable cv;
+    bool                    done = false;
+};
+class Pump {
+    std::mutex               mu_;
+    std::condition_variable  cv_;
+    std::deque<PumpJob*>     q_;
+    std::vector<PumpJob*>    pending_;   // touched by the pump thread only
+    bool                     started_ = false;
+
+    void run() {
+        HIP_OK(hipSetDevice(g_device));
+        for (;;) {
+            std::deque<PumpJob*> take;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (pending_.empty()) {
+                    cv_.wait(lk, [&] { return !q_.empty(); });
+                }
+                take.swap(q_);
+            }
+            for (PumpJob* j : take) {
+                j->issue();
+                HIP_OK(hipEventRecord(j->done_ev, j->stream));
+                pending_.push_back(j);
+            }
+            for (size_t i = 0; i < pending_.size();) {
+                PumpJob* j = pending_[i];
+                const hipError_t e = hipEventQuery(j->done_ev);
+                if (e == hipSuccess) {
+                    {
+                        std::lock_guard<std::mutex> lk(j->mu);
+                        j->done = true;
+                    }
+                    j->cv.notify_one();
+                    pending_[i] = pending_.back();
+                    pending_.pop_back();
+                } else if (e == hipErrorNotReady) {
+                    ++i;
+                } else {
+                    HIP_OK(e);
+                }
+            }
+            if (!pending_.empty() && take.empty()) {
+                for (int k = 0; k < 64; ++k) {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+            }
+        }
+    }
+
+public:
+    void submit_and_wait(PumpJob& j) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!started_) {
+                started_ = true;
+                std::thread([this] { run(); }).detach();   // lives as long as the process: idle, it sleeps on the condition variable
+            }
+            q_.push_back(&j);
+        }
+        cv_.notify_one();
+        std::unique_lock<std::mutex> lk(j.mu);
+        j.cv.wait(lk, [&] { return j.done; });
+    }
+};
+Pump& pump() {
+    static Pump* p = new Pump;   // (never destroyed: its thread may outlive static destruction)
+    return *p;
+}
+
 int flush_batch(Batch& b) {
     const size_t n = b.q.size();
     if (n == 0) {
@@ -896,29 +990,54 @@ int flush_batch(Batch& b) {
         b.d_pcmf.need(rows * 160);
         b.h_pcmf.need(rows * 160);
     }
-    s.up(b.d_frames.p, b.h_frames.p, bytes);
-    s.up(b.d_index.p, b.h_index.p, idx0 * sizeof(int32_t));
+    // SMALL flushes (many host threads, each with a share of the channels) move nothing with copy calls: the kernels read the frames
+    // and the index from, and write PCM / results / records to, the thread's PINNED host buffers directly (device-visible addresses),
+    // and the flush is then two or three trips into the HIP runtime -- launch, event, wait -- instead of a dozen.  What bounds the
+    // rate from many threads is the number of such trips, not the bytes (tools/fanin_evidence.py: no CPU throttling at sixteen
+    // threads, profiles/r05/fanin.json).  Large flushes keep the chunked copies: PCIe runs at its best with a DMA engine, and the
+    // host scatters one chunk while the next one crosses.  MBE_NEO_ZERO_COPY_FLUSH=0 switches it off (A/B timing).
+    static const bool zero_copy_on = [] {
+        const char* e = getenv("MBE_NEO_ZERO_COPY_FLUSH");
+        return !(e && e[0] == '0');
+    }();
+    const bool zero_copy = zero_copy_on && rows < 8192;
+    const uint8_t* const k_frames = zero_copy ? b.h_frames.p : b.d_frames.p;
+    const int32_t* const k_index = zero_copy ? b.h_index.p : b.d_index.p;
+    int16_t* const k_pcm16 = !any_short ? nullptr : (zero_copy ? b.h_pcm16.p : b.d_pcm16.p);
+    float* const k_pcmf = !any_float ? nullptr : (zero_copy ? b.h_pcmf.p : b.d_pcmf.p);
+    mbe_process_result* const k_results = zero_copy ? b.h_results.p : b.d_results.p;
+    mbx_param_record* const k_records = zero_copy ? b.h_records.p : b.d_records.p;
+    if (!zero_copy) {
+        s.up(b.d_frames.p, b.h_frames.p, bytes);
+        s.up(b.d_index.p, b.h_index.p, idx0 * sizeof(int32_t));
+    }
+    static const bool pump_on = [] {
+        const char* e = getenv("MBE_NEO_PUMP");
+        return !(e && e[0] == '0');
+    }();
+    const bool pumped = pump_on && zero_copy && upload.empty() && rows >= 256;
+    auto issue = [&]() {
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Group& g = groups[gi];
         if (b.mode == MBE_BATCH_STATE_RESIDENT) {   // the pool owns the state between flushes: no prev_mp_enhanced traffic, lazy prev_mp
-            must(mbx_process_batch_resident(g.codec, (int)g.nch, g.T, b.d_index.p + index_off[gi], b.d_frames.p + g.byte0, b.d_state.p,
-                                            b.d_elided.p, b.d_rng.p, any_short ? b.d_pcm16.p + g.row0 * 160 : nullptr,
-                                            any_float ? b.d_pcmf.p + g.row0 * 160 : nullptr, b.d_results.p + g.row0,
-                                            b.d_records.p + g.row0, s.stream),
+            must(mbx_process_batch_resident(g.codec, (int)g.nch, g.T, k_index + index_off[gi], k_frames + g.byte0, b.d_state.p,
+                                            b.d_elided.p, b.d_rng.p, k_pcm16 ? k_pcm16 + g.row0 * 160 : nullptr,
+                                            k_pcmf ? k_pcmf + g.row0 * 160 : nullptr, k_results + g.row0, k_records + g.row0, s.stream),
                  "mbx_process_batch_resident");
         } else {
-            must(mbx_process_batch_indexed(g.codec, (int)g.nch, g.T, b.d_index.p + index_off[gi], b.d_frames.p + g.byte0, b.d_state.p,
-                                           b.d_rng.p, any_short ? b.d_pcm16.p + g.row0 * 160 : nullptr,
-                                           any_float ? b.d_pcmf.p + g.row0 * 160 : nullptr, b.d_results.p + g.row0,
-                                           b.d_records.p + g.row0, s.stream),
+            must(mbx_process_batch_indexed(g.codec, (int)g.nch, g.T, k_index + index_off[gi], k_frames + g.byte0, b.d_state.p,
+                                           b.d_rng.p, k_pcm16 ? k_pcm16 + g.row0 * 160 : nullptr,
+                                           k_pcmf ? k_pcmf + g.row0 * 160 : nullptr, k_results + g.row0, k_records + g.row0, s.stream),
                  "mbx_process_batch_indexed");
         }
+    }
+    };
+    if (!pumped) {
+        issue();
     }
     // ---- outputs: the small arrays first, then the PCM in chunks -- the host hands chunk k to the callers' buffers while
     //      chunk k + 1 is still crossing PCIe (the scatter is as long as the copy: 5 MB per 16,384 frames each) ----
     constexpr int kMaxChunks = 4;
-    // small flushes (many host threads, each with a share of the channels) go out as one piece: every extra copy and event is a
-    // trip through the HIP runtime's per-device lock, which is what bounds the rate when sixteen threads flush at once
     const int kChunks = rows >= 8192 ? kMaxChunks : 1;
     if (!s.chunk_done[0]) {
         HIP_OK(hipEventCreateWithFlags(&s.chunk_done[0], hipEventDisableTiming | hipEventBlockingSync));   // the long wait sleeps
@@ -926,27 +1045,39 @@ int flush_batch(Batch& b) {
             HIP_OK(hipEventCreateWithFlags(&s.chunk_done[k], hipEventDisableTiming));
         }
     }
-    HIP_OK(hipMemcpyAsync(b.h_results.p, b.d_results.p, rows * sizeof(mbe_process_result), hipMemcpyDeviceToHost, s.stream));
-    HIP_OK(hipMemcpyAsync(b.h_records.p, b.d_records.p, rows * sizeof(mbx_param_record), hipMemcpyDeviceToHost, s.stream));
-    HIP_OK(hipEventRecord(s.chunk_done[0], s.stream));
     const size_t per_chunk = (rows + kChunks - 1) / kChunks;
-    for (int k = 0; k < kChunks; ++k) {
-        const size_t r0 = (size_t)k * per_chunk, r1 = r0 + per_chunk < rows ? r0 + per_chunk : rows;
-        if (r0 < r1) {
-            if (any_short) {
-                HIP_OK(hipMemcpyAsync(b.h_pcm16.p + r0 * 160, b.d_pcm16.p + r0 * 160, (r1 - r0) * 160 * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
+    if (pumped) {   // the pump makes the launches, records the event and wakes this thread when it has fired
+        PumpJob job;
+        job.issue = issue;
+        job.stream = s.stream;
+        job.done_ev = s.chunk_done[0];
+        pump().submit_and_wait(job);
+    } else if (zero_copy) {   // everything is already where the host reads it once the kernels have retired: ONE event for all of it
+        HIP_OK(hipEventRecord(s.chunk_done[0], s.stream));
+    } else {
+        HIP_OK(hipMemcpyAsync(b.h_results.p, b.d_results.p, rows * sizeof(mbe_process_result), hipMemcpyDeviceToHost, s.stream));
+        HIP_OK(hipMemcpyAsync(b.h_records.p, b.d_records.p, rows * sizeof(mbx_param_record), hipMemcpyDeviceToHost, s.stream));
+        HIP_OK(hipEventRecord(s.chunk_done[0], s.stream));
+        for (int k = 0; k < kChunks; ++k) {
+            const size_t r0 = (size_t)k * per_chunk, r1 = r0 + per_chunk < rows ? r0 + per_chunk : rows;
+            if (r0 < r1) {
+                if (any_short) {
+                    HIP_OK(hipMemcpyAsync(b.h_pcm16.p + r0 * 160, b.d_pcm16.p + r0 * 160, (r1 - r0) * 160 * sizeof(int16_t), hipMemcpyDeviceToHost, s.stream));
+                }
+                if (any_float) {
+                    HIP_OK(hipMemcpyAsync(b.h_pcmf.p + r0 * 160, b.d_pcmf.p + r0 * 160, (r1 - r0) * 160 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+                }
             }
-            if (any_float) {
-                HIP_OK(hipMemcpyAsync(b.h_pcmf.p + r0 * 160, b.d_pcmf.p + r0 * 160, (r1 - r0) * 160 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-            }
+            HIP_OK(hipEventRecord(s.chunk_done[k + 1], s.stream));
         }
-        HIP_OK(hipEventRecord(s.chunk_done[k + 1], s.stream));
     }
     std::vector<uint32_t> by_row(rows);
     for (size_t e = 0; e < n; ++e) {
         by_row[row_of[e]] = (uint32_t)e;
     }
-    if (rows < 256) {
+    if (pumped) {
+        // (done: the pump saw the event fire)
+    } else if (rows < 256) {
         HIP_OK(hipStreamSynchronize(s.stream));   // a small flush: spin, the sleeping wait's wake-up would be most of it
     } else {
         HIP_OK(hipEventSynchronize(s.chunk_done[0]));
@@ -962,7 +1093,9 @@ int flush_batch(Batch& b) {
     }
     for (int k = 0; k < kChunks; ++k) {   // PCM, chunk by chunk
         const size_t r0 = (size_t)k * per_chunk, r1 = r0 + per_chunk < rows ? r0 + per_chunk : rows;
-        HIP_OK(hipEventSynchronize(s.chunk_done[k + 1]));
+        if (!zero_copy) {
+            HIP_OK(hipEventSynchronize(s.chunk_done[k + 1]));
+        }
         for (size_t r = r0; r < r1; ++r) {
             const QEntry& qe = b.q[by_row[r]];
             if (qe.want_short) {
