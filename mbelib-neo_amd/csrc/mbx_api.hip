@@ -39,6 +39,10 @@ __global__ void imbe_stream_kernel_one_fused(int, int, const uint8_t*, mbx_param
                                              mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res1_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
                                               mbe_process_result*, DeviceTables);
+#ifdef MBX_EXP_PAIR
+__global__ void imbe_stream_kernel_lds_pairexp(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
+                                               mbe_process_result*, DeviceTables);
+#endif
 __global__ void imbe_stream_kernel_lds_slice(int, int, int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
                                              mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel_lds_slice(int, int, int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
@@ -1030,6 +1034,13 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
     }
     if (codec == MBX_CODEC_IMBE7200X4400) {
         if (lds_resident) {
+#ifdef MBX_EXP_PAIR   // experiment builds only (mbx_stream.hip, imbe_stream_kernel_lds_pairexp)
+            if ((S & 1) == 0 && !tabs.stream_map) {
+                hipLaunchKernelGGL(mbx::imbe_stream_kernel_lds_pairexp, dim3((unsigned)S / 2), dim3(128), 0, (hipStream_t)stream, S, T, d_records,
+                                   params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+                return check_launch("imbe_stream_kernel_lds_pairexp");
+            }
+#endif
             hipLaunchKernelGGL(mbx::imbe_stream_kernel_lds, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                                params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
             return check_launch("imbe_stream_kernel_lds");

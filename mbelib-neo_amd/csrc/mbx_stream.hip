@@ -2017,14 +2017,22 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                  int fec_codec = 0, FrameShadow shadow = FrameShadow{}, FrontLink link = FrontLink{}, FrameSlice slice = FrameSlice{}) {
     using ScratchT = WaveScratchT<kPark ? 0 : MBX_PARK_N>;
     ScratchT* scratch_ptr;
+#ifdef MBX_EXP_PAIR   // EXPERIMENT (never the product build): two streams per 128-thread workgroup, see imbe_stream_kernel_lds_pairexp
+    __shared__ ScratchT scratch_pair[2];
+    __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park_pair[2];
+    const int wave_in_group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 1;
+    scratch_ptr = &scratch_pair[wave_in_group];
+    auto& park = park_pair[wave_in_group];
+#else
     if constexpr (kFuse == 3) {
         scratch_ptr = reinterpret_cast<ScratchT*>(link.lds);
     } else {
         __shared__ ScratchT scratch_own;
         scratch_ptr = &scratch_own;
     }
-    ScratchT& scratch = *scratch_ptr;
     __shared__ std::conditional_t<kPark, ParkedPrevOnly, ParkedState<false>> park;
+#endif
+    ScratchT& scratch = *scratch_ptr;
     uint4 rec_in = make_uint4(0u, 0u, 0u, 0u);
     const int bpos = (kFuse == 3) ? link.pos : (slice.pos >= 0 ? slice.pos : (int)blockIdx.x);
     if (bpos >= S) {
@@ -2239,6 +2247,12 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             lane &= 63;
         }
         const DeviceTables& tabs = ft;
+#if defined(MBX_EXP_PAIR) && MBX_EXP_PAIR > 0   // the rendezvous a paired transform would need: MBX_EXP_PAIR barriers per frame
+#pragma unroll
+        for (int bq = 0; bq < MBX_EXP_PAIR; ++bq) {
+            __builtin_amdgcn_s_barrier();
+        }
+#endif
         if constexpr (kPark && !kFrame) {
             __builtin_amdgcn_s_setprio(MBX_PRIO_FRONT_IMBE);
         }
@@ -3590,6 +3604,21 @@ ambe2400_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ r
                            float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     ambe_stream_body<true, true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
+
+#ifdef MBX_EXP_PAIR
+// EXPERIMENT ("two streams per wave for the transform pair"): what does it cost two streams to share a
+// workgroup and meet at MBX_EXP_PAIR barriers per frame -- the rendezvous any pairing of their unvoiced transforms needs -- BEFORE
+// any of the pairing's arithmetic is saved?  Two waves per workgroup, wave w decodes stream 2 b + w with the unchanged body.
+// (An odd stream count would leave a wave without a partner at the barriers: the experiment runs even S only.)
+__global__ void __launch_bounds__(128, MBX_IMBE_LDS_WAVES_PER_SIMD)
+imbe_stream_kernel_lds_pairexp(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                               mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                               float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    FrameSlice sl;
+    sl.pos = 2 * (int)blockIdx.x + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: say so)
+    imbe_stream_body<true>(S, Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in, nullptr, 0, FrameShadow{}, FrontLink{}, sl);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Slice kernels (*_stream_kernel_lds_slice): the LDS-resident instances on a SLICE of every stream's frames -- frames t0 ..
