@@ -52,6 +52,7 @@ WORKLOADS = {
     "imbe_voiced_resident": (0, 65536, 1, "65,536 IMBE 7200x4400 streams x T=1, clean all-voiced frames, warm RESIDENT state (prev_mp_enhanced elided, prev_mp lazy)"),
     "imbe_mixed": (0, 65536, 16, "BASELINE configs[3]: 65,536 IMBE streams x T=16 random-bit frames (mixed voiced/unvoiced)"),
     "ambe_fec": (1, 65536, 1, "BASELINE configs[2]: 65,536 AMBE+2 streams x T=1, clean voice frames + 1% bit flips"),
+    "ambe_fec_resident": (1, 65536, 1, "65,536 AMBE+2 streams x T=1, clean voice frames + 1% bit flips, RESIDENT state (prev_mp_enhanced elided, prev_mp lazy)"),
     "ambe_stream": (1, 8192, 128, "BASELINE configs[4] per-GPU shard: 8,192 AMBE+2 streams x T=128 random-bit frames, int16 out"),
     # SURVEY.md §8(f) row 4 (not BASELINE configs): the other two codecs of the reference
     "imbe7100_mixed": (2, 65536, 16, "65,536 IMBE 7100x4400 streams x T=16 random-bit frames"),
@@ -72,7 +73,7 @@ def make_frames(name, codec, S, T, rank):
     rng = framegen.rng_for(0xBE0000 + 97 * rank + codec)
     if name in ("imbe_voiced", "imbe_voiced_resident"):
         return framegen.imbe_clean_voiced_frames(S * T, rng)
-    if name == "ambe_fec":
+    if name in ("ambe_fec", "ambe_fec_resident"):
         return framegen.ambe_noisy_voice_frames(S * T, rng, ber=0.01)
     if name.endswith("_soft_coded"):
         return framegen.soft_frames_coded(codec, S * T, rng)
@@ -867,7 +868,7 @@ def main():
     if extras and args.workload == "imbe_voiced":
         # the other three GPU configs of BASELINE.json, driver-timed in the same line (10 steps each)
         line["other_configs"] = {}
-        for other in ("imbe_voiced_resident", "ambe_fec", "imbe_mixed", "ambe_stream"):
+        for other in ("imbe_voiced_resident", "ambe_fec", "ambe_fec_resident", "imbe_mixed", "ambe_stream"):
             oc, oS, oT, odesc = WORKLOADS[other]
             om = run_workload(other, oS, oT, 10, 2, rank, 0, local_rank, blob, 1, dist, args)
             orf = roofline_of(other, oS, oT, om)

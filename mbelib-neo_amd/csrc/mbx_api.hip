@@ -55,6 +55,10 @@ __global__ void imbe_one_launch_kernel_res(int, int, const uint8_t*, mbx_param_r
                                            mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_one_launch_kernel(int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*, mbx_stream_rng*,
                                        int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe_one_launch_kernel_res(int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
+                                           mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe2400_one_launch_kernel_res(int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
+                                               mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe2400_one_launch_kernel(int, const uint8_t*, mbx_param_record*, FrameParams*, uint32_t*, uint32_t*, uint32_t, mbe_parms*,
                                            mbx_stream_rng*, int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe7100_stream_kernel_one_fused(int, int, const uint8_t*, mbx_param_record*, mbe_parms*, mbx_stream_rng*, int16_t*, float*,
@@ -63,6 +67,10 @@ __global__ void imbe7100_stream_kernel_res1_fused(int, int, const uint8_t*, mbx_
                                                   mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res1(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                         int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe_stream_kernel_res1(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                        int16_t*, float*, mbe_process_result*, DeviceTables);
+__global__ void ambe2400_stream_kernel_res1(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
+                                            int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void imbe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
                                        int16_t*, float*, mbe_process_result*, DeviceTables);
 __global__ void ambe_stream_kernel_res(int, int, const mbx_param_record*, const FrameParams*, mbe_parms*, mbx_stream_rng*,
@@ -1023,6 +1031,10 @@ static int launch_stream(Context* c, bool reverse, int codec, int S, int T, cons
         } else if (codec == MBX_CODEC_IMBE7200X4400) {
             hipLaunchKernelGGL(mbx::imbe_stream_kernel_res, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                                params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
+        } else if (T == 1 && params && res1_enabled()) {   // the AMBE codecs: one frame per stream on rows from the expand launch
+            auto* const k1 = codec == MBX_CODEC_AMBE3600X2400 ? mbx::ambe2400_stream_kernel_res1 : mbx::ambe_stream_kernel_res1;
+            hipLaunchKernelGGL(k1, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records, params, d_state, d_rng, d_pcm16, d_pcmf,
+                               d_results, tabs);
         } else if (codec == MBX_CODEC_AMBE3600X2400) {
             hipLaunchKernelGGL(mbx::ambe2400_stream_kernel_res, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, T, d_records,
                                params, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
@@ -1135,13 +1147,13 @@ static int front_lead_chunks() {
     return lead;
 }
 static bool ambe_codec(int codec) { return codec == MBX_CODEC_AMBE3600X2450 || codec == MBX_CODEC_AMBE3600X2400; }
-// resident: the AMBE codecs have no one-launch form on resident state (their resident launches take the LDS-resident instances)
 static bool fused_one_ok(int codec, int S, int T, const void* d_frames, bool resident = false) {
+    (void)resident;
     if (T != 1 || S <= kSmallBatchFrames || fused_one_mode() == 0) {
         return false;
     }
     if (ambe_codec(codec)) {
-        return fused_one_mode() == 2 && !resident;   // 9-byte frames: byte loads, any alignment
+        return fused_one_mode() == 2;   // 9-byte frames: byte loads, any alignment
     }
     return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) && (reinterpret_cast<uintptr_t>(d_frames) & 3u) == 0;
 }
@@ -1174,7 +1186,8 @@ static int launch_one_launch(Context* c, StreamSlot& slot, bool reverse, int cod
     slot.exp_codec = -1;   // the rows of an earlier mbx_expand_records() are being replaced
     const unsigned chunks = (unsigned)((S + 7) / 8);
     if (ambe_codec(codec)) {
-        auto* const akernel = codec == MBX_CODEC_AMBE3600X2400 ? mbx::ambe2400_one_launch_kernel : mbx::ambe_one_launch_kernel;
+        auto* const akernel = d_resident ? (codec == MBX_CODEC_AMBE3600X2400 ? mbx::ambe2400_one_launch_kernel_res : mbx::ambe_one_launch_kernel_res)
+                                         : (codec == MBX_CODEC_AMBE3600X2400 ? mbx::ambe2400_one_launch_kernel : mbx::ambe_one_launch_kernel);
         hipLaunchKernelGGL(akernel, dim3(9u * chunks), dim3(64), 0, (hipStream_t)stream, S, d_frames, d_records, slot.workspace, slot.flags,
                            slot.flags + (slot.frames + 7) / 8, slot.epoch, d_state, d_rng, d_pcm16, d_pcmf, d_results, tabs);
         return check_launch("ambe_one_launch_kernel");
@@ -1864,7 +1877,8 @@ int mbx_launch_slices(int codec, int S, int T) {
 const char* mbx_batch_kernel_name(int codec, int S, int T, int resident) {
     if (fused_one_ok(codec, S, T, nullptr, resident != 0)) {
         if (ambe_codec(codec)) {
-            return codec == MBX_CODEC_AMBE3600X2400 ? "ambe2400_one_launch_kernel" : "ambe_one_launch_kernel";
+            return codec == MBX_CODEC_AMBE3600X2400 ? (resident ? "ambe2400_one_launch_kernel_res" : "ambe2400_one_launch_kernel")
+                                                    : (resident ? "ambe_one_launch_kernel_res" : "ambe_one_launch_kernel");
         }
         if (codec == MBX_CODEC_IMBE7100X4400) {
             return resident ? "imbe7100_stream_kernel_res1_fused" : "imbe7100_stream_kernel_one_fused";
@@ -1884,9 +1898,10 @@ const char* mbx_batch_kernel_name(int codec, int S, int T, int resident) {
 
 const char* mbx_stream_kernel_name(int codec, int T) {
     if (T < 0) {   // the instances of the resident launches (mbx_process_batch_resident) with -T frames per stream
-        return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? ((T == -1 && res1_enabled()) ? "imbe_stream_kernel_res1" : "imbe_stream_kernel_res")
-               : (codec == MBX_CODEC_AMBE3600X2400)                                    ? "ambe2400_stream_kernel_res"
-                                                                                        : "ambe_stream_kernel_res";
+        const bool one = T == -1 && res1_enabled();
+        return (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) ? (one ? "imbe_stream_kernel_res1" : "imbe_stream_kernel_res")
+               : (codec == MBX_CODEC_AMBE3600X2400)                                    ? (one ? "ambe2400_stream_kernel_res1" : "ambe2400_stream_kernel_res")
+                                                                                        : (one ? "ambe_stream_kernel_res1" : "ambe_stream_kernel_res");
     }
     const bool lds = T >= kLdsResidentMinFrames && lds_resident_enabled();
     if (codec == MBX_CODEC_IMBE7200X4400 || codec == MBX_CODEC_IMBE7100X4400) {

@@ -2894,6 +2894,12 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     // resident launches (DeviceTables::resident): `synced` is carried from launch to launch in resident[slot], the struct of
     // prev_mp_enhanced is neither read nor written while it holds, and prev_mp comes into LDS lazily (see the IMBE kernel)
     uint32_t* const res = (kPark && kRes) ? tabs_in.resident : nullptr;
+    // kRes without kPark (with kOne): the HBM-slot instance for resident launches of ONE frame per stream (cf. imbe_stream_kernel_res1).
+    // `elided`: prev_mp_enhanced of the stream is elided (== cur_mp field for field): its view comes from cur_mp's struct, a frame that
+    // ends with prev_mp_enhanced := cur_mp stores nothing, and a frame that will leave prev_mp_enhanced alone while it changes cur_mp
+    // (tone class) first writes the still-unchanged cur_mp out as prev_mp_enhanced.
+    uint32_t* const res1 = (!kPark && kRes) ? tabs_in.resident : nullptr;
+    bool elided = res1 && (uni(res1[slot]) != 0u);
     bool prev_partial = false;
     // every request of the launch's first frame goes out before anything waits: see the IMBE body and load_header
     Parms enh_first, prev_first;
@@ -2956,13 +2962,14 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         } else {
             row_first = params[fbase].v[lane_in];   // the frame's FrameParams row: needed first, requested first
         }
+        const mbe_parms* const enh_src = elided ? slot_cur : slot_enh;
         const uint32_t h_cur = load_header(slot_cur, lane_in);
         h_prev_first = load_header(slot_prev, lane_in);
-        h_enh_first = load_header(slot_enh, lane_in);
+        h_enh_first = load_header(enh_src, lane_in);
         load_rng(rng, &rngs[slot]);
         load_prev_arrays(prev_first, slot_prev, lane_in);
         load_parms_arrays(cur, slot_cur, lane_in);
-        load_enh_arrays(enh_first, slot_enh, lane_in);
+        load_enh_arrays(enh_first, enh_src, lane_in);
         if constexpr (kFuse == 3) {   // the row comes from a front block of the same launch: see the IMBE body
             asm volatile("" ::: "memory");
             bool ready = uni(flag_v) == link.epoch;
@@ -3111,6 +3118,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     synced = true;
                 } else {
                     store_parms<kOne && MBX_AMBE_GATHER_STORES>(prev, slot_enh, lane);
+                    elided = false;   // (all three structs have just been written whole)
                     slot_fence<kPark>();
                     load_enh_view(enh, slot_enh, lane);
                 }
@@ -3125,6 +3133,15 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 if (keeps_enh && synced) {
                     store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, home_enh, lane);
                     synced = false;
+                }
+            }
+            if constexpr (!kPark && kRes) {   // the same for the one-frame resident instance: prev_mp_enhanced leaves its elision
+                const int cls = uni(__float_as_int(fp[63])) & 0xff;
+                const int c0v_early = ((flags & MBE_PROCESS_FLAG_C0_VALID) != 0u) ? c0 : 0;
+                const bool keeps_enh = k2400 ? ((cls >= 7) && (cls <= 122) && (c0v_early < 2) && (total < 3)) : (cls == 7);
+                if (keeps_enh && elided) {
+                    store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_enh, lane);
+                    elided = false;
                 }
             }
             cur.mutingThreshold = MBE_MUTING_THRESHOLD_AMBE;
@@ -3271,8 +3288,10 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                     copy_parms<kOne>(slot_prev, home_prev, lane);   // prev_mp returns to LDS
                     prev_partial = false;
                 }
+            } else if (res1 && action == kVoice) {
+                elided = true;   // prev_mp_enhanced := cur_mp, not written
             } else {
-                store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_enh, lane);
+                store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_enh, lane);   // (the replayed copy of an invalid tone is NOT cur_mp: it is stored)
             }
             if (action == kToneFallback) {
                 __threadfence_block();
@@ -3294,6 +3313,8 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             if constexpr (kPark) {
                 keep_enh_view(cur);
                 synced = true;
+            } else if (res1) {
+                elided = true;
             } else {
                 store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_enh, lane);
             }
@@ -3316,6 +3337,9 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
 
     store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_cur, lane_in);
     store_rng(rng, &rngs[slot], lane_in);
+    if (res1 && lane_in == 0) {
+        res1[slot] = elided ? 1u : 0u;
+    }
     if constexpr (kPark) {   // prev_mp goes home from LDS; prev_mp_enhanced from `cur` unless its home is already current
         if (res) {
             if (lane_in == 0) {
@@ -3535,7 +3559,7 @@ __device__ __forceinline__ void front_block_ambe(int chunk, int S, const uint8_t
         __hip_atomic_store(&flags[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-template <bool k2400>
+template <bool k2400, bool kRes = false>
 __device__ __forceinline__ void ambe_one_launch_body(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records,
                                                      FrameParams* __restrict__ rows, uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks,
                                                      uint32_t epoch, mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs,
@@ -3555,8 +3579,8 @@ __device__ __forceinline__ void ambe_one_launch_body(int S, const uint8_t* __res
     link.epoch = epoch;
     link.lds = lds;
     link.fallbacks = fallbacks;
-    ambe_stream_body<k2400, false, false, false, true, 3>(S, 1, records, rows, state, rngs, pcm16, pcmf, results, tabs_in, frames, FrameShadow{},
-                                                          FrameSlice{}, link);
+    ambe_stream_body<k2400, false, false, kRes, true, 3>(S, 1, records, rows, state, rngs, pcm16, pcmf, results, tabs_in, frames, FrameShadow{},
+                                                         FrameSlice{}, link);
 }
 __global__ void __launch_bounds__(64, MBX_AMBE_ONE_WAVES_PER_SIMD)
 ambe_one_launch_kernel(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
@@ -3564,6 +3588,20 @@ ambe_one_launch_kernel(int S, const uint8_t* __restrict__ frames, mbx_param_reco
                        mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
                        mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     ambe_one_launch_body<false>(S, frames, records, rows, flags, fallbacks, epoch, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+__global__ void __launch_bounds__(64, MBX_AMBE_ONE_WAVES_PER_SIMD)
+ambe_one_launch_kernel_res(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
+                           uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks, uint32_t epoch, mbe_parms* __restrict__ state,
+                           mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                           mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_one_launch_body<false, true>(S, frames, records, rows, flags, fallbacks, epoch, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+__global__ void __launch_bounds__(64, MBX_AMBE2400_WAVES_PER_SIMD)
+ambe2400_one_launch_kernel_res(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
+                               uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks, uint32_t epoch, mbe_parms* __restrict__ state,
+                               mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
+                               mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_one_launch_body<true, true>(S, frames, records, rows, flags, fallbacks, epoch, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 __global__ void __launch_bounds__(64, MBX_AMBE2400_WAVES_PER_SIMD)
 ambe2400_one_launch_kernel(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
@@ -3670,6 +3708,20 @@ imbe_stream_kernel_res1(int S, int Tn, const mbx_param_record* __restrict__ reco
                         mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                         float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     imbe_stream_body<false, false, true, true>(S, Tn > 1 ? 1 : Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+
+// one frame per stream on resident state: the HBM-slot bodies with the elision (see imbe_stream_kernel_res1)
+__global__ void __launch_bounds__(64, MBX_AMBE_ONE_WAVES_PER_SIMD)
+ambe_stream_kernel_res1(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<false, false, false, true, true>(S, Tn > 1 ? 1 : Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
+}
+__global__ void __launch_bounds__(64, MBX_AMBE2400_WAVES_PER_SIMD)
+ambe2400_stream_kernel_res1(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
+                            mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
+                            float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
+    ambe_stream_body<true, false, false, true, true>(S, Tn > 1 ? 1 : Tn, records, params, state, rngs, pcm16, pcmf, results, tabs_in);
 }
 
 __global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
