@@ -709,6 +709,16 @@ def roofline_of(name, S, T, m):
         r["note"] = "dominant kernel of this workload is the soft-decision FEC kernel: algorithmic bytes = n * (2 B per soft cell + 16 B record)"
     else:
         r["note"] = "algorithmic bytes = S*T*(wire frame + int16 PCM) + S*2*3*2604 state (SURVEY.md §8(d))"
+    if m["kernel"].endswith("_slice"):
+        # a sliced launch (include/mbx.h): the step is 3 groups of streams x ceil(T / slice) slices, issued on three internal HIP streams
+        # and overlapping on the device; kernel_ms brackets the whole step on the caller's stream (fork event to join events), a
+        # rocprofv3 AverageNs of `kernel` is ONE slice of one group
+        from mbelib_neo_amd import _native
+        tc = int(_native.lib().mbx_launch_slices(WORKLOADS[name][0], S, T))
+        r["kernel_launches_per_step"] = 3 * ((T + tc - 1) // tc) if tc > 0 else 1
+        r["slice_frames"] = tc
+        r["note"] += ("; SLICED launch: kernel_ms is the whole step (concurrent slices on three internal streams), one rocprofv3 dispatch of "
+                      "this kernel is one slice of one group of streams")
     return r
 
 

@@ -87,6 +87,9 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #ifndef MBX_FLAT_LOADS
 #define MBX_FLAT_LOADS 1   // one-launch T = 1 kernels: unconditional struct loads (see load_parms_arrays)
 #endif
+#ifndef MBX_EARLY_NOISE
+#define MBX_EARLY_NOISE 1   // the next overlap's jump-ahead constants requested ahead of the voiced bank (synth_core)
+#endif
 #ifndef MBX_PRIO_FRONT_BLOCK
 #define MBX_PRIO_FRONT_BLOCK 3
 #endif
@@ -1126,7 +1129,9 @@ __device__ __forceinline__ float div_by_uniform(float a, float b, float rcp_b) {
 // cur.PSIl are new), false when it left early (silence, comfort noise): the per-lane state is then still what
 // the snapshot holds.
 // kPark: the snapshot lives in LDS (the launch-resident copies of the T >= 4 kernel instances) instead of the stream's HBM slot.
-template <bool kSnap, bool kPark = false, class Scratch = WaveScratch>
+// kEarly: see kEarlyNoise below -- the one-frame instances only (A/B: 65,536 x 1 IMBE -0.9 %, resident -3.5 %; the looped HBM-slot
+// instances spill with it, the LDS-resident AMBE+2 one is 1.9 % slower over 128 frames)
+template <bool kSnap, bool kPark = false, class Scratch = WaveScratch, bool kEarly = false>
 __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
                            Scratch& S, const DeviceTables& tabs, int lane, const mbe_parms* snap_ptr = nullptr) {
     constexpr int kParkN = Scratch::kParkCols;
@@ -1240,6 +1245,17 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             const float pl = ((2.0f * (float)M_PI / 53125.0f) * nz[0]) - (float)M_PI;
             cur.PHIl = cur.PSIl + div_by_uniform((float)numUv * pl, (float)cur.L, inv_L);
         }
+    }
+
+    // The two jump-ahead constants of the NEXT frame's noise overlap depend on the lane only: requested here, ahead of the voiced
+    // bank, they are there when the bank is done -- an all-voiced frame then has no memory round trip between the bank and its
+    // overlap-add (tools/stage_times.py: that round trip was 1.05 us of a one-frame wave's 20).  Two more registers across the bank.
+    uint32_t q64_early = 0u, q128_early = 0u;
+    constexpr bool kEarlyNoise = MBX_EARLY_NOISE != 0 && kSnap && kEarly;
+    if (kEarlyNoise && snap && !cold) {
+        q64_early = lcg_req(lane + 64);
+        q128_early = lcg_req(lane < 32 ? lane + 128 : 160);
+        asm volatile("" ::: "memory");   // (requested HERE: not sunk to the use)
     }
 
     // ---- voiced bank -----------------------------------------------------------------------
@@ -1456,11 +1472,15 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             __threadfence_block();   // the snapshot was stored by this wave; its stores have long been issued
         }
         MBX_TS(6);   // voiced bank + its output through LDS
-        float old0 = snap_f(O_OVERLAP + lane);
-        float old1 = (lane < 32) ? snap_f(O_OVERLAP + 64 + lane) : 0.0f;
-        // every request of this stage first (see lcg_req), then ONE wait
-        uint32_t q64 = lcg_req(lane + 64), q128 = lcg_req(lane < 32 ? lane + 128 : 160), qm32 = 0u, q32 = 0u, q96 = 0u;
         const bool fft_noise = !MBX_ABL(tabs, 32) && any_unvoiced;   // the fresh samples of the transform's input (a voiced frame never needs them)
+        float old0 = 0.0f, old1 = 0.0f;
+        if (!kEarlyNoise || fft_noise) {   // (the old overlap is the transform's input: an all-voiced frame does not read it back)
+            old0 = snap_f(O_OVERLAP + lane);
+            old1 = (lane < 32) ? snap_f(O_OVERLAP + 64 + lane) : 0.0f;
+        }
+        // every request of this stage first (see lcg_req), then ONE wait
+        uint32_t q64 = kEarlyNoise ? q64_early : lcg_req(lane + 64), q128 = kEarlyNoise ? q128_early : lcg_req(lane < 32 ? lane + 128 : 160);
+        uint32_t qm32 = 0u, q32 = 0u, q96 = 0u;
         if (fft_noise) {
             qm32 = lcg_req(lane - 32);
             q32 = lcg_req(lane + 32);
@@ -2349,7 +2369,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             MBX_STAMP(5, false);
             if constexpr (kOne) { MBX_TS(4); }   // snapshot stored, enhanced
             if (!MBX_ABL(tabs, 128)) {
-                fresh = synth_core<true, kPark>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
+                fresh = synth_core<true, kPark, ScratchT, kOne>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
             }
             MBX_STAMP(6, false);
             if constexpr (kOne) { MBX_TS(12); }   // synthesised (soft clip)
@@ -3258,7 +3278,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         if (action == kVoice || action == kToneFallback) {
             const mbe_parms* snap = (kPark || action == kVoice) ? slot_prev : slot_enh;
-            const bool fresh = synth_core<true, kPark>(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane, snap);
+            const bool fresh = synth_core<true, kPark, ScratchT, kOne>(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane, snap);
             {
                 slot_fence<kPark>();
                 const float* f = reinterpret_cast<const float*>(snap);
