@@ -6,6 +6,9 @@
 #pragma once
 #include "mbx_device.h"
 #include "mbx_expand_ambe.h"   // xp::rbit
+#ifndef MBX_FTS
+#define MBX_FTS(i, v) do { } while (0)   // stage marks of the front blocks (mbx_stream.hip, MBX_STAGE_TIMES builds)
+#endif
 
 namespace mbx {
 namespace xp {
@@ -40,6 +43,7 @@ __device__ __forceinline__ void expand_imbe_frame_rec(bool have, uint4 rec, floa
     } else {
         rec = make_uint4(0u, 0u, 0u, 0u);
     }
+    MBX_FTS(5, L);   // b0 entry there: L known
     const int L9 = bad ? 0 : L - 9;
     const bool live = have && !bad;
     const bool block_lane = live && sub >= 1 && sub <= 6;
@@ -86,6 +90,7 @@ __device__ __forceinline__ void expand_imbe_frame_rec(bool have, uint4 rec, floa
     for (int k = 0; k < 10; ++k) {
         cosr[k] = rows[k];
     }
+    MBX_FTS(6, cosr[0]);   // every table request of the L round issued; block info and the first cosine row there
     wave_lds_sync();
     // Bit layout (ref src/imbe/imbe7200x4400.c:156-168): payload bit i feeds bit e[1] of word e[0].  The
     // eight lanes of a frame scatter ten payload bits each with LDS atomic ORs.
@@ -103,6 +108,7 @@ __device__ __forceinline__ void expand_imbe_frame_rec(bool have, uint4 rec, floa
         }
     }
     wave_lds_sync();
+    MBX_FTS(7, e[0]);   // bit layout there, words scattered
     float b2v = 0.0f;
     if (live && sub == 1) {
         b2v = T->imbe_B2[low_bits_x(words[2], 6)];   // the one look-up that depends on the frame's own bits
@@ -117,6 +123,7 @@ __device__ __forceinline__ void expand_imbe_frame_rec(bool have, uint4 rec, floa
         gains[sub] = G;
     }
     wave_lds_sync();
+    MBX_FTS(8, b2v);   // B2 there, gains
     if (have) {
         if (sub == 0) {
             uint32_t vlo = 0, vhi = 0;

@@ -25,6 +25,9 @@
 #pragma once
 #include "mbx_device.h"
 #include "mbx_expand_imbe.h"
+#ifndef MBX_FTS
+#define MBX_FTS(i, v) do { } while (0)
+#endif
 
 namespace mbx {
 
@@ -65,6 +68,7 @@ __device__ __forceinline__ uint4 front8_fec_imbe(bool have, const uint8_t* frame
         const uint64_t two = ((uint64_t)be(a) << 48) | ((uint64_t)be(b) << 32) | ((uint64_t)be(c) << 16);
         row = (uint32_t)((two << (start & 15)) >> (64 - width));
     }
+    MBX_FTS(1, row);   // the frame's words are there
     // C0: Golay(23,12) on row 0 (every lane forms the syndrome of its own row; only r = 0 uses it here)
     {
         const uint32_t syn = front_golay_syndrome(row, half_syn);
@@ -73,6 +77,7 @@ __device__ __forceinline__ uint4 front8_fec_imbe(bool have, const uint8_t* frame
             fix = *(const __attribute__((address_space(1))) uint16_t*)(T + offsetof(mbx_tables, golay_matrix) + 2u * syn);
         }
         row ^= fix << 11;   // (zero in the other lanes)
+        MBX_FTS(2, row);   // C0 corrected
         // c0 errors: kept in lane r = 0 as the low byte of the fourth record word (below)
         const uint32_t c0 = (uint32_t)__popc(fix);
         const uint32_t row0 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane & ~7) << 2, (int)row);
@@ -86,6 +91,7 @@ __device__ __forceinline__ uint4 front8_fec_imbe(bool have, const uint8_t* frame
             const uint64_t two = ((uint64_t)w.x << 32) | w.y;
             row ^= (uint32_t)((two << (p & 31)) >> (64 - width));
         }
+        MBX_FTS(3, row);   // demodulated
         // syndromes: Golay on rows 1..3, Hamming(15,11) on rows 4..6; one correction read per lane
         const uint32_t gsyn = front_golay_syndrome(row, half_syn);
         uint32_t hsyn = 0u;
@@ -106,6 +112,7 @@ __device__ __forceinline__ uint4 front8_fec_imbe(bool have, const uint8_t* frame
                 err = 1u;
             }
         }
+        MBX_FTS(4, row);   // corrections there
         // the record: 12 data bits of rows 0..3, 11 of rows 4..6, the 7 bits of row 7, in this order (88 bits, big-endian)
         const int count = r < 4 ? 12 : (r < 7 ? 11 : 7);
         const int off = r < 4 ? 12 * r : (r < 7 ? 4 + 11 * r : 81);   // 0, 12, 24, 36, 48, 59, 70, 81

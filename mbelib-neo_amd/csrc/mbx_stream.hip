@@ -61,6 +61,12 @@ __shared__ unsigned long long s_stage_prev;          // one wave per workgroup
 namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #define MBX_FSTAMP(i) do { g_frame_stamps[i] = wall_clock64(); } while (0)
 #endif
+// stage marks inside the front blocks (mbx_front_imbe.h, mbx_expand_imbe.h), MBX_STAGE_TIMES builds only; `v`: a value the mark waits for
+#ifdef MBX_STAGE_TIMES
+#define MBX_FTS(i, v) do { asm volatile("" :: "v"(v)); MBX_TS(i); } while (0)
+#else
+#define MBX_FTS(i, v) do { } while (0)
+#endif
 #include "mbx_fec_frame.h"
 #include "mbx_front_imbe.h"
 
@@ -2525,6 +2531,7 @@ __device__ __forceinline__ void front_block_imbe(int chunk, int S, const uint8_t
     const int fi = lane >> 3, sub = lane & 7;
     const int j = 8 * chunk + fi;
     const bool have = j < S;
+    MBX_TS(0);
     __builtin_amdgcn_s_setprio(MBX_PRIO_FRONT_BLOCK);   // a front block holds a wave slot for as long as its chain of table reads takes: first in line
     const int sj = have ? (tabs.reverse ? (S - 1 - j) : j) : 0;
     const uint4 rec = front8_fec_imbe(have, frames + 18u * (size_t)sj, tabs, lane);
@@ -2533,6 +2540,7 @@ __device__ __forceinline__ void front_block_imbe(int chunk, int S, const uint8_t
     }
     xp::expand_imbe_frame_rec(have, rec, tile[fi], words[fi], gains[fi], sub, tabs);
     wave_lds_sync();
+    MBX_TS(9);   // inverse DCTs done, rows in LDS
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int jq = 8 * chunk + q;
@@ -2543,6 +2551,7 @@ __device__ __forceinline__ void front_block_imbe(int chunk, int S, const uint8_t
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every row store of the wave has left ...
+    MBX_TS(10);   // rows written through
     if (lane == 0) {
         __hip_atomic_store(&flags[chunk], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag does
     }

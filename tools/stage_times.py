@@ -22,6 +22,9 @@ NAMES = {14: "(fused) entry -> the frame's bytes are there", 15: "(fused) -> C0 
          4: "-> snapshot stored, enhanced", 5: "-> smoothing, phases, bank coefficients", 6: "-> voiced bank (+ output through LDS)",
          7: "-> noise samples (table round trip)", 8: "-> transform pair (or nothing)", 9: "-> overlap-add",
          12: "-> soft clip, back in the body", 13: "-> every store issued"}
+FRONT = {1: "entry -> the frame's words are there", 2: "-> C0 corrected (one table read)", 3: "-> demodulated (sequence window read)",
+         4: "-> corrections there (one table read)", 5: "-> record assembled, b0 entry there: L known", 6: "-> L round requested, block info there, first cosine row there",
+         7: "-> bit layout there, words scattered", 8: "-> B2 there, gains", 9: "-> inverse DCTs (a cosine row per output, one ahead)", 10: "-> rows written through (drained)"}
 # (a mark a wave does not pass -- the transform pair of an all-voiced frame has none of its own -- keeps the value of an earlier launch
 #  or zero; marks 7 / 8 are only meaningful for workloads with unvoiced bands)
 
@@ -43,8 +46,19 @@ def main():
     marks = np.zeros((S, 16), dtype=np.uint32)
     assert fn(marks.ctypes.data, S) == 0
     t = marks.astype(np.float64) * 0.01
+    if "one_launch" in line["roofline"]["kernel"]:
+        # the grid is S/8 front blocks, then the stream blocks: the first rows of the buffer are FRONT blocks with marks of their own
+        nf = (S + 7) // 8
+        f = t[:nf]
+        t = t[nf:]
+        flife = f[:, sorted(FRONT)].sum(axis=1)
+        print(f"{wl}: {nf} front blocks (eight frames each): life mean {flife.mean():.2f} us, median {np.median(flife):.2f}, "
+              f"p10 {np.percentile(flife, 10):.2f}, p90 {np.percentile(flife, 90):.2f}")
+        for i in sorted(FRONT):
+            print(f"  {FRONT[i]:60s} mean {f[:, i].mean():6.2f} us  median {np.median(f[:, i]):6.2f}  {100.0 * f[:, i].mean() / flife.mean():5.1f} %")
+        print(f"  ({len(t)} of the {S} stream blocks follow: the buffer holds {S} workgroups)")
     life = t[:, sorted(NAMES)].sum(axis=1)
-    print(f"{wl}: kernel {line['roofline']['kernel']} {line['roofline']['kernel_ms']:.4f} ms (instrumented build), {S} waves of the last launch")
+    print(f"{wl}: kernel {line['roofline']['kernel']} {line['roofline']['kernel_ms']:.4f} ms (instrumented build), {len(t)} stream waves of the last launch")
     print(f"  wave life, entry to last store: mean {life.mean():.2f} us, median {np.median(life):.2f}, p10 {np.percentile(life, 10):.2f}, p90 {np.percentile(life, 90):.2f}")
     for i in NAMES:
         print(f"  {NAMES[i]:52s} mean {t[:, i].mean():6.2f} us  median {np.median(t[:, i]):6.2f}  {100.0 * t[:, i].mean() / life.mean():5.1f} %")
