@@ -357,6 +357,14 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
             return fail(MBX_EBADTABLE, "table blob: unexpected synthesis window shape");
         }
     }
+    // the IMBE expansion scatters payload bits without looking at the entries again (mbx_expand_imbe.h): word 0..57, bit 0..11
+    for (int l9 = 0; l9 < 48; ++l9) {
+        for (int i = 0; i < 79; ++i) {
+            if (host->imbe_bo[l9][i][0] >= 58 || host->imbe_bo[l9][i][1] >= 12) {
+                return fail(MBX_EBADTABLE, "table blob: IMBE bit-layout entry out of range");
+            }
+        }
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         return fail(MBX_ENODEVICE, "no HIP device");

@@ -121,6 +121,14 @@ constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;   // lane i <-> 7-i inside each group of 8
 constexpr int kDppMirror = 0x140;       // lane i <-> 15-i inside each row of 16
 
+// sum over each group of eight consecutive lanes, returned in all eight (DPP: xor 1, xor 2, mirror within 8); all lanes call it
+__device__ __forceinline__ uint32_t sum8(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kDppXor1, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kDppXor2, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kDppHalfMirror, 0xf, 0xf, true);
+    return v;
+}
+
 // Sum over the 64 lanes, returned wave-uniform (the same bits in every lane): four DPP steps reduce
 // each row of 16, the four row totals are read back with v_readlane and added in a fixed order.
 __device__ __forceinline__ float wave_sum(float v) {

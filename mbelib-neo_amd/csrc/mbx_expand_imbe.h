@@ -92,19 +92,19 @@ __device__ __forceinline__ void expand_imbe_frame_rec(bool have, uint4 rec, floa
     }
     MBX_FTS(6, cosr[0]);   // every table request of the L round issued; block info and the first cosine row there
     wave_lds_sync();
-    // Bit layout (ref src/imbe/imbe7200x4400.c:156-168): payload bit i feeds bit e[1] of word e[0].  The
-    // eight lanes of a frame scatter ten payload bits each with LDS atomic ORs.
-    if (live) {
-        const uint32_t w[3] = {rec.x, rec.y, rec.z};
+    // Bit layout (ref src/imbe/imbe7200x4400.c:156-168): payload bit i feeds bit e[1] of word e[0].  The eight lanes of a frame
+    // scatter ten payload bits each with LDS atomic ORs -- WITHOUT branches: the lane's ten bits are one 10-bit window of the record
+    // (record bits 10 sub + 6 .. 10 sub + 15), a bit that is zero ORs nothing (a missing frame's record is zero; a frame without an
+    // L scatters into words nobody reads), and mbx_init has checked every entry's range.
+    {
+        const int s0 = 10 * sub + 6;   // 6 .. 76: the window starts in word s0 >> 5 and ends in it or in the next (never past word 2)
+        const uint32_t hi = s0 < 32 ? rec.x : (s0 < 64 ? rec.y : rec.z), lo = s0 < 32 ? rec.y : (s0 < 64 ? rec.z : 0u);
+        uint32_t window = (uint32_t)(((((uint64_t)hi << 32) | lo) << (s0 & 31)) >> 54);
+        window &= (sub == 7) ? ~1u : ~0u;   // (payload bit 79 does not exist)
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
-            const int idx = 10 * sub + t;   // payload bit idx + 6
-            if (idx < 79) {
-                const uint32_t m = e[t] & 0xffu, pos = e[t] >> 8;
-                if (m < 58u && pos < 12u) {
-                    atomicOr(&words[m], (uint32_t)rbit(w, idx + 6) << pos);
-                }
-            }
+            const uint32_t m = e[t] & 0xffu, pos = e[t] >> 8;
+            atomicOr(&words[m], ((window >> (9 - t)) & 1u) << pos);
         }
     }
     wave_lds_sync();
@@ -124,20 +124,27 @@ __device__ __forceinline__ void expand_imbe_frame_rec(bool have, uint4 rec, floa
     }
     wave_lds_sync();
     MBX_FTS(8, b2v);   // B2 there, gains
+    // voicing: three harmonics per band, band K-1 first -- harmonic l takes bit max(K-1 - (l-1)/3, 0) of b1: band bit K-1-k covers
+    // l = 3k+1..3k+3, every harmonic past 3K shares bit 0 (src/imbe/imbe7200x4400.c:170-188).  The frame's eight lanes take bands
+    // sub and sub + 8 and add their (disjoint) masks up.
+    const uint32_t b1 = low_bits_x(words[1], 12);
+    uint32_t band_lo = 0u, band_hi = 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = sub + 8 * h;
+        if (k < 12 && k < K && ((b1 >> (K - 1 - k)) & 1u)) {
+            const unsigned long long m = 7ULL << (3 * k);
+            band_lo |= (uint32_t)m;
+            band_hi |= (uint32_t)(m >> 32);
+        }
+    }
+    band_lo = sum8(band_lo);
+    band_hi = sum8(band_hi);
     if (have) {
         if (sub == 0) {
             uint32_t vlo = 0, vhi = 0;
-            if (!bad) {   // voicing: three harmonics per band, band K-1 first
-                // harmonic l takes bit max(K-1 - (l-1)/3, 0) of b1: band bit K-1-k covers l = 3k+1..3k+3,
-                // every harmonic past 3K shares bit 0 (src/imbe/imbe7200x4400.c:170-188)
-                const uint32_t b1 = low_bits_x(words[1], 12);
-                unsigned long long v = 0ULL;
-#pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    if (k < K && ((b1 >> (K - 1 - k)) & 1u)) {
-                        v |= 7ULL << (3 * k);
-                    }
-                }
+            if (!bad) {
+                unsigned long long v = ((unsigned long long)band_hi << 32) | band_lo;
                 if (b1 & 1u) {
                     v |= ~0ULL << (3 * K);
                 }
@@ -167,33 +174,39 @@ __device__ __forceinline__ void expand_imbe_frame_rec(bool have, uint4 rec, floa
             }
 #pragma unroll
             for (int k = 2; k <= 10; ++k) {   // higher-order coefficients (:233-249); zero past the block length
+                // (no branch on Bm: with Bm = 0 the field is empty, (0 - 2^-1) + 0.5 = 0 and the step is 0; the word read may then lie
+                //  past the frame's 58 -- inside this wave's LDS either way)
                 const int Bm = (int)((bmw[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                float v = 0.0f;
-                if (Bm > 0) {
-                    const int bm = (int)low_bits_x(words[m0 + k - 2], Bm);
-                    v = (qstep[k] * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
-                }
+                const int bm = (int)low_bits_x(words[m0 + k - 2], Bm);
+                const float v = (qstep[k] * (((float)bm - ldexpf(1.0f, Bm - 1)) + 0.5f));
                 C2[k] = 2.0f * v;
             }
             // per-block inverse DCT (:251-270).  All ten terms are added unconditionally (x + 0*c == x for every x this
             // sum can take); the cosines of harmonic l are one contiguous row of a host-made table, fetched one
             // output ahead of the arithmetic.
+            // (two outputs per trip with the two row buffers swapping roles: no register copies)
             float next[10];
-            for (int j = 1; j <= ji; ++j) {
-                const float* nr = rows + 10 * (j < ji ? j : j - 1);
+            auto fetch = [&](float (&dst)[10], int j) {   // the row of output j + 1 (clamped: the last fetch is never used)
+                const float* nr = rows + 10 * (j < ji ? j : ji - 1);
 #pragma unroll
                 for (int k = 0; k < 10; ++k) {
-                    next[k] = nr[k];
+                    dst[k] = nr[k];
                 }
+            };
+            auto output = [&](const float (&c)[10], int j) {
                 float sum = 0;
 #pragma unroll
                 for (int k = 1; k <= 10; ++k) {
-                    sum = sum + (C2[k] * cosr[k - 1]);
+                    sum = sum + (C2[k] * c[k - 1]);
                 }
                 row[l0 + j - 1] = sum;
-#pragma unroll
-                for (int k = 0; k < 10; ++k) {
-                    cosr[k] = next[k];
+            };
+            for (int j = 1; j <= ji; j += 2) {
+                fetch(next, j);
+                output(cosr, j);
+                if (j + 1 <= ji) {
+                    fetch(cosr, j + 1);
+                    output(next, j + 1);
                 }
             }
         }

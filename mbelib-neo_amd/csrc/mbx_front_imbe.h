@@ -31,14 +31,6 @@
 
 namespace mbx {
 
-// sum over each group of eight consecutive lanes, returned in all eight (DPP: xor 1, xor 2, mirror within 8)
-__device__ __forceinline__ uint32_t sum8(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kDppXor1, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kDppXor2, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kDppHalfMirror, 0xf, 0xf, true);
-    return v;
-}
-
 __device__ __forceinline__ uint32_t front_golay_syndrome(uint32_t cw, uint32_t half_syn) {
     const uint32_t data = cw >> 11;
     const uint32_t e_hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((data >> 6) << 2), (int)half_syn) >> 16;
