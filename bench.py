@@ -601,7 +601,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
     L.mbx_set_stream_order(previous_order)
-    flags = decoder.results_numpy(out["results"])["flags"]
+    hist = decoder.result_histogram(out["results"], stream)   # the last launch's tally of flags, formed on the device (mbx_result_histogram)
     pcm_digest = int(out["pcm16"].to(torch.int64).sum().item())
     parity_obj = None
     if parity and not soft and not overlap and not args.ablate:
@@ -626,12 +626,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
         "kernel_ms_stats": {"mean": float(per_step.mean()), "median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),
                             "p90": float(np.percentile(per_step, 90)), "min": float(per_step.min()), "max": float(per_step.max()),
                             "launches": int(per_step.size)},
-        "frame_mix": {
-            "repeat": float(np.mean((flags & 0x40) != 0)),
-            "mute": float(np.mean((flags & 0x80) != 0)),
-            "erasure": float(np.mean((flags & 0x20) != 0)),
-            "tone": float(np.mean((flags & 0x10) != 0)),
-        },
+        "frame_mix": {k: hist[k] / max(hist["frames"], 1) for k in ("repeat", "mute", "erasure", "tone")},
     }
 
 

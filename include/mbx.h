@@ -341,6 +341,21 @@ int mbx_synthesize_speech(int S, mbe_parms* d_cur, mbe_parms* d_prev, mbx_stream
 /* ref: mbe_floattoshort  include/mbelib-neo/mbelib.h:675, src/core/mbelib.c:1148-1177 */
 int mbx_floattoshort(const float* d_in, int16_t* d_out, size_t nframes, void* stream);
 
+/* Per-batch counters over mbe_process_result (ref include/mbelib-neo/mbelib.h:154-166: what a host tallies from the flags and
+ * the error counts of every frame), formed on the device: 20 bytes read per frame instead of a copy of every result to the
+ * host.  The call ADDS the n results at d_results to *d_hist (device memory; zero it, e.g. with hipMemsetAsync, to start a new
+ * tally; any number of launches may accumulate into one).  Asynchronous on `stream`. */
+typedef struct mbx_result_hist {
+    uint64_t frames;               /* results counted */
+    uint64_t flag[8];              /* frames with bit k of `flags` set: 0 SOFT_INPUT, 1 C0_VALID, 2 C4_VALID, 4 TONE, 5 ERASURE, 6 REPEAT, 7 MUTE */
+    uint64_t c0_errors;            /* sums of the three counts and of their total ... */
+    uint64_t protected_errors;
+    uint64_t c4_errors;
+    uint64_t total_errors;
+    uint64_t frames_with_errors;   /* ... and the number of frames with total_errors > 0 */
+} mbx_result_hist;
+int mbx_result_histogram(const mbe_process_result* d_results, size_t n, mbx_result_hist* d_hist, void* stream);
+
 /* ---- single stages of the public API, batched (one wavefront per struct) ------------------- */
 
 /* ref: mbe_spectralAmpEnhance  include/mbelib-neo/mbelib.h:623, src/core/mbelib.c:641-666 */

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "mbx_decode_parms": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mbx_synthesize_speech": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mbx_floattoshort": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "mbx_result_histogram": (C.c_int, [_vp, _sz, _vp, _vp]),
     "mbx_spectral_amp_enhance": (C.c_int, [C.c_int, _vp, _vp]),
     "mbx_adaptive_smoothing": (C.c_int, [C.c_int, _vp, _vp, _vp]),
     "mbx_comfort_noise": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),

@@ -21,6 +21,7 @@ __global__ void fec_imbe7200x4400_kernel(const uint8_t*, size_t, mbx_param_recor
 __global__ void fec_ambe3600x2450_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
 __global__ void fec_imbe7100x4400_kernel(const uint8_t*, size_t, mbx_param_record*, DeviceTables);
 __global__ void floattoshort_kernel(const float*, int16_t*, size_t);
+__global__ void result_histogram_kernel(const mbe_process_result*, size_t, unsigned long long*);
 __global__ void stage_in_kernel(const uint8_t*, uint8_t*, size_t);
 __global__ void expand_imbe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
 __global__ void expand_ambe_kernel(const mbx_param_record*, size_t, FrameParams*, DeviceTables);
@@ -1706,6 +1707,21 @@ int mbx_floattoshort(const float* d_in, int16_t* d_out, size_t nframes, void* st
     const unsigned grid = (unsigned)((nsamples / 2 + 255) / 256);
     hipLaunchKernelGGL(mbx::floattoshort_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_in, d_out, nsamples);
     return check_launch("floattoshort_kernel");
+}
+
+int mbx_result_histogram(const mbe_process_result* d_results, size_t n, mbx_result_hist* d_hist, void* stream) {
+    static_assert(sizeof(mbx_result_hist) == mbx::kResultHistWords * sizeof(unsigned long long), "mbx_result_hist is 14 64-bit counters");
+    REQUIRE_CTX(c);
+    if (!d_results || !d_hist) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        return 0;
+    }
+    const size_t blocks = (n + 1023) / 1024;   // four frames per thread, at most 4,096 workgroups
+    hipLaunchKernelGGL(mbx::result_histogram_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, d_results, n,
+                       reinterpret_cast<unsigned long long*>(d_hist));
+    return check_launch("result_histogram_kernel");
 }
 
 int mbx_spectral_amp_enhance(int S, mbe_parms* d_parms, void* stream) {

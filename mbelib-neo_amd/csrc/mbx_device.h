@@ -57,6 +57,8 @@ struct DerivedTables {
                                   // whole b0 -> L law, so a wave that asks for it before it knows b0 has L without a memory round trip
 };
 
+constexpr int kResultHistWords = 14;   // mbx_result_hist (include/mbx.h) as 64-bit words
+
 // Output of the expand stage, input of the stream stage: 64 dwords per frame (layout in mbx_expand.hip).
 struct FrameParams {
     float v[64];

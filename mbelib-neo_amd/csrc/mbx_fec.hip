@@ -103,6 +103,52 @@ floattoshort_kernel(const float* __restrict__ in, int16_t* __restrict__ out, siz
 }
 
 
+// What a host tallies from the mbe_process_result of every frame (ref include/mbelib-neo/mbelib.h:154-166: the flag bits and
+// the three error counts), for a whole batch on the device: 20 bytes read per frame, one set of atomics per workgroup.
+// Integer sums only: the histogram of a batch does not depend on the launch geometry.
+__global__ void __launch_bounds__(256)
+result_histogram_kernel(const mbe_process_result* __restrict__ results, size_t n, unsigned long long* __restrict__ hist) {
+    unsigned v[kResultHistWords];
+#pragma unroll
+    for (int k = 0; k < kResultHistWords; ++k) {
+        v[k] = 0u;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const mbe_process_result r = results[i];
+        v[0] += 1u;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            v[1 + b] += (r.flags >> b) & 1u;
+        }
+        v[9] += (unsigned)r.c0_errors;
+        v[10] += (unsigned)r.protected_errors;
+        v[11] += (unsigned)r.c4_errors;
+        v[12] += (unsigned)r.total_errors;
+        v[13] += r.total_errors > 0 ? 1u : 0u;
+    }
+    __shared__ unsigned part[4][kResultHistWords];
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int k = 0; k < kResultHistWords; ++k) {   // (a thread holds at most n / (grid x 256) + 1 frames: the 32-bit partial sums cannot wrap
+        unsigned s = v[k];                          //  for the grid mbx_result_histogram launches)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            s += (unsigned)__shfl_xor((int)s, d, 64);
+        }
+        if (lane == 0) {
+            part[wave][k] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kResultHistWords) {
+        const unsigned long long s = (unsigned long long)part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (s != 0ULL) {
+            atomicAdd(&hist[threadIdx.x], s);
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------
 // The sub-stages of the frame decode as the reference exposes them one by one (in-place helpers of the classic
 // ecc -> demodulate -> ecc call sequence), batched: one thread per frame, packed frames in, packed frames out.

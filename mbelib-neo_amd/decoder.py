@@ -168,6 +168,22 @@ def results_numpy(t):
     return t.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
 
 
+RESULT_HIST_FIELDS = ("frames", "soft_input", "c0_valid", "c4_valid", "flag3", "tone", "erasure", "repeat", "mute", "c0_errors",
+                      "protected_errors", "c4_errors", "total_errors", "frames_with_errors")
+
+
+def result_histogram(results, stream=None):
+    """mbx_result_histogram over a device tensor of mbe_process_result (as the decoders return them): the per-batch tally of flags
+    and error counts, formed on the device (include/mbx.h: mbx_result_hist).  Returns a dict of Python ints."""
+    torch = _torch()
+    L = _native.lib()
+    n = results.numel() * results.element_size() // RESULT_DTYPE.itemsize
+    hist = torch.zeros(len(RESULT_HIST_FIELDS), dtype=torch.int64, device=results.device)
+    _native.check(L.mbx_result_histogram(results.data_ptr(), n, hist.data_ptr(), stream if stream is not None else torch.cuda.current_stream().cuda_stream),
+                  "mbx_result_histogram")
+    return dict(zip(RESULT_HIST_FIELDS, (int(v) for v in hist.cpu().tolist())))
+
+
 def records_numpy(t):
     return t.cpu().numpy().view(RECORD_DTYPE).reshape(-1)
 

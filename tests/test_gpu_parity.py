@@ -121,6 +121,52 @@ def test_floattoshort_exact(mbx, oracle):
     assert np.array_equal(decoder.floattoshort(x), oracle.floattoshort(x))
 
 
+# ---- the per-batch tally of results, formed on the device ---------------------------------------
+def test_result_histogram_counts_what_the_host_would(mbx, oracle):
+    """mbx_result_histogram (include/mbx.h; ref include/mbelib-neo/mbelib.h:154-166 -- the flags and error counts a host tallies per
+    frame): the device's counters over (a) synthetic results with every flag combination and (b) the results of a real mixed AMBE
+    batch equal a numpy tally of the same structs; launches accumulate; sizes that are no multiple of anything."""
+    import torch
+    from mbelib_neo_amd import decoder, framegen
+
+    def tally(r):
+        f = r["flags"].astype(np.int64)
+        t = {"frames": len(r), "c0_errors": int(r["c0_errors"].sum()), "protected_errors": int(r["protected_errors"].sum()),
+             "c4_errors": int(r["c4_errors"].sum()), "total_errors": int(r["total_errors"].sum()),
+             "frames_with_errors": int((r["total_errors"] > 0).sum())}
+        for b, name in enumerate(("soft_input", "c0_valid", "c4_valid", "flag3", "tone", "erasure", "repeat", "mute")):
+            t[name] = int(((f >> b) & 1).sum())
+        return t
+
+    rng = framegen.rng_for(77)
+    for n in (1, 255, 1024, 65536 + 3, 1 << 20):
+        r = np.zeros(n, dtype=decoder.RESULT_DTYPE)
+        r["flags"] = rng.integers(0, 256, size=n)
+        r["c0_errors"] = rng.integers(0, 4, size=n)
+        r["protected_errors"] = rng.integers(0, 12, size=n)
+        r["c4_errors"] = rng.integers(0, 2, size=n)
+        r["total_errors"] = np.where(rng.random(n) < 0.3, 0, r["c0_errors"] + r["protected_errors"])
+        d = torch.from_numpy(r.view(np.uint8).copy()).cuda()
+        assert decoder.result_histogram(d) == tally(r), n
+    # a real batch: AMBE+2 frames of random bits (voice, erasures, tones, repeats)
+    S, T = 512, 6
+    frames = framegen.random_frames(1, S * T, rng)
+    ref = oracle.process_batch(1, S, T, frames, oracle.init_state(S), oracle.rng_seeded(list(range(S))))
+    dec = decoder.BatchDecoder(1, S, seeds=list(range(S)))
+    out = dec.decode(frames, T)
+    torch.cuda.synchronize()
+    got = decoder.result_histogram(out["results"])
+    assert got == tally(np.asarray(ref["results"]))
+    assert got["frames"] == S * T and got["repeat"] + got["erasure"] + got["tone"] > 0
+    # two launches into one tally
+    L = mbx.lib()
+    hist = torch.zeros(len(decoder.RESULT_HIST_FIELDS), dtype=torch.int64, device="cuda")
+    for _ in range(2):
+        assert L.mbx_result_histogram(out["results"].data_ptr(), S * T, hist.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    assert hist.cpu().tolist() == [2 * got[k] for k in decoder.RESULT_HIST_FIELDS]
+    assert L.mbx_result_histogram(None, 1, hist.data_ptr(), None) == -1 and L.mbx_result_histogram(out["results"].data_ptr(), 0, hist.data_ptr(), None) == 0
+
+
 # ---- synthesis: golden hash scenario ----------------------------------------------------------
 def test_golden_synth_scenario(mbx, oracle):
     from mbelib_neo_amd import decoder
