@@ -25,7 +25,8 @@ list `cpu_baselines`: the reference's scalar and SIMD builds, full path and its 
 bench_unvoiced recipes, one core and all cores), `host_path` (what a C host sees from host memory to
 host memory) and `infinity_cache_assisted` (the same workload in the library's default alternating stream order; the
 headline itself is timed in a FIXED order, i.e. against HBM).  The timed region is at least --steps steps and at
-least --min-time-ms (50 ms) of wall time: `steps_effective`.
+least --min-time-ms (500 ms) of wall time: `steps_effective`; the warm-up ends with ~30 ms of untimed steps directly in front of it
+(`settle_steps`: past the load-onset transient of the power controller, profiles/r05/launch_series.txt).
 """
 import argparse
 import hashlib
@@ -582,6 +583,15 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             steps_eff = int(t[0])
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps_eff)]
+    # Load-onset transient (profiles/r05/launch_series.txt): after an idle gap the first ~6 launches run at the steady rate, the next
+    # ~100 up to 45 % slower (the power controller clamps, then relaxes), and only then the kernel time is what a decoder that runs tick
+    # after tick sees.  Building the events above IS such a gap, so the warm-up ends with `settle` more untimed steps (~30 ms of them)
+    # right in front of the timed region, and the timed region is long (--min-time-ms) against what the barrier's own gap re-triggers.
+    settle = 0
+    if min_time_s > 0:
+        settle = int(np.ceil(min(0.030, min_time_s) / max(est, 1e-6)))
+        for _ in range(settle):
+            step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -595,6 +605,8 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     torch.cuda.synchronize()
     dt_local = dt = time.perf_counter() - t0
     per_step = np.array([a.elapsed_time(b) for a, b in events])
+    if getattr(args, "dump_steps", None):   # diagnosis: the event-bracketed time of every timed launch, in order
+        np.savetxt(args.dump_steps, per_step, fmt="%.5f")
     kernel_ms = float(per_step.mean())
     if use_dist:
         t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=coll_device if coll_device is not None else torch.device("cuda", local_rank))
@@ -622,7 +634,7 @@ def run_workload(name, S, T, steps, warmup, rank, first_stream, local_rank, blob
     return {
         "dt": dt, "kernel_ms": kernel_ms, "kernel": kernel, "alg_bytes": alg_bytes, "frames_per_step": world * n,
         "value": world * n * steps_eff / dt, "ms_per_step": dt / steps_eff * 1e3, "pcm_digest": pcm_digest, "front_end_overlap": bool(overlap),
-        "steps_effective": steps_eff, "rank_value": n * steps_eff / dt_local, "parity": parity_obj,
+        "steps_effective": steps_eff, "settle_steps": settle, "rank_value": n * steps_eff / dt_local, "parity": parity_obj,
         "kernel_ms_stats": {"mean": float(per_step.mean()), "median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)),
                             "p90": float(np.percentile(per_step, 90)), "min": float(per_step.min()), "max": float(per_step.max()),
                             "launches": int(per_step.size)},
@@ -738,7 +750,8 @@ def main():
                     help="collectives backend; gloo (CPU tensors) only to rehearse N > 1 on a box with fewer GPUs than ranks, "
                          "together with MBX_BENCH_SHARE_GPU=1 (every rank on device 0)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only stage mask (development build of the library only); results invalid")
-    ap.add_argument("--min-time-ms", type=float, default=50.0,
+    ap.add_argument("--dump-steps", default=None, help="diagnosis: write the event-bracketed time (ms) of every timed step, in order, to this file")
+    ap.add_argument("--min-time-ms", type=float, default=500.0,
                     help="the timed region is at least --steps steps AND at least this much wall time (steps_effective in the line)")
     args = ap.parse_args()
 
@@ -806,6 +819,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "steps_effective": m["steps_effective"],
+        "settle_steps": m["settle_steps"],   # untimed steps directly in front of the timed region, beyond --warmup
         "warmup": args.warmup,
         "ms_per_step": m["ms_per_step"],
         "higher_is_better": True,
