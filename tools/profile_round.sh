@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the judged evidence for one bench workload on the GPU box:
-#   rocprofv3 --kernel-trace --stats, FETCH_SIZE and WRITE_SIZE PMC passes (separate passes), plus the same two counters
+#   FETCH_SIZE and WRITE_SIZE PMC passes (separate passes), plus the same two counters
 #   on state_copy_kernel, which moves a KNOWN byte count with the stream kernels' dword-per-lane accesses (the calibration
 #   MI355X_MICROARCH.md asks for before trusting an absolute FETCH_SIZE at an access width other than 16 B/lane), the SQ
-#   counter passes of tools/sq_profile.py, and LAST the un-profiled bench line -- after the two summaries have been
+#   counter passes of tools/sq_profile.py, rocprofv3 --kernel-trace --stats, and LAST the un-profiled bench line -- after the two summaries have been
 #   copied to profiles/<round>/ on the box, so that the line carries the traffic and issue figures of this very build.
 # usage: tools/profile_round.sh <out-prefix> [workload]   -> gpurun_out/<out-prefix>_{bench.json,kernel_stats.csv,pmc.json,sq.json}
 #        (out-prefix = <round>_<workload>, e.g. r03_imbe_voiced: the summaries land in profiles/r03/imbe_voiced_*.json)
@@ -16,12 +16,10 @@ cd /tmp && export TMPDIR=/tmp
 ROUND=${TAG%%_*}
 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --workload $WL > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err   # kernel name for the summary
 rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write /tmp/c_fetch /tmp/c_write
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --workload $WL > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 $R/bench.py --steps 5 --warmup 1 --min-time-ms 0 --no-cpu-baseline --no-extras --workload $WL > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 $R/bench.py --steps 5 --warmup 1 --min-time-ms 0 --no-cpu-baseline --no-extras --workload $WL > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/c_fetch -- python3 $R/tools/calibrate_fetch.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/c_write -- python3 $R/tools/calibrate_fetch.py > /dev/null 2>&1
-cp /tmp/p_stats/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 python3 - "$OUT/${TAG}_pmc.json" "$OUT/${TAG}_bench.json" "$WL" <<'PY'
 import csv, glob, collections, hashlib, json, os, sys
 
@@ -70,6 +68,10 @@ python3 $R/tools/sq_profile.py bench $WL $OUT/${TAG}_sq.json > $OUT/${TAG}_sq.lo
 mkdir -p $R/profiles/$ROUND
 cp $OUT/${TAG}_pmc.json $R/profiles/$ROUND/${WL}_pmc.json
 cp $OUT/${TAG}_sq.json $R/profiles/$ROUND/${WL}_sq.json
+# the --stats pass directly in front of the un-profiled line: the two are compared (profiles/README.md), and a box that has been under load for
+# minutes runs the same kernel up to 9 % slower than a fresh one
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --workload $WL > /dev/null 2>&1
+cp /tmp/p_stats/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 python3 $R/bench.py --steps 50 --warmup 5 --workload $WL > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cut -c1-60,150-230 $OUT/${TAG}_kernel_stats.csv
 python3 -c "
