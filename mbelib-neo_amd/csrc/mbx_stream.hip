@@ -253,7 +253,21 @@ __device__ __forceinline__ int write_lane(int v, int uniform_value, int k) {   /
 }
 // kGather: the fourteen scalar fields leave in ONE store (lane j writes header field j, as load_header reads them) instead of
 // fourteen one-lane stores -- for the instances whose structs live in HBM (a one-lane store occupies the memory pipeline like any other)
-template <bool kGather = false>
+// kNt: NON-TEMPORAL stores (`nt`: the lines are not kept in L2 / the Infinity Cache).  A one-frame launch writes 7.8 KB of state per
+// stream that nothing reads again before the next launch has swept a gigabyte: written as ordinary stores those lines push the
+// lines the launch is still READING out of the caches.  Measured, interleaved A/B (EXPERIMENTS.md 5.7): 65,536 x 1 IMBE -5.1 ... -9.9 % by box,
+// on resident state -1.9 ... -2.5 %, AMBE+2 -2.1 ... -5.2 %; long launches unchanged, SLICED launches +0.8 % (a slice finds the state of the
+// slice before it in the caches) -- so only the one-frame instances (= the gathered-header ones) store this way.  Non-temporal
+// LOADS of the state: +5 % (kept plain).  Stores to a caller's pinned host structs (the per-frame API) stay plain.
+template <bool kNt, class T>
+__device__ __forceinline__ void st_state(T* p, T v) {
+    if constexpr (kNt) {
+        __builtin_nontemporal_store(v, p);
+    } else {
+        *p = v;
+    }
+}
+template <bool kGather = false, bool kNt = kGather>
 __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restrict__ p, int lane) {
     float* f = reinterpret_cast<float*>(p);
     int* i = reinterpret_cast<int*>(p);
@@ -275,38 +289,38 @@ __device__ __forceinline__ void store_parms(const Parms& r, mbe_parms* __restric
         h = write_lane(h, __float_as_int(r.noiseSeed), H_NOISESEED);
         if (lane < 14) {
             const int idx = (lane < 3) ? lane : ((lane < 13) ? (O_GAMMA - H_GAMMA) + lane : O_NOISESEED);
-            i[idx] = h;
+            st_state<kNt>(&i[idx], (int)(h));
         }
     } else if (lane == 0) {
-        f[O_W0] = r.w0;
-        i[O_L] = r.L;
-        i[O_K] = r.K;
-        f[O_GAMMA] = r.gamma;
-        i[O_TONEPHASE] = (int)r.tonePhase;
-        i[O_SWN] = r.swn;
-        f[O_LOCALENERGY] = r.localEnergy;
-        i[O_AMPTHR] = r.amplitudeThreshold;
-        f[O_ERRORRATE] = r.errorRate;
-        i[O_ERRTOTAL] = r.errorCountTotal;
-        i[O_ERR4] = r.errorCount4;
-        i[O_REPEAT] = r.repeatCount;
-        f[O_MUTETHR] = r.mutingThreshold;
-        f[O_NOISESEED] = r.noiseSeed;
+        st_state<kNt>(&f[O_W0], (float)(r.w0));
+        st_state<kNt>(&i[O_L], (int)(r.L));
+        st_state<kNt>(&i[O_K], (int)(r.K));
+        st_state<kNt>(&f[O_GAMMA], (float)(r.gamma));
+        st_state<kNt>(&i[O_TONEPHASE], (int)((int)r.tonePhase));
+        st_state<kNt>(&i[O_SWN], (int)(r.swn));
+        st_state<kNt>(&f[O_LOCALENERGY], (float)(r.localEnergy));
+        st_state<kNt>(&i[O_AMPTHR], (int)(r.amplitudeThreshold));
+        st_state<kNt>(&f[O_ERRORRATE], (float)(r.errorRate));
+        st_state<kNt>(&i[O_ERRTOTAL], (int)(r.errorCountTotal));
+        st_state<kNt>(&i[O_ERR4], (int)(r.errorCount4));
+        st_state<kNt>(&i[O_REPEAT], (int)(r.repeatCount));
+        st_state<kNt>(&f[O_MUTETHR], (float)(r.mutingThreshold));
+        st_state<kNt>(&f[O_NOISESEED], (float)(r.noiseSeed));
     }
     if (lane < MBX_BAND_SLOTS) {
-        i[O_VL + lane] = r.Vl;
-        f[O_ML + lane] = r.Ml;
-        f[O_LOG2ML + lane] = r.log2Ml;
-        f[O_PHI + lane] = r.PHIl;
-        f[O_PSI + lane] = r.PSIl;
+        st_state<kNt>(&i[O_VL + lane], (int)(r.Vl));
+        st_state<kNt>(&f[O_ML + lane], (float)(r.Ml));
+        st_state<kNt>(&f[O_LOG2ML + lane], (float)(r.log2Ml));
+        st_state<kNt>(&f[O_PHI + lane], (float)(r.PHIl));
+        st_state<kNt>(&f[O_PSI + lane], (float)(r.PSIl));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        f[O_UW + lane + 64 * j] = r.uw[j];
+        st_state<kNt>(&f[O_UW + lane + 64 * j], (float)(r.uw[j]));
     }
-    f[O_OVERLAP + lane] = r.ov[0];
+    st_state<kNt>(&f[O_OVERLAP + lane], (float)(r.ov[0]));
     if (lane < 32) {
-        f[O_OVERLAP + 64 + lane] = r.ov[1];
+        st_state<kNt>(&f[O_OVERLAP + 64 + lane], (float)(r.ov[1]));
     }
 }
 
@@ -2452,8 +2466,8 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         if constexpr (kFrame) {
             if (shadow.state) {   // the device copy of what has just gone to the caller (prev_mp_enhanced is cur_mp after an IMBE frame)
-                store_parms<kOne>(cur, &shadow.state[0], lane_in);
-                store_parms<kOne>(cur, &shadow.state[2], lane_in);
+                store_parms<kOne, false>(cur, &shadow.state[0], lane_in);
+                store_parms<kOne, false>(cur, &shadow.state[2], lane_in);
                 copy_parms(&shadow.state[1], slot_prev, lane_in);
                 store_rng(rng, shadow.rng, lane_in);
                 if (lane_in == 0) {
@@ -3383,9 +3397,9 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         if constexpr (kFrame) {
             if (shadow.state) {   // the device copy of what has just gone to the caller; complete only if prev_mp_enhanced is cur_mp
-                store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, &shadow.state[0], lane_in);   // (a tone frame leaves prev_mp_enhanced at its pinned home alone: the next
+                store_parms<kOne && MBX_AMBE_GATHER_STORES, false>(cur, &shadow.state[0], lane_in);   // (a tone frame leaves prev_mp_enhanced at its pinned home alone: the next
                 if (synced) {                                  //  call then takes the state from the caller's structs again)
-                    store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, &shadow.state[2], lane_in);
+                    store_parms<kOne && MBX_AMBE_GATHER_STORES, false>(cur, &shadow.state[2], lane_in);
                 }
                 copy_parms(&shadow.state[1], slot_prev, lane_in);
                 store_rng(rng, shadow.rng, lane_in);
