@@ -3925,9 +3925,10 @@ state_copy_kernel(int S, mbe_parms* __restrict__ state) {
     load_parms(a, &state[3 * (size_t)s + 0], lane);
     load_parms(b, &state[3 * (size_t)s + 1], lane);
     load_parms(c, &state[3 * (size_t)s + 2], lane);
-    store_parms(a, &state[3 * (size_t)s + 0], lane);
-    store_parms(b, &state[3 * (size_t)s + 1], lane);
-    store_parms(c, &state[3 * (size_t)s + 2], lane);
+    // (non-temporal stores, like the one-frame stream instances this kernel is the no-arithmetic floor of)
+    store_parms<false, true>(a, &state[3 * (size_t)s + 0], lane);
+    store_parms<false, true>(b, &state[3 * (size_t)s + 1], lane);
+    store_parms<false, true>(c, &state[3 * (size_t)s + 2], lane);
 }
 
 }  // namespace mbx
