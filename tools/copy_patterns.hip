@@ -31,6 +31,25 @@ __global__ void __launch_bounds__(64) copy_dword(int S, float* state, float bias
     }
 }
 
+// the same with NON-TEMPORAL stores (what the one-frame stream instances use since round 5)
+__global__ void __launch_bounds__(64) copy_dword_nt(int S, float* state, float bias) {
+    const int s = blockIdx.x;
+    if (s >= S) return;
+    float* p = state + (size_t)s * kDwords;
+    const int lane = threadIdx.x;
+    float v[31];
+#pragma unroll
+    for (int i = 0; i < 31; ++i) {
+        const int k = lane + 64 * i;
+        v[i] = k < kDwords ? p[k] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 31; ++i) {
+        const int k = lane + 64 * i;
+        if (k < kDwords) __builtin_nontemporal_store(v[i] + bias, &p[k]);
+    }
+}
+
 typedef float f4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) U4 { f4 v; };   // 16-byte access at a 4-byte-aligned address
 
@@ -72,6 +91,11 @@ __global__ void __launch_bounds__(256) copy_flat(size_t n4, f4* p, float bias) {
     if (i < n4) p[i] = p[i] + bias;
 }
 
+__global__ void __launch_bounds__(256) copy_flat_nt(size_t n4, f4* p, float bias) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(p[i] + bias, &p[i]);
+}
+
 template <class F>
 static double time_ms(F launch) {
     hipEvent_t a, b;
@@ -97,6 +121,10 @@ int main() {
     const double t2 = time_ms([&] { hipLaunchKernelGGL(copy_x4, dim3(S), dim3(64), 0, 0, S, d, 1.0f); });
     const size_t n4 = bytes / 16;
     const double t3 = time_ms([&] { hipLaunchKernelGGL(copy_flat, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, n4, (f4*)d, 1.0f); });
+    const double t4 = time_ms([&] { hipLaunchKernelGGL(copy_dword_nt, dim3(S), dim3(64), 0, 0, S, d, 1.0f); });
+    const double t5 = time_ms([&] { hipLaunchKernelGGL(copy_flat_nt, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, n4, (f4*)d, 1.0f); });
+    printf("{\"dword_per_lane_nt_stores_ms\": %.4f, \"dword_per_lane_nt_stores_TBps\": %.3f, \"flat_aligned_x4_nt_stores_ms\": %.4f, \"flat_aligned_x4_nt_stores_TBps\": %.3f}\n",
+           t4, 2 * bytes / t4 / 1e9, t5, 2 * bytes / t5 / 1e9);
     printf("{\"bytes_each_way\": %zu, \"dword_per_lane_ms\": %.4f, \"dword_per_lane_TBps\": %.3f, \"x4_per_lane_unaligned_ms\": %.4f, \"x4_per_lane_unaligned_TBps\": %.3f, "
            "\"flat_aligned_x4_ms\": %.4f, \"flat_aligned_x4_TBps\": %.3f}\n",
            bytes, t1, 2 * bytes / t1 / 1e9, t2, 2 * bytes / t2 / 1e9, t3, 2 * bytes / t3 / 1e9);
