@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+LIB = os.environ.get("MBX_ORACLE_LIBRARY") or os.path.join(ROOT, "oracle", "liboracle.so")   # (override: the sanitizer build, oracle/Makefile)
 TABLES = os.path.join(ROOT, "mbelib-neo_amd", "data", "mbx_tables.bin")
 
 import sys
