@@ -103,6 +103,7 @@ _SIGNATURES = {
     "mbx_stream_kernel_name": (C.c_char_p, [C.c_int, C.c_int]),
     "mbx_batch_kernel_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mbx_debug_front_fallbacks": (C.c_longlong, [C.c_void_p]),
+    "mbx_debug_set_front_skip": (C.c_int, [C.c_int]),
     "mbx_launch_slices": (C.c_int, [C.c_int, C.c_int, C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -218,7 +218,7 @@ void free_context(Context& c) {   // caller holds g_init_mu and c.mu
     }
     c.slots.clear();
     c.d_blob = c.d_derived = nullptr;
-    c.tabs = mbx::DeviceTables{nullptr, nullptr, 0, 0, nullptr};
+    c.tabs = mbx::DeviceTables{nullptr, nullptr, 0, 0, 0, nullptr};
     c.reserve_frames = 0;
     c.checksum = 0;
     c.device = -1;
@@ -1874,6 +1874,16 @@ int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe
 
 // diagnostics: how many stream blocks of the one-launch kernel have expanded their own frame since the stream's workspace was
 // allocated (a stream block does that when its front block's rows are not there in time); synchronises the stream.  -1: no workspace.
+int mbx_debug_set_front_skip(int every) {
+    REQUIRE_CTX(c);
+    if (every < 0 || (every & (every - 1)) != 0) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->tabs.front_skip = every;
+    return 0;
+}
+
 long long mbx_debug_front_fallbacks(void* stream) {
     int crc;
     Context* c = current_ctx(&crc);

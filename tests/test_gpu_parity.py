@@ -555,6 +555,54 @@ def test_imbe_voiced_config2_full_shape(mbx, oracle):
     assert a[5] == c[5] and a[3].tobytes() == c[3].tobytes() and a[1].tobytes() == c[1].tobytes()
 
 
+@pytest.mark.parametrize("codec", [0, 1, 3])
+def test_one_launch_fall_back_path_gives_the_same_bytes(mbx, oracle, codec):
+    """A stream block of the one-launch kernels that does not see its front block's flag in time decodes its own frame (IMBE: FEC by
+    lanes + expansion in its own wave; AMBE: scalar-unit FEC + expansion by its first eight lanes).  No ordinary launch has ever taken
+    that path (mbx_debug_front_fallbacks = 0 everywhere), so it is FORCED here: mbx_debug_set_front_skip(4) makes every fourth front
+    block do nothing.  Records, results, PCM, state and RNG of four ticks must be the bytes of the undisturbed launches, and the
+    fall-back counter must have counted exactly the streams of the skipped chunks."""
+    import torch
+    from mbelib_neo_amd import decoder, framegen
+    from mbelib_neo_amd.layout import FRAME_BYTES
+
+    L = mbx.lib()
+    if b"one_launch" not in L.mbx_batch_kernel_name(codec, 4096, 1, 0):
+        pytest.skip("the one-launch form is switched off (MBX_FUSE_ONE)")
+    fb = FRAME_BYTES[codec]
+    S, T = 4096 + 5, 4
+    frames = framegen.random_frames(codec, S * T, framegen.rng_for(0x5A + codec)).reshape(S, T, fb)
+    frames[::3] &= framegen.random_frames(codec, ((S + 2) // 3) * T, framegen.rng_for(0x5B + codec)).reshape(-1, T, fb)
+    seeds = np.arange(S) + 5
+    strm = torch.cuda.current_stream().cuda_stream
+
+    def run(skip, resident):
+        assert L.mbx_debug_set_front_skip(skip) == 0
+        try:
+            dec = decoder.BatchDecoder(codec, S, seeds=seeds, resident=resident)
+            outs = []
+            for t in range(T):
+                o = dec.decode(np.ascontiguousarray(frames[:, t]), 1, want_float=True)
+                outs.append({k: v.cpu().numpy().copy() for k, v in o.items()})
+            return outs, dec.state_numpy(), dec.rng_numpy()
+        finally:
+            assert L.mbx_debug_set_front_skip(0) == 0
+
+    assert L.mbx_debug_set_front_skip(3) == -1   # (a power of two, or 0)
+    for resident in (False, True):
+        ref = run(0, resident)
+        before = L.mbx_debug_front_fallbacks(strm)
+        got = run(4, resident)
+        after = L.mbx_debug_front_fallbacks(strm)
+        for t in range(T):
+            for k in ("records", "results", "pcm16", "pcmf"):
+                assert got[0][t][k].tobytes() == ref[0][t][k].tobytes(), (resident, t, k)
+        assert got[1].tobytes() == ref[1].tobytes() and got[2].tobytes() == ref[2].tobytes()
+        chunks = (S + 7) // 8
+        skipped_streams = sum(min(8, S - 8 * c) for c in range(0, chunks, 4))
+        assert after - max(before, 0) == T * skipped_streams, (before, after, skipped_streams)
+
+
 @pytest.mark.parametrize("codec", [0, 1, 2, 3])
 def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
     """T = 1 and S > 256, all four codecs: mbx_process_batch (ONE launch: `imbe_one_launch_kernel` / `ambe_one_launch_kernel` /
