@@ -1308,6 +1308,38 @@ def test_bench_rccl_code_path_runs_with_one_rank():
     assert line["n_gpus"] == 1 and line["value"] > 0 and "process group initialised" in line["config"]["parallelism"]
 
 
+def test_bench_default_line_keeps_its_contract():
+    """`python bench.py` (the driver's call, shortened by --min-time-ms): ONE JSON line with the contract's keys -- the metric string
+    with both halves, whole-job value, roofline {bound, achieved, peak, unit, frac, traffic}, cpu_baseline {value, unit, cores, kind,
+    sample} and the parity object (no bound violated)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--min-time-ms", "20"], capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines[:3]
+    d = json.loads(lines[0])
+    assert "frames/sec" in d["metric"] and "PCM RMS error vs reference" in d["metric"]
+    assert d["unit"] and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["value"] > 1e7 and abs(d["ms_per_step"] * 1e-3 * d["value"] / d["config"]["frames_per_step"] - 1.0) < 0.02
+    assert "vs_baseline" in d and d["dtype"] and "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] > 0 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.2 < rf["frac"] < 1.0 and rf["kernel"] == "imbe_one_launch_kernel"
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["unit"] and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
+    par = d["parity"]
+    assert "FAILED" not in par and par["rel_rms"] <= 1e-4 and par["results_exact"] and par["state_in_tolerance"] and par["streams_checked"] >= 256
+
+
 def test_bench_two_ranks_self_launched_on_one_card():
     """`python bench.py --gpus 2` from a plain shell: bench.py starts the two ranks itself (no launcher), they shard the
     streams, run, meet at the barriers and rank 0 prints the line.  This box has one GPU, so both ranks use device 0
