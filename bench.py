@@ -5,8 +5,8 @@ Metric (BASELINE.json): 20 ms frames/s, whole job, IMBE 7200x4400.
 Workload (default, BASELINE.json configs[1]): 65,536 streams per GPU x T=1 frame per step,
 clean-encoded all-voiced IMBE frames, state warmed by one identical frame so both the
 previous and the current model are voiced.  One "step" = one pass of the hot path
-(mbx_process_batch: for this shape ONE launch, imbe_stream_kernel_one_fused -- FEC, parameter expansion and stream stage in
-the stream's own wave; other shapes: FEC kernel, [parameter-expansion kernel,] stream kernel) over the whole batch
+(mbx_process_batch: for this shape ONE launch, imbe_one_launch_kernel -- front blocks do FEC and parameter expansion for
+eight frames each, stream blocks the stream stage; other shapes: FEC kernel, [parameter-expansion kernel,] stream kernel) over the whole batch
 with every input already resident in HBM.  After the timed region a strided sample of the timed streams is replayed through
 the CPU oracle and the line carries the PCM error (`parity`: the metric's second half).  Streams are independent, so N GPUs = N independent
 shards (weak scaling, no data-path collective); the only collective is the RCCL broadcast of the
@@ -19,12 +19,14 @@ With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) bench.py starts
 relays rank 0's line; under torch.distributed.run it is one of the ranks.  `--workload ambe_stream
 --gpus 8` is BASELINE configs[4] (8 x 8,192 AMBE+2 streams x T = 128).
 
-Prints ONE JSON line on rank 0.  At N = 1 with the default workload the line also carries
-`other_configs` (the other three GPU configs of BASELINE.json, 10 steps each), `cpu_baseline` (+ the
-list `cpu_baselines`: the reference's scalar and SIMD builds, full path and its own bench_synth /
-bench_unvoiced recipes, one core and all cores), `host_path` (what a C host sees from host memory to
-host memory) and `infinity_cache_assisted` (the same workload in the library's default alternating stream order; the
-headline itself is timed in a FIXED order, i.e. against HBM).  The timed region is at least --steps steps and at
+Prints ONE COMPACT JSON line on rank 0 (the contract keys, `roofline`, `parity`, `cpu_baseline`, and per other config
+{value, ms_per_step, kernel, kernel_ms, frac}: at most 4 KB -- contract_line()) and writes everything else to the
+sidecar `bench_detail.json` next to this script (and to gpurun_out/ when that directory exists): `other_configs` in full
+(the other GPU configs of BASELINE.json, 10 steps each, with their SQ issue models), `cpu_baselines` (the reference's
+scalar and SIMD builds, full path and its own bench_synth / bench_unvoiced recipes, one core and all cores), `host_path`
+(what a C host sees from host memory to host memory), `infinity_cache_assisted` (the same workload in the library's
+default alternating stream order; the headline itself is timed in a FIXED order, i.e. against HBM), `valu`, `copy_floor`.
+Nothing but the compact line goes to stdout.  The timed region is at least --steps steps and at
 least --min-time-ms (500 ms) of wall time: `steps_effective`; the warm-up ends with ~30 ms of untimed steps directly in front of it
 (`settle_steps`: past the load-onset transient of the power controller, profiles/r05/launch_series.txt).
 """
@@ -388,58 +390,46 @@ def parity_vs_oracle(name, codec, S, T, frames, seeds, launches, dec, out, step,
     r16 = ref["pcm16"].reshape(len(pick), n, T, 160)
     rf = ref["pcmf"].reshape(len(pick), n, T, 160)
     rres = ref["results"].reshape(len(pick), n, T)
-    par.check_results(rres[:, n - 2].reshape(-1), np.ascontiguousarray(last_res).view(RESULT_DTYPE).reshape(-1), what="last timed step")
-    # PCM error of the untimed extra step (float) and of the last timed step (int16).  The figures are computed here rather than by
-    # parity.check_pcm: that helper also refuses workloads in which more than 35 % of the frames reach the soft clip (its 4-LSB bound
-    # for clipped frames is meant to govern a minority), and the headline workload -- the same clean all-voiced frame every tick, random
-    # amplitude bits -- sits in the clip in about half of its frames by construction.  The bounds themselves are the same.
-    ref_f = rf[:, n - 1].reshape(-1, 160).astype(np.float64)
-    got_f = pf.reshape(-1, 160).astype(np.float64)
-    rel = par.rel_rms(ref_f, got_f)
-    level = np.sqrt(np.mean(ref_f ** 2)) + 1e-30
-    err = np.sqrt(np.mean((ref_f - got_f) ** 2, axis=1))
-    worst = float((err / np.maximum(np.sqrt(np.mean(ref_f ** 2, axis=1)), 0.05 * level)).max())
-    d_last = np.abs(r16[:, n - 2].astype(np.int32) - last16.astype(np.int32)).reshape(-1, 160)
-    d_extra = np.abs(r16[:, n - 1].astype(np.int32) - p16.astype(np.int32)).reshape(-1, 160)
-    clip_last = par.clipped_frames(rf[:, n - 2])
-    clip_extra = par.clipped_frames(rf[:, n - 1])
-    below = max(int(d_last[~clip_last].max()) if (~clip_last).any() else 0, int(d_extra[~clip_extra].max()) if (~clip_extra).any() else 0)
-    inside = max(int(d_last[clip_last].max()) if clip_last.any() else 0, int(d_extra[clip_extra].max()) if clip_extra.any() else 0)
-    within1 = float(np.mean(d_last <= 1))
-    # a bound that does not hold is REPORTED in the object ("FAILED"), next to the numbers, not instead of them
     violations = []
+    results_exact = True
+    try:
+        par.check_results(rres[:, n - 2].reshape(-1), np.ascontiguousarray(last_res).view(RESULT_DTYPE).reshape(-1), what="last timed step")
+    except AssertionError as e:
+        results_exact = False
+        violations.append("results: " + str(e)[:200])
+    # PCM error of the untimed extra step (float) and of the last timed step + the extra step (int16).  Every bound is tests/parity.py's: the
+    # float criteria, and per frame int16_bound(the frame's pre-clip peak, which the oracle reports) -- the headline workload repeats one clean
+    # all-voiced frame per stream tick after tick and sits in the soft clip in about half of its frames by construction, so the bound that is
+    # relative to the amplitude a frame was computed at is the one that applies; nothing here is looser than what the test suite holds.
+    rel, worst, _ = par.pcm_float_stats(rf[:, n - 1], pf)
+    peaks = ref["peak"].reshape(len(pick), n, T)
+    st_last, bad_last = par.int16_stats(rf[:, n - 2], r16[:, n - 2], last16, peak=peaks[:, n - 2])
+    st_extra, bad_extra = par.int16_stats(rf[:, n - 1], r16[:, n - 1], p16, peak=peaks[:, n - 1])
     if rel > par.PCM_REL_RMS:
         violations.append(f"PCM relative RMS {rel:.3e} > {par.PCM_REL_RMS:.1e}")
     if worst > par.PCM_WORST_FRAME:
         violations.append(f"worst frame {worst:.3e} > {par.PCM_WORST_FRAME:.1e}")
-    if within1 < 0.999:
-        violations.append(f"only {within1:.5f} of the int16 samples within 1 LSB")
-    # Frames that reach the soft clip: the samples of such a frame that are NOT clipped are where a sum of amplitude 1e5 ... 4e5 crosses
-    # the output range, so 5e-6 of the amplitude is 3 ... 10 LSB (tests/parity.py).  The tests hold 4 LSB there on their inputs (random
-    # and recorded frames); the bench workloads repeat ONE frame per stream tick after tick, which drives the AMBE+2 workloads' clipped
-    # frames further out: up to 8 LSB observed, depending on which tick the timed region happens to end on
-    # (profiles/r05/parity_by_replay_length.log).  The reference's own IEEE and FMA-target builds differ by 8 ... 55 LSB on frames
-    # of this kind (tests/golden/tail_cases.npz), so the bench bounds them at 16 and reports the figure; the float criteria (1e-4 / 1e-3,
-    # met with two orders of magnitude to spare) and the 3-LSB bound below the clip are what decide.
-    inside_bound = 16
-    if below > par.INT16_MAX_LSB or inside > inside_bound:
-        violations.append(f"int16 differs by {below} / {inside} LSB (below / inside the clip; bounds {par.INT16_MAX_LSB} / {inside_bound})")
+    violations += ["last timed step: " + b for b in bad_last] + ["extra step: " + b for b in bad_extra]
     state_ok = True
     try:
         par.check_state(ref["state"], state)
     except AssertionError as e:
         state_ok = False
         violations.append("state: " + str(e)[:200])
-    return {
+    return {   # a bound that does not hold is REPORTED in the object ("FAILED"), next to the numbers, not instead of them
         **({"FAILED": "bench parity: " + "; ".join(violations)} if violations else {}),
-        "rel_rms": rel, "worst_frame": worst, "int16_max_inside_clip": inside,
-        "int16_within_1": within1, "int16_max": max(below, inside), "int16_max_below_clip": below,
-        "int16_exact": float(np.mean(d_last == 0)), "clipped_frames": float(np.mean(clip_last)),
+        "rel_rms": rel, "worst_frame": worst,
+        "int16_within_1": st_last["int16_within_1"], "int16_exact": st_last["int16_exact"],
+        "int16_max": max(st_last["int16_max"], st_extra["int16_max"]),
+        "int16_max_below_clip": max(st_last["int16_max_below_clip"], st_extra["int16_max_below_clip"]),
+        "int16_max_inside_clip": max(st_last["int16_max_inside_clip"], st_extra["int16_max_inside_clip"]),
+        "int16_margin": min(st_last["int16_margin"], st_extra["int16_margin"]),   # smallest (bound - difference) over the checked frames
+        "int16_bound": st_last["int16_bound"], "clipped_frames": st_last["clipped_frames"],
+        "preclip_peak_max": float(max(peaks[:, n - 2].max(), peaks[:, n - 1].max())),
         "streams_checked": int(len(pick)), "launches_replayed": int(n), "frames_checked": int(len(pick) * T),
-        "results_exact": True, "state_in_tolerance": state_ok,
-        "tolerance": {"rel_rms": par.PCM_REL_RMS, "worst_frame": par.PCM_WORST_FRAME, "int16_max_lsb": par.INT16_MAX_LSB,
-                      "int16_max_lsb_clipped_frames": inside_bound,
-                      "int16_max_lsb_clipped_frames_in_the_tests": par.INT16_MAX_LSB_CLIPPED},
+        "results_exact": results_exact, "state_in_tolerance": state_ok,
+        "tolerance": {"rel_rms": par.PCM_REL_RMS, "worst_frame": par.PCM_WORST_FRAME, "int16": "tests/parity.py int16_bound(pre-clip peak)",
+                      "int16_within_1_share": 0.999},
         "oracle": "oracle/mbx_oracle.c (CPU restatement pinned on the reference's golden vectors; double-precision FFT form)",
         "what": "strided sample of the timed workload's streams replayed through the oracle over every launch since the decoder's "
                 "construction: results + int16 PCM of the last timed step, float PCM of one more untimed step, final state",
@@ -750,6 +740,75 @@ def roofline_of(name, S, T, m):
     return r
 
 
+LINE_LIMIT = 4096   # bytes: the driver keeps only the tail of stdout, and a 20 KB line (round 5) was not parsed
+
+
+def _sig(x, digits=6):
+    """floats of the compact line to `digits` significant digits (ints, strings, None untouched)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{digits}g}")
+
+
+def _pick(d, keys, digits=6):
+    return {k: _sig(d[k], digits) for k in keys if d is not None and k in d}
+
+
+def contract_line(detail):
+    """The ONE stdout line: the bench contract's keys plus `roofline`, `parity`, `cpu_baseline` and a five-number summary per
+    other config.  `detail` is the full measurement dict (what bench_detail.json holds).  Pure (no torch, no GPU): covered by a CPU
+    test on a canned dict.  Never longer than LINE_LIMIT bytes: free-text fields are clipped first, and should a future key push it
+    over, `other_configs` and then the free text are dropped before anything the contract names."""
+    line = _pick(detail, ("metric", "value", "unit", "n_gpus", "steps", "steps_effective", "warmup", "ms_per_step", "higher_is_better",
+                          "scaling", "vs_baseline", "dtype", "data"), digits=7)
+    cfg = detail.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "streams_per_gpu", "frames_per_stream_per_step", "frames_per_step", "output", "parallelism"))
+    rf = detail.get("roofline") or {}
+    line["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                  "traffic_over_algorithmic", "algorithmic_bytes_per_launch", "kernel_ms", "dispatches_per_step"))
+    par = detail.get("parity")
+    if par is not None:
+        line["parity"] = _pick(par, ("FAILED", "rel_rms", "worst_frame", "int16_within_1", "int16_max", "int16_bound", "streams_checked",
+                                     "launches_replayed", "results_exact", "state_in_tolerance"), digits=4)
+    cb = detail.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "build", "sample"))
+    oc = detail.get("other_configs")
+    if oc:
+        line["other_configs"] = {k: _pick(v, ("value", "ms_per_step", "kernel", "kernel_ms", "frac"), digits=5) for k, v in oc.items()}
+    if detail.get("detail_file"):
+        line["detail"] = detail["detail_file"]
+
+    def size():
+        return len(json.dumps(line))
+
+    for obj, key, keep in ((line["config"], "workload", 160), (line.get("cpu_baseline") or {}, "sample", 200), (line["roofline"], "traffic_source", 80),
+                           (line.get("parity") or {}, "FAILED", 300), (line["config"], "parallelism", 80)):
+        if size() > LINE_LIMIT and isinstance(obj.get(key), str) and len(obj[key]) > keep:
+            obj[key] = obj[key][:keep - 3] + "..."
+    for victim in ("other_configs", "detail"):
+        if size() > LINE_LIMIT:
+            line.pop(victim, None)
+    assert size() <= LINE_LIMIT, size()
+    return line
+
+
+def write_detail(detail):
+    """the sidecar: next to this script, and under gpurun_out/ (merged back from the GPU box) when that directory exists"""
+    written = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(detail, f, indent=1)
+                written.append(os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT))
+            except OSError:
+                pass
+    return written
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -981,7 +1040,9 @@ def main():
                 }
             except Exception as e:   # noqa: BLE001 -- the headline must not depend on the extras
                 line["host_path"] = {"error": str(e)[:300]}
-        print(json.dumps(line), flush=True)
+        line["detail_file"] = "bench_detail.json"
+        write_detail(line)
+        print(json.dumps(contract_line(line)), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -444,12 +444,9 @@ const char* mbx_batch_kernel_name(int codec, int S, int T, int resident);
 /* diagnostics of the one-launch kernel: the number of its stream blocks that did not find their front block's rows in time and
  * expanded their own frame instead, since the workspace of `stream` was allocated (expected 0; results are the same either way).
  * Synchronises the stream.  -1: the stream has no workspace yet. */
-long long mbx_debug_front_fallbacks(void* stream);
-/* TESTING hook for that fall-back path, which no ordinary launch has ever taken: every = 2^k > 0 makes the front blocks of chunks
- * 0, 2^k, 2 * 2^k, ... (a chunk = eight consecutive streams of the launch) of the one-launch kernels on the calling thread's device do
- * nothing, so that their stream blocks wait out their ~40 us and decode their own frames; 0 (the default) switches it off.  Results
- * are the same bytes either way (tests/test_gpu_parity.py holds that); only the time differs.  Not for production use. */
-int mbx_debug_set_front_skip(int every);
+long long mbx_front_fallbacks(void* stream);
+/* (The fault-injection hook that FORCES that fall-back path is not part of this library: it exists only in the -DMBX_TESTING build,
+ * libmbx_hip_testing.so -- `make -C mbelib-neo_amd/csrc testing` -- which tests/ load in a child process through MBX_HIP_LIBRARY.) */
 /* Sliced launches.  A launch of S streams x T >= 32 frames whose S does not fill the device's resident wave slots evenly (the
  * last round of waves would run part-empty: 8,192 streams on 5,120 slots are 1.6 rounds) is cut into three groups of streams x
  * slices of 16 frames, issued in order on three internal HIP streams that are forked from and joined to the caller's stream with

@@ -12,8 +12,8 @@ class NativeLibraryError(RuntimeError):
 
 
 def library_path():
-    """The product library, or -- for tools/ only -- the development build named by MBX_HIP_LIBRARY
-    (libmbx_hip_ablate.so, which additionally exports mbx_debug_set_ablation)."""
+    """The product library, or the build named by MBX_HIP_LIBRARY: for tools/ the development builds (libmbx_hip_ablate.so, which
+    additionally exports mbx_debug_set_ablation), for one test the fault-injection build (libmbx_hip_testing.so: mbx_testing_set_front_skip)."""
     return os.environ.get("MBX_HIP_LIBRARY") or os.path.join(_HERE, _LIB_NAME)
 
 
@@ -102,8 +102,7 @@ _SIGNATURES = {
     "mbx_rng_seed": (None, [_vp, C.c_uint32]),
     "mbx_stream_kernel_name": (C.c_char_p, [C.c_int, C.c_int]),
     "mbx_batch_kernel_name": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "mbx_debug_front_fallbacks": (C.c_longlong, [C.c_void_p]),
-    "mbx_debug_set_front_skip": (C.c_int, [C.c_int]),
+    "mbx_front_fallbacks": (C.c_longlong, [C.c_void_p]),
     "mbx_launch_slices": (C.c_int, [C.c_int, C.c_int, C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -138,6 +137,9 @@ def lib():
                 raise NativeLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
+        if hasattr(handle, "mbx_testing_set_front_skip"):   # libmbx_hip_testing.so only (tests/front_skip_case.py)
+            handle.mbx_testing_set_front_skip.restype = C.c_int
+            handle.mbx_testing_set_front_skip.argtypes = [C.c_int]
         if hasattr(handle, "mbx_debug_set_ablation"):   # development build only
             handle.mbx_debug_set_ablation.restype = None
             handle.mbx_debug_set_ablation.argtypes = [C.c_int]

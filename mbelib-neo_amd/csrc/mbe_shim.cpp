@@ -832,10 +832,13 @@ class Pump {
                 const hipError_t e = hipEventQuery(j->done_ev);
                 if (e == hipSuccess) {
                     {
+                        // The job lives on the producer's stack: it is gone as soon as the producer has seen `done` under j->mu.  So the
+                        // wake-up is made while the mutex is still held (the producer cannot leave its wait before this block ends) and
+                        // nothing of *j is touched after the unlock.
                         std::lock_guard<std::mutex> lk(j->mu);
                         j->done = true;
+                        j->cv.notify_one();
                     }
-                    j->cv.notify_one();
                     pending_[i] = pending_.back();
                     pending_.pop_back();
                 } else if (e == hipErrorNotReady) {

@@ -709,7 +709,9 @@ static int ensure_workspace(Context* c, StreamSlot& slot, size_t frames, void* s
     slot.frames = want;
     slot.flags = reinterpret_cast<uint32_t*>(slot.workspace + want);
     slot.epoch = 0;
-    HIP_TRY(hipMemset(slot.flags, 0, flag_bytes));   // (no launch has epoch 0)
+    // (no launch has epoch 0.)  On the LAUNCH stream: a non-blocking stream is not ordered against the null stream, so a null-stream
+    // memset could land after the first launch's front blocks have published their flags.  (Not capturing: checked above.)
+    HIP_TRY(hipMemsetAsync(slot.flags, 0, flag_bytes, (hipStream_t)stream));
     return 0;
 }
 
@@ -1872,9 +1874,11 @@ int mbx_decode_parms(int codec, const mbx_param_record* d_records, size_t n, mbe
     return check_launch("decode_parms_kernel");
 }
 
-// diagnostics: how many stream blocks of the one-launch kernel have expanded their own frame since the stream's workspace was
-// allocated (a stream block does that when its front block's rows are not there in time); synchronises the stream.  -1: no workspace.
-int mbx_debug_set_front_skip(int every) {
+#ifdef MBX_TESTING
+// libmbx_hip_testing.so only (make testing; the tests load it through MBX_HIP_LIBRARY in a child process): fault injection for the
+// fall-back path of the one-launch kernels, which no ordinary launch has ever taken.  every = 2^k > 0 makes the front blocks of chunks
+// 0, 2^k, 2 * 2^k, ... do nothing, so that their stream blocks wait out their ~40 us and decode their own frames; 0 switches it off.
+extern "C" int mbx_testing_set_front_skip(int every) {
     REQUIRE_CTX(c);
     if (every < 0 || (every & (every - 1)) != 0) {
         return MBE_STATUS_INVALID_ARGUMENT;
@@ -1883,8 +1887,11 @@ int mbx_debug_set_front_skip(int every) {
     c->tabs.front_skip = every;
     return 0;
 }
+#endif
 
-long long mbx_debug_front_fallbacks(void* stream) {
+// diagnostics: how many stream blocks of the one-launch kernel have expanded their own frame since the stream's workspace was
+// allocated (a stream block does that when its front block's rows are not there in time); synchronises the stream.  -1: no workspace.
+long long mbx_front_fallbacks(void* stream) {
     int crc;
     Context* c = current_ctx(&crc);
     if (!c) {

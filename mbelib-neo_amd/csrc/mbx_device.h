@@ -69,8 +69,8 @@ struct DeviceTables {
     const DerivedTables* d;
     int                  ablate;   // timing-only stage mask; read only by the -DMBX_ABLATE development build (tools/)
     int                  reverse;  // stream kernels: workgroup b takes stream S - 1 - b (see launch_stream, mbx_api.hip)
-    int                  front_skip;   // one-launch kernels, TESTING hook (mbx_debug_set_front_skip): 2^k > 0 -- the front blocks of chunks 0, 2^k, 2 x 2^k, ...
-                                       // do nothing, so that their stream blocks take the fall-back path (which no ordinary launch has ever taken)
+    int                  front_skip;   // read only by the -DMBX_TESTING build (mbx_testing_set_front_skip): 2^k > 0 -- the front blocks of chunks 0, 2^k,
+                                       // 2 x 2^k, ... of the one-launch kernels do nothing, so that their stream blocks take the fall-back path; always 0 in the product
     const int32_t*       stream_map;   // stream kernels: batch row s works on state / rng slot stream_map[s] (nullptr: slot s)
     // Resident state (sessions, queue mode; nullptr: the ABI triplet is kept whole, what every mbx_process_* entry point does).
     // resident[slot] != 0 says "prev_mp_enhanced of this stream is elided: it equals cur_mp field for field" -- true after every

@@ -2599,9 +2599,11 @@ __device__ __forceinline__ void imbe_one_launch_body(int S, int lead, const uint
     constexpr size_t kFrontLds = 8 * 65 * 4 + 8 * 64 * 4 + 8 * 8 * 4, kStreamLds = sizeof(WaveScratchT<MBX_PARK_N>);
     __shared__ alignas(16) char lds[kFrontLds > kStreamLds ? kFrontLds : kStreamLds];   // ONE block of LDS for either kind of workgroup
     if (chunk >= 0) {
+#ifdef MBX_TESTING   // libmbx_hip_testing.so only (mbx_testing_set_front_skip): this chunk's stream blocks will not find their rows
         if (tabs_in.front_skip > 0 && (chunk & (tabs_in.front_skip - 1)) == 0) {
-            return;   // (testing hook: this chunk's stream blocks will not find their rows)
+            return;
         }
+#endif
         front_block_imbe(chunk, S, frames, records, rows, flags, epoch, tabs_in, lds);
         return;
     }
@@ -3616,9 +3618,11 @@ __device__ __forceinline__ void ambe_one_launch_body(int S, const uint8_t* __res
     constexpr size_t kFrontLds = 8 * 65 * 4, kStreamLds = sizeof(WaveScratchT<MBX_PARK_N>);
     __shared__ alignas(16) char lds[kFrontLds > kStreamLds ? kFrontLds : kStreamLds];
     if (bid < C) {
+#ifdef MBX_TESTING   // libmbx_hip_testing.so only (mbx_testing_set_front_skip)
         if (tabs_in.front_skip > 0 && (bid & (tabs_in.front_skip - 1)) == 0) {
-            return;   // (testing hook: this chunk's stream blocks will not find their rows)
+            return;
         }
+#endif
         front_block_ambe<k2400>(bid, S, frames, records, rows, flags, epoch, tabs_in, lds);
         return;
     }

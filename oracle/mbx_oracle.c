@@ -1969,6 +1969,11 @@ fft256(double* re, double* im, int inverse) {
  *        :1230-1262 (twiddles), :2018-2040 (ordering)
  * ===================================================================================== */
 static int g_fft_float = 0;
+/* Diagnostic for the parity checker (tests/parity.py int16_bound): the largest |sample| of the frame's sum BEFORE the soft clip, so that
+ * the int16 bound of a frame driven far beyond the output range can be stated relative to the amplitude it was computed at.  The
+ * reference keeps no such figure; nothing in the decode reads it. */
+static __thread float g_preclip_peak = 0.0f;
+static __thread float* g_preclip_peaks_out = 0;
 
 void
 mbxo_set_fft_float(int on) {
@@ -2422,6 +2427,10 @@ synth_core(float* out, mbe_parms* cur, mbe_parms* prev, int have_rm0, float rm0,
     /* soft clip (:669-689) */
     const float clip = (32767.0f * 0.95f) / 7.0f;
     for (int n = 0; n < N; ++n) {
+        float a = fabsf(out[n]);
+        if (a > g_preclip_peak) { /* diagnostic only: how far beyond the output range the frame's sum went (mbxo_set_preclip_peaks) */
+            g_preclip_peak = a;
+        }
         if (out[n] > clip) {
             out[n] = clip;
         } else if (out[n] < -clip) {
@@ -2882,6 +2891,11 @@ mbxo_fec_batch(int codec, size_t n, const uint8_t* frames, mbx_param_record* rec
     return 0;
 }
 
+void
+mbxo_set_preclip_peaks(float* out) {
+    g_preclip_peaks_out = out;
+}
+
 /* `soft` != 0: frames are mbe_soft_bit arrays (184 | 96 per frame) through the soft-decision FEC */
 static int
 process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_parms* state, mbx_stream_rng* rng,
@@ -2905,6 +2919,7 @@ process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_p
             mbe_process_result res;
             float pcm[160];
             char bits[88];
+            g_preclip_peak = 0.0f;
             if (imbe) {
                 if (soft && codec == MBX_CODEC_IMBE7100X4400) {
                     mbxo_fec_imbe7100x4400_soft((const mbe_soft_bit(*)[24])fr, &rec);
@@ -2931,6 +2946,9 @@ process_batch_impl(int codec, int S, int Tn, const void* frames, int soft, mbe_p
                 } else {
                     mbxo_process_ambe2450_dataf(pcm, &res, bits, cur, prev, enh, &rng[s]);
                 }
+            }
+            if (g_preclip_peaks_out) {
+                g_preclip_peaks_out[f] = g_preclip_peak;
             }
             if (records) {
                 records[f] = rec;

@@ -69,6 +69,8 @@ class Oracle:
         h.mbxo_rng_default.argtypes = [_vp]
         h.mbxo_rng_seed.restype = None
         h.mbxo_rng_seed.argtypes = [_vp, C.c_uint32]
+        h.mbxo_set_preclip_peaks.restype = None
+        h.mbxo_set_preclip_peaks.argtypes = [C.c_void_p]
         h.mbxo_set_fft_float.restype = None
         h.mbxo_set_fft_float.argtypes = [C.c_int]
         h.mbxo_fnv1a32.restype = C.c_uint32
@@ -224,13 +226,18 @@ class Oracle:
         pcmf = np.zeros((n, 160), dtype=np.float32)
         results = np.zeros(n, dtype=RESULT_DTYPE)
         records = np.zeros(n, dtype=RECORD_DTYPE)
+        peak = np.zeros(n, dtype=np.float32)   # largest |sample| before the soft clip, per frame (parity.int16_bound)
         fn = self.h.mbxo_process_batch_soft if soft else self.h.mbxo_process_batch
-        rc = fn(
-            codec, S, T, frames.ctypes.data, state.ctypes.data, rng.ctypes.data, pcm16.ctypes.data, pcmf.ctypes.data,
-            results.ctypes.data, records.ctypes.data,
-        )
+        self.h.mbxo_set_preclip_peaks(peak.ctypes.data)
+        try:
+            rc = fn(
+                codec, S, T, frames.ctypes.data, state.ctypes.data, rng.ctypes.data, pcm16.ctypes.data, pcmf.ctypes.data,
+                results.ctypes.data, records.ctypes.data,
+            )
+        finally:
+            self.h.mbxo_set_preclip_peaks(None)
         assert rc == 0
-        return {"pcm16": pcm16, "pcmf": pcmf, "results": results, "records": records, "state": state, "rng": rng}
+        return {"pcm16": pcm16, "pcmf": pcmf, "results": results, "records": records, "state": state, "rng": rng, "peak": peak}
 
     def synthesize_speech(self, cur, prev, rng):
         cur = np.ascontiguousarray(cur).copy()

@@ -3,12 +3,12 @@
 Tolerances: everything integer is bit-exact (parameter bits, error counts,
 flags, return codes, L/K/Vl, repeat counters, thresholds, the LCG noise state); float PCM
 relative RMS <= 1e-4 per batch and <= 1e-3 for the worst single frame; int16 PCM within
-1 LSB on >= 99.9 % of samples and never more than 3 LSB -- except in frames that are driven INTO THE SOFT CLIP
-(a float sample of the reference at +-4446.95, i.e. harmonic amplitudes beyond the output range: random channel bits
-decode to 60,000-80,000 against +-4,447), where the bound is 4 LSB: the worst difference observed in 94 M samples, pinned
-by the fixture below (SURVEY.md section 8(c) says 3 everywhere; this is the one stated deviation from it).  check_pcm also
-fails when more than 35 % of a workload's frames fall under the clipped bound (random channel bits: 20 %), so a workload
-cannot drift under the looser bound unnoticed.
+1 LSB on >= 99.9 % of samples and never more than 3 LSB -- except in frames that are driven FAR INTO THE SOFT CLIP
+(harmonic amplitudes beyond the output range: random channel bits decode to sums of 60,000-130,000 against +-4,447), where the
+bound is relative to the amplitude the frame was computed at: int16_bound() below, ONE rule for the tests, bench.py and tools/
+(SURVEY.md section 8(c) says 3 everywhere; this is the one stated deviation from it, and it only ever applies to frames whose
+pre-clip peak exceeds 42,857).  Comparisons against fixtures of the real reference, which carry no pre-clip figure, use the stricter
+constants 3 / 4 and refuse workloads with more than 35 % of their frames at the clip.
 
 WHICH CHECKER: `ref_*` arguments come either from the ORACLE (oracle/mbx_oracle.c: the CPU restatement.  Its unvoiced FFT is
 double precision by default -- 6e-8 relative away from the reference's float PFFFT, every integer and every decision identical
@@ -32,9 +32,29 @@ PCM_REL_RMS = 1e-4
 PCM_WORST_FRAME = 1e-3
 STATE_REL_RMS = 1e-4
 INT16_MAX_LSB = 3            # frames below the clip
-INT16_MAX_LSB_CLIPPED = 4    # frames with a sample at the soft-clip level: the observed worst case (see the module docstring)
-MAX_CLIPPED_SHARE = 0.35     # of a workload's frames (random channel bits drive 20 % of the frames into the clip)
-CLIP_LEVEL = 32767.0 * 0.95 / 7.0   # ref src/core/mbelib.c:1148-1177 soft clip of the float PCM
+INT16_MAX_LSB_CLIPPED = 4    # frames with a sample at the soft-clip level, when the frame's pre-clip amplitude is NOT known (see int16_bound)
+INT16_REL_OF_PEAK = 1e-5     # per-sample float error allowed in a frame, relative to the frame's largest |sample| BEFORE the soft clip
+INT16_GAIN = 7.0             # float PCM -> int16 (ref src/core/mbelib.c:1148-1177)
+MAX_CLIPPED_SHARE = 0.35     # of a workload's frames (random channel bits drive 20 % of the frames into the clip); legacy form only
+CLIP_LEVEL = 32767.0 * 0.95 / 7.0   # ref src/core/mbelib.c:669-689 soft clip of the float PCM
+
+
+def int16_bound(peak):
+    """THE int16 bound table (tests, bench.py `parity`, tools/ all import this): the allowed |int16 difference| of a frame whose sum
+    reached `peak` = largest |sample| before the soft clip (the oracle reports it per frame: oracle_lib process_batch()["peak"]).
+
+        bound = max(3, ceil(7 * 1e-5 * peak))
+
+    Below the clip (peak < 4,447) and up to peak 42,857 that is the 3 LSB of SURVEY.md section 8(c).  Beyond, the samples of a frame that are NOT
+    clipped are where a sum of amplitude `peak` happens to cross the output range, and the error there is relative to that amplitude:
+    1e-5 of it (a tenth of the 1e-4 relative-RMS criterion, applied per sample) times the int16 gain 7.  Measured: the HIP path's worst
+    frames in 94 M samples of random bits (tests/golden/tail_cases.npz: peaks 58,000 ... 129,000, 2 ... 4 LSB) sit at 1.5e-5 ... 3.8e-5
+    LSB per unit of peak = 2.2e-6 ... 5.5e-6 of the peak, half the bound or less; the REFERENCE's own IEEE and FMA-target builds
+    differ on those very frames by 3 ... 55 LSB = up to 1e-4 of the peak.  Workloads that repeat one frame per stream tick after tick (bench.py)
+    drive the AMBE+2 prediction further out (peaks of several 1e5, 8 LSB seen): the same rule covers them, which is why there is no
+    per-workload constant any more (bench.py's former `inside_bound = 16`)."""
+    peak = np.asarray(peak, dtype=np.float64)
+    return np.maximum(INT16_MAX_LSB, np.ceil(INT16_GAIN * INT16_REL_OF_PEAK * peak)).astype(np.int64)
 
 
 def clipped_frames(ref_f):
@@ -52,32 +72,61 @@ def rel_rms(ref, got):
     return float(np.sqrt(num / den)) if den > 0 else float(np.sqrt(num))
 
 
-def check_pcm(ref_f, got_f, ref_s=None, got_s=None, rel=PCM_REL_RMS, worst=PCM_WORST_FRAME, what="pcm"):
-    ref_f = np.asarray(ref_f).reshape(-1, 160)
-    got_f = np.asarray(got_f).reshape(-1, 160)
+def pcm_float_stats(ref_f, got_f):
+    """(relative RMS of the batch, worst single frame relative to max(its own RMS, 5 % of the batch level), index of that frame)"""
+    ref_f = np.asarray(ref_f).reshape(-1, 160).astype(np.float64)
+    got_f = np.asarray(got_f).reshape(-1, 160).astype(np.float64)
     total = rel_rms(ref_f, got_f)
+    level = np.sqrt(np.mean(ref_f ** 2)) + 1e-30   # silent frames must not blow the ratio up
+    err = np.sqrt(np.mean((ref_f - got_f) ** 2, axis=1))
+    ratio = err / np.maximum(np.sqrt(np.mean(ref_f ** 2, axis=1)), 0.05 * level)
+    return total, float(ratio.max()), int(ratio.argmax())
+
+
+def int16_stats(ref_f, ref_s, got_s, peak=None):
+    """int16 figures of a batch and the list of bounds they violate (empty = pass).  peak: the oracle's pre-clip peak per frame -> every
+    frame is held to int16_bound(its peak).  Without it (fixtures written by the real reference, which reports no such figure) the stricter
+    legacy constants apply: 3 LSB below the clip, 4 in frames at the clip level, and at most 35 % of the frames under the latter."""
+    d = np.abs(np.asarray(ref_s, dtype=np.int32).reshape(-1, 160) - np.asarray(got_s, dtype=np.int32).reshape(-1, 160))
+    clip = clipped_frames(ref_f) if ref_f is not None else np.zeros(d.shape[0], dtype=bool)
+    worst = d.max(axis=1)
+    out = {
+        "int16_within_1": float(np.mean(d <= 1)), "int16_exact": float(np.mean(d == 0)), "int16_max": int(d.max()) if d.size else 0,
+        "int16_max_below_clip": int(worst[~clip].max()) if (~clip).any() else 0,
+        "int16_max_inside_clip": int(worst[clip].max()) if clip.any() else 0,
+        "clipped_frames": float(np.mean(clip)) if clip.size else 0.0,
+    }
+    bad = []
+    if out["int16_within_1"] < 0.999:
+        bad.append(f"only {out['int16_within_1']:.5f} of int16 samples within 1 LSB")
+    if peak is not None:
+        bound = int16_bound(np.asarray(peak).reshape(-1))
+        over = np.nonzero(worst > bound)[0]
+        out["int16_bound"] = f"max(3, ceil(7e-5 * pre-clip peak)) per frame; largest bound in this batch {int(bound.max()) if bound.size else 3}"
+        out["int16_margin"] = int((bound - worst).min()) if bound.size else 0
+        if over.size:
+            k = over[np.argmax(worst[over] - bound[over])]
+            bad.append(f"int16 differs by {int(worst[k])} LSB in frame {int(k)} (pre-clip peak {float(np.asarray(peak).reshape(-1)[k]):.0f}: bound {int(bound[k])}); {over.size} frames over")
+    else:
+        out["int16_bound"] = f"{INT16_MAX_LSB} below the clip / {INT16_MAX_LSB_CLIPPED} in frames at the clip level (no pre-clip peak available)"
+        if out["int16_max_below_clip"] > INT16_MAX_LSB:
+            bad.append(f"int16 differs by {out['int16_max_below_clip']} LSB in a frame below the clip")
+        if out["int16_max_inside_clip"] > INT16_MAX_LSB_CLIPPED:
+            bad.append(f"int16 differs by {out['int16_max_inside_clip']} LSB in a clipped frame")
+        if out["clipped_frames"] > MAX_CLIPPED_SHARE:
+            bad.append(f"{out['clipped_frames']:.2f} of the frames reach the soft clip -- too many for the clipped-frame constant to govern (pass peak=)")
+    return out, bad
+
+
+def check_pcm(ref_f, got_f, ref_s=None, got_s=None, rel=PCM_REL_RMS, worst=PCM_WORST_FRAME, what="pcm", peak=None):
+    total, worst_ratio, worst_at = pcm_float_stats(ref_f, got_f)
     assert total <= rel, f"{what}: relative RMS {total:.3e} > {rel:.1e}"
-    # worst frame, relative to the batch RMS level so silent frames do not blow the ratio up
-    level = np.sqrt(np.mean(ref_f.astype(np.float64) ** 2)) + 1e-30
-    err = np.sqrt(np.mean((ref_f.astype(np.float64) - got_f.astype(np.float64)) ** 2, axis=1))
-    frame_rms = np.sqrt(np.mean(ref_f.astype(np.float64) ** 2, axis=1))
-    ratio = err / np.maximum(frame_rms, 0.05 * level)
-    assert ratio.max() <= worst, f"{what}: worst frame relative error {ratio.max():.3e} > {worst:.1e} (frame {ratio.argmax()})"
-    out = {"rel_rms": total, "worst_frame": float(ratio.max())}
+    assert worst_ratio <= worst, f"{what}: worst frame relative error {worst_ratio:.3e} > {worst:.1e} (frame {worst_at})"
+    out = {"rel_rms": total, "worst_frame": worst_ratio}
     if ref_s is not None:
-        d = np.abs(np.asarray(ref_s, dtype=np.int32).reshape(-1, 160) - np.asarray(got_s, dtype=np.int32).reshape(-1, 160))
-        frac = float(np.mean(d <= 1))
-        clip = clipped_frames(ref_f)
-        below = int(d[~clip].max()) if (~clip).any() else 0
-        inside = int(d[clip].max()) if clip.any() else 0
-        assert below <= INT16_MAX_LSB, f"{what}: int16 differs by {below} LSB in a frame below the clip"
-        assert inside <= INT16_MAX_LSB_CLIPPED, f"{what}: int16 differs by {inside} LSB in a clipped frame"
-        assert frac >= 0.999, f"{what}: only {frac:.5f} of int16 samples within 1 LSB"
-        assert float(np.mean(clip)) <= MAX_CLIPPED_SHARE, f"{what}: {np.mean(clip):.2f} of the frames reach the soft clip -- too many for the clipped-frame bound to govern"
-        out["int16_exact"] = float(np.mean(d == 0))
-        out["int16_max"] = int(d.max())
-        out["int16_max_below_clip"] = below
-        out["clipped_frames"] = float(np.mean(clip))
+        st, bad = int16_stats(ref_f, ref_s, got_s, peak)
+        assert not bad, f"{what}: " + "; ".join(bad)
+        out.update(st)
     return out
 
 

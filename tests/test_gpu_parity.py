@@ -559,48 +559,31 @@ def test_imbe_voiced_config2_full_shape(mbx, oracle):
 def test_one_launch_fall_back_path_gives_the_same_bytes(mbx, oracle, codec):
     """A stream block of the one-launch kernels that does not see its front block's flag in time decodes its own frame (IMBE: FEC by
     lanes + expansion in its own wave; AMBE: scalar-unit FEC + expansion by its first eight lanes).  No ordinary launch has ever taken
-    that path (mbx_debug_front_fallbacks = 0 everywhere), so it is FORCED here: mbx_debug_set_front_skip(4) makes every fourth front
-    block do nothing.  Records, results, PCM, state and RNG of four ticks must be the bytes of the undisturbed launches, and the
-    fall-back counter must have counted exactly the streams of the skipped chunks."""
-    import torch
-    from mbelib_neo_amd import decoder, framegen
-    from mbelib_neo_amd.layout import FRAME_BYTES
+    that path (mbx_front_fallbacks = 0 everywhere), so it is FORCED -- by a hook the product library does not have: a child process
+    (tests/front_skip_case.py) loads libmbx_hip_testing.so, the -DMBX_TESTING build of the same sources, makes every fourth front block
+    do nothing, and holds records, results, PCM, state and RNG of four ticks to the bytes of its undisturbed launches and the fall-back
+    counter to exactly the streams of the skipped chunks.  Here: the product library on the same input gives those same bytes, and
+    does not export the hook."""
+    import json
+    import subprocess
+    import sys
+
+    import front_skip_case
 
     L = mbx.lib()
+    assert not hasattr(L, "mbx_testing_set_front_skip") and not hasattr(L, "mbx_debug_set_front_skip")
     if b"one_launch" not in L.mbx_batch_kernel_name(codec, 4096, 1, 0):
         pytest.skip("the one-launch form is switched off (MBX_FUSE_ONE)")
-    fb = FRAME_BYTES[codec]
-    S, T = 4096 + 5, 4
-    frames = framegen.random_frames(codec, S * T, framegen.rng_for(0x5A + codec)).reshape(S, T, fb)
-    frames[::3] &= framegen.random_frames(codec, ((S + 2) // 3) * T, framegen.rng_for(0x5B + codec)).reshape(-1, T, fb)
-    seeds = np.arange(S) + 5
-    strm = torch.cuda.current_stream().cuda_stream
-
-    def run(skip, resident):
-        assert L.mbx_debug_set_front_skip(skip) == 0
-        try:
-            dec = decoder.BatchDecoder(codec, S, seeds=seeds, resident=resident)
-            outs = []
-            for t in range(T):
-                o = dec.decode(np.ascontiguousarray(frames[:, t]), 1, want_float=True)
-                outs.append({k: v.cpu().numpy().copy() for k, v in o.items()})
-            return outs, dec.state_numpy(), dec.rng_numpy()
-        finally:
-            assert L.mbx_debug_set_front_skip(0) == 0
-
-    assert L.mbx_debug_set_front_skip(3) == -1   # (a power of two, or 0)
+    here = os.path.dirname(os.path.abspath(__file__))
+    testing = os.path.join(os.path.dirname(here), "mbelib-neo_amd", "libmbx_hip_testing.so")
+    assert os.path.exists(testing), "build it: make -C mbelib-neo_amd/csrc testing (part of __graft_entry__.build())"
+    r = subprocess.run([sys.executable, os.path.join(here, "front_skip_case.py"), str(codec)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MBX_HIP_LIBRARY=testing))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    child = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert child["fallbacks_counted"] > 0
     for resident in (False, True):
-        ref = run(0, resident)
-        before = L.mbx_debug_front_fallbacks(strm)
-        got = run(4, resident)
-        after = L.mbx_debug_front_fallbacks(strm)
-        for t in range(T):
-            for k in ("records", "results", "pcm16", "pcmf"):
-                assert got[0][t][k].tobytes() == ref[0][t][k].tobytes(), (resident, t, k)
-        assert got[1].tobytes() == ref[1].tobytes() and got[2].tobytes() == ref[2].tobytes()
-        chunks = (S + 7) // 8
-        skipped_streams = sum(min(8, S - 8 * c) for c in range(0, chunks, 4))
-        assert after - max(before, 0) == T * skipped_streams, (before, after, skipped_streams)
+        assert front_skip_case.run(codec, resident) == child["resident" if resident else "abi"], resident
 
 
 @pytest.mark.parametrize("codec", [0, 1, 2, 3])
@@ -635,7 +618,7 @@ def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
             outs.append({k: v.cpu().numpy().copy() for k, v in o.items()})
         return outs, dec.state_numpy(), dec.rng_numpy()
 
-    fallbacks_before = max(L.mbx_debug_front_fallbacks(torch.cuda.current_stream().cuda_stream), 0)   # (the counter lives as long as the stream's workspace)
+    fallbacks_before = max(L.mbx_front_fallbacks(torch.cuda.current_stream().cuda_stream), 0)   # (the counter lives as long as the stream's workspace)
     fo, fs, fr = run(False)
     so, ss, sr = run(True)
     for t in range(T):
@@ -660,7 +643,7 @@ def test_fused_one_frame_launch_equals_the_staged_launches(mbx, oracle, codec):
         torch.cuda.synchronize()
         for k in ("records", "results", "pcm16", "pcmf"):
             assert out[k].cpu().numpy().tobytes() == fo[t][k].tobytes(), (t, k)
-    fallbacks = L.mbx_debug_front_fallbacks(strm)
+    fallbacks = L.mbx_front_fallbacks(strm)
     print("front-block fall-backs of this test's launches:", fallbacks - fallbacks_before if fallbacks >= 0 else fallbacks)
     assert fallbacks <= 0 or fallbacks - fallbacks_before < S // 50   # (a stream block that does not find its row in time expands its own frame: rare, never wrong)
 
@@ -1326,7 +1309,13 @@ def test_bench_default_line_keeps_its_contract():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [x for x in r.stdout.splitlines() if x.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), lines[:3]
+    assert len(lines[0]) <= 4096, len(lines[0])   # the driver keeps the tail of stdout: a 20 KB line was not parsed (round 5)
+    assert r.stderr.strip() == "" or "amdgpu.ids" in r.stderr or len(r.stderr) < 2000, r.stderr[-500:]
     d = json.loads(lines[0])
+    detail = json.load(open(os.path.join(root, d["detail"])))   # everything else: the sidecar next to bench.py
+    assert detail["value"] == pytest.approx(d["value"], rel=1e-5) and "cpu_baselines" in detail and "host_path" in detail
+    assert set(d["other_configs"]) == set(detail["other_configs"]) and all(
+        set(v) == {"value", "ms_per_step", "kernel", "kernel_ms", "frac"} for v in d["other_configs"].values())
     assert "frames/sec" in d["metric"] and "PCM RMS error vs reference" in d["metric"]
     assert d["unit"] and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["value"] > 1e7 and abs(d["ms_per_step"] * 1e-3 * d["value"] / d["config"]["frames_per_step"] - 1.0) < 0.02
@@ -1338,6 +1327,8 @@ def test_bench_default_line_keeps_its_contract():
     assert cb["value"] > 0 and cb["unit"] and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
     par = d["parity"]
     assert "FAILED" not in par and par["rel_rms"] <= 1e-4 and par["results_exact"] and par["state_in_tolerance"] and par["streams_checked"] >= 256
+    for oc in detail["other_configs"].values():   # the other configs' own parity legs, if they ran one, hold the same bounds
+        assert "FAILED" not in (oc.get("parity") or {})
 
 
 def test_bench_two_ranks_self_launched_on_one_card():
@@ -1416,7 +1407,8 @@ def test_tail_cases_through_hip(mbx, oracle, golden_dir):
         got = _host_batch(mbx, codec, 1, t + 1, frames, init_state(1), rng_seeded([seed]))
         g16 = np.asarray(got["pcm16"]).reshape(t + 1, 160)[t].astype(np.int32)
         d = int(np.abs(g16 - fx[f"c{k}_oracle"].astype(np.int32)).max())
-        assert d <= parity.INT16_MAX_LSB_CLIPPED, (k, d)
+        peak = oracle.process_batch(codec, 1, t + 1, frames, oracle.init_state(1), oracle.rng_seeded([seed]))["peak"][t]
+        assert d <= parity.INT16_MAX_LSB_CLIPPED and d <= int(parity.int16_bound(peak)), (k, d, float(peak))
         assert d <= max(diff, 3), (k, d, diff)
         assert d <= int(np.abs(fx[f"c{k}_ref_fma"].astype(np.int32) - fx[f"c{k}_ref_ieee"].astype(np.int32)).max())
 
@@ -1440,6 +1432,56 @@ def test_int16_tail_over_ten_million_samples(mbx, oracle, codec):
     assert d.size >= 10_000_000
     assert float(np.mean(d <= 1)) >= 0.9999
     print(f"codec {codec} tail:", m, np.bincount(np.minimum(d, 7), minlength=8).tolist())
+
+
+@pytest.mark.parametrize("name", ["ambe_fec", "ambe_fec_resident", "imbe_voiced"])
+def test_replayed_frame_workloads_hold_the_int16_bound(mbx, oracle, name):
+    """bench.py's T = 1 workloads repeat ONE frame per stream, launch after launch, for thousands of launches; the AMBE+2 ones drive
+    their prediction far beyond the output range (pre-clip peaks of several 1e5) and showed up to 8 LSB against the oracle in frames
+    at the clip, depending on which launch the timed region ended on (profiles/r05/parity_by_replay_length.log).  Here the same
+    workloads (bench.make_frames, the bench's kernel instances: 4,096 streams, one launch per tick) run for 2,300 launches and a
+    strided sample of 64 streams is compared with the oracle at eight launches along the way -- the ones that log names and the
+    last -- under THE bound of tests/parity.py: per frame int16_bound(pre-clip peak), float criteria, results exact.  Checker: oracle."""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mbelib_neo_amd import _native, decoder
+    from mbelib_neo_amd.layout import FRAME_BYTES, RESULT_DTYPE
+
+    codec, _, T, _ = bench.WORKLOADS[name]
+    S, n_launch, resident = 4096, 2300, name.endswith("_resident")
+    marks = [353, 382, 954, 1055, 2000, 2249, 2299, 2300]
+    frames = bench.make_frames(name, codec, S, T, rank=0)
+    seeds = np.arange(S) + 1234
+    dec = decoder.BatchDecoder(codec, S, seeds=seeds, resident=resident)
+    kernel = _native.lib().mbx_batch_kernel_name(codec, S, T, 1 if resident else 0).decode()
+    assert "one_launch" in kernel, kernel
+    d_frames = dec.to_device(frames)
+    out = dec.make_outputs(T, want_pcm16=True, want_float=True, want_results=True)
+    pick = np.arange(S // 128, S, S // 64)[:64]
+    d_pick = torch.from_numpy(pick).cuda()
+    seen = {}
+    for k in range(1, n_launch + 1):
+        dec.decode(d_frames, T, out=out)
+        if k in marks:
+            seen[k] = tuple(out[x].reshape(S, -1)[d_pick].cpu().numpy() for x in ("pcm16", "pcmf", "results"))
+    state = dec.state_numpy()[pick]
+    fb = FRAME_BYTES[codec]
+    hist = np.ascontiguousarray(np.tile(np.asarray(frames).reshape(S, T, fb)[pick], (1, n_launch, 1))).reshape(-1, fb)
+    ref = oracle.process_batch(codec, len(pick), n_launch, hist, oracle.init_state(len(pick)), oracle.rng_seeded(seeds[pick]))
+    r16, rf = ref["pcm16"].reshape(len(pick), n_launch, 160), ref["pcmf"].reshape(len(pick), n_launch, 160)
+    rres, peak = ref["results"].reshape(len(pick), n_launch), ref["peak"].reshape(len(pick), n_launch)
+    worst = {}
+    for k in marks:
+        g16, gf, gres = seen[k]
+        parity.check_results(rres[:, k - 1], np.ascontiguousarray(gres).view(RESULT_DTYPE).reshape(-1), what=f"{name} launch {k}")
+        m = parity.check_pcm(rf[:, k - 1], gf, r16[:, k - 1], g16, peak=peak[:, k - 1], what=f"{name} launch {k}")
+        worst[k] = (m["int16_max"], m["int16_margin"], float(peak[:, k - 1].max()))
+    parity.check_state(ref["state"], state)
+    print(name, "launch: (int16 max, margin to the bound, largest pre-clip peak)", worst)
 
 
 # ---- AMBE+2 frame classes inside LDS-resident launches ---------------------------------------------------------------

@@ -29,6 +29,12 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f"libmbx_hip.so does not export {name}"
     assert declared == set(_native.EXPORTED_SYMBOLS)
+    # no fault-injection or debug hook in the shipping ABI: those live in the -DMBX_TESTING / -DMBX_ABLATE builds only
+    import subprocess
+
+    exported = subprocess.run(["nm", "-D", "--defined-only", m.library_path()], capture_output=True, text=True).stdout
+    assert "mbx_process_batch" in exported
+    assert "mbx_testing_" not in exported and "mbx_debug_set_" not in exported
 
 
 def test_launchers_fail_loudly_without_init_or_device():
@@ -417,3 +423,42 @@ def test_single_frame_fec_closed_form_sequence_and_header_gather():
         assert offset_of(name) == 4 * idx, (name, offset_of(name), idx)
     ksrc = open(os.path.join(ROOT, "mbelib-neo_amd", "csrc", "mbx_stream.hip")).read()
     assert "(j < 3) ? j : ((j < 13) ? (O_GAMMA - H_GAMMA) + j : O_NOISESEED)" in ksrc and "O_GAMMA = 288" in ksrc and "O_NOISESEED = 554" in ksrc
+
+
+def test_bench_contract_line_is_compact_and_complete():
+    """bench.contract_line(): the ONE stdout line the driver parses, built from a canned full measurement (tests/golden/bench_detail_canned.json:
+    round 5's 20 KB line, the one the driver could not parse): every contract key, roofline / parity / cpu_baseline, five numbers per other
+    config, at most 4,096 bytes -- also when the free-text fields grow."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    detail = json.load(open(os.path.join(root, "tests", "golden", "bench_detail_canned.json")))
+    assert len(json.dumps(detail)) > 15000
+    line = bench.contract_line(detail)
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT == 4096
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["value"] == float(f"{detail['value']:.7g}") and line["config"]["workload"].startswith("BASELINE configs[1]") and "model" not in line["config"]
+    assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms"} <= set(line["roofline"])
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-5
+    assert {"rel_rms", "worst_frame", "int16_within_1", "int16_max", "streams_checked", "results_exact"} <= set(line["parity"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert all(set(v) == {"value", "ms_per_step", "kernel", "kernel_ms", "frac"} for v in line["other_configs"].values()) and len(line["other_configs"]) == 5
+    for k in ("issue", "kernel_ms_stats", "copy_floor"):
+        assert k not in line["roofline"]
+    for k in ("cpu_baselines", "host_path", "valu", "infinity_cache_assisted", "convert", "distributed"):
+        assert k not in line
+    # growth: long free text is clipped, and in the last resort other_configs goes before any contract key does
+    fat = json.loads(json.dumps(detail))
+    fat["config"]["workload"] *= 20
+    fat["cpu_baseline"]["sample"] *= 20
+    fat["parity"]["FAILED"] = "x" * 5000
+    fat["other_configs"].update({f"extra{i}": fat["other_configs"]["ambe_fec"] for i in range(40)})
+    thin = bench.contract_line(fat)
+    assert len(json.dumps(thin)) <= 4096 and "other_configs" not in thin and thin["parity"]["FAILED"].startswith("xxx") and "roofline" in thin and "cpu_baseline" in thin
