@@ -768,6 +768,8 @@ def contract_line(detail):
     rf = detail.get("roofline") or {}
     line["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                   "traffic_over_algorithmic", "algorithmic_bytes_per_launch", "kernel_ms", "dispatches_per_step"))
+    if line["roofline"].get("achieved") and line["roofline"].get("peak"):   # self-consistent after the rounding: frac IS achieved / peak
+        line["roofline"]["frac"] = line["roofline"]["achieved"] / line["roofline"]["peak"]
     par = detail.get("parity")
     if par is not None:
         line["parity"] = _pick(par, ("FAILED", "rel_rms", "worst_frame", "int16_within_1", "int16_max", "int16_bound", "streams_checked",

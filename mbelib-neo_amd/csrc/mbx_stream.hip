@@ -99,6 +99,9 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #ifndef MBX_PRIO_FRONT_BLOCK
 #define MBX_PRIO_FRONT_BLOCK 3
 #endif
+#ifndef MBX_BANK_ALWAYS_DRIFT
+#define MBX_BANK_ALWAYS_DRIFT 0    // 1 (A/B builds only): the voiced bank always forms its first-order drift sums, as up to round 5
+#endif
 #ifndef MBX_PARK_N
 #define MBX_PARK_N 8   // how many per-lane values wait in LDS across the unvoiced transform pair (synth_core)
 #endif
@@ -1151,7 +1154,8 @@ __device__ __forceinline__ float div_by_uniform(float a, float b, float rcp_b) {
 // kPark: the snapshot lives in LDS (the launch-resident copies of the T >= 4 kernel instances) instead of the stream's HBM slot.
 // kEarly: see kEarlyNoise below -- the one-frame instances only (A/B: 65,536 x 1 IMBE -0.9 %, resident -3.5 %; the looped HBM-slot
 // instances spill with it, the LDS-resident AMBE+2 one is 1.9 % slower over 128 frames)
-template <bool kSnap, bool kPark = false, class Scratch = WaveScratch, bool kEarly = false>
+// kDriftUnrolled: the voiced bank's rarer loop form unrolled too (the IMBE one-frame instances: see bank_loop)
+template <bool kSnap, bool kPark = false, class Scratch = WaveScratch, bool kEarly = false, bool kDriftUnrolled = false>
 __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0, float rm0, StreamRng& rng,
                            Scratch& S, const DeviceTables& tabs, int lane, const mbe_parms* snap_ptr = nullptr) {
     constexpr int kParkN = Scratch::kParkCols;
@@ -1374,6 +1378,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         if (any) {
             constexpr double kInv2Pi = 0.15915494309189533577;
             constexpr int kMidPrev = 52, kMidCur = 108;
+            float drift_w;   // >= |d_l| g_l of this lane's harmonic, both models
             {   // lane = harmonic: g (cos psi, sin psi, d sin psi, d cos psi) for the prev and the cur model
                 const float fl = (float)lane;
                 const float pw0l = pw0 * fl, cw0l = cw0 * fl;
@@ -1399,7 +1404,18 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 }
                 S.coef_amp[lane] = ca;
                 S.coef_drift[lane] = cd;
+                // |d_l| g_l <= |d_l g sin psi| + |d_l g cos psi| (<= sqrt 2 of it): the bound from the coefficients themselves, no extra live value
+                drift_w = (fabsf(cd.x) + fabsf(cd.z)) + (fabsf(cd.y) + fabsf(cd.w));
             }
+            // Whether the harmonic loop forms its drift sums is decided per frame, wave-uniformly (round 6): they correct a
+            // sample by k sum_l d_l g_l sin(..), at most 52 sum_l |d_l| g_l float units = 364 sum_l |d_l| g_l int16 LSB.  Where that BOUND
+            // is below 1/8 LSB they are not formed -- two of the loop's eight packed instructions and one of its two LDS reads: 82 % of the
+            // frames of random-bit IMBE streams, 98 % of AMBE+2's, 61 % of the headline's (counted with the oracle on the bench workloads);
+            // frames driven far into the clip keep them, and so does a non-finite amplitude (the compare is false on NaN).  Measured,
+            // interleaved A/B (profiles/r06/ab_bank_variants.log): 65,536 x 16 IMBE -6.1 %, 8,192 x 128 AMBE+2 -5.5 %, 65,536 x 1 -2.1 / -1.6 %.
+            // (Also tried there and NOT kept: running the loop on one model's half alone, in plain VOP2 instructions, when the other model
+            // has no windowed-voiced harmonic -- 37 % of AMBE+2's random-bit frames: +0.9 ... +1.9 %.)
+            const bool need_drift = MBX_BANK_ALWAYS_DRIFT || !(wave_sum(drift_w) * (float)(kMidPrev * 7) < 0.125f);
             v2f Ec, Es;   // per-distance steps e^{i w0 k} (.x prev model, .y cur model); their error is amplified by l
             {
                 float c, d;
@@ -1417,37 +1433,41 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             wave_lds_sync();
             MBX_TS(5);   // smoothing, phases, bank coefficients
             __builtin_amdgcn_s_setprio(MBX_PRIO_BANK);
-            v2f Qc = Ec, Qs = Es;   // harmonic 1
             v2f even = {0.0f, 0.0f}, odd = {0.0f, 0.0f}, even_d = {0.0f, 0.0f}, odd_d = {0.0f, 0.0f};
             const int last = uni(maxl);
-#ifdef MBX_BANK_SKIP
-            const unsigned long long live = __ballot(wv_p || wv_c);   // harmonics with a coefficient in either model
-#pragma unroll 2
-            for (int l = 1; l <= last; ++l) {
-                if ((live >> l) & 1ULL) {
-                    const float4 a = S.coef_amp[l], b = S.coef_drift[l];   // wave-uniform address: LDS broadcasts
+            auto bank_loop = [&](auto drift_c) {
+                constexpr bool kDrift = decltype(drift_c)::value;
+                v2f Qc = Ec, Qs = Es;   // harmonic 1
+                auto harmonic = [&](int l) {
+                    const float4 a = S.coef_amp[l];   // wave-uniform address: LDS broadcasts
                     even = __builtin_elementwise_fma(Qc, v2f{a.x, a.y}, even);
                     odd = __builtin_elementwise_fma(Qs, v2f{a.z, a.w}, odd);
-                    even_d = __builtin_elementwise_fma(Qc, v2f{b.x, b.y}, even_d);
-                    odd_d = __builtin_elementwise_fma(Qs, v2f{b.z, b.w}, odd_d);
-                }
-                const v2f nq = __builtin_elementwise_fma(Qc, Ec, -(Qs * Es));
-                Qs = __builtin_elementwise_fma(Qs, Ec, Qc * Es);
-                Qc = nq;
-            }
-#else
+                    if constexpr (kDrift) {
+                        const float4 b = S.coef_drift[l];
+                        even_d = __builtin_elementwise_fma(Qc, v2f{b.x, b.y}, even_d);
+                        odd_d = __builtin_elementwise_fma(Qs, v2f{b.z, b.w}, odd_d);
+                    }
+                    const v2f nq = __builtin_elementwise_fma(Qc, Ec, -(Qs * Es));
+                    Qs = __builtin_elementwise_fma(Qs, Ec, Qc * Es);
+                    Qc = nq;
+                };
+                if constexpr (kDrift && !kDriftUnrolled) {   // the rarer form (2 ... 18 % of the frames of the long launches and of AMBE): not
+#pragma unroll 1                                             // unrolled, so that it never costs the common form a register (unrolled, two long
+                    for (int l = 1; l <= last; ++l) {        // instances spilled and three AMBE one-frame instances lost a wave per SIMD); the
+                        harmonic(l);                         // IMBE one-frame instances have the registers, and 39 % of the headline's frames
+                    }                                        // take this form
+                } else {
 #pragma unroll 2
-            for (int l = 1; l <= last; ++l) {
-                const float4 a = S.coef_amp[l], b = S.coef_drift[l];   // wave-uniform address: LDS broadcasts
-                even = __builtin_elementwise_fma(Qc, v2f{a.x, a.y}, even);
-                odd = __builtin_elementwise_fma(Qs, v2f{a.z, a.w}, odd);
-                even_d = __builtin_elementwise_fma(Qc, v2f{b.x, b.y}, even_d);
-                odd_d = __builtin_elementwise_fma(Qs, v2f{b.z, b.w}, odd_d);
-                const v2f nq = __builtin_elementwise_fma(Qc, Ec, -(Qs * Es));
-                Qs = __builtin_elementwise_fma(Qs, Ec, Qc * Es);
-                Qc = nq;
+                    for (int l = 1; l <= last; ++l) {
+                        harmonic(l);
+                    }
+                }
+            };
+            if (need_drift) {
+                bank_loop(std::true_type{});
+            } else {
+                bank_loop(std::false_type{});
             }
-#endif
             // sample centre + k: even - odd - k (even_d + odd_d); centre - k: even + odd + k (even_d - odd_d)
             __builtin_amdgcn_s_setprio(0);
             const v2f kf = splat((float)lane);
@@ -2389,7 +2409,7 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             MBX_STAMP(5, false);
             if constexpr (kOne) { MBX_TS(4); }   // snapshot stored, enhanced
             if (!MBX_ABL(tabs, 128)) {
-                fresh = synth_core<true, kPark, ScratchT, kOne>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
+                fresh = synth_core<true, kPark, ScratchT, kOne, kOne>(out, cur, enh, true, rm0, rng, scratch, tabs, lane, slot_prev);
             }
             MBX_STAMP(6, false);
             if constexpr (kOne) { MBX_TS(12); }   // synthesised (soft clip)
@@ -3383,7 +3403,14 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
     }
 
-    store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_cur, lane_in);
+    {
+        // The struct's per-lane address (slot + 4 lane, a VGPR pair) was formed for the loads at the top of the wave; kept for this store it
+        // was the T = 2, 3 instance's 12-byte spill.  Laundering the wave-uniform base through the scalar file makes
+        // the store form its address again from the SGPR pair: one v_lshl_add_u64 instead of a scratch round trip.
+        mbe_parms* slot_cur_again = slot_cur;
+        asm volatile("" : "+s"(slot_cur_again));
+        store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_cur_again, lane_in);
+    }
     store_rng(rng, &rngs[slot], lane_in);
     if (res1 && lane_in == 0) {
         res1[slot] = elided ? 1u : 0u;

@@ -446,7 +446,7 @@ def test_bench_contract_line_is_compact_and_complete():
         assert k in line, k
     assert line["value"] == float(f"{detail['value']:.7g}") and line["config"]["workload"].startswith("BASELINE configs[1]") and "model" not in line["config"]
     assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms"} <= set(line["roofline"])
-    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-5
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-12
     assert {"rel_rms", "worst_frame", "int16_within_1", "int16_max", "streams_checked", "results_exact"} <= set(line["parity"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
     assert all(set(v) == {"value", "ms_per_step", "kernel", "kernel_ms", "frac"} for v in line["other_configs"].values()) and len(line["other_configs"]) == 5
