@@ -119,11 +119,13 @@ def library_sha():
 
 
 def measured_traffic(workload, S, T):
-    """HBM bytes per launch of the dominant kernel from a committed PMC summary of this workload and size
+    """HBM bytes per STEP (= per mbx_process_batch call) of the dominant kernel from a committed PMC summary of this workload and size
     (profiles/rNN/<workload>_pmc.json, written by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate
-    rocprofv3 passes, each calibrated on state_copy_kernel's known byte count).  PMC counters cannot be read from
-    inside this process, so the summary must come from the SAME build: it records the sha256 of libmbx_hip.so it was
-    taken with, and a summary of another build gives (None, reason)."""
+    rocprofv3 passes, each calibrated on state_copy_kernel's known byte count).  A step that is ONE dispatch of the kernel: that
+    dispatch's bytes; a SLICED step (k dispatches of the same kernel on three queues): the sum over its k dispatches
+    (`traffic_bytes_per_launch` = mean per dispatch x `dispatches_per_step`; round 5 reported one slice's bytes against a whole step's
+    time).  PMC counters cannot be read from inside this process, so the summary must come from the SAME build: it records the sha256
+    of libmbx_hip.so it was taken with, and a summary of another build gives (None, reason)."""
     import glob
 
     sha = library_sha()
@@ -727,16 +729,19 @@ def roofline_of(name, S, T, m):
         r["note"] = "dominant kernel of this workload is the soft-decision FEC kernel: algorithmic bytes = n * (2 B per soft cell + 16 B record)"
     else:
         r["note"] = "algorithmic bytes = S*T*(wire frame + int16 PCM) + S*2*3*2604 state (SURVEY.md §8(d))"
+    r["dispatches_per_step"] = 1
     if m["kernel"].endswith("_slice"):
-        # a sliced launch (include/mbx.h): the step is 3 groups of streams x ceil(T / slice) slices, issued on three internal HIP streams
+        # a sliced launch (include/mbx.h): the step is 3 groups of streams x ceil(T / slice) slices, issued on three HIP queues
         # and overlapping on the device; kernel_ms brackets the whole step on the caller's stream (fork event to join events), a
-        # rocprofv3 AverageNs of `kernel` is ONE slice of one group
+        # rocprofv3 AverageNs of `kernel` is ONE slice of one group.  `traffic` and the issue model are per STEP: sums over the
+        # step's dispatches (tools/profile_round.sh, tools/sq_profile.py)
         from mbelib_neo_amd import _native
         tc = int(_native.lib().mbx_launch_slices(WORKLOADS[name][0], S, T))
-        r["kernel_launches_per_step"] = 3 * ((T + tc - 1) // tc) if tc > 0 else 1
+        r["dispatches_per_step"] = 3 * ((T + tc - 1) // tc) if tc > 0 else 1
         r["slice_frames"] = tc
-        r["note"] += ("; SLICED launch: kernel_ms is the whole step (concurrent slices on three internal streams), one rocprofv3 dispatch of "
-                      "this kernel is one slice of one group of streams")
+        r["note"] += ("; SLICED launch: kernel_ms is the whole step (concurrent slices on three queues), one rocprofv3 dispatch of "
+                      "this kernel is one slice of one group of streams; traffic / issue = sums over the step's dispatches")
+    r["traffic_over_algorithmic"] = (traffic / m["alg_bytes"]) if traffic else None
     return r
 
 

@@ -784,98 +784,23 @@ void unpack_bits_fast(const mbx_param_record& r, int nbits, char* out) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The pump: ONE thread per process that makes the HIP calls of the decoder threads' small flushes.
-// A host with a decoder thread per core flushes from sixteen or thirty-two threads at once; each flush is a few launches and an
-// event, and that many threads inside the HIP runtime (and that many streams on its four hardware queues) is what collapses:
-// measured without any CPU throttling (profiles/r05/fanin.json: nr_throttled = 0), queue mode gave 33 M frames/s from four threads
-// and 3-14 M, erratically, from sixteen.  A producer hands the pump the launch part of its flush as a closure and sleeps on a
-// condition variable; the pump issues it on the producer's own stream, records the producer's event, and polls the events of
-// everything in flight -- so exactly one thread talks to the runtime, nobody spins but the pump, and a producer is woken by a
-// futex instead of by the driver's interrupt path.  Only steady-state small flushes go this way (no new channels, rows < 8,192):
-// large flushes overlap their chunked copies with the host's scatter and stay with their thread.
-// MBE_NEO_PUMP=0 switches it off (A/B timing).  ref (threading contract): include/mbelib-neo/mbelib.h:28-30, README.md:299-302.
-// ------------------------------------------------------------------------------------------------------------------
-struct PumpJob {
-    std::function<void()>   issue;     // the HIP calls of one flush (launches on `stream`)
-    hipStream_t             stream = nullptr;
-    hipEvent_t              done_ev = nullptr;
-    std::mutex              mu;
-    std::condition_variable cv;
-    bool                    done = false;
+// MBE_NEO_TRACE_FLUSH=1 (development): where a thread's flushes spend their wall time, summed per thread and printed to stderr when the
+// thread leaves queue mode -- host preparation (grouping, frame gather), the trips into the HIP runtime,
+// the wait for the device, and the scatter into the callers' buffers.
+struct FlushTrace {
+    double prep = 0, issue = 0, wait = 0, scatter = 0;
+    long   flushes = 0, rows = 0, seen = 0;
 };
-class Pump {
-    std::mutex               mu_;
-    std::condition_variable  cv_;
-    std::deque<PumpJob*>     q_;
-    std::vector<PumpJob*>    pending_;   // touched by the pump thread only
-    bool                     started_ = false;
-
-    void run() {
-        HIP_OK(hipSetDevice(g_device));
-        for (;;) {
-            std::deque<PumpJob*> take;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                if (pending_.empty()) {
-                    cv_.wait(lk, [&] { return !q_.empty(); });
-                }
-                take.swap(q_);
-            }
-            for (PumpJob* j : take) {
-                j->issue();
-                HIP_OK(hipEventRecord(j->done_ev, j->stream));
-                pending_.push_back(j);
-            }
-            for (size_t i = 0; i < pending_.size();) {
-                PumpJob* j = pending_[i];
-                const hipError_t e = hipEventQuery(j->done_ev);
-                if (e == hipSuccess) {
-                    {
-                        // The job lives on the producer's stack: it is gone as soon as the producer has seen `done` under j->mu.  So the
-                        // wake-up is made while the mutex is still held (the producer cannot leave its wait before this block ends) and
-                        // nothing of *j is touched after the unlock.
-                        std::lock_guard<std::mutex> lk(j->mu);
-                        j->done = true;
-                        j->cv.notify_one();
-                    }
-                    pending_[i] = pending_.back();
-                    pending_.pop_back();
-                } else if (e == hipErrorNotReady) {
-                    ++i;
-                } else {
-                    HIP_OK(e);
-                }
-            }
-            if (!pending_.empty() && take.empty()) {
-                for (int k = 0; k < 64; ++k) {
-#if defined(__x86_64__)
-                    __builtin_ia32_pause();
-#endif
-                }
-            }
-        }
-    }
-
-public:
-    void submit_and_wait(PumpJob& j) {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            if (!started_) {
-                started_ = true;
-                std::thread([this] { run(); }).detach();   // lives as long as the process: idle, it sleeps on the condition variable
-            }
-            q_.push_back(&j);
-        }
-        cv_.notify_one();
-        std::unique_lock<std::mutex> lk(j.mu);
-        j.cv.wait(lk, [&] { return j.done; });
-    }
-};
-Pump& pump() {
-    static Pump* p = new Pump;   // (never destroyed: its thread may outlive static destruction)
-    return *p;
+static double trace_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+static const bool g_trace_flush = [] {
+    const char* e = getenv("MBE_NEO_TRACE_FLUSH");
+    return e && e[0] == '1';
+}();
+thread_local FlushTrace t_flush_trace;
 
 int flush_batch(Batch& b) {
     const size_t n = b.q.size();
@@ -883,6 +808,7 @@ int flush_batch(Batch& b) {
         return 0;
     }
     Slot& s = slot();
+    const double tr0 = g_trace_flush ? trace_now() : 0.0;
     // ---- state upload.  Resident mode: the channels first seen since the last flush, appended at slots [resident, total).
     //      Write-back mode: every channel that has frames this time, at slots [0, k); nothing stays afterwards. ----
     const size_t total = b.channels.size();
@@ -999,6 +925,10 @@ int flush_batch(Batch& b) {
     // rate from many threads is the number of such trips, not the bytes (tools/fanin_evidence.py: no CPU throttling at sixteen
     // threads, profiles/r05/fanin.json).  Large flushes keep the chunked copies: PCIe runs at its best with a DMA engine, and the
     // host scatters one chunk while the next one crosses.  MBE_NEO_ZERO_COPY_FLUSH=0 switches it off (A/B timing).
+    // (Round 5 also handed the launches of such flushes to ONE "pump" thread.  Timed over a region long enough to mean something --
+    // the same number of frames per thread at every thread count, tools/src/host_bench.c -- every thread launching for itself is as
+    // fast or faster: 4 / 8 / 16 threads 43 / 72 / 50 M frames/s against 36 / 63 / 37-59 M through the pump, reworked or not
+    // (profiles/r06/fanin_pump_ab.log).  The pump is gone, and with it the stack-lifetime hazard ADVICE r5 found in its wake-up.)
     static const bool zero_copy_on = [] {
         const char* e = getenv("MBE_NEO_ZERO_COPY_FLUSH");
         return !(e && e[0] == '0');
@@ -1014,12 +944,7 @@ int flush_batch(Batch& b) {
         s.up(b.d_frames.p, b.h_frames.p, bytes);
         s.up(b.d_index.p, b.h_index.p, idx0 * sizeof(int32_t));
     }
-    static const bool pump_on = [] {
-        const char* e = getenv("MBE_NEO_PUMP");
-        return !(e && e[0] == '0');
-    }();
-    const bool pumped = pump_on && zero_copy && upload.empty() && rows >= 256;
-    auto issue = [&]() {
+    const double tr1 = g_trace_flush ? trace_now() : 0.0;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Group& g = groups[gi];
         if (b.mode == MBE_BATCH_STATE_RESIDENT) {   // the pool owns the state between flushes: no prev_mp_enhanced traffic, lazy prev_mp
@@ -1034,10 +959,6 @@ int flush_batch(Batch& b) {
                  "mbx_process_batch_indexed");
         }
     }
-    };
-    if (!pumped) {
-        issue();
-    }
     // ---- outputs: the small arrays first, then the PCM in chunks -- the host hands chunk k to the callers' buffers while
     //      chunk k + 1 is still crossing PCIe (the scatter is as long as the copy: 5 MB per 16,384 frames each) ----
     constexpr int kMaxChunks = 4;
@@ -1049,13 +970,7 @@ int flush_batch(Batch& b) {
         }
     }
     const size_t per_chunk = (rows + kChunks - 1) / kChunks;
-    if (pumped) {   // the pump makes the launches, records the event and wakes this thread when it has fired
-        PumpJob job;
-        job.issue = issue;
-        job.stream = s.stream;
-        job.done_ev = s.chunk_done[0];
-        pump().submit_and_wait(job);
-    } else if (zero_copy) {   // everything is already where the host reads it once the kernels have retired: ONE event for all of it
+    if (zero_copy) {   // everything is already where the host reads it once the kernels have retired: ONE event for all of it
         HIP_OK(hipEventRecord(s.chunk_done[0], s.stream));
     } else {
         HIP_OK(hipMemcpyAsync(b.h_results.p, b.d_results.p, rows * sizeof(mbe_process_result), hipMemcpyDeviceToHost, s.stream));
@@ -1078,13 +993,13 @@ int flush_batch(Batch& b) {
     for (size_t e = 0; e < n; ++e) {
         by_row[row_of[e]] = (uint32_t)e;
     }
-    if (pumped) {
-        // (done: the pump saw the event fire)
-    } else if (rows < 256) {
+    const double tr2 = g_trace_flush ? trace_now() : 0.0;
+    if (rows < 256) {
         HIP_OK(hipStreamSynchronize(s.stream));   // a small flush: spin, the sleeping wait's wake-up would be most of it
     } else {
         HIP_OK(hipEventSynchronize(s.chunk_done[0]));
     }
+    const double tr3 = g_trace_flush ? trace_now() : 0.0;
     for (size_t e = 0; e < n; ++e) {   // results and parameter bits
         const QEntry& qe = b.q[e];
         const size_t r = row_of[e];
@@ -1106,6 +1021,18 @@ int flush_batch(Batch& b) {
             } else {
                 memcpy(qe.aout, b.h_pcmf.p + r * 160, 160 * sizeof(float));
             }
+        }
+    }
+    if (g_trace_flush) {
+        FlushTrace& t = t_flush_trace;
+        const double tr4 = trace_now();
+        if (++t.seen > 2) {   // (the first flushes of a thread allocate and upload: not the steady state)
+            t.prep += tr1 - tr0;
+            t.issue += tr2 - tr1;
+            t.wait += tr3 - tr2;
+            t.scatter += tr4 - tr3;
+            t.flushes += 1;
+            t.rows += (long)rows;
         }
     }
     s.npending = 0;
@@ -1655,6 +1582,13 @@ int mbe_batchEnd(void) {
             owners[c] = (int)c;
         }
         pool_download(b, slot(), 0, owners, false);
+    }
+    if (g_trace_flush && t_flush_trace.flushes) {
+        const FlushTrace& t = t_flush_trace;
+        fprintf(stderr, "[flush trace] %ld flushes, %.0f rows each: prep %.1f us, issue%s %.1f us, wait %.1f us, scatter %.1f us per flush\n", t.flushes,
+                (double)t.rows / (double)t.flushes, 1e6 * t.prep / t.flushes, "", 1e6 * t.issue / t.flushes, 1e6 * t.wait / t.flushes,
+                1e6 * t.scatter / t.flushes);
+        t_flush_trace = FlushTrace{};
     }
     b.channels.clear();
     b.index.clear();

@@ -58,9 +58,16 @@ out = {
 fk = [k for k in fetch if k.split("::")[-1] == kern] or [k for k in fetch if kern in k]
 if fk:
     k = fk[0]
+    # a step = ONE mbx_process_batch call = `n` dispatches of the dominant kernel (1, or the 3 x ceil(T / slice) slices of a sliced launch,
+    # every one of them a dispatch of the same kernel: the step's bytes are the mean per dispatch x n)
+    n = int(bench["roofline"].get("dispatches_per_step") or 1)
     rd, wr = fetch[k][0] * 1024.0 * f_fac, write[k][0] * 1024.0 * w_fac
-    out["dominant_kernel"] = {"kernel": k, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-                              "traffic_bytes_per_launch": rd + wr}
+    out["dominant_kernel"] = {"kernel": k, "dispatches_per_step": n,
+                              "read_bytes_per_dispatch": rd, "write_bytes_per_dispatch": wr,
+                              "read_bytes_per_launch": rd * n, "write_bytes_per_launch": wr * n,
+                              "traffic_bytes_per_launch": (rd + wr) * n,
+                              "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+                              "traffic_over_algorithmic": (rd + wr) * n / bench["roofline"]["algorithmic_bytes_per_launch"]}
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out.get("dominant_kernel")), json.dumps(out["calibration"]))
 PY
@@ -73,6 +80,7 @@ cp $OUT/${TAG}_sq.json $R/profiles/$ROUND/${WL}_sq.json
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --workload $WL > /dev/null 2>&1
 cp /tmp/p_stats/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 python3 $R/bench.py --steps 50 --warmup 5 --workload $WL > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+cp $R/bench_detail.json $OUT/${TAG}_bench_detail.json   # the full measurement behind the compact line
 cut -c1-60,150-230 $OUT/${TAG}_kernel_stats.csv
 python3 -c "
 import json; d=json.load(open('$OUT/${TAG}_bench.json')); print(d['value'], d['roofline'], d['cpu_baseline'])"

@@ -86,17 +86,27 @@ COST_VALU, COST_TRANS = 3.1, 6.06
 COST_VALU_CHEAP, CHEAP_SHARE = 2.07, 0.5
 
 
-def issue_model(c, kernel_ns, frames):
-    """derived figures of one dispatch from its counters (c), duration and the frames it decoded"""
+def issue_model(c, kernel_ns, frames, step_ns=None):
+    """derived figures of one STEP from its counters (c: sums over the step's dispatches of the dominant kernel), the time those dispatches
+    took under the profiler (kernel_ns: their durations added up -- the counter passes serialise dispatches) and the frames the step
+    decoded.  step_ns: for a SLICED step (several dispatches that overlap on three queues when not profiled) the un-profiled step time;
+    the utilisation figures are then taken over THAT envelope (cycles = step time x the clock the profiled dispatches ran at), not over
+    the serialised sum -- instruction counts do not depend on the overlap, the time they are issued in does."""
     g = c.get
     cycles = g("GRBM_GUI_ACTIVE", 0.0) / XCDS
     if not cycles or not kernel_ns:
         return None
+    clock = cycles / kernel_ns
+    serialised_cycles = cycles
+    if step_ns:
+        cycles = step_ns * clock
     valu, trans = g("SQ_INSTS_VALU", 0.0), g("SQ_INSTS_VALU_TRANS_F32", 0.0)
     wave_q = g("SQ_WAVE_CYCLES", 0.0)
     m = {
-        "clock_ghz": cycles / kernel_ns,
+        "clock_ghz": clock,
         "kernel_cycles": cycles,
+        **({"envelope": "un-profiled step time x profiled clock (sliced step: dispatches overlap on three queues)",
+            "serialised_cycles_under_pmc": serialised_cycles} if step_ns else {}),
         "waves_per_simd_resident": wave_q * 4 / (SIMDS * cycles),
         "per_frame": {k: g(n, 0.0) / frames for k, n in (("valu", "SQ_INSTS_VALU"), ("valu_trans", "SQ_INSTS_VALU_TRANS_F32"),
                                                            ("valu_f64", None), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"),
@@ -135,7 +145,7 @@ def main():
         out["workload"] = workload
         out["command"] = " ".join(cmd)
         merged, durs = {}, []
-        target = None
+        target, per_step, step_ns = None, 1, None
         for i, p in enumerate(passes):
             if not p:
                 continue
@@ -144,28 +154,41 @@ def main():
                 try:
                     line = json.loads(r.stdout.strip().splitlines()[-1])
                     target = line["roofline"]["kernel"]
+                    per_step = int(line["roofline"].get("dispatches_per_step") or 1)
+                    step_ns = line["roofline"]["kernel_ms"] * 1e6 if per_step > 1 else None   # (under the profiler: only used when the line below cannot be had)
                     out["streams_per_gpu"] = line["config"]["streams_per_gpu"]
                     out["frames_per_stream_per_step"] = line["config"]["frames_per_stream_per_step"]
                 except Exception:   # noqa: BLE001
                     out.setdefault("errors", []).append({"pass": i, "stdout": r.stdout[-500:], "stderr": r.stderr[-1500:]})
                     continue
-            ids = sorted(d for d, k in kern.items() if short(k) == target)[-steps:]   # the timed dispatches
+            ids = sorted(d for d, k in kern.items() if short(k) == target)[-steps * per_step:]   # the timed dispatches: `steps` steps of `per_step` each
             if not ids:
                 out.setdefault("errors", []).append({"pass": i, "note": "no dispatch of " + str(target), "stderr": r.stderr[-800:]})
                 continue
+            nsteps = len(ids) / per_step
             for c in p + ["GRBM_GUI_ACTIVE"]:
                 xs = [vals[d].get(c) for d in ids if c in vals[d]]
                 if xs:
-                    merged.setdefault(c, []).append(sum(xs) / len(xs))
-            durs += [dur[d] for d in ids if d in dur]
+                    merged.setdefault(c, []).append(sum(xs) / nsteps)   # per STEP: summed over the step's dispatches
+            if all(d in dur for d in ids):
+                durs.append(sum(dur[d] for d in ids) / nsteps)
             out["grid_threads"] = vals[ids[-1]].get("_grid")
         out["kernel"] = target
-        out["counters_per_dispatch"] = {k: sum(v) / len(v) for k, v in merged.items()}
-        out["kernel_ns_under_pmc"] = (sum(durs) / len(durs)) if durs else None
+        out["dispatches_per_step"] = per_step
+        out["counters_per_step"] = {k: sum(v) / len(v) for k, v in merged.items()}   # (= per dispatch where a step is one dispatch)
+        out["kernel_ns_under_pmc"] = (sum(durs) / len(durs)) if durs else None       # the step's dispatches, durations added up
+        if per_step > 1:   # the envelope of a sliced step must come from an UN-profiled run: the counter passes serialise the dispatches
+            r = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--min-time-ms", "300", "--no-cpu-baseline",
+                                "--no-extras", "--workload", workload], capture_output=True, text=True, cwd="/tmp")
+            try:
+                step_ns = json.loads(r.stdout.strip().splitlines()[-1])["roofline"]["kernel_ms"] * 1e6
+                out["step_ns_unprofiled"] = step_ns
+            except Exception:   # noqa: BLE001
+                out.setdefault("errors", []).append({"note": "no un-profiled step time", "stderr": r.stderr[-800:]})
         out["libmbx_hip_sha256_16"] = hashlib.sha256(open(os.path.join(ROOT, "mbelib-neo_amd", "libmbx_hip.so"), "rb").read()).hexdigest()[:16]
         if "streams_per_gpu" in out:
-            out["issue_model"] = issue_model(out["counters_per_dispatch"], out["kernel_ns_under_pmc"],
-                                             out["streams_per_gpu"] * out["frames_per_stream_per_step"])
+            out["issue_model"] = issue_model(out["counters_per_step"], out["kernel_ns_under_pmc"],
+                                             out["streams_per_gpu"] * out["frames_per_stream_per_step"], step_ns if per_step > 1 else None)
     else:
         path = sys.argv[2]
         cmd = [os.path.join(ROOT, "tools", "bin", "valu_issue")]

@@ -217,8 +217,9 @@ int main(int argc, char** argv) {
 
     /* ---- queue mode: C channels, one frame per channel and tick ---- */
     const int C = S < 16384 ? S : 16384, ticks = 12;
-    double queue_rate[2], queue_call_ns[2], queue_flush_ms[2];
-    {
+    double queue_rate[2] = {0, 0}, queue_call_ns[2] = {0, 0}, queue_flush_ms[2] = {0, 0};
+    const int threads_only = getenv("HB_THREADS_ONLY") != NULL;   /* development: only the N-thread sections (with HB_THREADS) */
+    if (!threads_only) {
         mbe_parms* st = (mbe_parms*)malloc((size_t)C * 3 * sizeof(mbe_parms));
         short* pcm = (short*)malloc((size_t)C * 160 * sizeof(short));
         char(*cells)[8][23] = (char(*)[8][23])malloc((size_t)C * 184);
@@ -263,8 +264,8 @@ int main(int argc, char** argv) {
     }
 
     /* ---- sessions: S streams x T = 1 per submit ---- */
-    double sess_rate[2], sess_rate_res = 0;
-    {
+    double sess_rate[2] = {0, 0}, sess_rate_res = 0;
+    if (!threads_only) {
         const int K = 40;
         for (int pinned = 1; pinned >= 0; --pinned) {
             mbx_session* h = NULL;
@@ -323,8 +324,10 @@ int main(int argc, char** argv) {
     double tq[3], ts[3];
     for (int i = 0; i < 3; ++i) {
         const int per_q = (16384 / tn[i]) < S ? (16384 / tn[i]) : S, per_s = (S / tn[i]) > 0 ? (S / tn[i]) : 1;
-        tq[i] = run_threads(0, tn[i], per_q, 12, frames, S, device);
-        ts[i] = run_threads(1, tn[i], per_s, 40, frames, S, device);
+        /* the same number of frames per THREAD whatever the thread count (12 / 40 ticks of the whole set from one thread): with a fixed
+         * tick count sixteen threads were timed over 4 ms, and one late wake-up at the barrier decided the figure */
+        tq[i] = run_threads(0, tn[i], per_q, 12 * tn[i], frames, S, device);
+        ts[i] = run_threads(1, tn[i], per_s, 40 * tn[i], frames, S, device);
     }
     int ndev = 1;
     (void)hipGetDeviceCount(&ndev);
