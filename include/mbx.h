@@ -59,6 +59,13 @@ int mbx_device_ready(int device);
  * Cache; 0 = always forwards.  Results do not depend on it.  Returns the previous setting.  (No reference counterpart:
  * the reference decodes one stream per call.) */
 int mbx_set_stream_order(int alternate);
+/* Tone synthesis on (the default) or off, process-wide and for every initialised device: the run-time form of the reference's
+ * NOTONES build option (-DDISABLE_AMBE_TONES: ref CMakeLists.txt:41,330-337), the one compile-time option that changes what this
+ * path computes.  Off: AMBE+2 / D-STAR tone frames (mbe_synthesizeTonef, mbe_synthesizeTonefdstar and the tone frames inside
+ * mbe_processAmbe*) synthesise 160 samples of silence and leave swn / tonePhase alone (ref src/core/mbelib.c:747-751,815-819);
+ * flags, results and every other frame are unchanged.  MBX_DISABLE_TONES=1 in the environment starts with it off.  Takes effect
+ * for launches issued after the call.  Returns the previous setting (1 = on). */
+int mbx_set_tone_synthesis(int enabled);
 /* FNV-1a-32 of the table blob resident on the current device (for the per-rank checksum after the broadcast). */
 uint32_t mbx_table_checksum(void);
 /* message of the last failure on the calling thread */

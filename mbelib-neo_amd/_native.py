@@ -31,6 +31,7 @@ _SIGNATURES = {
     "mbx_workspace_bytes": (_sz, [_sz]),
     "mbx_device_ready": (C.c_int, [C.c_int]),
     "mbx_set_stream_order": (C.c_int, [C.c_int]),
+    "mbx_set_tone_synthesis": (C.c_int, [C.c_int]),
     "mbx_table_checksum": (C.c_uint32, []),
     "mbx_last_error": (C.c_char_p, []),
     "mbx_comm_unique_id": (C.c_int, [_vp]),

@@ -99,7 +99,7 @@ __global__ void enhance_kernel(int, mbe_parms*);
 __global__ void smoothing_kernel(int, mbe_parms*, const mbe_parms*);
 __global__ void comfort_noise_kernel(int, mbx_stream_rng*, float*, int16_t*);
 __global__ void state_copy_kernel(int, mbe_parms*);
-__global__ void tone_kernel(int, const mbx_param_record*, const int32_t*, mbe_parms*, float*, int16_t*);
+__global__ void tone_kernel(int, const mbx_param_record*, const int32_t*, mbe_parms*, float*, int16_t*, int);
 __global__ void ecc_words_kernel(int, const uint32_t*, size_t, uint32_t*, int32_t*, DeviceTables);
 __global__ void pack_cells_kernel(int, const char*, size_t, uint8_t*, int32_t*);
 __global__ void fec_stage_kernel(int, int, const uint8_t*, size_t, uint8_t*, mbx_param_record*, DeviceTables);
@@ -218,7 +218,7 @@ void free_context(Context& c) {   // caller holds g_init_mu and c.mu
     }
     c.slots.clear();
     c.d_blob = c.d_derived = nullptr;
-    c.tabs = mbx::DeviceTables{nullptr, nullptr, 0, 0, 0, nullptr};
+    c.tabs = mbx::DeviceTables{};   // (every field zero: mbx_init sets what it needs)
     c.reserve_frames = 0;
     c.checksum = 0;
     c.device = -1;
@@ -250,6 +250,14 @@ std::atomic<int>& stream_order_flag() {
     return flag;
 }
 bool reverse_enabled() { return stream_order_flag().load(std::memory_order_relaxed) != 0; }
+// 1: AMBE tone frames are synthesised (the reference's default build); MBX_DISABLE_TONES=1 in the environment starts with 0
+std::atomic<int>& tones_flag() {
+    static std::atomic<int> flag{[] {
+        const char* e = getenv("MBX_DISABLE_TONES");
+        return (e && e[0] == '1') ? 0 : 1;
+    }()};
+    return flag;
+}
 
 uint32_t fnv1a(const uint8_t* p, size_t n) {
     uint32_t h = 2166136261u;
@@ -563,6 +571,7 @@ int mbx_init(int device, const void* table_blob, size_t table_bytes) {
     HIP_TRY(hipMemcpy(ctx.d_blob, table_blob, sizeof(mbx_tables), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx.d_derived, &d, sizeof(d), hipMemcpyHostToDevice));
     ctx.tabs.t = static_cast<const mbx_tables*>(ctx.d_blob);
+    ctx.tabs.tones_off = tones_flag().load(std::memory_order_relaxed) ? 0 : 1;
     ctx.tabs.d = static_cast<const mbx::DerivedTables*>(ctx.d_derived);
     ctx.device = device;
     int cus = 0;
@@ -594,6 +603,18 @@ void mbx_shutdown(void) {
 }
 
 int mbx_set_stream_order(int alternate) { return stream_order_flag().exchange(alternate ? 1 : 0, std::memory_order_relaxed); }
+
+// Tone synthesis on / off, process-wide: the run-time form of the reference's one compile-time option that changes what this
+// path computes (NOTONES = -DDISABLE_AMBE_TONES, ref CMakeLists.txt:41,330-337; src/core/mbelib.c:747-751,815-819).  The flag
+// lives in every context's DeviceTables (a kernel argument): launches issued after the call see the new value.
+int mbx_set_tone_synthesis(int enabled) {
+    const int before = tones_flag().exchange(enabled ? 1 : 0, std::memory_order_relaxed);
+    for (int dev = 0; dev < kMaxDevices; ++dev) {
+        std::lock_guard<std::mutex> lock(g_ctx[dev].mu);
+        g_ctx[dev].tabs.tones_off = enabled ? 0 : 1;
+    }
+    return before;
+}
 
 int mbx_device_ready(int device) {
     return device >= 0 && device < kMaxDevices && g_ctx[device].ready.load(std::memory_order_acquire) ? 1 : 0;
@@ -1781,7 +1802,7 @@ int mbx_synthesize_tone(int S, const mbx_param_record* d_records, const int32_t*
         return 0;
     }
     hipLaunchKernelGGL(mbx::tone_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, S, d_records, d_dstar_ids, d_cur,
-                       d_pcmf, d_pcm16);
+                       d_pcmf, d_pcm16, c->tabs.tones_off);
     return check_launch("tone_kernel");
 }
 

@@ -71,6 +71,8 @@ struct DeviceTables {
     int                  reverse;  // stream kernels: workgroup b takes stream S - 1 - b (see launch_stream, mbx_api.hip)
     int                  front_skip;   // read only by the -DMBX_TESTING build (mbx_testing_set_front_skip): 2^k > 0 -- the front blocks of chunks 0, 2^k,
                                        // 2 x 2^k, ... of the one-launch kernels do nothing, so that their stream blocks take the fall-back path; always 0 in the product
+    int                  tones_off;    // != 0: AMBE tone frames synthesise silence and leave the tone phases alone -- the reference's NOTONES build
+                                       // (mbx_set_tone_synthesis; ref CMakeLists.txt:330-337, src/core/mbelib.c:747-751,815-819)
     const int32_t*       stream_map;   // stream kernels: batch row s works on state / rng slot stream_map[s] (nullptr: slot s)
     // Resident state (sessions, queue mode; nullptr: the ABI triplet is kept whole, what every mbx_process_* entry point does).
     // resident[slot] != 0 says "prev_mp_enhanced of this stream is elided: it equals cur_mp field for field" -- true after every

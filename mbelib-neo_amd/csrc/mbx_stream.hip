@@ -2833,7 +2833,12 @@ __device__ __forceinline__ float tone_sample(uint32_t phase) {
 }
 
 // mbe_synthesizeTonef with a tone id already known to be valid
-__device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int lane) {
+// tones_off (DeviceTables): the reference built with NOTONES -- silence, tone phases untouched (ref src/core/mbelib.c:747-751)
+__device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int lane, int tones_off) {
+    if (tones_off) {
+        out[0] = out[1] = out[2] = 0.0f;
+        return;
+    }
     const int u0 = (int)(w[0] >> 20);
     const int u1 = (int)((w[0] >> 8) & 0xfffu);
     const unsigned long long two = ((unsigned long long)w[0] << 32) | w[1];
@@ -2874,7 +2879,11 @@ __device__ void tone_frame(float out[3], const uint32_t w[3], Parms& cur, int la
 #endif
 // D-STAR single tone (ref src/core/mbelib.c:813-856 + :708-736): 156.25 Hz (index 5), 187.5 Hz (6) or 31.25 Hz x index
 // (7..122) at the fixed amplitude 103
-__device__ void tone_dstar_frame(float out[3], int id1, Parms& cur, int lane) {
+__device__ void tone_dstar_frame(float out[3], int id1, Parms& cur, int lane, int tones_off) {
+    if (tones_off) {   // (ref src/core/mbelib.c:815-819)
+        out[0] = out[1] = out[2] = 0.0f;
+        return;
+    }
     out[0] = out[1] = out[2] = 0.0f;
     float f1 = 0.0f;
     if (id1 == 5) {
@@ -3366,9 +3375,9 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
                 load_parms<kOne>(cur, slot_cur, lane);
             }
         } else if (action == kTone) {
-            tone_frame(out, tw, cur, lane);
+            tone_frame(out, tw, cur, lane, tabs.tones_off);
         } else if (action == kToneDstar) {
-            tone_dstar_frame(out, bad, cur, lane);
+            tone_dstar_frame(out, bad, cur, lane, tabs.tones_off);
             store_parms<kOne && MBX_AMBE_GATHER_STORES>(cur, slot_prev, lane);   // mbe_moveMbeParms(cur_mp, prev_mp)
             prev_partial = false;
         } else {
@@ -3845,7 +3854,7 @@ synth_speech_kernel(int S, mbe_parms* __restrict__ curs, mbe_parms* __restrict__
 // / mbe_synthesizeTonefdstar (ids[s] = D-STAR tone index, ref :813-856), batched: one wavefront per struct
 __global__ void __launch_bounds__(64)
 tone_kernel(int S, const mbx_param_record* __restrict__ records, const int32_t* __restrict__ ids, mbe_parms* __restrict__ curs,
-            float* __restrict__ pcmf, int16_t* __restrict__ pcm16) {
+            float* __restrict__ pcmf, int16_t* __restrict__ pcm16, int tones_off) {
     const int s = blockIdx.x;
     if (s >= S) {
         return;
@@ -3855,11 +3864,11 @@ tone_kernel(int S, const mbx_param_record* __restrict__ records, const int32_t* 
     load_parms(cur, &curs[s], lane);
     float out[3];
     if (ids) {
-        tone_dstar_frame(out, ids[s], cur, lane);
+        tone_dstar_frame(out, ids[s], cur, lane, tones_off);
     } else {
         const uint4 rec = *reinterpret_cast<const uint4*>(&records[s]);
         const uint32_t w[3] = {rec.x, rec.y, rec.z};
-        tone_frame(out, w, cur, lane);
+        tone_frame(out, w, cur, lane, tones_off);
     }
     store_pcm(out, (size_t)s, pcm16, pcmf, lane);
     store_parms(cur, &curs[s], lane);

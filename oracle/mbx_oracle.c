@@ -2489,13 +2489,21 @@ tone_sample(uint32_t phase) {
     return sinf(angle);
 }
 
+/* the reference's NOTONES build option (-DDISABLE_AMBE_TONES, ref CMakeLists.txt:330-337) as a switch of the restatement:
+ * off = tone frames are 160 zeros and the tone phases stay (ref src/core/mbelib.c:747-751, 815-819) */
+static int g_tones_on = 1;
+void
+mbxo_set_tones(int on) {
+    g_tones_on = on ? 1 : 0;
+}
+
 void
 mbxo_tonef(float* out, const char* d, mbe_parms* cur) {
     if (!out) {
         return;
     }
     memset(out, 0, 160 * sizeof(float));
-    if (!cur || validate_bits(d, 49u) < 0) {
+    if (!g_tones_on || !cur || validate_bits(d, 49u) < 0) {
         return;
     }
     int u0 = 0, u1 = 0, u3 = 0;
@@ -2544,7 +2552,7 @@ mbxo_tone_dstarf(float* out, mbe_parms* cur, int id1) {
         return;
     }
     memset(out, 0, 160 * sizeof(float));
-    if (!cur) {
+    if (!g_tones_on || !cur) {
         return;
     }
     float f1 = 0.0f;

@@ -30,6 +30,7 @@ extern "C" {
 
 /* tables -------------------------------------------------------------------------- */
 void mbxo_set_preclip_peaks(float* out); /* diagnostic: when non-NULL, mbxo_process_batch[_soft] writes per frame the largest |sample| before the soft clip (0 for frames that do not run the synthesiser); calling thread only */
+void mbxo_set_tones(int on); /* 0: the reference's NOTONES build (tone frames = silence, phases untouched); 1 (default): tones synthesised */
 void mbxo_set_fft_float(int on); /* 1: the unvoiced FFT as FFTPACK's float real transform (= the reference's PFFFT, bit for bit); 0 (default): double precision */
 int mbxo_load_tables(const void* blob, size_t n); /* 0, or -1 on bad magic/size/checksum */
 

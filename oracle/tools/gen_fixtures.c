@@ -39,6 +39,7 @@ extern int mbe_processImbe7200x4400Framef(float*, mbe_process_result*, const cha
 extern int mbe_processAmbe3600x2450Framef(float*, mbe_process_result*, const char[4][24], char[49], mbe_parms*,
                                           mbe_parms*, mbe_parms*);
 extern int mbe_processImbe4400Dataf(float*, mbe_process_result*, const char[88], mbe_parms*, mbe_parms*, mbe_parms*);
+extern int mbe_processAmbe2450Dataf(float*, mbe_process_result*, const char[49], mbe_parms*, mbe_parms*, mbe_parms*); /* :415 */
 /* tones: include/mbelib-neo/mbelib.h:630, 638 */
 extern void mbe_synthesizeTonef(float*, const char*, mbe_parms*);
 extern void mbe_synthesizeTonefdstar(float*, const char*, mbe_parms*, int);
@@ -999,10 +1000,121 @@ gen_tones(const char* dir) {
     printf("tone_kat.bin written\n");
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* notones_kat.bin: written by THIS program linked against the reference built with its NOTONES option
+ * (-DDISABLE_AMBE_TONES, ref CMakeLists.txt:330-337; `make -C oracle notones`): tone frames synthesise silence and leave the
+ * tone phases alone (ref src/core/mbelib.c:747-751, 815-819), everything else is the ordinary build.
+ *   part A  the layout of tone_kat.bin (gen_tones): every output 160 zeros, swn / tonePhase unchanged
+ *   part B  u32 S, u32 T, per stream T x { char d[49], i32 total_in, i32 ret, result(20), float pcm[160] }, then cur, prev,
+ *           prev_enh: mbe_processAmbe2450Dataf (AMBE+2) on scripted parameter bits -- voice, tone frames (valid and invalid
+ *           indices), with a given total error count; seeds 7000 + s
+ *   part C  the same through mbe_processAmbe2400Dataf (D-STAR tone indices), seeds 8000 + s                                   */
+static void
+scripted_tone_streams(FILE* f, int dstar, uint32_t S, uint32_t T, uint32_t seed0) {
+    static const int tone_list[12] = {5, 6, 7, 20, 64, 122, 123, 4, 130, 163, 164, 255};
+    static const int totals[8] = {0, 0, 0, 0, 1, 2, 4, 5};
+    static const int i_tone_hi[3] = {6, 7, 8};
+    static const int def_of[8] = {1, 2, 3, 4, 0, 7, 6, 5};
+    W(f, &S, 4);
+    W(f, &T, 4);
+    long tones = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        mbe_parms cur, prev, enh;
+        mbe_initMbeParms(&cur, &prev, &enh);
+        mbe_setThreadRngSeed(seed0 + s);
+        for (uint32_t t = 0; t < T; ++t) {
+            char d[49];
+            float out[160];
+            for (int c = 0; c < 49; ++c) {
+                d[c] = (char)(splitmix64() & 1u);
+            }
+            if (splitmix64() % 10u < 6) { /* voice: the tone signature (bits 0..5 all set) must not appear */
+                if (d[0] && d[1] && d[2] && d[3] && d[4] && d[5]) {
+                    d[(int)(splitmix64() % 6u)] = 0;
+                }
+            } else { /* tone class with a chosen index */
+                for (int c = 0; c < 6; ++c) {
+                    d[c] = 1;
+                }
+                const int idx = tone_list[splitmix64() % 12u];
+                if (dstar) { /* as gen_ambe2400 scripts them */
+                    put_bits_msb(d, i_tone_hi, 3, def_of[(idx >> 5) & 7]);
+                    d[9] = (char)((idx >> 4) & 1);
+                    d[42] = (char)((idx >> 3) & 1);
+                    d[43] = (char)((idx >> 2) & 1);
+                    d[10] = (char)((idx >> 1) & 1);
+                    d[11] = (char)(idx & 1);
+                } else { /* AMBE+2: ID1 = bits 11..4 of u1 = d[12..19] (gen_tones) */
+                    for (int b = 0; b < 8; ++b) {
+                        d[12 + b] = (char)((idx >> (7 - b)) & 1);
+                    }
+                    if (splitmix64() % 4u) { /* verified tone (ref src/ambe/ambe3600x2450.c:475-490: low four bits of u3 zero); a
+                                                quarter stay unverified: tone fundamental -> erasure (:536-541) */
+                        d[45] = d[46] = d[47] = d[48] = 0;
+                    }
+                }
+            }
+            mbe_process_result r;
+            mbe_initProcessResult(&r);
+            int32_t total_in = totals[splitmix64() % 8u];
+            r.total_errors = total_in;
+            int32_t ret = dstar ? mbe_processAmbe2400Dataf(out, &r, d, &cur, &prev, &enh) : mbe_processAmbe2450Dataf(out, &r, d, &cur, &prev, &enh);
+            tones += (r.flags & MBE_PROCESS_FLAG_TONE) != 0;
+            W(f, d, 49);
+            W(f, &total_in, 4);
+            W(f, &ret, 4);
+            W(f, &r, sizeof(r));
+            W(f, out, sizeof(out));
+        }
+        W(f, &cur, sizeof(cur));
+        W(f, &prev, sizeof(prev));
+        W(f, &enh, sizeof(enh));
+    }
+    printf("  scripted %s streams: %u x %u frames, %ld flagged TONE\n", dstar ? "AMBE 3600x2400" : "AMBE+2 3600x2450", S, T, tones);
+}
+
+static void
+gen_notones(const char* dir) {
+    /* refuse to write the fixture from an ordinary build: a tone frame must come out silent */
+    {
+        mbe_parms cur, prev, enh;
+        float out[160];
+        mbe_initMbeParms(&cur, &prev, &enh);
+        mbe_synthesizeTonefdstar(out, NULL, &cur, 50);
+        for (int n = 0; n < 160; ++n) {
+            if (out[n] != 0.0f) {
+                fprintf(stderr, "gen_fixtures notones: this reference build synthesises tones (link the -DDISABLE_AMBE_TONES build)\n");
+                exit(3);
+            }
+        }
+    }
+    gen_tones(dir); /* part A, into tone_kat.bin of `dir` ... */
+    char a[1024], b[1024];
+    snprintf(a, sizeof(a), "%s/tone_kat.bin", dir);
+    snprintf(b, sizeof(b), "%s/notones_kat.bin", dir);
+    FILE* in = fopen(a, "rb");
+    FILE* f = fopen(b, "wb");
+    if (!in || !f) {
+        perror("notones_kat.bin");
+        exit(2);
+    }
+    int ch;
+    while ((ch = fgetc(in)) != EOF) { /* ... moved to the head of notones_kat.bin */
+        fputc(ch, f);
+    }
+    fclose(in);
+    remove(a);
+    sm_state = 0x9E3779B97F4A7C15ULL ^ 0x707E5ULL;
+    scripted_tone_streams(f, 0, 12, 24, 7000u);
+    scripted_tone_streams(f, 1, 12, 24, 8000u);
+    fclose(f);
+    printf("notones_kat.bin written\n");
+}
+
 int
 main(int argc, char** argv) {
     if (argc != 2 && argc != 3) {
-        fprintf(stderr, "usage: %s outdir [soft|imbe7100|ambe2400|tones]\n", argv[0]);
+        fprintf(stderr, "usage: %s outdir [soft|imbe7100|ambe2400|tones|notones]\n", argv[0]);
         return 2;
     }
     const char* dir = argv[1];
@@ -1020,6 +1132,10 @@ main(int argc, char** argv) {
     }
     if (argc == 3 && strcmp(argv[2], "tones") == 0) {
         gen_tones(dir);
+        return 0;
+    }
+    if (argc == 3 && strcmp(argv[2], "notones") == 0) { /* only with the NOTONES build of the reference (oracle/Makefile `notones`) */
+        gen_notones(dir);
         return 0;
     }
     gen_ecc(dir);

@@ -200,3 +200,27 @@ def tone_kat():
     c = b[off + 4 : off + 4 + n2 * d2.itemsize].view(d2)
     assert off + 4 + n2 * d2.itemsize == b.size
     return a, c
+
+
+def notones_kat():
+    """notones_kat.bin (layout: oracle/tools/gen_fixtures.c gen_notones; written by the reference built with its NOTONES option):
+    (AMBE+2 tone frames, D-STAR tone frames) as tone_kat(), then scripted data-level streams (AMBE+2 3600x2450, AMBE 3600x2400)"""
+    b = _read("notones_kat.bin")
+    d1 = np.dtype([("bits", "i1", (49,)), ("pcmf", "<f4", (160,)), ("swn", "<i4"), ("tonePhase", "<u4")])
+    d2 = np.dtype([("id", "<i4"), ("pcmf", "<f4", (160,)), ("swn", "<i4"), ("tonePhase", "<u4")])
+    n1 = int(b[:4].view("<u4")[0])
+    a = b[4 : 4 + n1 * d1.itemsize].view(d1)
+    off = 4 + n1 * d1.itemsize
+    n2 = int(b[off : off + 4].view("<u4")[0])
+    c = b[off + 4 : off + 4 + n2 * d2.itemsize].view(d2)
+    off += 4 + n2 * d2.itemsize
+    streams = []
+    for _ in range(2):
+        S, T = (int(x) for x in b[off : off + 8].view("<u4"))
+        off += 8
+        dframe = np.dtype([("bits", "i1", (49,)), ("total_in", "<i4"), ("ret", "<i4"), ("result", RESULT_DTYPE), ("pcmf", "<f4", (160,))])
+        per_stream = np.dtype([("frames", dframe, (T,)), ("final", PARMS_DTYPE, (3,))])
+        streams.append(b[off : off + S * per_stream.itemsize].view(per_stream))
+        off += S * per_stream.itemsize
+    assert off == b.size
+    return a, c, streams[0], streams[1]

@@ -69,6 +69,8 @@ class Oracle:
         h.mbxo_rng_default.argtypes = [_vp]
         h.mbxo_rng_seed.restype = None
         h.mbxo_rng_seed.argtypes = [_vp, C.c_uint32]
+        h.mbxo_set_tones.restype = None
+        h.mbxo_set_tones.argtypes = [C.c_int]
         h.mbxo_set_preclip_peaks.restype = None
         h.mbxo_set_preclip_peaks.argtypes = [C.c_void_p]
         h.mbxo_set_fft_float.restype = None
@@ -168,13 +170,14 @@ class Oracle:
         ret = self.h.mbxo_decode_imbe7100x4400_frame(cells.ctypes.data, d.ctypes.data, res.ctypes.data)
         return d, ret, res[0]
 
-    def process_ambe2400_data(self, bits49, total_errors, state3, rng1):
-        """one mbe_processAmbe2400Dataf call: state3 = (cur, prev, enh) array of 3, updated in place"""
+    def process_ambe2400_data(self, bits49, total_errors, state3, rng1, plus2=False):
+        """one mbe_processAmbe2400Dataf (plus2: mbe_processAmbe2450Dataf) call: state3 = (cur, prev, enh) array of 3, updated in place"""
         d = np.ascontiguousarray(bits49, dtype=np.int8)
         res = np.zeros(1, dtype=RESULT_DTYPE)
         res[0]["total_errors"] = int(total_errors)
         pcm = np.zeros(160, dtype=np.float32)
-        ret = self.h.mbxo_process_ambe2400_dataf(
+        fn = self.h.mbxo_process_ambe2450_dataf if plus2 else self.h.mbxo_process_ambe2400_dataf
+        ret = fn(
             pcm.ctypes.data, res.ctypes.data, d.ctypes.data, state3[0:1].ctypes.data, state3[1:2].ctypes.data,
             state3[2:3].ctypes.data, rng1.ctypes.data,
         )
@@ -253,6 +256,10 @@ class Oracle:
         out = np.zeros(pcmf.shape, dtype=np.int16)
         self.h.mbxo_floattoshort_batch(pcmf.ctypes.data, out.ctypes.data, pcmf.shape[0])
         return out
+
+    def set_tones(self, on):
+        """0: the restatement of the reference's NOTONES build (tone frames = silence); 1 (default): tones synthesised"""
+        self.h.mbxo_set_tones(1 if on else 0)
 
     def set_fft_float(self, on):
         """1: the unvoiced FFT as FFTPACK's float real transform (what the reference's PFFFT runs: float PCM identical to the

@@ -983,6 +983,57 @@ def test_ambe2400_scripted_data_streams_match_reference(mbx):
     assert np.any(flags & 0x10) and np.any(flags & 0x40)
 
 
+def test_notones_switch_matches_the_reference_built_with_notones(mbx):
+    """mbx_set_tone_synthesis(0) = the reference's NOTONES build option at run time (ref CMakeLists.txt:330-337, src/core/mbelib.c:747-751,
+    815-819).  Against tests/golden/notones_kat.bin, written by the reference built with -DDISABLE_AMBE_TONES: the tone kernel
+    (mbx_synthesize_tone: silence, phases untouched) and scripted data-level streams of both AMBE codecs through mbx_process_records
+    -- results, PCM and final state -- and after mbx_set_tone_synthesis(1) the ordinary fixture again.  Checker: reference-made fixtures."""
+    import torch
+
+    from mbelib_neo_amd import _native, decoder
+    from mbelib_neo_amd.layout import PARMS_DTYPE, init_state, rng_seeded
+
+    L = mbx.lib()
+    ambe, dstar, plus2, dst = golden_io.notones_kat()
+    strm = torch.cuda.current_stream().cuda_stream
+
+    def tone_rows(rows, by_id):
+        """each row of a tone fixture on its own copy of the default state (the phases are checked against the row before it)"""
+        n = len(rows)
+        cur = torch.from_numpy(np.ascontiguousarray(init_state(n)[:, 0]).view(np.uint8).reshape(-1)).cuda()
+        pcm = torch.full((n, 160), 7.0, dtype=torch.float32, device="cuda")
+        if by_id:
+            ids = torch.from_numpy(np.ascontiguousarray(rows["id"], dtype=np.int32)).cuda()
+            rc = L.mbx_synthesize_tone(n, None, ids.data_ptr(), cur.data_ptr(), pcm.data_ptr(), None, strm)
+        else:
+            rec = decoder.records_from_bits(rows["bits"], total_errors=np.zeros(n, dtype=np.int32))
+            d_rec = torch.from_numpy(np.ascontiguousarray(rec).view(np.uint8).reshape(-1)).cuda()
+            rc = L.mbx_synthesize_tone(n, d_rec.data_ptr(), None, cur.data_ptr(), pcm.data_ptr(), None, strm)
+        _native.check(rc, "mbx_synthesize_tone")
+        return pcm.cpu().numpy(), cur.cpu().numpy().view(PARMS_DTYPE)
+
+    assert L.mbx_set_tone_synthesis(0) == 1
+    try:
+        default = init_state(1)[0, 0]
+        for rows, by_id in ((ambe, False), (dstar, True)):
+            pcm, cur = tone_rows(rows, by_id)
+            assert not pcm.any() and np.all(cur["swn"] == default["swn"]) and np.all(cur["tonePhase"] == default["tonePhase"])
+        for data, codec, seed0 in ((plus2, 1, 7000), (dst, 3, 8000)):
+            S, T = data.shape[0], data["frames"].shape[1]
+            fr = data["frames"].reshape(-1)
+            rec = decoder.records_from_bits(fr["bits"], total_errors=fr["total_in"])
+            out = decoder.process_records_host(codec, S, T, rec, init_state(S), rng_seeded([seed0 + s for s in range(S)]))
+            parity.check_results(fr["result"], out["results"])
+            parity.check_pcm(fr["pcmf"], out["pcmf"])
+            parity.check_state(data["final"], out["state"])
+            assert np.count_nonzero(fr["result"]["flags"] & 0x10) >= 40
+    finally:
+        assert L.mbx_set_tone_synthesis(1) == 0
+    loud, _ = golden_io.tone_kat()
+    pcm, _ = tone_rows(loud[:1], False)   # (tones are back: the fixture's first row starts from the default state, like this call)
+    assert np.max(np.abs(pcm - loud["pcmf"][:1])) <= 2e-3 and pcm.any()
+
+
 def test_batch_api_concurrent_threads_and_streams(mbx, oracle):
     """The batch launcher from 4 host threads, each on its own HIP stream with its own decoder (AMBE+2 and IMBE at
     T = 1 both go through the per-stream expand workspace): every thread gets what it gets alone."""

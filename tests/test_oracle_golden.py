@@ -393,6 +393,46 @@ def test_tone_frames_match_reference(oracle):
         assert int(cur["swn"][0]) == row["swn"] and int(cur["tonePhase"][0]) == row["tonePhase"]
 
 
+def test_notones_option_matches_the_reference_built_with_it(oracle):
+    """The reference's NOTONES build option (-DDISABLE_AMBE_TONES, ref CMakeLists.txt:330-337): tone frames are silence and the tone
+    phases stay (ref src/core/mbelib.c:747-751, 815-819).  tests/golden/notones_kat.bin was written by the reference built that way
+    (oracle/Makefile `notones`); the restatement with set_tones(0) must reproduce it: the tone entry points, and scripted data-level
+    streams of both AMBE codecs (voice, verified / unverified / invalid tones, error-count driven repeats) with results, PCM and
+    final state.  And the ordinary fixture (tone_kat.bin) must NOT be silent, or the option would prove nothing."""
+    ambe, dstar, plus2, dst = golden_io.notones_kat()
+    loud, _ = golden_io.tone_kat()
+    assert np.any(loud["pcmf"] != 0.0) and not np.any(ambe["pcmf"] != 0.0) and not np.any(dstar["pcmf"] != 0.0)
+    oracle.set_tones(0)
+    try:
+        cur = oracle.init_state(1)[0, 0:1].copy()
+        for row in ambe:
+            pcm = np.ones(160, dtype=np.float32)
+            bits = np.ascontiguousarray(row["bits"])
+            oracle.h.mbxo_tonef(pcm.ctypes.data, bits.ctypes.data, cur.ctypes.data)
+            assert not pcm.any() and int(cur["swn"][0]) == row["swn"] and int(cur["tonePhase"][0]) == row["tonePhase"]
+        for row in dstar:
+            pcm = np.ones(160, dtype=np.float32)
+            oracle.h.mbxo_tone_dstarf(pcm.ctypes.data, cur.ctypes.data, int(row["id"]))
+            assert not pcm.any() and int(cur["swn"][0]) == row["swn"] and int(cur["tonePhase"][0]) == row["tonePhase"]
+        for data, seed0, is_plus2 in ((plus2, 7000, True), (dst, 8000, False)):
+            tones = 0
+            for s, stream in enumerate(data):
+                state = oracle.init_state(1)[0]
+                rng = oracle.rng_seeded([seed0 + s])
+                pcm = np.zeros((len(stream["frames"]), 160), dtype=np.float32)
+                for t, fr in enumerate(stream["frames"]):
+                    pcm[t], ret, res = oracle.process_ambe2400_data(fr["bits"], fr["total_in"], state, rng, plus2=is_plus2)
+                    assert ret == fr["ret"]
+                    for name in ("c0_errors", "protected_errors", "c4_errors", "total_errors", "flags"):
+                        assert res[name] == fr["result"][name], (is_plus2, s, t, name)
+                    tones += bool(res["flags"] & 0x10)
+                parity.check_pcm(stream["frames"]["pcmf"], pcm, rel=2e-6, worst=2e-5)
+                parity.check_state(stream["final"].reshape(1, 3), state.reshape(1, 3))
+            assert tones >= 40
+    finally:
+        oracle.set_tones(1)
+
+
 def test_tail_cases_fixture_is_pinned_and_shows_the_references_own_spread(oracle, golden_dir):
     """tests/golden/tail_cases.npz (oracle/tools/gen_tail_fixture.py): the frames with the largest HIP-vs-oracle int16
     differences found in 94 M samples.  Here, without a GPU: the oracle reproduces the REFERENCE's IEEE build on them
