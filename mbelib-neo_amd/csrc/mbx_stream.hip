@@ -99,6 +99,9 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #ifndef MBX_PRIO_FRONT_BLOCK
 #define MBX_PRIO_FRONT_BLOCK 3
 #endif
+#ifndef MBX_BANK_TRIM
+#define MBX_BANK_TRIM 1            // 0 (A/B builds only): the voiced bank's loop always starts at harmonic 1
+#endif
 #ifndef MBX_BANK_ALWAYS_DRIFT
 #define MBX_BANK_ALWAYS_DRIFT 0    // 1 (A/B builds only): the voiced bank always forms its first-order drift sums, as up to round 5
 #endif
@@ -1434,16 +1437,40 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
             MBX_TS(5);   // smoothing, phases, bank coefficients
             __builtin_amdgcn_s_setprio(MBX_PRIO_BANK);
             v2f even = {0.0f, 0.0f}, odd = {0.0f, 0.0f}, even_d = {0.0f, 0.0f}, odd_d = {0.0f, 0.0f};
-            const int last = uni(maxl);
+            // The loop runs over the harmonics that HAVE a coefficient in either model, not over 1..maxl (round 6): it ends at the highest
+            // such harmonic -- random-bit AMBE+2 frames carry their voiced bands low: 20.4 of 32.6 harmonics on average, IMBE 34.1 of 38.6
+            // (counted with the oracle on the bench workloads) -- and where harmonics 1..7 have none (they went to the interpolated
+            // branch above: every frame of a held pitch, the headline workload) it starts at harmonic 8 with e^{i 8 w0 k} from three
+            // squarings of the step (the same first-order error growth as the seven rotations they replace).
+            const unsigned long long live = __ballot(wv_p || wv_c);   // != 0 here
+            const int last = 63 - __clzll((long long)live);
+            const bool from8 = MBX_BANK_TRIM && (live & 0xfeULL) == 0ULL;
+            const int first = from8 ? 8 : 1;
+            v2f Qc0 = Ec, Qs0 = Es;   // harmonic 1
+            if (from8) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const v2f cc = __builtin_elementwise_fma(Qc0, Qc0, -(Qs0 * Qs0));
+                    const v2f cs = Qc0 * Qs0;
+                    Qs0 = cs + cs;
+                    Qc0 = cc;
+                }
+            }
+            // (the loops count from zero over a base pointer: written as `for (l = first; l <= last; ++l)` the compiler gave up the
+            // unrolled body that asks for both harmonics' coefficients before it waits -- one exposed LDS round trip per harmonic,
+            // +2 ... +3 % on the long launches with FEWER trips)
+            const float4* const amp = &S.coef_amp[first];
+            const float4* const drift = &S.coef_drift[first];
+            const int trips = last - first + 1;
             auto bank_loop = [&](auto drift_c) {
                 constexpr bool kDrift = decltype(drift_c)::value;
-                v2f Qc = Ec, Qs = Es;   // harmonic 1
-                auto harmonic = [&](int l) {
-                    const float4 a = S.coef_amp[l];   // wave-uniform address: LDS broadcasts
+                v2f Qc = Qc0, Qs = Qs0;
+                auto harmonic = [&](int i) {
+                    const float4 a = amp[i];   // wave-uniform address: LDS broadcasts
                     even = __builtin_elementwise_fma(Qc, v2f{a.x, a.y}, even);
                     odd = __builtin_elementwise_fma(Qs, v2f{a.z, a.w}, odd);
                     if constexpr (kDrift) {
-                        const float4 b = S.coef_drift[l];
+                        const float4 b = drift[i];
                         even_d = __builtin_elementwise_fma(Qc, v2f{b.x, b.y}, even_d);
                         odd_d = __builtin_elementwise_fma(Qs, v2f{b.z, b.w}, odd_d);
                     }
@@ -1453,13 +1480,13 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 };
                 if constexpr (kDrift && !kDriftUnrolled) {   // the rarer form (2 ... 18 % of the frames of the long launches and of AMBE): not
 #pragma unroll 1                                             // unrolled, so that it never costs the common form a register (unrolled, two long
-                    for (int l = 1; l <= last; ++l) {        // instances spilled and three AMBE one-frame instances lost a wave per SIMD); the
-                        harmonic(l);                         // IMBE one-frame instances have the registers, and 39 % of the headline's frames
+                    for (int i = 0; i < trips; ++i) {        // instances spilled and three AMBE one-frame instances lost a wave per SIMD); the
+                        harmonic(i);                         // IMBE one-frame instances have the registers, and 39 % of the headline's frames
                     }                                        // take this form
                 } else {
 #pragma unroll 2
-                    for (int l = 1; l <= last; ++l) {
-                        harmonic(l);
+                    for (int i = 0; i < trips; ++i) {
+                        harmonic(i);
                     }
                 }
             };
