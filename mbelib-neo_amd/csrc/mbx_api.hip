@@ -949,12 +949,15 @@ static int choose_slice_frames(int S, int T, int slots) {
     const double plain = (double)((S + slots - 1) / slots);
     return (plain >= 1.06 * ideal) ? Tc : 0;   // what the part-empty last round costs must be worth the extra launches
 }
+// resident waves per SIMD of the kernel a long launch of `codec` takes (the kernels' own launch bounds: mbx_device.h)
+static int lds_kernel_waves_per_simd(int codec) {
+    return (codec == MBX_CODEC_IMBE7200X4400) ? MBX_IMBE_LDS_WAVES_PER_SIMD : MBX_AMBE_LDS_WAVES_PER_SIMD;
+}
 // caller holds c->mu.  0: issued (*rc); 1: not applicable (take the plain launch)
 static int try_sliced_launch(Context* c, StreamSlot& slot, mbx::DeviceTables tabs, int codec, int S, int T, const mbx_param_record* d_records,
                              const mbx::FrameParams* params, mbe_parms* d_state, mbx_stream_rng* d_rng, int16_t* d_pcm16, float* d_pcmf,
                              mbe_process_result* d_results, void* stream, int* rc) {
-    const int waves = (codec == MBX_CODEC_IMBE7200X4400) ? 6 : 5;   // MBX_IMBE_LDS_WAVES_PER_SIMD / MBX_AMBE_LDS_WAVES_PER_SIMD (mbx_stream.hip)
-    const int Tc = choose_slice_frames(S, T, waves * c->simds);
+    const int Tc = choose_slice_frames(S, T, lds_kernel_waves_per_simd(codec) * c->simds);
     if (Tc <= 0) {
         return 1;
     }
@@ -964,9 +967,14 @@ static int try_sliced_launch(Context* c, StreamSlot& slot, mbx::DeviceTables tab
     if (capturing) {
         return 1;
     }
-    if (!slot.fork) {   // first sliced launch on this stream: its two internal streams and three events
+    static const int groups = [] {
+        const char* e = getenv("MBX_SLICE_GROUPS");
+        const int v = e ? atoi(e) : 3;
+        return v < 2 ? 2 : (v > 4 ? 4 : v);
+    }();
+    if (!slot.fork) {   // first sliced launch on this stream: the internal streams of the groups (at most four, MBX_SLICE_GROUPS) and their events
         bool ok = hipEventCreateWithFlags(&slot.fork, hipEventDisableTiming) == hipSuccess;
-        for (int g = 0; g < 4 && ok; ++g) {
+        for (int g = 0; g < groups && ok; ++g) {
             ok = hipStreamCreateWithFlags(&slot.side[g], hipStreamNonBlocking) == hipSuccess
                  && hipEventCreateWithFlags(&slot.join[g], hipEventDisableTiming) == hipSuccess;
         }
@@ -981,11 +989,6 @@ static int try_sliced_launch(Context* c, StreamSlot& slot, mbx::DeviceTables tab
         return 1;
     }
     int result = 0;
-    static const int groups = [] {
-        const char* e = getenv("MBX_SLICE_GROUPS");
-        const int v = e ? atoi(e) : 3;
-        return v < 2 ? 2 : (v > 4 ? 4 : v);
-    }();
     // Group 0 runs on the caller's stream itself -- its kernels are queued before the stream waits for the other groups --, so g
     // groups occupy g hardware queues, not g + 1, and one group needs no hand-over at all: 2.51 -> 2.42 ms on 8,192 x 128 AMBE+2
     // (interleaved A/B; four groups are +26 % either way).  MBX_SLICE_OWN=0 puts every group on an internal stream (A/B timing; read once).
@@ -993,15 +996,18 @@ static int try_sliced_launch(Context* c, StreamSlot& slot, mbx::DeviceTables tab
         const char* e = getenv("MBX_SLICE_OWN");
         return !(e && e[0] == '0');
     }();
+    // Every fork-side wait is queued BEFORE any group's kernels: should one fail, nothing has been launched yet and the state is
+    // untouched (the caller then gets the plain launch).  A wait queued on an internal stream and never followed by work is harmless.
+    for (int g = (own ? 1 : 0); g < groups; ++g) {
+        if (hipStreamWaitEvent(slot.side[g], slot.fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+    }
     for (int g = 0; g < groups; ++g) {
         const int s0 = (int)((long long)S * g / groups), Sg = (int)((long long)S * (g + 1) / groups) - s0;
         const bool on_caller = own && g == 0;
         hipStream_t st = on_caller ? (hipStream_t)stream : slot.side[g];
-        if (!on_caller && hipStreamWaitEvent(st, slot.fork, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            result = fail(MBX_ENODEVICE, "sliced launch: hipStreamWaitEvent");
-            break;
-        }
         mbx::DeviceTables tg = tabs;
         if (tg.stream_map) {
             tg.stream_map += s0;
@@ -1940,7 +1946,7 @@ int mbx_launch_slices(int codec, int S, int T) {
         return 0;
     }
     const int sc = codec == MBX_CODEC_IMBE7100X4400 ? MBX_CODEC_IMBE7200X4400 : codec;
-    return choose_slice_frames(S, T, ((sc == MBX_CODEC_IMBE7200X4400) ? 6 : 5) * c->simds);
+    return choose_slice_frames(S, T, lds_kernel_waves_per_simd(sc) * c->simds);
 }
 
 // the dominant kernel of mbx_process_batch / _resident for a batch shape (frames 4-byte aligned, as device allocations are)

@@ -57,6 +57,14 @@ struct DerivedTables {
                                   // whole b0 -> L law, so a wave that asks for it before it knows b0 has L without a memory round trip
 };
 
+// Resident waves per SIMD of the LDS-resident (T >= 4) stream kernels: the launch bounds of those kernels (mbx_stream.hip) AND the
+// slot count the launcher's slicing heuristic prices a launch against (mbx_api.hip) -- one definition, so the two cannot drift apart.
+#ifndef MBX_IMBE_LDS_WAVES_PER_SIMD
+#define MBX_IMBE_LDS_WAVES_PER_SIMD 6   // 5,244 B of LDS per wave = 30 waves per CU: the register file decides (80 VGPRs)
+#endif
+#ifndef MBX_AMBE_LDS_WAVES_PER_SIMD
+#define MBX_AMBE_LDS_WAVES_PER_SIMD 5   // 7,328 B of LDS per wave = 21 waves per CU; 80 registers (six waves) would spill
+#endif
 constexpr int kResultHistWords = 14;   // mbx_result_hist (include/mbx.h) as 64-bit words
 
 // Output of the expand stage, input of the stream stage: 64 dwords per frame (layout in mbx_expand.hip).

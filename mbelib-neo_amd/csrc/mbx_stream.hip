@@ -99,6 +99,9 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #ifndef MBX_PRIO_FRONT_BLOCK
 #define MBX_PRIO_FRONT_BLOCK 3
 #endif
+#ifndef MBX_RES_VIEW_FROM_CUR
+#define MBX_RES_VIEW_FROM_CUR 1    // 0 (A/B builds only): resident one-frame instances load prev_mp_enhanced's view separately (see enh_view_of)
+#endif
 #ifndef MBX_BANK_TRIM
 #define MBX_BANK_TRIM 1            // 0 (A/B builds only): the voiced bank's loop always starts at harmonic 1
 #endif
@@ -412,6 +415,20 @@ __device__ __forceinline__ void load_enh_view(Parms& r, const mbe_parms* __restr
     const uint32_t h = load_header(p, lane);
     load_enh_arrays(r, p, lane);
     set_enh_header(r, h);
+}
+
+// Resident one-frame instances: while prev_mp_enhanced is elided it EQUALS cur_mp, and cur_mp is being loaded whole anyway -- the
+// enhanced model's view is then taken from cur_mp's registers instead of a second set of loads from the same struct (seven vector
+// loads per wave less), and the resident flag, a scalar load at the very top of the wave, is first needed AFTER every other request
+// of the wave has gone out (it used to pick the address of the third load: one exposed round trip before the other twenty).
+__device__ __forceinline__ void enh_view_of(Parms& r, const Parms& cur) {
+    r = Parms{};
+    r.Vl = cur.Vl;
+    r.Ml = cur.Ml;
+    r.PHIl = cur.PHIl;
+    r.PSIl = cur.PSIl;
+    r.uw[2] = cur.uw[2];
+    r.uw[3] = cur.uw[3];
 }
 
 // the synthesis-continuity fields an AMBE erasure keeps from prev_mp
@@ -2085,6 +2102,13 @@ struct FrameSlice {
     int t0 = 0;       // first frame of the slice
     int pos = -1;     // the workgroup's position among the streams (its blockIdx.x when < 0)
 };
+// INVARIANT of the hand-over: it uses RELAXED agent-scope atomics, a hand-written `s_waitcnt vmcnt(0)` between the
+// producer's row stores and its flag store, and compiler barriers -- no release / acquire pair.  That is sound ONLY because every word
+// that crosses (the 64 dwords of a FrameParams row, the flag, an AMBE record) is written with an sc1 (write-through) atomic store and
+// read with an sc1 atomic load, which go past the XCD's L2 on gfx942 / gfx950 (MI355X_MICROARCH.md, inter-workgroup visibility).
+// A PLAIN load of handed-over data -- the rest of a row, `records[]` in a stream block -- would read a stale line and no bit-equality
+// test would catch it deterministically: anything a stream block reads from its front block must go through the same atomics.
+static_assert(sizeof(FrameParams) == 64 * sizeof(uint32_t), "a row is exactly the 64 dwords one wave hands over with one sc1 store per lane");
 struct FrontLink {
     const uint32_t* flag = nullptr;   // the ready word of this stream's chunk of eight: == epoch once the chunk's rows are in `params`
     uint32_t        epoch = 0u;
@@ -2237,11 +2261,21 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         constexpr bool kFlat = MBX_FLAT_LOADS && kFuse != 0;
         const uint32_t h_cur = load_header(slot_cur, lane_in);
         h_prev_first = load_header(slot_prev, lane_in);
-        h_enh_first = load_header(enh_src, lane_in);
+        if constexpr (!(kRes && MBX_RES_VIEW_FROM_CUR)) {
+            h_enh_first = load_header(enh_src, lane_in);
+        }
         load_rng(rng, &rngs[slot]);
         load_prev_arrays<kFlat>(prev_first, slot_prev, lane_in);
         load_parms_arrays<kFlat>(cur, slot_cur, lane_in);
-        load_enh_arrays<kFlat>(enh_first, enh_src, lane_in);
+        if constexpr (kRes && MBX_RES_VIEW_FROM_CUR) {
+            asm volatile("" ::: "memory");   // (everything above is requested before the flag is looked at)
+            if (!elided1) {   // (elided: the view is taken from cur_mp's registers where the frame loop starts, see enh_view_of)
+                h_enh_first = load_header(slot_enh, lane_in);
+                load_enh_arrays<kFlat>(enh_first, slot_enh, lane_in);
+            }
+        } else {
+            load_enh_arrays<kFlat>(enh_first, enh_src, lane_in);
+        }
         mbx_param_record* const rec_out = const_cast<mbx_param_record*>(&records[fbase]);
         auto L_of = [&](int b0) -> int {   // wave-uniform b0
             return (b0 <= 207) ? (int)((__builtin_amdgcn_readlane((int)l_lanes, b0 & 63) >> (8 * (b0 >> 6))) & 0xff) : 0;
@@ -2355,10 +2389,18 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             enh = enh_keep;
             load_prev_view_lds(prev, slot_prev, lane);
         } else if constexpr (kOne) {   // requested at the start, together with cur_mp
-            enh = enh_first;
             prev = prev_first;
             set_prev_header(prev, h_prev_first);
-            set_enh_header(enh, h_enh_first);
+            if (kRes && MBX_RES_VIEW_FROM_CUR && elided1) {   // cur_mp still holds what the last frame left: that IS prev_mp_enhanced
+                enh_view_of(enh, cur);
+                enh.w0 = cur.w0;
+                enh.L = cur.L;
+                enh.localEnergy = cur.localEnergy;
+                enh.amplitudeThreshold = cur.amplitudeThreshold;
+            } else {
+                enh = enh_first;
+                set_enh_header(enh, h_enh_first);
+            }
         } else {
             load_enh_view(enh, elided1 ? slot_cur : slot_enh, lane);
             load_prev_view(prev, slot_prev, lane);
@@ -2683,9 +2725,7 @@ imbe_one_launch_kernel_res(int S, int lead, const uint8_t* __restrict__ frames, 
 // file decides the occupancy: 79 VGPRs = six waves per SIMD.  Measured on configs[3] (65,536 x T=16) with padded LDS:
 // two waves per SIMD 5.15 ms, three 3.91, four (round 2) 3.40, five 2.86, six 2.76.
 #define MBX_LDS_KERNEL_ATTR(waves) __launch_bounds__(64, waves)
-#ifndef MBX_IMBE_LDS_WAVES_PER_SIMD
-#define MBX_IMBE_LDS_WAVES_PER_SIMD 6   // 5,200 B of LDS per wave = 25 waves per CU: the register file decides (80 VGPRs)
-#endif
+// (MBX_IMBE_LDS_WAVES_PER_SIMD / MBX_AMBE_LDS_WAVES_PER_SIMD: mbx_device.h, shared with the launcher's slicing heuristic)
 __global__ void MBX_LDS_KERNEL_ATTR(MBX_IMBE_LDS_WAVES_PER_SIMD)
 imbe_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
@@ -3008,6 +3048,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
     // every request of the launch's first frame goes out before anything waits: see the IMBE body and load_header
     Parms enh_first, prev_first;
     uint32_t h_enh_first = 0u, h_prev_first = 0u;
+    bool enh_from_cur = false;   // resident one-frame instances: the enhanced view is cur_mp's own registers (enh_view_of)
     float row_first = 0.0f;
     if constexpr (kPark) {
         slot_prev = &park.prev;
@@ -3069,11 +3110,22 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         const mbe_parms* const enh_src = elided ? slot_cur : slot_enh;
         const uint32_t h_cur = load_header(slot_cur, lane_in);
         h_prev_first = load_header(slot_prev, lane_in);
-        h_enh_first = load_header(enh_src, lane_in);
+        if constexpr (!(kRes && MBX_RES_VIEW_FROM_CUR)) {
+            h_enh_first = load_header(enh_src, lane_in);
+        }
         load_rng(rng, &rngs[slot]);
         load_prev_arrays(prev_first, slot_prev, lane_in);
         load_parms_arrays(cur, slot_cur, lane_in);
-        load_enh_arrays(enh_first, enh_src, lane_in);
+        if constexpr (kRes && MBX_RES_VIEW_FROM_CUR) {
+            asm volatile("" ::: "memory");   // (everything above is requested before the flag is looked at)
+            enh_from_cur = elided;
+            if (!elided) {   // (elided: the view is taken from cur_mp's registers where the frame loop starts, see enh_view_of)
+                h_enh_first = load_header(slot_enh, lane_in);
+                load_enh_arrays(enh_first, slot_enh, lane_in);
+            }
+        } else {
+            load_enh_arrays(enh_first, enh_src, lane_in);
+        }
         if constexpr (kFuse == 3) {   // the row comes from a front block of the same launch: see the IMBE body
             asm volatile("" ::: "memory");
             bool ready = uni(flag_v) == link.epoch;
@@ -3187,11 +3239,19 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             enh = enh_keep;
             load_prev_view_lds(prev, slot_prev, lane);
         } else if constexpr (kOne) {   // requested at the start, together with cur_mp
-            enh = enh_first;
             prev = prev_first;
             scratch.x.fp[lane] = row_first;
             set_prev_header(prev, h_prev_first);
-            set_enh_header(enh, h_enh_first);
+            if (kRes && MBX_RES_VIEW_FROM_CUR && enh_from_cur) {   // cur_mp still holds what the last frame left: that IS prev_mp_enhanced
+                enh_view_of(enh, cur);
+                enh.w0 = cur.w0;
+                enh.L = cur.L;
+                enh.localEnergy = cur.localEnergy;
+                enh.amplitudeThreshold = cur.amplitudeThreshold;
+            } else {
+                enh = enh_first;
+                set_enh_header(enh, h_enh_first);
+            }
             wave_lds_sync();
             fp = scratch.x.fp;
         } else {
@@ -3742,9 +3802,6 @@ ambe2400_stream_kernel(int S, int Tn, const mbx_param_record* __restrict__ recor
 }
 
 // T >= 4: prev_mp / prev_mp_enhanced resident in LDS (see the IMBE kernel)
-#ifndef MBX_AMBE_LDS_WAVES_PER_SIMD
-#define MBX_AMBE_LDS_WAVES_PER_SIMD 5   // 5,200 B of LDS per wave = 25 waves per CU; 80 registers (six waves) would spill
-#endif
 __global__ void MBX_LDS_KERNEL_ATTR(MBX_AMBE_LDS_WAVES_PER_SIMD)
 ambe_stream_kernel_lds(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
@@ -3778,7 +3835,7 @@ imbe_stream_kernel_lds_pairexp(int S, int Tn, const mbx_param_record* __restrict
 // Slice kernels (*_stream_kernel_lds_slice): the LDS-resident instances on a SLICE of every stream's frames -- frames t0 ..
 // t0 + n - 1 of the `stride` frames a stream has in the batch arrays.  A slice IS a launch of n frames per stream (state in from
 // HBM, state out to HBM); the launcher (mbx_api.hip, sliced_launch) cuts a launch whose stream count does not fill the device's
-// wave slots evenly into groups of streams x slices of frames and issues them on two internal HIP streams, so that the slots one
+// wave slots evenly into groups of streams x slices of frames and issues them on the caller's stream and two internal HIP streams (three groups), so that the slots one
 // group's slice leaves empty are taken by the other group's.
 // ------------------------------------------------------------------------------------------
 __global__ void MBX_LDS_KERNEL_ATTR(MBX_IMBE_LDS_WAVES_PER_SIMD)
