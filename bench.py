@@ -681,10 +681,13 @@ def convert_rate(local_rank, nframes=1 << 20, steps=20):
             "what": "float PCM resident in HBM -> int16 PCM, 1,048,576 frames per launch (the device counterpart of the reference's bench_convert)"}
 
 
-def copy_floor(local_rank, S=65536, steps=20):
+def copy_floor(local_rank, S=65536, min_time_s=0.25):
     """state_copy_kernel: every stream's three structs loaded and stored with exactly the stream kernels' accesses (one wave per
     stream, a dword per lane) and nothing else -- what the chip gives THIS access pattern, timed in this very run.  The T = 1
-    stream kernels are priced against it beside the 8 TB/s datasheet roofline (roofline.copy_floor)."""
+    stream kernels are priced against it beside the 8 TB/s datasheet roofline (roofline.copy_floor).
+    Timed like the headline: ~30 ms of untimed launches first, then at least `min_time_s` of launches between two events -- twenty
+    launches behind an idle gap (how rounds 1-5 timed it) sit in the load-onset transient of the power controller and read 8 % low
+    (5.4 instead of 5.9 TB/s; tools/copy_patterns2.hip, profiles/r06/copy_patterns2.json)."""
     import torch
 
     from mbelib_neo_amd import _native, decoder
@@ -692,18 +695,28 @@ def copy_floor(local_rank, S=65536, steps=20):
     L = _native.lib()
     dec = decoder.BatchDecoder(0, S, device=local_rank)
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(3):
-        _native.check(L.mbx_state_copy(S, dec.state.data_ptr(), stream), "mbx_state_copy")
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    for a, b in ev:
-        a.record()
-        _native.check(L.mbx_state_copy(S, dec.state.data_ptr(), stream), "mbx_state_copy")
-        b.record()
+
+    def run(n):
+        for _ in range(n):
+            _native.check(L.mbx_state_copy(S, dec.state.data_ptr(), stream), "mbx_state_copy")
+
+    run(5)
     torch.cuda.synchronize()
-    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    t0 = time.perf_counter()
+    run(20)
+    torch.cuda.synchronize()
+    est = max((time.perf_counter() - t0) / 20, 1e-6)
+    n = max(20, int(min_time_s / est))
+    run(max(1, int(0.030 / est)))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    run(n)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / n
     nbytes = 2 * S * 3 * 2604
-    return {"kernel": "state_copy_kernel", "bytes_per_launch": nbytes, "kernel_ms": ms, "rate_GBps": nbytes / (ms * 1e-3) / 1e9,
-            "what": "load + store of the three structs of 65,536 streams with the stream kernels' access pattern, no arithmetic"}
+    return {"kernel": "state_copy_kernel", "bytes_per_launch": nbytes, "kernel_ms": ms, "rate_GBps": nbytes / (ms * 1e-3) / 1e9, "launches_timed": n,
+            "what": "load + store of the three structs of 65,536 streams with the stream kernels' access pattern, no arithmetic; steady state"}
 
 
 def roofline_of(name, S, T, m):

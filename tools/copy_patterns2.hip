@@ -8,6 +8,8 @@
 //   k2  in per STRUCT: aligned dwordx4 loads (+ edge dwords) -> LDS -> registers; dword per lane out
 //   k3  k2's loads + k1's stores
 //   k4  k3 with the whole 7,812-byte triplet as ONE span (8 KB of LDS per wave)
+//   k5  round 5's "dword per lane" (the triplet as one run, 31 dwords per lane)      } the two ends of profiles/r05/copy_patterns.json,
+//   k6  round 5's flat copy: no per-stream structure, 16 B per lane, aligned         } timed HERE like everything else
 //   hipcc --offload-arch=gfx950 -O2 -o tools/bin/copy_patterns2 tools/copy_patterns2.hip && tools/bin/copy_patterns2
 #include <hip/hip_runtime.h>
 
@@ -134,6 +136,29 @@ __global__ void __launch_bounds__(64) copy_triplet_span(int S, float* state, flo
     lds_to_span<kTriplet>(g, lds, lane);
 }
 
+// the two patterns of copy_patterns.hip (round 5) in THIS harness: the triplet as one run of 31 dwords per lane, and the flat copy
+__global__ void __launch_bounds__(64) copy_triplet_dword(int S, float* state, float bias) {
+    const int s = blockIdx.x;
+    if (s >= S) return;
+    float* p = state + (size_t)s * kTriplet;
+    const int lane = threadIdx.x;
+    float v[31];
+#pragma unroll
+    for (int i = 0; i < 31; ++i) {
+        const int k = lane + 64 * i;
+        v[i] = k < kTriplet ? p[k] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 31; ++i) {
+        const int k = lane + 64 * i;
+        if (k < kTriplet) __builtin_nontemporal_store(v[i] + bias, &p[k]);
+    }
+}
+__global__ void __launch_bounds__(256) copy_flat_x4(size_t n4, f4* p, float bias) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(p[i] + bias, &p[i]);
+}
+
 template <class F>
 static double time_ms(F launch) {
     hipEvent_t a, b;
@@ -161,17 +186,21 @@ int main() {
     CHECK(hipMalloc(&d, bytes + 64));
     // correctness first: every variant must add exactly `bias` to every dword and touch nothing else
     float* h = (float*)malloc(bytes + 64);
-    const char* names[5] = {"k0_dword_in_dword_out", "k1_dword_in_x4_out", "k2_x4_in_dword_out", "k3_x4_in_x4_out", "k4_triplet_span"};
+    const char* names[7] = {"k0_dword_in_dword_out", "k1_dword_in_x4_out", "k2_x4_in_dword_out", "k3_x4_in_x4_out", "k4_triplet_span",
+                            "k5_triplet_dword_31_per_lane", "k6_flat_aligned_x4"};
+    const size_t n4 = (size_t)S * kTriplet / 4;
     auto launch = [&](int k, float bias) {
         switch (k) {
             case 0: hipLaunchKernelGGL((copy_struct_spans<false, false>), dim3(S), dim3(64), 0, 0, S, d, bias); break;
             case 1: hipLaunchKernelGGL((copy_struct_spans<false, true>), dim3(S), dim3(64), 0, 0, S, d, bias); break;
             case 2: hipLaunchKernelGGL((copy_struct_spans<true, false>), dim3(S), dim3(64), 0, 0, S, d, bias); break;
             case 3: hipLaunchKernelGGL((copy_struct_spans<true, true>), dim3(S), dim3(64), 0, 0, S, d, bias); break;
-            default: hipLaunchKernelGGL(copy_triplet_span, dim3(S), dim3(64), 0, 0, S, d, bias); break;
+            case 4: hipLaunchKernelGGL(copy_triplet_span, dim3(S), dim3(64), 0, 0, S, d, bias); break;
+            case 5: hipLaunchKernelGGL(copy_triplet_dword, dim3(S), dim3(64), 0, 0, S, d, bias); break;
+            default: hipLaunchKernelGGL(copy_flat_x4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, n4, (f4*)d, bias); break;
         }
     };
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 7; ++k) {
         for (size_t i = 0; i < n + 16; ++i) h[i] = (float)(i % 4093);
         CHECK(hipMemcpy(d, h, bytes + 64, hipMemcpyHostToDevice));
         launch(k, 1.0f);
@@ -190,7 +219,7 @@ int main() {
     CHECK(hipMemset(d, 0, bytes));
     printf("{\"bytes_each_way\": %zu", bytes);
     for (int round = 0; round < 2; ++round) {   // twice, interleaved: box drift shows as a difference between the rounds
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < 7; ++k) {
             const double t = time_ms([&] { launch(k, 0.0f); });
             printf(", \"%s_ms_%d\": %.4f, \"%s_TBps_%d\": %.3f", names[k], round, t, names[k], round, 2 * bytes / t / 1e9);
         }
