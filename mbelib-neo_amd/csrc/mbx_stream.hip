@@ -99,6 +99,10 @@ namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #ifndef MBX_PRIO_FRONT_BLOCK
 #define MBX_PRIO_FRONT_BLOCK 3
 #endif
+#ifndef MBX_AMBE_EARLY_NOISE
+#define MBX_AMBE_EARLY_NOISE 0     // 1: the AMBE one-frame instances request the next overlap's jump-ahead constants ahead of the bank too (kEarly);
+                                   // off since round 6: its two registers across the bank are what kept those instances at six waves per SIMD
+#endif
 #ifndef MBX_RES_VIEW_FROM_CUR
 #define MBX_RES_VIEW_FROM_CUR 1    // 0 (A/B builds only): resident one-frame instances load prev_mp_enhanced's view separately (see enh_view_of)
 #endif
@@ -1331,12 +1335,16 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         const float dw0 = cw0 - pw0;
         // 2 amp cos(theta) for two (harmonic, sample) combinations at once.  kFlat: the two frames have the same
         // fundamental (dw0 == 0, e.g. a held pitch), so the quadratic phase term is an exact zero and is not formed.
-        auto term = [&](auto flat, v2f phi, v2f a, v2f fl, v2f amp0, v2f damp, v2f nf, v2f nsq, v2f nfrac) -> v2f {
+        auto term = [&](auto flat, v2f phi, v2f a, v2f fl, v2f amp0, v2f damp, v2f nf, v2f nfrac) -> v2f {
             // (float)(l*n*n) is exact below 2^24, so l * n^2 in float is the same value; the division by
             // 2N = 320 becomes a multiplication by its rounded reciprocal (<= 1 ulp of a phase term < 16 rad)
             v2f theta = phi + (a * nf);
             if constexpr (!decltype(flat)::value) {
-                theta = theta + ((splat(dw0) * (fl * nsq)) * splat(1.0f / 320.0f));
+                // n^2 is formed here, per term (exact: n^2 < 2^24), not held in three registers across the loop: one more instruction per
+                // term of the varying-pitch form buys the seven-wave AMBE one-frame instances their last registers
+                v2f nq = nf;
+                asm volatile("" : "+v"(nq));   // (or the optimiser hoists the square out of the loop again)
+                theta = theta + ((splat(dw0) * (fl * (nq * nq))) * splat(1.0f / 320.0f));
             }
             const v2f hi = theta * splat(0.15915494f);   // revolutions: theta / 2 pi as hi + lo
             const v2f lo = __builtin_elementwise_fma(theta, splat(6.4206382e-9f),
@@ -1347,9 +1355,8 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         };
         const float nf0 = (float)lane, nf2 = nf0 + 128.0f;
         const v2f nf01 = {nf0, nf0 + 64.0f};
-        const v2f nsq01 = nf01 * nf01;                            // exact: n^2 < 2^24
         const v2f nfrac01 = {D->nfrac[lane], D->nfrac[lane + 64]};   // (float)n / (float)N, the reference's quotient (host table)
-        const float nsq2 = nf2 * nf2, nfrac2 = D->nfrac[lane + 128];
+        const float nfrac2 = D->nfrac[lane + 128];
         v2f acc01 = {0.0f, 0.0f}, acc2 = {0.0f, 0.0f};
         auto run = [&](auto flat) {
             while (imask) {
@@ -1358,12 +1365,12 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
                 const int lb = imask ? (__ffsll((long long)imask) - 1) : 0;   // slot 0 holds zero amplitudes
                 imask &= imask - 1;
                 const float4 ka = S.icoef[la], kb = S.icoef[lb];
-                acc01 += term(flat, splat(ka.x), splat(ka.y), splat((float)la), splat(ka.z), splat(ka.w), nf01, nsq01, nfrac01);
+                acc01 += term(flat, splat(ka.x), splat(ka.y), splat((float)la), splat(ka.z), splat(ka.w), nf01, nfrac01);
                 if (lb) {
-                    acc01 += term(flat, splat(kb.x), splat(kb.y), splat((float)lb), splat(kb.z), splat(kb.w), nf01, nsq01, nfrac01);
+                    acc01 += term(flat, splat(kb.x), splat(kb.y), splat((float)lb), splat(kb.z), splat(kb.w), nf01, nfrac01);
                 }
                 acc2 += term(flat, v2f{ka.x, kb.x}, v2f{ka.y, kb.y}, v2f{(float)la, (float)lb}, v2f{ka.z, kb.z}, v2f{ka.w, kb.w},
-                             splat(nf2), splat(nsq2), splat(nfrac2));
+                             splat(nf2), splat(nfrac2));
             }
         };
         if (dw0 == 0.0f) {
@@ -3422,7 +3429,7 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         if (action == kVoice || action == kToneFallback) {
             const mbe_parms* snap = (kPark || action == kVoice) ? slot_prev : slot_enh;
-            const bool fresh = synth_core<true, kPark, ScratchT, kOne>(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane, snap);
+            const bool fresh = synth_core<true, kPark, ScratchT, kOne && MBX_AMBE_EARLY_NOISE>(out, cur, enh, action == kVoice, rm0, rng, scratch, tabs, lane, snap);
             {
                 slot_fence<kPark>();
                 const float* f = reinterpret_cast<const float*>(snap);
@@ -3671,8 +3678,13 @@ frame_server_kernel(mbx_frame_mailbox* mb, unsigned idle_ticks /* of the 100 MHz
 
 // T = 1: the HBM-slot bodies without a frame loop (see imbe_stream_kernel_one)
 #ifndef MBX_AMBE_ONE_WAVES_PER_SIMD
-#define MBX_AMBE_ONE_WAVES_PER_SIMD 6   // asked for six, the allocator lands at 72 VGPRs without a spill = SEVEN waves resident (asked for
-#endif                                  // seven it spills 8 B); the looped instance needs 80 + 12 B of scratch at six
+#define MBX_AMBE_ONE_WAVES_PER_SIMD 7   // round 6: SEVEN waves (72 VGPRs, no scratch) once the one-frame AMBE instances stopped requesting the next
+#endif                                  // overlap's noise constants ahead of the bank (MBX_AMBE_EARLY_NOISE 0: two registers across the bank) and the
+                                        // interpolated branch stopped holding n^2 across its loop: 65,536 x 1 AMBE+2 -1.7 %, resident -2.5 %
+                                        // (profiles/r06/ab_ambe_seven_waves.log; round 5 forced seven with 44 B of scratch: +7.8 %)
+#ifndef MBX_AMBE_ONE_RES_WAVES_PER_SIMD
+#define MBX_AMBE_ONE_RES_WAVES_PER_SIMD 6   // ambe_one_launch_kernel_res alone still needs 12 B of scratch at seven (the transform pair's peak)
+#endif
 __global__ void __launch_bounds__(64, MBX_AMBE_ONE_WAVES_PER_SIMD)
 ambe_stream_kernel_one(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
@@ -3765,7 +3777,7 @@ ambe_one_launch_kernel(int S, const uint8_t* __restrict__ frames, mbx_param_reco
                        mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
     ambe_one_launch_body<false>(S, frames, records, rows, flags, fallbacks, epoch, state, rngs, pcm16, pcmf, results, tabs_in);
 }
-__global__ void __launch_bounds__(64, MBX_AMBE_ONE_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64, MBX_AMBE_ONE_RES_WAVES_PER_SIMD)
 ambe_one_launch_kernel_res(int S, const uint8_t* __restrict__ frames, mbx_param_record* __restrict__ records, FrameParams* __restrict__ rows,
                            uint32_t* __restrict__ flags, uint32_t* __restrict__ fallbacks, uint32_t epoch, mbe_parms* __restrict__ state,
                            mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16, float* __restrict__ pcmf,
