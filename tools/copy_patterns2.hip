@@ -10,6 +10,7 @@
 //   k4  k3 with the whole 7,812-byte triplet as ONE span (8 KB of LDS per wave)
 //   k5  round 5's "dword per lane" (the triplet as one run, 31 dwords per lane)      } the two ends of profiles/r05/copy_patterns.json,
 //   k6  round 5's flat copy: no per-stream structure, 16 B per lane, aligned         } timed HERE like everything else
+//   k7  exactly the one-frame stream instances' accesses: gathered header + 57-dword band arrays + previousUw + overlap, per struct
 //   hipcc --offload-arch=gfx950 -O2 -o tools/bin/copy_patterns2 tools/copy_patterns2.hip && tools/bin/copy_patterns2
 #include <hip/hip_runtime.h>
 
@@ -159,6 +160,41 @@ __global__ void __launch_bounds__(256) copy_flat_x4(size_t n4, f4* p, float bias
     if (i < n4) __builtin_nontemporal_store(p[i] + bias, &p[i]);
 }
 
+// k7: EXACTLY the one-frame stream instances' accesses (mbx_stream.hip load_header / load_parms_arrays<kFlat> / store_parms<kGather, kNt>):
+// per struct one gathered header load (lanes 0..13: dwords 0, 1, 2, 288..297, 554), five 57-dword band arrays, previousUw in four
+// rows, the noise overlap in a row and a half -- twelve loads and twelve (masked, non-temporal) stores per struct
+__global__ void __launch_bounds__(64) copy_fieldwise(int S, float* state, float bias) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= S) return;
+    const int j = lane & 15;
+    const int hidx = (j < 3) ? j : ((j < 13) ? 285 + j : 554);
+    float h[3], band[3][5], uw[3][4], ov0[3], ov1[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float* p = state + (size_t)s * kTriplet + q * kStruct;
+        h[q] = p[hidx];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) band[q][a] = p[3 + 57 * a + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) uw[q][r] = p[298 + lane + 64 * r];
+        ov0[q] = p[555 + lane];
+        ov1[q] = p[619 + (lane & 31)];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float* p = state + (size_t)s * kTriplet + q * kStruct;
+        if (lane < 14) __builtin_nontemporal_store(h[q] + bias, &p[hidx]);
+        if (lane < 57) {
+#pragma unroll
+            for (int a = 0; a < 5; ++a) __builtin_nontemporal_store(band[q][a] + bias, &p[3 + 57 * a + lane]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(uw[q][r] + bias, &p[298 + lane + 64 * r]);
+        __builtin_nontemporal_store(ov0[q] + bias, &p[555 + lane]);
+        if (lane < 32) __builtin_nontemporal_store(ov1[q] + bias, &p[619 + lane]);
+    }
+}
+
 template <class F>
 static double time_ms(F launch) {
     hipEvent_t a, b;
@@ -186,8 +222,8 @@ int main() {
     CHECK(hipMalloc(&d, bytes + 64));
     // correctness first: every variant must add exactly `bias` to every dword and touch nothing else
     float* h = (float*)malloc(bytes + 64);
-    const char* names[7] = {"k0_dword_in_dword_out", "k1_dword_in_x4_out", "k2_x4_in_dword_out", "k3_x4_in_x4_out", "k4_triplet_span",
-                            "k5_triplet_dword_31_per_lane", "k6_flat_aligned_x4"};
+    const char* names[8] = {"k0_dword_in_dword_out", "k1_dword_in_x4_out", "k2_x4_in_dword_out", "k3_x4_in_x4_out", "k4_triplet_span",
+                            "k5_triplet_dword_31_per_lane", "k6_flat_aligned_x4", "k7_fieldwise_as_the_one_frame_kernels"};
     const size_t n4 = (size_t)S * kTriplet / 4;
     auto launch = [&](int k, float bias) {
         switch (k) {
@@ -197,10 +233,11 @@ int main() {
             case 3: hipLaunchKernelGGL((copy_struct_spans<true, true>), dim3(S), dim3(64), 0, 0, S, d, bias); break;
             case 4: hipLaunchKernelGGL(copy_triplet_span, dim3(S), dim3(64), 0, 0, S, d, bias); break;
             case 5: hipLaunchKernelGGL(copy_triplet_dword, dim3(S), dim3(64), 0, 0, S, d, bias); break;
-            default: hipLaunchKernelGGL(copy_flat_x4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, n4, (f4*)d, bias); break;
+            case 6: hipLaunchKernelGGL(copy_flat_x4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, n4, (f4*)d, bias); break;
+            default: hipLaunchKernelGGL(copy_fieldwise, dim3(S), dim3(64), 0, 0, S, d, bias); break;
         }
     };
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 8; ++k) {
         for (size_t i = 0; i < n + 16; ++i) h[i] = (float)(i % 4093);
         CHECK(hipMemcpy(d, h, bytes + 64, hipMemcpyHostToDevice));
         launch(k, 1.0f);
@@ -219,7 +256,7 @@ int main() {
     CHECK(hipMemset(d, 0, bytes));
     printf("{\"bytes_each_way\": %zu", bytes);
     for (int round = 0; round < 2; ++round) {   // twice, interleaved: box drift shows as a difference between the rounds
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < 8; ++k) {
             const double t = time_ms([&] { launch(k, 0.0f); });
             printf(", \"%s_ms_%d\": %.4f, \"%s_TBps_%d\": %.3f", names[k], round, t, names[k], round, 2 * bytes / t / 1e9);
         }
