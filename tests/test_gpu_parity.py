@@ -421,7 +421,7 @@ def test_ambe_long_streams_config5_shape(mbx, oracle):
     L = mbx.lib()
     Tc = L.mbx_launch_slices(1, S, T)
     print("slice length for 8,192 x 128:", Tc)
-    if os.environ.get("MBX_SLICE") != "0":
+    if os.environ.get("MBX_SLICE") != "0" and not os.environ.get("MBX_NO_LDS_RESIDENT"):   # (tools/test_env_matrix.sh runs the suite under those switches too)
         assert Tc == 16 and L.mbx_launch_slices(1, S, 8) == 0 and L.mbx_launch_slices(0, 65536, 16) == 0
         assert L.mbx_batch_kernel_name(1, S, T, 0) == b"ambe_stream_kernel_lds_slice"
     d = run([8] * 16)
@@ -1509,7 +1509,7 @@ def test_replayed_frame_workloads_hold_the_int16_bound(mbx, oracle, name):
     seeds = np.arange(S) + 1234
     dec = decoder.BatchDecoder(codec, S, seeds=seeds, resident=resident)
     kernel = _native.lib().mbx_batch_kernel_name(codec, S, T, 1 if resident else 0).decode()
-    assert "one_launch" in kernel, kernel
+    assert "one_launch" in kernel or os.environ.get("MBX_FUSE_ONE") in ("0", "1"), kernel   # (tools/test_env_matrix.sh: the other T = 1 forms)
     d_frames = dec.to_device(frames)
     out = dec.make_outputs(T, want_pcm16=True, want_float=True, want_results=True)
     pick = np.arange(S // 128, S, S // 64)[:64]
