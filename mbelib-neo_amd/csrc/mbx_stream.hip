@@ -57,6 +57,13 @@ __shared__ unsigned long long s_stage_prev;          // one wave per workgroup
 #else
 #define MBX_TS(i) do { } while (0)
 #endif
+// finer marks inside the synthesiser's first stage (MBX_STAGE_TIMES builds with -DMBX_STAGE_SUB: they reuse the marks of the in-wave front end,
+// which a one-launch kernel's stream blocks do not pass): 14 after smoothing + noise, 15 after the phases, 10 after the interpolated branch
+#if defined(MBX_STAGE_TIMES) && defined(MBX_STAGE_SUB)
+#define MBX_TSX(i) MBX_TS(i)
+#else
+#define MBX_TSX(i) do { } while (0)
+#endif
 #ifdef MBX_FRAME_STAMPS
 namespace mbx { __device__ unsigned long long g_frame_stamps[16]; }
 #define MBX_FSTAMP(i) do { g_frame_stamps[i] = wall_clock64(); } while (0)
@@ -1263,6 +1270,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         cur.ov[0] = cur.ov[1] = 0.0f;
     }
 
+    MBX_TSX(14);
     // ---- reconcile the two model lengths ---------------------------------------------------
     int maxl;
     if (cur.L > prev.L) {
@@ -1306,6 +1314,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         asm volatile("" ::: "memory");   // (requested HERE: not sunk to the use)
     }
 
+    MBX_TSX(15);
     // ---- voiced bank -----------------------------------------------------------------------
     const bool band = lane >= 1 && lane <= maxl;
     const bool cv = band && (cur.Vl == 1);
@@ -1385,6 +1394,7 @@ __device__ bool synth_core(float out[3], Parms& cur, Parms& prev, bool have_rm0,
         }
     }
 
+    MBX_TSX(10);
     // (2) windowed oscillators.  The reference advances one oscillator per harmonic sample by sample
     //     (src/core/mbelib.c:213-218).  Here the recurrence runs along the OTHER axis: loop over the harmonics
     //     l = 1..maxl, and a sample's phasor e^{i l w0 m} is advanced from harmonic to harmonic by its own step
