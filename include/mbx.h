@@ -143,6 +143,22 @@ void mbx_unpack_records(const mbx_param_record* rec, size_t n, int nbits /* 88|4
  * deinterleaver that fills imbe_fr[r][j] / ambe_fr[r][j] per the air-interface tables would emit the bits of row r. */
 int mbx_pack_cells(int codec, const char* d_cells, size_t n, uint8_t* d_packed, int32_t* d_status, void* stream);
 
+/* From an air-interface burst straight to the wire frame.  The reference's callers deinterleave a voice
+ * burst into imbe_fr[r][j] / ambe_fr[r][j] with tables of their own (the reference holds none: ref include/mbelib-neo/mbelib.h:429,505
+ * take the filled arrays); such a host can fold its tables into ONE permutation that writes the packed frame directly, without the
+ * 184 / 96-byte cell array in between:
+ *     mbx_wire_bit_of_cell(codec, r, j)   where cell [r][j] sits in the wire frame: bit index from the frame's first bit (index 0 = bit 7
+ *                                         of byte 0; rows of 23,23,23,23,15,15,15,7 | 19,24,23,23,15,15,23 | 24,23,11,14 cells, row after
+ *                                         row, inside a row from the highest cell down to cell 0), or -1 for a cell the codec does not use
+ *     mbx_wire_permutation(codec, cell_row, cell_col, n, wire_bit)
+ *                                         for a burst of n = 144 | 142 | 72 channel bits whose i-th received bit the caller's tables send to
+ *                                         cell (cell_row[i], cell_col[i]): wire_bit[i] = its index in the wire frame.  Returns
+ *                                         MBE_STATUS_INVALID_ARGUMENT unless the schedule is a bijection onto the codec's cells.
+ * A frame is then `for i: if (bit[i]) frame[wire_bit[i] >> 3] |= 0x80 >> (wire_bit[i] & 7)` on a zeroed 18 / 9 byte buffer -- the bytes
+ * mbx_pack_* would have produced from the filled array (tests/test_host_logic.py holds that for random schedules).  Host-only. */
+int mbx_wire_bit_of_cell(int codec, int row, int col);
+int mbx_wire_permutation(int codec, const int* cell_row, const int* cell_col, int n, int* wire_bit);
+
 /* ---- FEC stage: frames -> parameter records (stateless, one thread per frame) ---------- */
 
 /* ref: mbe_decodeImbe7200x4400Frame  include/mbelib-neo/mbelib.h:471, src/imbe/imbe7200x4400.c:709-744

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "mbx_pack_imbe7200x4400": (C.c_int, [_vp, _sz, _vp]),
     "mbx_pack_ambe3600x2450": (C.c_int, [_vp, _sz, _vp]),
     "mbx_pack_cells": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "mbx_wire_bit_of_cell": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mbx_wire_permutation": (C.c_int, [C.c_int, _vp, _vp, C.c_int, _vp]),
     "mbx_unpack_records": (None, [_vp, _sz, C.c_int, _vp, _vp]),
     "mbx_fec_imbe7200x4400": (C.c_int, [_vp, _sz, _vp, _vp]),
     "mbx_fec_ambe3600x2450": (C.c_int, [_vp, _sz, _vp, _vp]),

@@ -626,6 +626,61 @@ uint32_t mbx_table_checksum(void) {
     return c ? c->checksum : 0u;
 }
 
+// Where cell [row][col] of the reference's frame array sits in the packed wire frame: bit index from the frame's first bit (bit 7 of
+// byte 0 = index 0), -1 for a cell the codec does not use.  The row widths are the packers' (pack_rows: row after row, inside a row
+// from the highest cell down to cell 0).
+static const int* wire_row_widths(int codec, int* rows) {
+    static const int imbe7200[8] = {23, 23, 23, 23, 15, 15, 15, 7}, imbe7100[7] = {19, 24, 23, 23, 15, 15, 23}, ambe[4] = {24, 23, 11, 14};
+    switch (codec) {
+        case MBX_CODEC_IMBE7200X4400: *rows = 8; return imbe7200;
+        case MBX_CODEC_IMBE7100X4400: *rows = 7; return imbe7100;
+        case MBX_CODEC_AMBE3600X2450:
+        case MBX_CODEC_AMBE3600X2400: *rows = 4; return ambe;
+        default: *rows = 0; return nullptr;
+    }
+}
+int mbx_wire_bit_of_cell(int codec, int row, int col) {
+    int rows = 0;
+    const int* w = wire_row_widths(codec, &rows);
+    if (!w || row < 0 || row >= rows || col < 0 || col >= w[row]) {
+        return -1;
+    }
+    int pos = 0;
+    for (int r = 0; r < row; ++r) {
+        pos += w[r];
+    }
+    return pos + (w[row] - 1 - col);
+}
+
+// Folds a caller's deinterleave schedule into one table: the caller knows, for each of the n channel bits of a voice burst in the order
+// it receives them, the cell (cell_row[i], cell_col[i]) its air-interface tables send that bit to; wire_bit[i] is where the same bit
+// goes in the packed wire frame.  Refuses a schedule that is not a bijection onto the codec's cells (a wrong table is caught here,
+// once, not as noise in the audio).
+int mbx_wire_permutation(int codec, const int* cell_row, const int* cell_col, int n, int* wire_bit) {
+    int rows = 0;
+    const int* w = wire_row_widths(codec, &rows);
+    if (!w || !cell_row || !cell_col || !wire_bit) {
+        return MBE_STATUS_INVALID_ARGUMENT;
+    }
+    int total = 0;
+    for (int r = 0; r < rows; ++r) {
+        total += w[r];
+    }
+    if (n != total) {
+        return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_wire_permutation: the schedule must name every channel bit of the codec once");
+    }
+    bool seen[192] = {false};
+    for (int i = 0; i < n; ++i) {
+        const int b = mbx_wire_bit_of_cell(codec, cell_row[i], cell_col[i]);
+        if (b < 0 || seen[b]) {
+            return fail(MBE_STATUS_INVALID_ARGUMENT, "mbx_wire_permutation: a cell outside the codec's frame, or named twice");
+        }
+        seen[b] = true;
+        wire_bit[i] = b;
+    }
+    return 0;
+}
+
 int mbx_pack_imbe7200x4400(const char* frames, size_t n, uint8_t* packed) {
     static const int width[8] = {23, 23, 23, 23, 15, 15, 15, 7};
     int rc = validate_bits(frames, n * 184u);

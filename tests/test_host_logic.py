@@ -462,3 +462,54 @@ def test_bench_contract_line_is_compact_and_complete():
     fat["other_configs"].update({f"extra{i}": fat["other_configs"]["ambe_fec"] for i in range(40)})
     thin = bench.contract_line(fat)
     assert len(json.dumps(thin)) <= 4096 and "other_configs" not in thin and thin["parity"]["FAILED"].startswith("xxx") and "roofline" in thin and "cpu_baseline" in thin
+
+
+def test_wire_permutation_from_a_callers_deinterleave_tables():
+    """a host folds its own burst -> cell tables into one permutation that writes the packed wire frame
+    directly (include/mbx.h, mbx_wire_bit_of_cell / mbx_wire_permutation).  For random schedules (a random bijection from received-bit
+    order onto the codec's cells -- the reference holds no air-interface table to test against) and random bits: scattering the bits
+    through the permutation gives the bytes mbx_pack_* produce from the cell array the same schedule fills; schedules that name a cell
+    twice, leave the frame or have the wrong length are refused.  Host-only: no device needed."""
+    from mbelib_neo_amd import _native
+    from mbelib_neo_amd.layout import FRAME_BYTES, FRAME_CELLS, ROW_WIDTHS
+
+    try:
+        L = _native.lib()
+    except _native.NativeLibraryError as e:
+        pytest.skip(str(e))
+    rng = np.random.default_rng(7)
+    packers = {0: L.mbx_pack_imbe7200x4400, 1: L.mbx_pack_ambe3600x2450, 2: L.mbx_pack_imbe7100x4400, 3: L.mbx_pack_ambe3600x2450}
+    for codec in (0, 1, 2, 3):
+        rows, cols = FRAME_CELLS[codec]
+        widths = ROW_WIDTHS[codec]
+        cells = [(r, j) for r in range(rows) for j in range(widths[r])]
+        n = len(cells)
+        assert n == {0: 144, 1: 72, 2: 142, 3: 72}[codec]
+        assert L.mbx_wire_bit_of_cell(codec, 0, widths[0] - 1) == 0 and L.mbx_wire_bit_of_cell(codec, 0, 0) == widths[0] - 1
+        assert L.mbx_wire_bit_of_cell(codec, rows - 1, 0) == n - 1 and L.mbx_wire_bit_of_cell(codec, 0, widths[0]) == -1
+        assert L.mbx_wire_bit_of_cell(codec, rows, 0) == -1 and L.mbx_wire_bit_of_cell(7, 0, 0) == -1
+        for _ in range(8):
+            order = rng.permutation(n)
+            cr = np.ascontiguousarray([cells[k][0] for k in order], dtype=np.int32)
+            cc = np.ascontiguousarray([cells[k][1] for k in order], dtype=np.int32)
+            wb = np.zeros(n, dtype=np.int32)
+            assert L.mbx_wire_permutation(codec, cr.ctypes.data, cc.ctypes.data, n, wb.ctypes.data) == 0
+            assert sorted(wb.tolist()) == list(range(n))
+            bits = rng.integers(0, 2, size=n)
+            frame = np.zeros(FRAME_BYTES[codec], dtype=np.uint8)
+            for i in range(n):
+                if bits[i]:
+                    frame[wb[i] >> 3] |= 0x80 >> (wb[i] & 7)
+            arr = np.zeros((rows, cols), dtype=np.int8)   # what the caller's deinterleaver would have filled
+            arr[cr, cc] = bits
+            want = np.zeros(FRAME_BYTES[codec], dtype=np.uint8)
+            assert packers[codec](arr.ctypes.data, 1, want.ctypes.data) == 0
+            assert frame.tobytes() == want.tobytes(), codec
+        bad = cr.copy()
+        bad_c = cc.copy()
+        bad[1], bad_c[1] = bad[0], bad_c[0]   # a cell named twice
+        assert L.mbx_wire_permutation(codec, bad.ctypes.data, bad_c.ctypes.data, n, wb.ctypes.data) == -1
+        assert L.mbx_wire_permutation(codec, cr.ctypes.data, cc.ctypes.data, n - 1, wb.ctypes.data) == -1
+        bad_c = cc.copy()
+        bad_c[0] = 24   # outside every row
+        assert L.mbx_wire_permutation(codec, cr.ctypes.data, bad_c.ctypes.data, n, wb.ctypes.data) == -1
