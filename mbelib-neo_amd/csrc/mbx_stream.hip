@@ -432,6 +432,17 @@ __device__ __forceinline__ void load_enh_view(Parms& r, const mbe_parms* __restr
 // enhanced model's view is then taken from cur_mp's registers instead of a second set of loads from the same struct (seven vector
 // loads per wave less), and the resident flag, a scalar load at the very top of the wave, is first needed AFTER every other request
 // of the wave has gone out (it used to pick the address of the third load: one exposed round trip before the other twenty).
+// ... and so do the five scalars the decode reads of prev_mp: while the flag is set, prev_mp is the snapshot the last frame took of
+// cur_mp after its decode (voice frames: `mbe_moveMbeParms(cur, prev)` before the enhancement, ref src/imbe/imbe7200x4400.c:835,
+// src/ambe/ambe3600x2450.c:789; erasures and re-initialisations copy the whole struct), and nothing after the snapshot touches L, gamma,
+// errorRate, repeatCount or mutingThreshold -- so they are cur_mp's, and prev_mp's two header lines are not fetched at all.
+__device__ __forceinline__ void prev_header_of(Parms& r, const Parms& cur) {
+    r.L = cur.L;
+    r.gamma = cur.gamma;
+    r.errorRate = cur.errorRate;
+    r.repeatCount = cur.repeatCount;
+    r.mutingThreshold = cur.mutingThreshold;
+}
 __device__ __forceinline__ void enh_view_of(Parms& r, const Parms& cur) {
     r = Parms{};
     r.Vl = cur.Vl;
@@ -2277,8 +2288,8 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         constexpr bool kFlat = MBX_FLAT_LOADS && kFuse != 0;
         const uint32_t h_cur = load_header(slot_cur, lane_in);
-        h_prev_first = load_header(slot_prev, lane_in);
         if constexpr (!(kRes && MBX_RES_VIEW_FROM_CUR)) {
+            h_prev_first = load_header(slot_prev, lane_in);
             h_enh_first = load_header(enh_src, lane_in);
         }
         load_rng(rng, &rngs[slot]);
@@ -2286,7 +2297,8 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         load_parms_arrays<kFlat>(cur, slot_cur, lane_in);
         if constexpr (kRes && MBX_RES_VIEW_FROM_CUR) {
             asm volatile("" ::: "memory");   // (everything above is requested before the flag is looked at)
-            if (!elided1) {   // (elided: the view is taken from cur_mp's registers where the frame loop starts, see enh_view_of)
+            if (!elided1) {   // (elided: both come from cur_mp's registers where the frame loop starts, see enh_view_of / prev_header_of)
+                h_prev_first = load_header(slot_prev, lane_in);
                 h_enh_first = load_header(slot_enh, lane_in);
                 load_enh_arrays<kFlat>(enh_first, slot_enh, lane_in);
             }
@@ -2407,14 +2419,15 @@ imbe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
             load_prev_view_lds(prev, slot_prev, lane);
         } else if constexpr (kOne) {   // requested at the start, together with cur_mp
             prev = prev_first;
-            set_prev_header(prev, h_prev_first);
             if (kRes && MBX_RES_VIEW_FROM_CUR && elided1) {   // cur_mp still holds what the last frame left: that IS prev_mp_enhanced
+                prev_header_of(prev, cur);
                 enh_view_of(enh, cur);
                 enh.w0 = cur.w0;
                 enh.L = cur.L;
                 enh.localEnergy = cur.localEnergy;
                 enh.amplitudeThreshold = cur.amplitudeThreshold;
             } else {
+                set_prev_header(prev, h_prev_first);
                 enh = enh_first;
                 set_enh_header(enh, h_enh_first);
             }
@@ -3126,8 +3139,8 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         }
         const mbe_parms* const enh_src = elided ? slot_cur : slot_enh;
         const uint32_t h_cur = load_header(slot_cur, lane_in);
-        h_prev_first = load_header(slot_prev, lane_in);
         if constexpr (!(kRes && MBX_RES_VIEW_FROM_CUR)) {
+            h_prev_first = load_header(slot_prev, lane_in);
             h_enh_first = load_header(enh_src, lane_in);
         }
         load_rng(rng, &rngs[slot]);
@@ -3136,7 +3149,8 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         if constexpr (kRes && MBX_RES_VIEW_FROM_CUR) {
             asm volatile("" ::: "memory");   // (everything above is requested before the flag is looked at)
             enh_from_cur = elided;
-            if (!elided) {   // (elided: the view is taken from cur_mp's registers where the frame loop starts, see enh_view_of)
+            if (!elided) {   // (elided: both come from cur_mp's registers where the frame loop starts, see enh_view_of / prev_header_of)
+                h_prev_first = load_header(slot_prev, lane_in);
                 h_enh_first = load_header(slot_enh, lane_in);
                 load_enh_arrays(enh_first, slot_enh, lane_in);
             }
@@ -3258,14 +3272,15 @@ ambe_stream_body(int S, int Tn, const mbx_param_record* __restrict__ records, co
         } else if constexpr (kOne) {   // requested at the start, together with cur_mp
             prev = prev_first;
             scratch.x.fp[lane] = row_first;
-            set_prev_header(prev, h_prev_first);
             if (kRes && MBX_RES_VIEW_FROM_CUR && enh_from_cur) {   // cur_mp still holds what the last frame left: that IS prev_mp_enhanced
+                prev_header_of(prev, cur);
                 enh_view_of(enh, cur);
                 enh.w0 = cur.w0;
                 enh.L = cur.L;
                 enh.localEnergy = cur.localEnergy;
                 enh.amplitudeThreshold = cur.amplitudeThreshold;
             } else {
+                set_prev_header(prev, h_prev_first);
                 enh = enh_first;
                 set_enh_header(enh, h_enh_first);
             }
