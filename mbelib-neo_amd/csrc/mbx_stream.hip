@@ -3905,7 +3905,10 @@ ambe2400_stream_kernel_lds_slice(int S, int stride, int t0, int n, const mbx_par
 
 // Resident state (DeviceTables::resident, mbx_process_batch_resident): the LDS-resident bodies with prev_mp_enhanced elided
 // while it equals cur_mp and prev_mp fetched lazily -- at every T, T = 1 included (sessions, queue mode).
-__global__ void MBX_LDS_KERNEL_ATTR(MBX_IMBE_LDS_WAVES_PER_SIMD)
+#ifndef MBX_IMBE_RES_WAVES_PER_SIMD
+#define MBX_IMBE_RES_WAVES_PER_SIMD MBX_IMBE_LDS_WAVES_PER_SIMD
+#endif
+__global__ void MBX_LDS_KERNEL_ATTR(MBX_IMBE_RES_WAVES_PER_SIMD)
 imbe_stream_kernel_res(int S, int Tn, const mbx_param_record* __restrict__ records, const FrameParams* __restrict__ params,
                        mbe_parms* __restrict__ state, mbx_stream_rng* __restrict__ rngs, int16_t* __restrict__ pcm16,
                        float* __restrict__ pcmf, mbe_process_result* __restrict__ results, DeviceTables tabs_in) {
